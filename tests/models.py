@@ -1,0 +1,50 @@
+"""Seeded synthetic libsvm-3.12 text models and synthetic clouds (test / bench inputs; data only)."""
+import numpy as np
+
+
+def write_random_model(path, nsv, D=323, seed=0, gamma=None, rho=0.1, density=1.0):
+    """C-SVC / RBF model in libsvm's text format (svm.cpp:2599-2691 writer layout).
+
+    SURVEY.md §8(d): SV values U(-1,1) printed %.8g, coef ~ U(0,2) with the class sign (printed %.16g),
+    gamma = 1/D, rho 0.1, labels "1 -1", first half of the SVs belong to label 1.
+    """
+    rng = np.random.RandomState(seed)
+    gamma = 1.0 / D if gamma is None else gamma
+    n0 = nsv // 2
+    n1 = nsv - n0
+    sv = rng.uniform(-1.0, 1.0, size=(nsv, D))
+    keep = rng.uniform(size=(nsv, D)) < density
+    coef = rng.uniform(0.0, 2.0, size=nsv)
+    coef[n0:] *= -1.0
+    with open(path, "w") as f:
+        f.write("svm_type c_svc\nkernel_type rbf\ngamma %g\nnr_class 2\ntotal_sv %d\nrho %g\nlabel 1 -1\nnr_sv %d %d\nSV\n"
+                % (gamma, nsv, rho, n0, n1))
+        for i in range(nsv):
+            parts = ["%.16g " % coef[i]]
+            row = sv[i]
+            for k in range(D):
+                if keep[i, k]:
+                    parts.append("%d:%.8g " % (k + 1, row[k]))
+            f.write("".join(parts) + "\n")
+    return path
+
+
+def synthetic_cloud(grid=512, k=2, seed=0, cell=0.01):
+    """SURVEY.md §8(d) C5 cloud: for each 1 cm cell of a grid x grid area centred on the origin, k points at
+    uniform-random xy inside the cell, z = 0.05 + 0.20*smooth(x,y) + U(0,0.005) with smooth = mean of 8 seeded
+    cosines mapped to [0,1].  Returns float32 [grid*grid*k, 3]."""
+    rng = np.random.RandomState(seed)
+    half = grid * cell / 2.0
+    ii, jj = np.meshgrid(np.arange(grid), np.arange(grid), indexing="ij")
+    x = (ii[..., None] + rng.uniform(0.02, 0.98, size=(grid, grid, k))) * cell - half
+    y = (jj[..., None] + rng.uniform(0.02, 0.98, size=(grid, grid, k))) * cell - half
+    fx = rng.uniform(2.0, 40.0, size=8)
+    fy = rng.uniform(2.0, 40.0, size=8)
+    ph = rng.uniform(0, 2 * np.pi, size=8)
+    s = np.zeros_like(x)
+    for a, b, p in zip(fx, fy, ph):
+        s += np.cos(a * x + b * y + p)
+    s = 0.5 + 0.5 * s / 8.0
+    z = 0.05 + 0.20 * s + rng.uniform(0.0, 0.005, size=x.shape)
+    pts = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+    return pts
