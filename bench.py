@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the grasp-scoring hot path on MI355X.
+
+Metric (BASELINE.json): grid-cell x rotation SVM evals/sec (whole job), plus end-to-end grasp latency per cloud.
+Workload at every N: BASELINE config C5 -- synthetic 512x512 height map (524 288 points), 36 rolls of 5 degrees,
+512x512 search area, seeded random libsvm RBF model with the full SV set (default nSV = 4096, D = 323) -- one cloud
+per GPU per step (weak scaling: rolls x cells of independent clouds shard across ranks with no data-path collective;
+the only exchange is one 8-byte RCCL all-reduce(max) per step that elects the best grasp of the batch).
+
+A step = one pass of the whole hot path (bin -> integral -> mask -> features+text round trips+scale -> RBF decision
+-> guard-band recheck -> vote/argmax -> pose) over one cloud per rank, inputs already resident in HBM.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+D_ATTR = 323                       # algorithmic work 2*D*nSV flop per eval, D unpadded
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nsv", type=int, default=4096, help="support vectors of the seeded random model")
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--rolls", type=int, default=36)
+    ap.add_argument("--roll-step", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=84, help="grid size of the CPU-baseline sample (one roll)")
+    ap.add_argument("--no-latency", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(feat, rng_file, model_path, xyz, args):
+    """The oracle (scalar C port of the reference's arithmetic incl. both text round trips) on a bounded sample of the
+    same workload: the central crop x crop cells of the same cloud, one roll, same model.  1 core."""
+    from oracle import oracle as O
+    o = O.Oracle(feat, rng_file, model_path)
+    c = args.cpu_crop
+    half = c * 0.01 / 2
+    sel = (np.abs(xyz[:, 0]) < half) & (np.abs(xyz[:, 1]) < half)
+    pts = np.ascontiguousarray(xyz[sel])
+    cfg = O.make_cfg(H=c, W=c, n_rolls=1, roll_step_deg=args.roll_step)
+    inp = O.make_input(length_x=c, length_y=c)
+    t0 = time.perf_counter()
+    r = o.run(pts, cfg, inp, debug=False)
+    dt = time.perf_counter() - t0
+    return dict(value=r["n_evals"] / dt, unit="evals/s", cores=1, kind="port",
+                sample="oracle/haf_oracle.c end to end (features, %%.4g/%%g text round trips, svm-scale, libsvm-order fp64 RBF "
+                       "over nSV=%d, vote) on the central %dx%d crop of the same cloud, 1 roll: %d evals in %.1f s"
+                       % (args.nsv, c, c, r["n_evals"], dt))
+
+
+def latency_c2(feat, rng_file, device):
+    """BASELINE config C2 (pcd2.pcd, 32x32 cm area, 12 rolls, surrogate model), host-resident cloud: wall time of one
+    haf_score call including the PCIe copies -- the second half of the metric."""
+    from haf_grasping_amd import capi
+    model = os.path.join(ROOT, "tests", "golden", "surrogate.model")
+    xyz = capi.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "pcd2.pcd"))
+    eng = capi.Engine(feat, rng_file, model, device=device)
+    inp = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32)
+    for _ in range(3):
+        out = eng.score(xyz, inp)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        out = eng.score(xyz, inp)
+        ts.append(time.perf_counter() - t0)
+    eng.close()
+    return dict(workload="C2: pcd2.pcd 5088 pts, 32x32 cm, 12 rolls, surrogate model nSV=172, host cloud (PCIe included)",
+                ms_median=1e3 * float(np.median(ts)), ms_min=1e3 * float(np.min(ts)), evals=out["n_evals"], eval=out["eval"])
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one rank per GPU: launch with torch.distributed.run" % args.gpus)
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+
+    import models
+    from haf_grasping_amd import capi
+
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    feat, rng_file = os.path.join(data, "Features.txt"), os.path.join(data, "range21062012_allfeatures")
+    tmp = tempfile.mkdtemp(prefix="hafbench_%d_" % rank)
+    model_path = os.path.join(tmp, "rand%d.model" % args.nsv)
+    models.write_random_model(model_path, args.nsv, D=D_ATTR, seed=1234, balanced=True)
+
+    G = args.grid
+    eng = capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
+                      roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2, flags=capi.FLAG_PROFILE)
+    xyz = models.synthetic_cloud(grid=G, k=2, seed=rank)
+    d_xyz = torch.from_numpy(xyz).cuda()                    # resident in HBM before the timed region
+    cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
+    inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
+    key = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def step():
+        rec = eng.score_rolls([cloud], [inp], 0, args.rolls)[0]
+        out = eng.finalize(inp, rec)
+        if world > 1:
+            # best grasp of the batch: one all-reduce(max) of (vote, -rank) packed into 8 bytes, over xGMI
+            key[0] = (int(out["best_vote"]) + 1000) * 1024 + (1023 - rank)
+            dist.all_reduce(key, op=dist.ReduceOp.MAX)
+        return rec, out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    svm_ms, stage_acc, evals_rank, rechecked = [], {}, 0, 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec, out = step()
+        evals_rank += int(rec["n_evals"].sum())
+        rechecked += eng.last_counts()["n_rechecked"]
+        st = eng.stage_ms()
+        svm_ms.append(st["svm"])
+        for k, v in st.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ev = torch.tensor([evals_rank], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_evals = int(ev.item())
+
+    if rank == 0:
+        evals_per_launch = evals_rank / args.steps
+        svm_s = float(np.mean(svm_ms)) * 1e-3
+        flop = evals_per_launch * 2.0 * D_ATTR * args.nsv           # algorithmic: 646*nSV per eval, one pass
+        achieved = flop / svm_s / 1e12
+        line = {
+            "metric": "grid-cell x rotation SVM evals/sec",
+            "value": total_evals / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C5: synthetic %dx%d heightmap (%d points), %d rolls x %d deg, %dx%d cm area, seeded random "
+                                   "libsvm RBF model nSV=%d D=323 gamma=1/323, one cloud per GPU per step, cloud resident in HBM"
+                                   % (G, G, xyz.shape[0], args.rolls, args.roll_step, G, G, args.nsv),
+                       "evals_per_cloud": int(evals_per_launch), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
+                       "sharding": "clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step"},
+            "roofline": {"kernel": "k_svm_rbf", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": svm_s * 1e3, "flop_per_launch": flop},
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
+            "rechecked_per_step": rechecked / args.steps,
+            "best": {"eval": out["eval"], "row": out["best_row"], "col": out["best_col"], "roll": out["best_roll"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(feat, rng_file, model_path, xyz, args)
+        else:
+            line["cpu_baseline"] = None
+        if world == 1 and not args.no_latency:
+            eng.close()
+            line["grasp_latency"] = latency_c2(feat, rng_file, local_rank)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+"""ctypes binding of include/hafgrasp.h (libhafgrasp.so).  No torch types cross this boundary: plain pointers and
+sizes only.  The library is gfx950-only and has no CPU fallback; loading works anywhere, haf_create needs the GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhafgrasp.so")
+
+HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+FLAG_KEEP_DEBUG, FLAG_PROFILE = 1, 2
+DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM = range(6)
+STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "recheck", "vote", "download"]
+
+
+class Config(C.Structure):
+    _fields_ = [("feature_file", C.c_char_p), ("range_file", C.c_char_p), ("model_file", C.c_char_p),
+                ("nr_features_without_shaf", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
+                ("n_rolls", C.c_int32), ("roll_step_deg", C.c_int32), ("z_shift", C.c_float),
+                ("graspval_top", C.c_int32), ("device", C.c_int32), ("max_clouds", C.c_int32),
+                ("max_points", C.c_int64), ("flags", C.c_uint32)]
+
+
+class GraspInput(C.Structure):
+    _fields_ = [("grasp_area_center", C.c_double * 3), ("grasp_area_length_x", C.c_float),
+                ("grasp_area_length_y", C.c_float), ("approach_vector", C.c_double * 3),
+                ("max_calculation_time", C.c_double), ("show_only_best_grasp", C.c_int32),
+                ("threshold_grasp_evaluation", C.c_int32), ("gripper_opening_width", C.c_int32)]
+
+
+class GraspOutput(C.Structure):
+    _fields_ = [("eval", C.c_int32), ("grasp_point1", C.c_double * 3), ("grasp_point2", C.c_double * 3),
+                ("averaged_grasp_point", C.c_double * 3), ("approach_vector", C.c_double * 3), ("roll", C.c_float),
+                ("best_row", C.c_int32), ("best_col", C.c_int32), ("best_roll", C.c_int32), ("best_vote", C.c_int32),
+                ("rolls_done", C.c_int32), ("n_evals", C.c_int64), ("n_rechecked", C.c_int64)]
+
+
+class RollRecord(C.Structure):
+    _fields_ = [("vote", C.c_int32), ("row", C.c_int16), ("col", C.c_int16), ("h_locmax", C.c_float),
+                ("n_evals", C.c_int32)]
+
+
+class Cloud(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("n_points", C.c_size_t), ("stride_floats", C.c_size_t), ("on_device", C.c_int32)]
+
+
+ROLL_RECORD_DTYPE = np.dtype([("vote", np.int32), ("row", np.int16), ("col", np.int16), ("h_locmax", np.float32),
+                              ("n_evals", np.int32)])
+assert ROLL_RECORD_DTYPE.itemsize == C.sizeof(RollRecord) == 16
+
+_lib = None
+
+
+class HafError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hafgrasp error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Loads libhafgrasp.so.  Raises if it has not been built: the product path never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
+                               "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        E = C.c_void_p
+        L.haf_abi_version.restype = C.c_int
+        L.haf_config_default.argtypes = [C.POINTER(Config)]
+        L.haf_grasp_input_default.argtypes = [C.POINTER(GraspInput)]
+        L.haf_create.argtypes = [C.POINTER(Config), C.POINTER(E)]
+        L.haf_destroy.argtypes = [E]
+        L.haf_last_error.restype = C.c_char_p
+        L.haf_last_error.argtypes = [E]
+        L.haf_score.argtypes = [E, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
+        L.haf_score_batch.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
+        L.haf_score_rolls.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.c_int32, C.c_int32,
+                                      C.c_void_p]
+        L.haf_finalize.argtypes = [E, C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
+        L.haf_get_roll_grid.argtypes = [E, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.haf_debug_fetch.argtypes = [E, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
+        L.haf_set_stream.argtypes = [E, C.c_void_p]
+        L.haf_get_stream.restype = C.c_void_p
+        L.haf_get_stream.argtypes = [E]
+        L.haf_get_stage_ms.argtypes = [E, C.POINTER(C.c_float)]
+        L.haf_model_info.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
+                                   C.c_size_t]
+        L.haf_free.argtypes = [C.c_void_p]
+        L.haf_test_decq_host.restype = C.c_double
+        L.haf_test_decq_host.argtypes = [C.c_double, C.c_int]
+        L.haf_test_scale_host.restype = C.c_double
+        L.haf_test_scale_host.argtypes = [C.c_double] * 5
+        L.haf_test_decq_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.haf_test_scale_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                            C.c_int]
+        L.haf_test_feature_table.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int]
+        L.haf_test_range_table.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.haf_test_model.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.haf_test_roll_geo.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+        L.haf_test_finalize.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
+        _lib = L
+    return _lib
+
+
+def default_config(**kw):
+    cfg = Config()
+    lib().haf_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if k in ("feature_file", "range_file", "model_file") and isinstance(v, str):
+            v = v.encode()
+        setattr(cfg, k, v)
+    return cfg
+
+
+def default_input(**kw):
+    gi = GraspInput()
+    lib().haf_grasp_input_default(C.byref(gi))
+    for k, v in kw.items():
+        if k in ("grasp_area_center", "approach_vector"):
+            v = (C.c_double * 3)(*v)
+        setattr(gi, k, v)
+    return gi
+
+
+def output_to_dict(o):
+    return dict(eval=o.eval, grasp_point1=tuple(o.grasp_point1), grasp_point2=tuple(o.grasp_point2),
+                averaged_grasp_point=tuple(o.averaged_grasp_point), approach_vector=tuple(o.approach_vector),
+                roll=o.roll, best_row=o.best_row, best_col=o.best_col, best_roll=o.best_roll, best_vote=o.best_vote,
+                rolls_done=o.rolls_done, n_evals=o.n_evals, n_rechecked=o.n_rechecked)
+
+
+def load_pcd(path):
+    """PCD file -> float32 [N, 3] through the library's own reader (haf_pcd_load)."""
+    p = C.POINTER(C.c_float)()
+    n = C.c_size_t()
+    err = C.create_string_buffer(256)
+    rc = lib().haf_pcd_load(path.encode(), C.byref(p), C.byref(n), err, 256)
+    if rc != HAF_OK:
+        raise HafError(rc, err.value.decode())
+    try:
+        return np.ctypeslib.as_array(p, shape=(n.value, 3)).copy()
+    finally:
+        lib().haf_free(p)
+
+
+class Engine:
+    """Owns one haf_engine handle (one GPU)."""
+
+    def __init__(self, feature_file, range_file, model_file, **cfg):
+        self._L = lib()
+        self.cfg = default_config(feature_file=feature_file, range_file=range_file, model_file=model_file, **cfg)
+        self._h = C.c_void_p()
+        rc = self._L.haf_create(C.byref(self.cfg), C.byref(self._h))
+        if rc != HAF_OK:
+            raise HafError(rc, (self._L.haf_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.haf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != HAF_OK:
+            raise HafError(rc, (self._L.haf_last_error(self._h) or b"").decode())
+
+    @staticmethod
+    def _cloud(xyz):
+        """numpy float32 [N, >=3] (host) or (device_ptr, n_points, stride_floats) tuple (HBM resident)."""
+        if isinstance(xyz, tuple):
+            ptr, n, stride = xyz
+            return Cloud(C.c_void_p(ptr), n, stride, 1), None
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] >= 3
+        return Cloud(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0), a
+
+    def model_info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.haf_model_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_sv=a.value, dim=b.value, n_features=c.value)
+
+    def last_counts(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._L.haf_last_counts(self._h, C.byref(a), C.byref(b)))
+        return dict(n_evals=a.value, n_rechecked=b.value)
+
+    def score(self, xyz, grasp_input):
+        return self.score_batch([xyz], [grasp_input])[0]
+
+    def score_batch(self, clouds, inputs):
+        n = len(clouds)
+        keep = []
+        arr = (Cloud * n)()
+        for i, c in enumerate(clouds):
+            arr[i], k = self._cloud(c)
+            keep.append(k)
+        gi = (GraspInput * n)(*inputs)
+        out = (GraspOutput * n)()
+        self._check(self._L.haf_score_batch(self._h, n, arr, gi, out))
+        return [output_to_dict(o) for o in out]
+
+    def score_rolls(self, clouds, inputs, roll_first, roll_count):
+        n = len(clouds)
+        keep = []
+        arr = (Cloud * n)()
+        for i, c in enumerate(clouds):
+            arr[i], k = self._cloud(c)
+            keep.append(k)
+        gi = (GraspInput * n)(*inputs)
+        rec = np.zeros((n, roll_count), dtype=ROLL_RECORD_DTYPE)
+        self._check(self._L.haf_score_rolls(self._h, n, arr, gi, roll_first, roll_count, rec.ctypes.data))
+        return rec
+
+    def finalize(self, grasp_input, records):
+        rec = np.ascontiguousarray(records, dtype=ROLL_RECORD_DTYPE)
+        assert rec.shape == (self.cfg.n_rolls,)
+        out = GraspOutput()
+        self._check(self._L.haf_finalize(self._h, C.byref(grasp_input), rec.ctypes.data, C.byref(out)))
+        return output_to_dict(out)
+
+    def roll_grid(self, cloud, roll):
+        H, W = self.cfg.grid_h, self.cfg.grid_w
+        ev = np.zeros((H, W), np.float32)
+        mask = np.zeros((H, W), np.uint8)
+        self._check(self._L.haf_get_roll_grid(self._h, cloud, roll, ev.ctypes.data, mask.ctypes.data))
+        return ev, mask
+
+    def debug(self, what, cloud, roll):
+        H, W = self.cfg.grid_h, self.cfg.grid_w
+        shape, dt = {DBG_HEIGHTS: ((H, W), np.float32), DBG_INTEGRAL: ((H + 1, W + 1), np.float32),
+                     DBG_MASK: ((H, W), np.uint8), DBG_LABELS: ((H, W), np.int8), DBG_DECISION: ((H, W), np.float64),
+                     DBG_TRANSFORM: ((4, 4), np.float32)}[what]
+        a = np.zeros(shape, dt)
+        self._check(self._L.haf_debug_fetch(self._h, what, cloud, roll, a.ctypes.data, a.nbytes))
+        return a
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._L.haf_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def stage_ms(self):
+        ms = (C.c_float * len(STAGES))()
+        self._check(self._L.haf_get_stage_ms(self._h, ms))
+        return dict(zip(STAGES, list(ms)))

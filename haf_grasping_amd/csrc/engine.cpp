@@ -1,0 +1,905 @@
+// engine.cpp -- host side of libhafgrasp.so: the C-ABI of include/hafgrasp.h over the gfx950 kernels.
+//
+// What stays on the host, and why: the per-roll 4x4 transform and the rotated-rectangle scalars of pnt_in_box
+// (a few dozen fp32 operations per roll that use glibc sinf/cosf/atan2f exactly as the reference does), the
+// sequential cross-roll rule, and the final grasp pose (once per goal).  Everything that scales with points, cells
+// or support vectors runs in kernels.hip.  There is no CPU implementation of those stages in this library.
+#include "../../include/hafgrasp.h"
+#include "kernels.h"
+#include "parsers.h"
+#include "decq.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace haf;
+
+namespace {
+
+constexpr double kPi = 3.141592653;   // server.cpp:94 -- the reference's truncated constant, NOT M_PI
+
+thread_local std::string g_create_error;
+
+struct Mat4 {
+    float a[4][4];
+    static Mat4 identity()
+    {
+        Mat4 m;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m.a[i][j] = (i == j) ? 1.0f : 0.0f;
+        return m;
+    }
+};
+
+// fp32 product, inner sum in index order, unfused (this TU is built with -ffp-contract=off).  Eigen's evaluation
+// order for `A*B*C*D*E*F` is not pinned by the reference; this is the definition of record.
+Mat4 operator*(const Mat4 &l, const Mat4 &r)
+{
+    Mat4 o;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float s = l.a[i][0] * r.a[0][j];
+            s = s + l.a[i][1] * r.a[1][j];
+            s = s + l.a[i][2] * r.a[2][j];
+            s = s + l.a[i][3] * r.a[3][j];
+            o.a[i][j] = s;
+        }
+    return o;
+}
+
+struct NormalisedInput {
+    double av[3];      // approach vector after server.cpp:270-273
+    int sx, sy;        // grasp_search_area_size_{x,y}_dir (266-267)
+    int width;         // gripper_opening_width (281)
+};
+
+NormalisedInput normalise(const haf_grasp_input &in)
+{
+    NormalisedInput n;
+    float len = (float)std::sqrt(in.approach_vector[0] * in.approach_vector[0] + in.approach_vector[1] * in.approach_vector[1] +
+                                 in.approach_vector[2] * in.approach_vector[2]);
+    for (int k = 0; k < 3; k++) n.av[k] = in.approach_vector[k] / len;
+    n.sx = (int)in.grasp_area_length_x;
+    n.sy = (int)in.grasp_area_length_y;
+    n.width = in.gripper_opening_width;
+    return n;
+}
+
+// mat_transform of generate_grid (423-483) when from_float_av, of transform_gp_in_wcs_and_publish (1276-1334) otherwise:
+// the two differ in whether atan2/sqrt see the float copy of the approach vector or the double message fields.
+Mat4 roll_transform(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, bool from_float_av)
+{
+    Mat4 scale = Mat4::identity(), to_orig = Mat4::identity(), rot_z = Mat4::identity(), rot_x = Mat4::identity(),
+         from_orig = Mat4::identity(), rot = Mat4::identity();
+    scale.a[0][0] = (float)n.width;
+    to_orig.a[0][3] = (float)(-in.grasp_area_center[0]);
+    to_orig.a[1][3] = (float)(-in.grasp_area_center[1]);
+    to_orig.a[2][3] = (float)(-in.grasp_area_center[2]);
+    from_orig.a[2][3] = 0 + cfg.z_shift;
+    float about_z, about_x = 0;
+    if (from_float_av) {
+        float x = (float)n.av[0], y = (float)n.av[1], z = (float)n.av[2];
+        if (y == 0 && x == 0) {
+            about_z = 0;
+            about_x = (z >= 0) ? 0.0f : (float)kPi;
+        } else {
+            about_z = (float)(90 * kPi / 180.0 - std::atan2(y, x));                       // float overloads
+            about_x = (float)(90 * kPi / 180.0 - std::atan2(z, std::sqrt(y * y + x * x)));
+        }
+    } else {
+        double x = n.av[0], y = n.av[1], z = n.av[2];
+        if (y == 0 && x == 0) {
+            about_z = 0;
+            about_x = (z >= 0) ? 0.0f : (float)kPi;
+        } else {
+            about_z = (float)(90 * kPi / 180.0 - std::atan2(y, x));
+            about_x = (float)(90 * kPi / 180.0 - std::atan2(z, std::sqrt(y * y + x * x)));
+        }
+    }
+    float angle = (float)(roll * cfg.roll_step_deg * kPi / 180);
+    rot.a[0][0] = std::cos(angle); rot.a[0][1] = -std::sin(angle);
+    rot.a[1][0] = std::sin(angle); rot.a[1][1] = std::cos(angle);
+    rot_z.a[0][0] = std::cos(about_z); rot_z.a[0][1] = -std::sin(about_z);
+    rot_z.a[1][0] = std::sin(about_z); rot_z.a[1][1] = std::cos(about_z);
+    rot_x.a[1][1] = std::cos(about_x); rot_x.a[1][2] = -std::sin(about_x);
+    rot_x.a[2][1] = std::sin(about_x); rot_x.a[2][2] = std::cos(about_x);
+    return scale * rot * from_orig * rot_x * rot_z * to_orig;
+}
+
+void fill_roll_geo(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, RollGeo &g)
+{
+    Mat4 m = roll_transform(cfg, in, n, roll, true);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) g.m[i * 4 + j] = m.a[i][j];
+    // pnt_in_box scalars, server.cpp:679-696, with the reference's float/double mix
+    const float boxrot_angle_init = 0.0f;                 // never assigned in the reference; zero in practice
+    float alpha_deg = (float)(-roll * cfg.roll_step_deg - boxrot_angle_init * 180 / kPi);
+    float alpha = (float)(alpha_deg * kPi / 180);
+    float cx = (float)(cfg.grid_h / 2), cy = (float)(cfg.grid_h / 2);
+    float boarder = 7.0f;
+    float height_r = n.sx / 2 - boarder;
+    float width_r = n.sy / 2 - boarder;
+    g.sa = std::sin(alpha);
+    g.ca = std::cos(alpha);
+    g.cx1 = cx - std::sin(alpha) * height_r;
+    g.cy1 = cy + std::cos(alpha) * height_r;
+    g.cx2 = cx + std::sin(alpha) * height_r;
+    g.cy2 = cy - std::cos(alpha) * height_r;
+    g.cx3 = (float)(cx - std::sin(alpha + kPi / 2) * width_r);    // double sin/cos here (alpha + PI/2 is a double)
+    g.cy3 = (float)(cy + std::cos(alpha + kPi / 2) * width_r);
+    g.cx4 = (float)(cx + std::sin(alpha + kPi / 2) * width_r);
+    g.cy4 = (float)(cy - std::cos(alpha + kPi / 2) * width_r);
+    g.pad[0] = g.pad[1] = 0;
+}
+
+// 4x4 inverse: Gauss-Jordan with partial pivoting in double, rounded to float (Eigen's inverse() order is unpinned)
+bool invert(const Mat4 &m, Mat4 &inv)
+{
+    double w[4][8];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) { w[i][j] = m.a[i][j]; w[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 4; r++) if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
+        if (w[piv][c] == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 8; j++) std::swap(w[piv][j], w[c][j]);
+        double d = w[c][c];
+        for (int j = 0; j < 8; j++) w[c][j] /= d;
+        for (int r = 0; r < 4; r++) {
+            if (r == c) continue;
+            double f = w[r][c];
+            if (f != 0.0) for (int j = 0; j < 8; j++) w[r][j] -= f * w[c][j];
+        }
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) inv.a[i][j] = (float)w[i][4 + j];
+    return true;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct haf_engine {
+    haf_config cfg{};
+    std::string feature_file, range_file, model_file;
+    std::vector<FeatureRow> features;
+    RangeTable range;
+    SvmModel model;
+    int nf = 0, kx = 0, n_sv_tiles = 0, n_sv_pad = 0;
+    int gv0 = 0, gv1 = 0;
+    double sum_abs_coef = 0;
+    SvmParams svm{};
+    ExactParams exact{};
+    std::string error;
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[HAF_ST_COUNT + 1] = {};
+    float stage_ms[HAF_ST_COUNT] = {};
+
+    long max_evals = 0, max_evals_pad = 0;
+    int flag_cap = 0;
+    size_t cells_cap = 0;   // B*R*H*W
+
+    DevBuf<CloudDev> d_clouds;
+    DevBuf<float> d_points;
+    DevBuf<RollGeo> d_geo;
+    DevBuf<int> d_heights;          // ordered keys during binning, fp32 heights afterwards
+    DevBuf<double> d_rowsum;
+    DevBuf<float> d_ii;
+    DevBuf<uint8_t> d_mask;
+    DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list;
+    DevBuf<float> d_X, d_ax, d_dec, d_svt;
+    DevBuf<int8_t> d_labels;
+    DevBuf<double> d_dec_exact, d_sv64, d_coef64;
+    DevBuf<short> d_ev16;
+    DevBuf<RollRecordDev> d_rec;
+    DevBuf<FeatDesc> d_fd;
+
+    // pinned host staging
+    CloudDev *h_clouds = nullptr;
+    RollGeo *h_geo = nullptr;
+    RollRecordDev *h_rec = nullptr;
+    int *h_counters = nullptr;
+    float *h_points = nullptr;
+
+    // last call
+    int last_B = 0, last_R = 0, last_roll_first = 0;
+    int last_evals = 0, last_flagged = 0;
+    std::vector<haf_grasp_input> last_inputs;
+};
+
+namespace {
+
+#define HIPCHK(e, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t err__ = (call);                                                                        \
+        if (err__ != hipSuccess) {                                                                        \
+            (e)->error = std::string(#call) + ": " + hipGetErrorString(err__);                            \
+            return HAF_E_DEVICE;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+int fail(haf_engine *e, int code, const std::string &msg)
+{
+    e->error = msg;
+    return code;
+}
+
+int label_grid_value(int label)
+{
+    char buf[32];
+    snprintf(buf, sizeof buf, "%g", (double)label);   // what svm-predict prints (svm-predict.c:127)
+    buf[2] = 0;                                       // line.substr(0,2) (server.cpp:843)
+    return atoi(buf);
+}
+
+int build_tables(haf_engine *e)
+{
+    const haf_config &c = e->cfg;
+    const int ld = c.grid_w + 1;
+    e->nf = (int)e->features.size();
+    if (e->nf > kKP) return fail(e, HAF_E_ARG, "feature file has more than 324 rows; this build's contraction kernel is sized for 324 attributes");
+    if (e->model.dim > kKP) return fail(e, HAF_E_ARG, "model attribute dimension exceeds 324");
+    e->kx = std::max(e->nf, e->model.dim);
+
+    std::vector<FeatDesc> fd((size_t)e->nf);
+    for (int f = 0; f < e->nf; f++) {
+        const FeatureRow &r = e->features[(size_t)f];
+        FeatDesc &d = fd[(size_t)f];
+        memset(&d, 0, sizeof d);
+        d.shaf = (f >= c.nr_features_without_shaf) ? 1 : 0;
+        for (int k = 0; k < 3; k++) {                 // region 3 carries weight 0 in every feature: never evaluated
+            int x1 = r.reg[k * 4], x2 = r.reg[k * 4 + 1], y1 = r.reg[k * 4 + 2], y2 = r.reg[k * 4 + 3];
+            float w = r.w[k];
+            bool skip = (w == 0.0f) || (x2 < x1) || (y2 < y1) || (x2 == 0 && y2 == 0);   // fv.cpp:155-159
+            if (skip) continue;
+            if (x1 < 0 || y1 < 0 || x2 > 13 || y2 > 13)
+                return fail(e, HAF_E_IO, "feature region outside the 14x14 window in " + e->feature_file);
+            d.active |= 1 << k;
+            d.w[k] = w;
+            d.off[k][0] = (x2 + 1) * ld + (y2 + 1);
+            d.off[k][1] = x1 * ld + (y2 + 1);
+            d.off[k][2] = (x2 + 1) * ld + y1;
+            d.off[k][3] = x1 * ld + y1;
+        }
+        const int idx = f + 1;
+        if (idx <= e->range.max_index && e->range.present[(size_t)idx]) {
+            d.fmin = e->range.fmin[(size_t)idx];
+            d.fmax = e->range.fmax[(size_t)idx];
+            d.skip = (d.fmin == d.fmax) ? 1 : 0;      // svm-scale.c:336
+        } else {
+            // Attribute not listed in the range file: svm-scale would take min/max from the rows of each roll's
+            // file (svm-scale.c:165-198).  That is data-independent only for a structurally constant feature
+            // (no active region: HAF gives 0, SHAF gives -1 in every row), which svm-scale then drops.
+            if (d.active != 0) {
+                char msg[160];
+                snprintf(msg, sizeof msg, "attribute %d is missing from the range file and is not constant; per-file ranges are not supported", idx);
+                return fail(e, HAF_E_ARG, msg);
+            }
+            d.skip = 1;
+        }
+    }
+    if (hipSuccess != e->d_fd.alloc(fd.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(features)");
+    HIPCHK(e, hipMemcpy(e->d_fd.p, fd.data(), fd.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
+
+    // ---- SVM images ----
+    const SvmModel &m = e->model;
+    const double log2e = 1.4426950408889634;
+    e->n_sv_tiles = (m.n_sv + kTile - 1) / kTile;
+    e->n_sv_pad = e->n_sv_tiles * kTile;
+    std::vector<float> svt((size_t)e->n_sv_tiles * kTileFloats, 0.0f);
+    e->sum_abs_coef = 0;
+    for (int n = 0; n < m.n_sv; n++) {
+        const int t = n / kTile, j = n % kTile;
+        float *tile = svt.data() + (size_t)t * kTileFloats;
+        double ss = 0;
+        for (int k = 0; k < m.dim; k++) {
+            float s = (float)m.sv[(size_t)n * m.dim + k];
+            tile[k * kTile + j] = s;
+            ss += (double)s * (double)s;
+        }
+        tile[kKP * kTile + j] = (float)(-m.gamma * log2e * ss);
+        tile[(kKP + 1) * kTile + j] = (float)m.coef[(size_t)n];
+        e->sum_abs_coef += std::fabs(m.coef[(size_t)n]);
+    }
+    if (hipSuccess != e->d_svt.alloc(svt.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(sv tiles)");
+    HIPCHK(e, hipMemcpy(e->d_svt.p, svt.data(), svt.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    std::vector<double> sv64((size_t)e->kx * e->n_sv_pad, 0.0), coef64((size_t)e->n_sv_pad, 0.0);
+    for (int n = 0; n < m.n_sv; n++) {
+        for (int k = 0; k < m.dim; k++) sv64[(size_t)k * e->n_sv_pad + n] = m.sv[(size_t)n * m.dim + k];
+        coef64[(size_t)n] = m.coef[(size_t)n];
+    }
+    if (hipSuccess != e->d_sv64.alloc(sv64.size()) || hipSuccess != e->d_coef64.alloc(coef64.size()))
+        return fail(e, HAF_E_DEVICE, "hipMalloc(fp64 model)");
+    HIPCHK(e, hipMemcpy(e->d_sv64.p, sv64.data(), sv64.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_coef64.p, coef64.data(), coef64.size() * sizeof(double), hipMemcpyHostToDevice));
+
+    e->gv0 = label_grid_value(m.label[0]);
+    e->gv1 = label_grid_value(m.label[1]);
+    if (e->gv0 < -128 || e->gv0 > 127 || e->gv1 < -128 || e->gv1 > 127) return fail(e, HAF_E_ARG, "model labels out of range");
+
+    e->svm.two_gamma2 = (float)(2.0 * m.gamma * log2e);
+    e->svm.neg_gamma2 = (float)(-m.gamma * log2e);
+    e->svm.rho = (float)m.rho;
+    // Guard band: a fast decision is trusted when |dec| > guard * sum_n |coef_n| K_n + guard_abs.  2^-15 covers the
+    // worst-case fp32 error of the contraction (324-term fma chain, fp32 attributes, v_exp_f32) per unit of
+    // sum|coef|K; DESIGN.md "Guard band" derives it and tests/test_engine_gpu.py measures the margin.
+    double guard = 1.0 / 32768.0;
+    if (const char *g = getenv("HAF_GUARD_REL")) guard = atof(g);
+    e->svm.guard = (float)guard;
+    e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
+    e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
+    e->exact.gamma = m.gamma; e->exact.rho = m.rho;
+    e->exact.lower = e->range.lower; e->exact.upper = e->range.upper;
+    e->exact.n_sv = m.n_sv; e->exact.n_sv_pad = e->n_sv_pad; e->exact.kx = e->kx;
+    e->exact.gv0 = e->gv0; e->exact.gv1 = e->gv1;
+    return HAF_OK;
+}
+
+int alloc_buffers(haf_engine *e)
+{
+    const haf_config &c = e->cfg;
+    const size_t B = (size_t)c.max_clouds, R = (size_t)c.n_rolls, H = (size_t)c.grid_h, W = (size_t)c.grid_w;
+    e->cells_cap = B * R * H * W;
+    e->max_evals = (long)(B * R * (H - 14) * (W - 14));
+    e->max_evals_pad = (e->max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+    e->flag_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 4), 1L << 24);
+    bool ok = true;
+    ok &= hipSuccess == e->d_clouds.alloc(B);
+    ok &= hipSuccess == e->d_points.alloc((size_t)c.max_points * 3);
+    ok &= hipSuccess == e->d_geo.alloc(B * R);
+    ok &= hipSuccess == e->d_heights.alloc(e->cells_cap);
+    ok &= hipSuccess == e->d_rowsum.alloc(e->cells_cap);
+    ok &= hipSuccess == e->d_ii.alloc(B * R * (H + 1) * (W + 1));
+    ok &= hipSuccess == e->d_mask.alloc(e->cells_cap);
+    ok &= hipSuccess == e->d_rowcount.alloc(B * R * H);
+    ok &= hipSuccess == e->d_rowoff.alloc(B * R * H + 1);
+    ok &= hipSuccess == e->d_brcount.alloc(B * R);
+    ok &= hipSuccess == e->d_counters.alloc(CNT_COUNT);
+    ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
+    ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->flag_cap);
+    ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * kTileFloats);
+    ok &= hipSuccess == e->d_ax.alloc((size_t)e->max_evals_pad);
+    ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
+    ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
+    ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->flag_cap);
+    ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
+    ok &= hipSuccess == e->d_rec.alloc(B * R);
+    if (!ok) return fail(e, HAF_E_DEVICE, std::string("hipMalloc of working buffers failed: ") + hipGetErrorString(hipGetLastError()));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_clouds, B * sizeof(CloudDev)));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_geo, B * R * sizeof(RollGeo)));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_rec, B * R * sizeof(RollRecordDev)));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_counters, CNT_COUNT * sizeof(int)));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_points, (size_t)c.max_points * 3 * sizeof(float)));
+    return HAF_OK;
+}
+
+void mark(haf_engine *e, int idx)
+{
+    if (e->cfg.flags & HAF_FLAG_PROFILE) (void)hipEventRecord(e->ev[idx], e->stream);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int haf_abi_version(void) { return HAF_ABI_VERSION; }
+
+void haf_config_default(haf_config *c)
+{
+    memset(c, 0, sizeof *c);
+    c->nr_features_without_shaf = 302;
+    c->grid_h = 56; c->grid_w = 56;
+    c->n_rolls = 190 / 15;
+    c->roll_step_deg = 15;
+    c->z_shift = 0.15f;
+    c->graspval_top = 119;
+    c->device = 0;
+    c->max_clouds = 1;
+    c->max_points = 1 << 20;
+    c->flags = 0;
+}
+
+void haf_grasp_input_default(haf_grasp_input *in)
+{
+    memset(in, 0, sizeof *in);
+    in->grasp_area_length_x = 32;
+    in->grasp_area_length_y = 44;
+    in->approach_vector[2] = 1.0;
+    in->max_calculation_time = 50.0;
+    in->gripper_opening_width = 1;
+}
+
+const char *haf_last_error(const haf_engine *e) { return e ? e->error.c_str() : g_create_error.c_str(); }
+
+void haf_destroy(haf_engine *e)
+{
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->d_clouds.release(); e->d_points.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release();
+    e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
+    e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
+    e->d_dec.release(); e->d_svt.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_sv64.release();
+    e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_fd.release();
+    if (e->h_clouds) (void)hipHostFree(e->h_clouds);
+    if (e->h_geo) (void)hipHostFree(e->h_geo);
+    if (e->h_rec) (void)hipHostFree(e->h_rec);
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
+    if (e->h_points) (void)hipHostFree(e->h_points);
+    for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int haf_create(const haf_config *cfg, haf_engine **out)
+{
+    if (out) *out = nullptr;
+    if (!cfg || !out) { g_create_error = "haf_create: null argument"; return HAF_E_ARG; }
+    haf_engine *e = new haf_engine();
+    auto bail = [&](int code) { g_create_error = e->error; haf_destroy(e); return code; };
+    e->cfg = *cfg;
+    if (!cfg->feature_file || !cfg->range_file || !cfg->model_file) { e->error = "feature_file, range_file and model_file are required"; return bail(HAF_E_ARG); }
+    e->feature_file = cfg->feature_file; e->range_file = cfg->range_file; e->model_file = cfg->model_file;
+    e->cfg.feature_file = e->feature_file.c_str(); e->cfg.range_file = e->range_file.c_str(); e->cfg.model_file = e->model_file.c_str();
+    if (cfg->grid_h != cfg->grid_w) { e->error = "grid_h must equal grid_w (the reference's mask geometry assumes a square grid, server.cpp:681-682, 705)"; return bail(HAF_E_ARG); }
+    if (cfg->grid_h < 15 || cfg->grid_h > 4096) { e->error = "grid size must be in [15, 4096]"; return bail(HAF_E_ARG); }
+    if (cfg->n_rolls < 1 || cfg->n_rolls > 4096 || cfg->max_clouds < 1 || cfg->max_points < 1) { e->error = "n_rolls, max_clouds and max_points must be positive"; return bail(HAF_E_ARG); }
+    if ((double)cfg->max_clouds * cfg->n_rolls * cfg->grid_h * cfg->grid_w > 2.0e9) { e->error = "max_clouds*n_rolls*grid cells exceeds 2^31"; return bail(HAF_E_CAPACITY); }
+
+    if (!load_features(e->feature_file, e->features, e->error)) return bail(HAF_E_IO);
+    if (!load_range(e->range_file, e->range, e->error)) return bail(HAF_E_IO);
+    if (!load_model(e->model_file, e->model, e->error)) return bail(HAF_E_IO);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { e->error = "no HIP device available: this engine has no CPU fallback"; return bail(HAF_E_DEVICE); }
+    if (cfg->device < 0 || cfg->device >= ndev) { e->error = "device ordinal out of range"; return bail(HAF_E_DEVICE); }
+    if (hipSetDevice(cfg->device) != hipSuccess) { e->error = "hipSetDevice failed"; return bail(HAF_E_DEVICE); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { e->error = "hipGetDeviceProperties failed"; return bail(HAF_E_DEVICE); }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { e->error = std::string("device is ") + prop.gcnArchName + ", the kernels are built for gfx950 only"; return bail(HAF_E_DEVICE); }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { e->error = "hipStreamCreate failed"; return bail(HAF_E_DEVICE); }
+    e->own_stream = true;
+    for (auto &ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { e->error = "hipEventCreate failed"; return bail(HAF_E_DEVICE); }
+
+    int rc = build_tables(e);
+    if (rc != HAF_OK) return bail(rc);
+    rc = alloc_buffers(e);
+    if (rc != HAF_OK) return bail(rc);
+    *out = e;
+    return HAF_OK;
+}
+
+int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_features)
+{
+    if (!e) return HAF_E_ARG;
+    if (n_sv) *n_sv = e->model.n_sv;
+    if (dim) *dim = e->model.dim;
+    if (n_features) *n_features = e->nf;
+    return HAF_OK;
+}
+
+int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked)
+{
+    if (!e) return HAF_E_ARG;
+    if (n_evals) *n_evals = e->last_evals;
+    if (n_rechecked) *n_rechecked = e->last_flagged;
+    return HAF_OK;
+}
+
+int haf_set_stream(haf_engine *e, void *s)
+{
+    if (!e) return HAF_E_ARG;
+    if (e->own_stream && e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    e->stream = (hipStream_t)s;
+    e->own_stream = false;
+    return HAF_OK;
+}
+
+void *haf_get_stream(haf_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
+                    int32_t roll_count, haf_roll_record *records)
+{
+    if (!e) return HAF_E_ARG;
+    if (!clouds || !in || !records || n_clouds < 1) return fail(e, HAF_E_ARG, "haf_score_rolls: null or empty argument");
+    const haf_config &c = e->cfg;
+    if (n_clouds > c.max_clouds) return fail(e, HAF_E_CAPACITY, "more clouds than max_clouds");
+    if (roll_first < 0 || roll_count < 1 || roll_first + roll_count > c.n_rolls) return fail(e, HAF_E_ARG, "roll range outside [0, n_rolls)");
+    HIPCHK(e, hipSetDevice(c.device));
+    const int B = n_clouds, R = roll_count, H = c.grid_h, W = c.grid_w;
+
+    // ---- host preparation ----
+    size_t host_pts = 0;
+    int max_n = 0;
+    for (int b = 0; b < B; b++) {
+        if (clouds[b].n_points && !clouds[b].xyz) return fail(e, HAF_E_ARG, "cloud with null xyz");
+        if (clouds[b].stride_floats < 3) return fail(e, HAF_E_ARG, "stride_floats must be >= 3");
+        if (clouds[b].n_points > (size_t)INT32_MAX) return fail(e, HAF_E_CAPACITY, "cloud too large");
+        if ((int)in[b].max_calculation_time < 0) return fail(e, HAF_E_BUDGET, "max_calculation_time expired before the first roll");
+        if (!clouds[b].on_device) host_pts += clouds[b].n_points;
+        max_n = std::max(max_n, (int)clouds[b].n_points);
+    }
+    if (host_pts > (size_t)c.max_points) return fail(e, HAF_E_CAPACITY, "more host points than max_points");
+    size_t off = 0;
+    for (int b = 0; b < B; b++) {
+        NormalisedInput n = normalise(in[b]);
+        for (int r = 0; r < R; r++) fill_roll_geo(c, in[b], n, roll_first + r, e->h_geo[b * R + r]);
+        CloudDev &cd = e->h_clouds[b];
+        cd.n = (int)clouds[b].n_points;
+        if (clouds[b].on_device) {
+            cd.xyz = clouds[b].xyz;
+            cd.stride = (int)clouds[b].stride_floats;
+        } else {
+            float *dst = e->h_points + off * 3;
+            const float *src = clouds[b].xyz;
+            const size_t st = clouds[b].stride_floats;
+            if (st == 3) memcpy(dst, src, clouds[b].n_points * 3 * sizeof(float));
+            else for (size_t i = 0; i < clouds[b].n_points; i++) { dst[i * 3] = src[i * st]; dst[i * 3 + 1] = src[i * st + 1]; dst[i * 3 + 2] = src[i * st + 2]; }
+            cd.xyz = e->d_points.p + off * 3;
+            cd.stride = 3;
+            off += clouds[b].n_points;
+        }
+    }
+    hipStream_t s = e->stream;
+    mark(e, 0);
+    if (off) HIPCHK(e, hipMemcpyAsync(e->d_points.p, e->h_points, off * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(e->d_clouds.p, e->h_clouds, (size_t)B * sizeof(CloudDev), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(e->d_geo.p, e->h_geo, (size_t)B * R * sizeof(RollGeo), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s));
+    const size_t cells = (size_t)B * R * H * W;
+    HIPCHK(e, hipMemsetAsync(e->d_labels.p, 0xFF, cells, s));            // -1: no feature vector for this cell (server.cpp:828-829)
+    mark(e, HAF_ST_BIN);
+
+    Dims d;
+    d.H = H; d.W = W; d.R = R; d.B = B; d.nf = e->nf; d.n_sv = e->model.n_sv; d.n_sv_tiles = e->n_sv_tiles;
+    const float r_row = (float)((0.5 * (float)H) / 100.0), r_col = (float)((0.5 * (float)W) / 100.0);   // server.cpp:410-411
+    const long evals_cap = (long)B * R * (H - 14) * (W - 14);
+
+    float minus_one = -1.0f;
+    int key_m1;
+    memcpy(&key_m1, &minus_one, 4);
+    key_m1 ^= 0x7FFFFFFF;                                                // ordered key of -1.0f (499-501)
+    launch_fill_i32(e->d_heights.p, key_m1, cells, s);
+    launch_bin(e->d_clouds.p, max_n, e->d_geo.p, e->d_heights.p, d, r_row, r_col, s);
+    mark(e, HAF_ST_INTEGRAL);
+    launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, d, s);
+    mark(e, HAF_ST_MASK);
+    launch_mask_count(e->d_ii.p, e->d_geo.p, e->d_mask.p, e->d_rowcount.p, d, s);
+    launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
+    launch_compact(e->d_mask.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
+    mark(e, HAF_ST_FEATURES);
+    launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower, e->range.upper,
+                    e->svm.neg_gamma2, evals_cap, s);
+    mark(e, HAF_ST_SVM);
+    launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+               e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
+    mark(e, HAF_ST_RECHECK);
+    launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag_list.p, e->flag_cap,
+                   e->d_counters.p, e->d_dec_exact.p, e->d_labels.p, d, s);
+    mark(e, HAF_ST_VOTE);
+    launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_rec.p, d, s);
+    mark(e, HAF_ST_DOWNLOAD);
+    HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+    mark(e, HAF_ST_COUNT);
+    HIPCHK(e, hipStreamSynchronize(s));
+    HIPCHK(e, hipGetLastError());
+
+    if (c.flags & HAF_FLAG_PROFILE)
+        for (int i = 0; i < HAF_ST_COUNT; i++) (void)hipEventElapsedTime(&e->stage_ms[i], e->ev[i], e->ev[i + 1]);
+
+    e->last_B = B; e->last_R = R; e->last_roll_first = roll_first;
+    e->last_evals = e->h_counters[CNT_EVALS];
+    e->last_flagged = e->h_counters[CNT_FLAGGED];
+    e->last_inputs.assign(in, in + B);
+    if (e->last_flagged > e->flag_cap) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "%d of %d evaluations fell inside the guard band, more than the recheck capacity %d", e->last_flagged,
+                 e->last_evals, e->flag_cap);
+        return fail(e, HAF_E_CAPACITY, msg);
+    }
+    for (int i = 0; i < B * R; i++) {
+        records[i].vote = e->h_rec[i].vote;
+        records[i].row = e->h_rec[i].row;
+        records[i].col = e->h_rec[i].col;
+        records[i].h_locmax = e->h_rec[i].h_locmax;
+        records[i].n_evals = e->h_rec[i].n_evals;
+    }
+    return HAF_OK;
+}
+
+// cross-roll rule + pose; pure host arithmetic on the configuration, so it is also reachable without a device
+static int finalize_impl(const haf_config &c, const haf_grasp_input *in, const haf_roll_record *rec, haf_grasp_output *out,
+                         std::string &error)
+{
+    memset(out, 0, sizeof *out);
+    // loop_control + show_predicted_gps bookkeeping: server.cpp:322-326, 362-365, 953-960
+    int o_row = -1, o_col = -1, o_roll = -1, o_top = -1000, done = 0;
+    int64_t evals = 0;
+    for (int r = 0; r < c.n_rolls; r++) {
+        if (in->show_only_best_grasp && o_top >= c.graspval_top) break;
+        if (rec[r].vote > o_top) { o_top = rec[r].vote; o_row = rec[r].row; o_col = rec[r].col; o_roll = r; }
+        evals += rec[r].n_evals;
+        done++;
+    }
+    out->best_row = o_row; out->best_col = o_col; out->best_roll = o_roll; out->best_vote = o_top;
+    out->rolls_done = done;
+    out->n_evals = evals;
+    out->eval = o_top - 20;                                                   // 390
+    if (o_roll < 0) return HAF_OK;
+
+    NormalisedInput n = normalise(*in);
+    Mat4 m = roll_transform(c, *in, n, o_roll, false), inv;
+    float x_gp_roll = -((float)(c.grid_h / 2 - o_row)) / 100;                 // 1339
+    float y_gp_roll = -((float)(c.grid_w / 2 - o_col)) / 100;                 // 1340
+    float h_locmax = rec[o_roll].h_locmax;                                    // 1342-1351 (device, k_vote)
+    h_locmax = (float)(h_locmax - 0.01);                                      // 1354
+    const float x_gp_dis = 0.03f;                                             // 1360
+    const float gp[2][4] = {{x_gp_roll - x_gp_dis, y_gp_roll, h_locmax, 1.0f}, {x_gp_roll + x_gp_dis, y_gp_roll, h_locmax, 1.0f}};
+    if (!invert(m, inv)) { error = "transform is singular (gripper_opening_width 0?)"; return HAF_E_ARG; }
+    float w[2][3];
+    for (int p = 0; p < 2; p++)
+        for (int i = 0; i < 3; i++) {                                         // 1367-1368
+            float s = inv.a[i][0] * gp[p][0];
+            s = s + inv.a[i][1] * gp[p][1];
+            s = s + inv.a[i][2] * gp[p][2];
+            s = s + inv.a[i][3] * gp[p][3];
+            w[p][i] = s;
+        }
+    for (int i = 0; i < 3; i++) {
+        out->grasp_point1[i] = w[0][i];
+        out->grasp_point2[i] = w[1][i];
+        out->averaged_grasp_point[i] = (w[0][i] + w[1][i]) / 2.0;            // 1395-1397
+    }
+    // av_trans_mat is the matrix of the LAST roll generate_grid ran (484); its third row does not depend on the roll
+    Mat4 last = roll_transform(c, *in, n, std::max(0, done - 1), true);
+    out->approach_vector[0] = last.a[2][0];                                   // 1370-1374
+    out->approach_vector[1] = last.a[2][1];
+    out->approach_vector[2] = last.a[2][2];
+    out->roll = (float)((o_roll * c.roll_step_deg * kPi) / 180);              // 1401
+    return HAF_OK;
+}
+
+int haf_finalize(haf_engine *e, const haf_grasp_input *in, const haf_roll_record *rec, haf_grasp_output *out)
+{
+    if (!e) return HAF_E_ARG;
+    if (!in || !rec || !out) return fail(e, HAF_E_ARG, "haf_finalize: null argument");
+    return finalize_impl(e->cfg, in, rec, out, e->error);
+}
+
+int haf_score_batch(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, haf_grasp_output *out)
+{
+    if (!e) return HAF_E_ARG;
+    if (!out) return fail(e, HAF_E_ARG, "haf_score_batch: null output");
+    std::vector<haf_roll_record> rec((size_t)std::max(1, n_clouds) * e->cfg.n_rolls);
+    int rc = haf_score_rolls(e, n_clouds, clouds, in, 0, e->cfg.n_rolls, rec.data());
+    if (rc != HAF_OK) return rc;
+    for (int b = 0; b < n_clouds; b++) {
+        rc = haf_finalize(e, &in[b], rec.data() + (size_t)b * e->cfg.n_rolls, &out[b]);
+        if (rc != HAF_OK) return rc;
+    }
+    // rechecks are counted per batch; attribute them to the first cloud's output and leave the others at 0
+    out[0].n_rechecked = e->last_flagged;
+    return HAF_OK;
+}
+
+int haf_score(haf_engine *e, const haf_cloud *cloud, const haf_grasp_input *in, haf_grasp_output *out)
+{
+    return haf_score_batch(e, 1, cloud, in, out);
+}
+
+int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask)
+{
+    if (!e) return HAF_E_ARG;
+    const int rl = roll - e->last_roll_first;
+    if (cloud < 0 || cloud >= e->last_B || rl < 0 || rl >= e->last_R) return fail(e, HAF_E_ARG, "haf_get_roll_grid: (cloud, roll) not in the last scored batch");
+    const size_t HW = (size_t)e->cfg.grid_h * e->cfg.grid_w, base = ((size_t)cloud * e->last_R + rl) * HW;
+    if (eval_grid) {
+        std::vector<short> tmp(HW);
+        HIPCHK(e, hipMemcpy(tmp.data(), e->d_ev16.p + base, HW * sizeof(short), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < HW; i++) eval_grid[i] = (float)tmp[i];
+    }
+    if (mask) HIPCHK(e, hipMemcpy(mask, e->d_mask.p + base, HW, hipMemcpyDeviceToHost));
+    return HAF_OK;
+}
+
+int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes)
+{
+    if (!e) return HAF_E_ARG;
+    if (!dst) return fail(e, HAF_E_ARG, "haf_debug_fetch: null dst");
+    const int rl = roll - e->last_roll_first;
+    if (cloud < 0 || cloud >= e->last_B || rl < 0 || rl >= e->last_R) return fail(e, HAF_E_ARG, "haf_debug_fetch: (cloud, roll) not in the last scored batch");
+    const size_t H = (size_t)e->cfg.grid_h, W = (size_t)e->cfg.grid_w, HW = H * W;
+    const size_t br = (size_t)cloud * e->last_R + rl;
+    auto need = [&](size_t n) { return dst_bytes >= n; };
+    switch (what) {
+        case HAF_DBG_HEIGHTS:
+            if (!need(HW * 4)) break;
+            HIPCHK(e, hipMemcpy(dst, e->d_heights.p + br * HW, HW * 4, hipMemcpyDeviceToHost));
+            return HAF_OK;
+        case HAF_DBG_INTEGRAL:
+            if (!need((H + 1) * (W + 1) * 4)) break;
+            HIPCHK(e, hipMemcpy(dst, e->d_ii.p + br * (H + 1) * (W + 1), (H + 1) * (W + 1) * 4, hipMemcpyDeviceToHost));
+            return HAF_OK;
+        case HAF_DBG_MASK:
+            if (!need(HW)) break;
+            HIPCHK(e, hipMemcpy(dst, e->d_mask.p + br * HW, HW, hipMemcpyDeviceToHost));
+            return HAF_OK;
+        case HAF_DBG_LABELS:
+            if (!need(HW)) break;
+            HIPCHK(e, hipMemcpy(dst, e->d_labels.p + br * HW, HW, hipMemcpyDeviceToHost));
+            return HAF_OK;
+        case HAF_DBG_TRANSFORM: {
+            if (!need(16 * 4)) break;
+            NormalisedInput n = normalise(e->last_inputs[(size_t)cloud]);
+            Mat4 m = roll_transform(e->cfg, e->last_inputs[(size_t)cloud], n, roll, true);
+            memcpy(dst, m.a, 16 * 4);
+            return HAF_OK;
+        }
+        case HAF_DBG_DECISION: {
+            if (!need(HW * 8)) break;
+            double *g = (double *)dst;
+            for (size_t i = 0; i < HW; i++) g[i] = NAN;
+            const size_t ne = (size_t)e->last_evals;
+            if (!ne) return HAF_OK;
+            std::vector<int> cell(ne);
+            std::vector<float> dec(ne);
+            HIPCHK(e, hipMemcpy(cell.data(), e->d_evalcell.p, ne * 4, hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(dec.data(), e->d_dec.p, ne * 4, hipMemcpyDeviceToHost));
+            const size_t nfl = (size_t)std::min(e->last_flagged, e->flag_cap);
+            std::vector<int> fl(nfl);
+            std::vector<double> ex(nfl);
+            if (nfl) {
+                HIPCHK(e, hipMemcpy(fl.data(), e->d_flag_list.p, nfl * 4, hipMemcpyDeviceToHost));
+                HIPCHK(e, hipMemcpy(ex.data(), e->d_dec_exact.p, nfl * 8, hipMemcpyDeviceToHost));
+            }
+            std::vector<double> d64(dec.begin(), dec.end());
+            for (size_t k = 0; k < nfl; k++) d64[(size_t)fl[k]] = ex[k];
+            for (size_t k = 0; k < ne; k++) {
+                size_t cb = (size_t)cell[k] / HW;
+                if (cb == br) g[(size_t)cell[k] - cb * HW] = d64[k];
+            }
+            return HAF_OK;
+        }
+        default:
+            return fail(e, HAF_E_ARG, "haf_debug_fetch: unknown item");
+    }
+    return fail(e, HAF_E_ARG, "haf_debug_fetch: dst too small");
+}
+
+int haf_get_stage_ms(haf_engine *e, float *ms)
+{
+    if (!e || !ms) return HAF_E_ARG;
+    if (!(e->cfg.flags & HAF_FLAG_PROFILE)) return fail(e, HAF_E_ARG, "engine was created without HAF_FLAG_PROFILE");
+    memcpy(ms, e->stage_ms, sizeof e->stage_ms);
+    return HAF_OK;
+}
+
+int haf_pcd_load(const char *path, float **xyz, size_t *n_points, char *err, size_t err_cap)
+{
+    if (!path || !xyz || !n_points) return HAF_E_ARG;
+    std::vector<float> v;
+    std::string msg;
+    if (!load_pcd(path, v, msg)) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", msg.c_str());
+        return HAF_E_IO;
+    }
+    *n_points = v.size() / 3;
+    *xyz = (float *)malloc(std::max<size_t>(1, v.size()) * sizeof(float));
+    if (!*xyz) return HAF_E_INTERNAL;
+    memcpy(*xyz, v.data(), v.size() * sizeof(float));
+    return HAF_OK;
+}
+
+void haf_free(void *p) { free(p); }
+
+
+// host-only hooks: parsers, per-roll geometry and the cross-roll rule/pose, none of which touches a device
+int haf_test_feature_table(const char *path, int *n, int *reg /* cap*16 */, float *w /* cap*4 */, int cap)
+{
+    std::vector<FeatureRow> rows;
+    std::string err;
+    if (!load_features(path, rows, err)) return HAF_E_IO;
+    *n = (int)rows.size();
+    for (int i = 0; i < *n && i < cap; i++) {
+        memcpy(reg + i * 16, rows[(size_t)i].reg, sizeof rows[0].reg);
+        memcpy(w + i * 4, rows[(size_t)i].w, sizeof rows[0].w);
+    }
+    return HAF_OK;
+}
+
+int haf_test_range_table(const char *path, double *lower, double *upper, int *max_index, double *fmin, double *fmax,
+                         unsigned char *present, int cap)
+{
+    RangeTable rt;
+    std::string err;
+    if (!load_range(path, rt, err)) return HAF_E_IO;
+    *lower = rt.lower; *upper = rt.upper; *max_index = rt.max_index;
+    for (int i = 0; i <= rt.max_index && i < cap; i++) { fmin[i] = rt.fmin[(size_t)i]; fmax[i] = rt.fmax[(size_t)i]; present[i] = rt.present[(size_t)i]; }
+    return HAF_OK;
+}
+
+int haf_test_model(const char *path, double *gamma, double *rho, int *n_sv, int *dim, int *n_sv_class, int *label, double *coef,
+                   double *sv, long cap_sv_values)
+{
+    SvmModel m;
+    std::string err;
+    if (!load_model(path, m, err)) return HAF_E_IO;
+    *gamma = m.gamma; *rho = m.rho; *n_sv = m.n_sv; *dim = m.dim;
+    n_sv_class[0] = m.n_sv_class[0]; n_sv_class[1] = m.n_sv_class[1];
+    label[0] = m.label[0]; label[1] = m.label[1];
+    if (coef && sv && (long)m.sv.size() <= cap_sv_values) {
+        memcpy(coef, m.coef.data(), m.coef.size() * sizeof(double));
+        memcpy(sv, m.sv.data(), m.sv.size() * sizeof(double));
+    }
+    return HAF_OK;
+}
+
+// out: 12 transform floats, then sa, ca, cx1, cy1, cx2, cy2, cx3, cy3, cx4, cy4; full 4x4 (generate_grid form) in m16
+int haf_test_roll_geo(const haf_config *cfg, const haf_grasp_input *in, int roll, float *out22, float *m16, float *m16_pose)
+{
+    NormalisedInput n = normalise(*in);
+    RollGeo g;
+    fill_roll_geo(*cfg, *in, n, roll, g);
+    memcpy(out22, g.m, 12 * 4);
+    const float tail[10] = {g.sa, g.ca, g.cx1, g.cy1, g.cx2, g.cy2, g.cx3, g.cy3, g.cx4, g.cy4};
+    memcpy(out22 + 12, tail, sizeof tail);
+    if (m16) { Mat4 m = roll_transform(*cfg, *in, n, roll, true); memcpy(m16, m.a, 64); }
+    if (m16_pose) { Mat4 m = roll_transform(*cfg, *in, n, roll, false); memcpy(m16_pose, m.a, 64); }
+    return HAF_OK;
+}
+
+int haf_test_finalize(const haf_config *cfg, const haf_grasp_input *in, const haf_roll_record *rec, haf_grasp_output *out)
+{
+    std::string err;
+    return finalize_impl(*cfg, in, rec, out, err);
+}
+
+// ---- test hooks (host and device builds of the decimal round-trip arithmetic; see tests/) ----
+double haf_test_decq_host(double x, int digits) { return hafq::decq(x, digits); }
+double haf_test_scale_host(double q4, double fmin, double fmax, double lower, double upper) { return hafq::scale_q6(q4, fmin, fmax, lower, upper); }
+
+int haf_test_decq_device(const double *in, double *out, int n, int digits)
+{
+    double *di = nullptr, *dout = nullptr;
+    if (hipMalloc((void **)&di, (size_t)n * 8) != hipSuccess || hipMalloc((void **)&dout, (size_t)n * 8) != hipSuccess) return HAF_E_DEVICE;
+    (void)hipMemcpy(di, in, (size_t)n * 8, hipMemcpyHostToDevice);
+    launch_decq_test(di, dout, n, digits, nullptr);
+    hipError_t rc = hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(di); (void)hipFree(dout);
+    return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
+
+int haf_test_scale_device(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out, int n)
+{
+    double *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto &p : d) if (hipMalloc((void **)&p, (size_t)n * 8) != hipSuccess) return HAF_E_DEVICE;
+    (void)hipMemcpy(d[0], q4, (size_t)n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d[1], fmin, (size_t)n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d[2], fmax, (size_t)n * 8, hipMemcpyHostToDevice);
+    launch_scale_test(d[0], d[1], d[2], lower, upper, d[3], n, nullptr);
+    hipError_t rc = hipMemcpy(out, d[3], (size_t)n * 8, hipMemcpyDeviceToHost);
+    for (auto &p : d) (void)hipFree(p);
+    return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// kernels.h -- device data layout and launch wrappers shared by engine.cpp and kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace haf {
+
+// ---- fixed geometry of the RBF contraction kernel -------------------------------------------------
+constexpr int kKP = 324;            // attribute dimension padded to an even count (2 k-values per MFMA step)
+constexpr int kKSteps = kKP / 2;    // 162 v_mfma_f32_32x32x2_f32 per 32x32 output tile
+constexpr int kDP = 328;            // rows per tile image: kKP attribute rows + row kKP (a_s) + row kKP+1 (coef), padded to 8
+constexpr int kTile = 32;           // evals per A tile / SVs per B tile
+constexpr int kTileFloats = kDP * kTile;          // 10496 floats = 41 KiB: 41 LDS-DMA wave instructions of 1 KiB
+constexpr int kSvmBlockEvals = 256; // 8 waves x 32 evals
+constexpr int kSvmThreads = 512;
+
+struct CloudDev {
+    const float *xyz;
+    int n;
+    int stride;      // floats per point
+};
+
+// per (cloud, roll): rows 0..2 of the fp32 transform (server.cpp:483) and the rotated-rectangle scalars of
+// pnt_in_box (server.cpp:679-696), all computed on the host with the reference's float/double mix
+struct RollGeo {
+    float m[12];
+    float sa, ca;                 // sinf(alpha), cosf(alpha)
+    float cx1, cy1, cx2, cy2, cx3, cy3, cx4, cy4;
+    float pad[2];
+};
+
+// one HAF/SHAF feature (fv.cpp:141-199) with its svm-scale range (svm-scale.c:333-353)
+struct FeatDesc {
+    int   off[3][4];              // II offsets of the 4 corners of region k relative to the window origin: A-B-C+D
+    float w[3];                   // region weights; the 4th region's weight is always 0 in the reference (CHaarFeature.cpp:56-60)
+    int   active;                 // bit k: region k survives the skip rule (fv.cpp:155-159)
+    int   shaf;                   // feature index >= nr_features_without_shaf
+    int   skip;                   // attribute dropped by svm-scale (feature_max == feature_min, svm-scale.c:336)
+    int   pad;
+    double fmin, fmax;
+};
+
+struct Dims {
+    int H, W, R, B;               // grid, rolls in this launch, clouds
+    int nf;                       // feature rows (324)
+    int n_sv, n_sv_tiles;
+};
+
+struct SvmParams {
+    float two_gamma2;             // 2*gamma*log2(e)
+    float neg_gamma2;             // -gamma*log2(e)
+    float rho;
+    float guard;                  // |dec| <= guard * sum|coef|K + guard_abs -> exact fp64 recheck
+    float guard_abs;
+    int   gv0, gv1;               // grid values of label[0] / label[1] (atoi of the "%g" label text, server.cpp:843)
+};
+
+struct ExactParams {
+    double gamma, rho, lower, upper;
+    int n_sv, n_sv_pad, kx;       // kx = rows of the fp64 k-major SV image
+    int gv0, gv1;
+};
+
+// counters[] slots in device memory
+enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_COUNT = 8 };
+
+struct RollRecordDev { int vote; short row, col; float h_locmax; int n_evals; };
+
+void launch_fill_i32(int *p, int v, size_t n, hipStream_t s);
+void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkeys, Dims d, float r_row, float r_col,
+                hipStream_t s);
+void launch_integral(int *hkeys_heights, double *rowsum, float *ii, Dims d, hipStream_t s);
+void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s);
+void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
+void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
+void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
+                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, hipStream_t s);
+void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
+                SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
+                long max_evals, hipStream_t s);
+void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
+                    ExactParams p, const int *flag_list, int flag_cap, const int *counters, double *dec_exact,
+                    int8_t *labels, Dims d, hipStream_t s);
+void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, RollRecordDev *rec, Dims d,
+                 hipStream_t s);
+void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s);
+void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
+                       int n, hipStream_t s);
+
+}  // namespace haf

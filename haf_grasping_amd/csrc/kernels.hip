@@ -1,0 +1,663 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the grasp-scoring hot path.
+//
+// Stage -> reference function it replaces (src/calc_grasppoints_action_server.cpp unless noted):
+//   k_bin            generate_grid 406-529 (transform + max-z binning)
+//   k_integral       generate_grid 522-528 (empty cells -> 0) + calc_intimage 577-613
+//   k_mask_count / k_scan / k_compact   pnt_in_box 666-749 + the row-major cell order of calc_featurevectors 637-643
+//   k_features       CIntImage_to_Featurevec::calc_featurevalue (fv.cpp:141-199), the "%.4g" text round trip
+//                    (fv.cpp:133 -> svm-scale.c:270), svm-scale restore+output (svm-scale.c:333-353) and the
+//                    "%g" round trip (svm-scale.c:350 -> svm-predict.c:108)
+//   k_svm_rbf        svm_predict_values / Kernel::k_function RBF (libsvm svm.cpp:325-365, 2478-2532) as an
+//                    fp32 MFMA contraction with an exp epilogue and a guard band
+//   k_recheck        the same decision in libsvm's exact fp64 order for guard-band evaluations
+//   k_vote           show_predicted_gps 865-932 (29-tap vote, first-wins argmax, longest-run centring) and the
+//                    z window of transform_gp_in_wcs_and_publish 1342-1351
+//
+// Built with -ffp-contract=off: every fp32/fp64 expression that must match the CPU restatement bit for bit is
+// written with explicit *_rn intrinsics as well; fma() is used only where a fused operation is intended.
+#include "kernels.h"
+#include "decq.h"
+
+namespace haf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int f2key(float f)
+{
+    int b = __float_as_int(f);
+    return b >= 0 ? b : (b ^ 0x7FFFFFFF);
+}
+__device__ __forceinline__ float key2f(int k)
+{
+    return __int_as_float(k >= 0 ? k : (k ^ 0x7FFFFFFF));
+}
+
+__global__ void k_fill_i32(int *p, int v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) p[i] = v;
+}
+
+void launch_fill_i32(int *p, int v, size_t n, hipStream_t s)
+{
+    if (!n) return;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fill_i32, dim3(blocks), dim3(256), 0, s, p, v, n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a1: transform + binning.  One thread per point, all rolls of its cloud; max-z via atomicMax on an
+// order-preserving integer key (max is order independent, so the grid is deterministic).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bin(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
+                                             int *__restrict__ hkeys, Dims d, float r_row, float r_col)
+{
+    const int b = blockIdx.y;
+    const CloudDev c = clouds[b];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c.n) return;
+    const float *p = c.xyz + (size_t)i * c.stride;
+    const float x = p[0], y = p[1], z = p[2];
+    const int HW = d.H * d.W;
+    for (int r = 0; r < d.R; r++) {
+        const RollGeo &g = geo[b * d.R + r];
+        // pcl::transformPointCloud (488): fp32, left to right, unfused
+        float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
+        float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
+        float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
+        if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
+            int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row)));                   // 513
+            int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col)));                   // 514
+            if (ix >= 0 && ix < d.H && iy >= 0 && iy < d.W) {
+                int *cell = hkeys + (size_t)(b * d.R + r) * HW + ix * d.W + iy;
+                int key = f2key(pz);
+                if (key > *cell) atomicMax(cell, key);   // stale read is safe: the cell only grows
+            }
+        }
+    }
+}
+
+void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkeys, Dims d, float r_row, float r_col,
+                hipStream_t s)
+{
+    if (max_n <= 0) return;
+    dim3 grid((max_n + 255) / 256, d.B);
+    hipLaunchKernelGGL(k_bin, grid, dim3(256), 0, s, clouds, geo, hkeys, d, r_row, r_col);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a1 tail + a2: finalise heights (cells < -0.99 -> 0, 522-528) and build the integral image in the
+// reference's summation ORDER: running fp64 row sum, then add the row above (cv::integral CV_64F), so the
+// fp64 partial sums and the fp32 narrowing (599-601) are bit-identical for any input, not only when the
+// sums happen to be exact.  One workgroup per (cloud, roll): thread-per-row pass, then thread-per-column pass.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_integral(int *__restrict__ hk, double *__restrict__ rowsum, float *__restrict__ ii,
+                                                  Dims d)
+{
+    const int br = blockIdx.x;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    int *keys = hk + (size_t)br * H * W;
+    float *hts = reinterpret_cast<float *>(keys);
+    double *rs = rowsum + (size_t)br * H * W;
+    float *I = ii + (size_t)br * (H + 1) * W1;
+    for (int row = threadIdx.x; row < H; row += blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < W; c++) {
+            float h = key2f(keys[row * W + c]);
+            if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare)
+            hts[row * W + c] = h;
+            s = __dadd_rn(s, (double)h);              // 589: widened before the integral
+            rs[row * W + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < W1; c += blockDim.x) {
+        I[c] = 0.0f;
+        if (c == 0) {
+            for (int r = 0; r < H; r++) I[(r + 1) * W1] = 0.0f;
+        } else {
+            double acc = 0.0;
+            for (int r = 0; r < H; r++) {
+                acc = __dadd_rn(acc, rs[r * W + (c - 1)]);
+                I[(r + 1) * W1 + c] = (float)acc;     // 601
+            }
+        }
+    }
+}
+
+void launch_integral(int *hk, double *rowsum, float *ii, Dims d, hipStream_t s)
+{
+    int threads = d.H >= 256 ? 512 : (d.H > 64 ? 256 : 64);
+    hipLaunchKernelGGL(k_integral, dim3(d.B * d.R), dim3(threads), 0, s, hk, rowsum, ii, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a3: mask.  One wave per grid row; the rotated-rectangle scalars come from the host (glibc sinf/cosf with the
+// reference's float/double mix), the per-cell tests are plain IEEE fp32 operations.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cell_in_box(const float *__restrict__ I, int W1, int H, int i, int j, const RollGeo &g)
+{
+    if (!(i > 6 && i < H - 7 && j > 6 && j < H - 7)) return false;                                 // 713
+    const int th = 4;
+    float box = __fsub_rn(I[(i + th) * W1 + (j + th)], I[(i - th - 1) * W1 + (j + th)]);
+    box = __fsub_rn(box, I[(i + th) * W1 + (j - th - 1)]);
+    box = __fadd_rn(box, I[(i - th - 1) * W1 + (j - th - 1)]);                                       // 714-717
+    if (!(box > 0.03f)) return false;
+    const float fj = (float)j, fi = (float)i;
+    float t1 = __fadd_rn(__fmul_rn(-g.sa, __fadd_rn(-g.cx1, fj)), __fmul_rn(g.ca, __fadd_rn(-g.cy1, fi)));   // 718
+    float t2 = __fadd_rn(__fmul_rn(-g.sa, __fadd_rn(-g.cx2, fj)), __fmul_rn(g.ca, __fadd_rn(-g.cy2, fi)));   // 719
+    float t3 = __fadd_rn(__fmul_rn(g.ca, __fadd_rn(-g.cx3, fj)), __fmul_rn(g.sa, __fadd_rn(-g.cy3, fi)));    // 720
+    float t4 = __fadd_rn(__fmul_rn(g.ca, __fadd_rn(-g.cx4, fj)), __fmul_rn(g.sa, __fadd_rn(-g.cy4, fi)));    // 721
+    return ((double)t1 < 0.00001) && ((double)t2 > -0.00001) && ((double)t3 > -0.00001) && ((double)t4 < 0.00001);
+}
+
+__global__ __launch_bounds__(64) void k_mask_count(const float *__restrict__ ii, const RollGeo *__restrict__ geo,
+                                                   uint8_t *__restrict__ mask, int *__restrict__ rowcount, Dims d)
+{
+    const int i = blockIdx.x, br = blockIdx.y, lane = threadIdx.x;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    const float *I = ii + (size_t)br * (H + 1) * W1;
+    const RollGeo &g = geo[br];
+    uint8_t *mrow = mask + ((size_t)br * H + i) * W;
+    int cnt = 0;
+    for (int j0 = 0; j0 < W; j0 += 64) {
+        int j = j0 + lane;
+        bool m = (j < W) && cell_in_box(I, W1, H, i, j, g);
+        if (j < W) mrow[j] = m ? 1 : 0;
+        cnt += __popcll(__ballot(m));
+    }
+    if (lane == 0) rowcount[br * H + i] = cnt;
+}
+
+void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mask_count, dim3(d.H, d.B * d.R), dim3(64), 0, s, ii, geo, mask, rowcount, d);
+}
+
+// exclusive scan of the per-row counts (n = B*R*H entries), single workgroup
+__global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ rowcount, int *__restrict__ rowoff,
+                                               int *__restrict__ brcount, int *__restrict__ counters, Dims d)
+{
+    __shared__ int part[1024];
+    const int n = d.B * d.R * d.H;
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk, hi = min(n, lo + chunk);
+    int s = 0;
+    for (int k = lo; k < hi; k++) s += rowcount[k];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int k = lo; k < hi; k++) { rowoff[k] = run; run += rowcount[k]; }
+    if (t == 1023) { rowoff[n] = part[1023]; counters[CNT_EVALS] = part[1023]; }
+    __syncthreads();
+    for (int br = t; br < d.B * d.R; br += 1024) {
+        int e0 = rowoff[br * d.H];
+        int e1 = (br + 1 == d.B * d.R) ? part[1023] : rowoff[(br + 1) * d.H];
+        brcount[br] = e1 - e0;
+    }
+}
+
+void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, rowcount, rowoff, brcount, counters, d);
+}
+
+__global__ __launch_bounds__(64) void k_compact(const uint8_t *__restrict__ mask, const int *__restrict__ rowoff,
+                                                int *__restrict__ evalcell, Dims d)
+{
+    const int i = blockIdx.x, br = blockIdx.y, lane = threadIdx.x;
+    const int H = d.H, W = d.W;
+    const uint8_t *mrow = mask + ((size_t)br * H + i) * W;
+    int base = rowoff[br * H + i];
+    for (int j0 = 0; j0 < W; j0 += 64) {
+        int j = j0 + lane;
+        bool m = (j < W) && mrow[j];
+        unsigned long long bal = __ballot(m);
+        if (m) {
+            int pre = __popcll(bal & ((1ull << lane) - 1ull));
+            evalcell[base + pre] = (br * H + i) * W + j;
+        }
+        base += __popcll(bal);
+    }
+}
+
+void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact, dim3(d.H, d.B * d.R), dim3(64), 0, s, mask, rowoff, evalcell, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a5/a6: one feature value from the 15x15 integral window (fv.cpp:141-199).  fp32, strict order, unfused.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float region_sum(const float *__restrict__ win, const int *off)
+{
+    float s = __fsub_rn(win[off[0]], win[off[1]]);
+    s = __fsub_rn(s, win[off[2]]);
+    return __fadd_rn(s, win[off[3]]);                                    // fv.cpp:161-162 / 183-184
+}
+
+__device__ __forceinline__ float feature_value(const float *__restrict__ win, const FeatDesc &f)
+{
+    if (!f.shaf) {
+        float rv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (f.active & (1 << k)) rv = __fadd_rn(rv, __fmul_rn(f.w[k], region_sum(win, f.off[k])));
+        return rv;
+    }
+    float r[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (f.active & (1 << k)) r[k] = __fmul_rn(f.w[k], region_sum(win, f.off[k]));
+    if (r[1] > r[0] && r[1] > r[2]) {                                    // fv.cpp:187-191
+        float a = __fsub_rn(r[1], r[0]), b = __fsub_rn(r[1], r[2]);
+        return (b < a) ? b : a;
+    }
+    return -1.0f;
+}
+
+// fp32 feature -> attribute value svm-predict would parse (both decimal text round trips emulated exactly)
+__device__ __forceinline__ double attribute_value(const float *__restrict__ win, const FeatDesc &f, double lower, double upper)
+{
+    float v = feature_value(win, f);
+    double q4 = hafq::decq((double)v, 4);
+    return hafq::scale_q6(q4, f.fmin, f.fmax, lower, upper);
+}
+
+// X image: tiles of 32 evals, k-major inside a tile ([tile][kDP][32] fp32) -- the exact register image of the MFMA
+// A operand, so the contraction kernel fills its A fragments with fully coalesced 256-byte loads.
+__global__ __launch_bounds__(256) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                  const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
+                                                  float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
+                                                  double upper, float neg_gamma2)
+{
+    const int n_evals = counters[CNT_EVALS];
+    const long n_pad = ((long)n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if ((long)blockIdx.x * 256 >= n_pad) return;
+    float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
+    if (e >= n_evals) {                       // padding rows of the last 256-eval block: zeros
+        for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
+        ax[e] = 0.0f;
+        return;
+    }
+    const int H = d.H, W = d.W, W1 = W + 1;
+    const int cell = evalcell[e];
+    const int br = cell / (H * W);
+    const int rem = cell - br * H * W;
+    const int i = rem / W, j = rem - i * W;
+    const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+    double xx = 0.0;
+    for (int f = 0; f < d.nf; f++) {
+        const FeatDesc &F = fd[f];
+        float xf = 0.0f;
+        if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+        xcol[f * kTile] = xf;
+        xx = fma((double)xf, (double)xf, xx);
+    }
+    for (int k = d.nf; k < kKP; k++) xcol[k * kTile] = 0.0f;
+    ax[e] = neg_gamma2 * (float)xx;           // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+}
+
+void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
+                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, hipStream_t s)
+{
+    long blocks = (max_evals + 255) / 256;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_features, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
+                       upper, neg_gamma2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a8: RBF decision as an fp32 MFMA contraction.
+//   dec(e) = sum_n coef_n * exp(-gamma * |x_e - s_n|^2) - rho,   |x-s|^2 = |x|^2 + |s|^2 - 2 x.s
+// Workgroup = 8 waves = 256 evals.  Each wave keeps its 32 evals x 324 attributes in 162 VGPRs (the A operand of
+// v_mfma_f32_32x32x2_f32, loaded once) and sweeps every 32-SV tile: the tile image [328][32] (324 attribute rows,
+// one row of -g2*|s|^2, one row of coefficients) is streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4),
+// double buffered, and read back as the B operand with conflict-free 256-byte ds_read_b32.  The 32x32 fp32
+// accumulator goes straight through exp2 and the coefficient FMA in registers; only 4 bytes per eval leave the CU.
+// Two waves per SIMD: one wave's exp/FMA epilogue hides under the other's MFMAs.
+// ---------------------------------------------------------------------------------------------------
+// The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA like an ordinary load and parks an
+// s_waitcnt vmcnt(0) in front of the first ds_read of the tile being computed, which serialises load and compute.
+// Hidden from its scoreboard, the pieces of tile t+1 stay in flight under the 162 MFMAs of tile t; the explicit
+// s_waitcnt vmcnt(0) + barrier at the end of the iteration is the only wait (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void stage_sv_tile(const float *__restrict__ gtile, unsigned lds_byte_off, int wave, int lane)
+{
+    // 41 KiB = 41 wave-instructions of 1 KiB; LDS destination = M0 (wave-uniform) + lane*16
+    for (int p = wave; p < kTileFloats / 256; p += 8) {
+        const char *g = reinterpret_cast<const char *>(gtile) + p * 1024 + lane * 16;
+        unsigned l = __builtin_amdgcn_readfirstlane(lds_byte_off + p * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
+    }
+}
+
+__global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restrict__ X, const float *__restrict__ ax,
+                                                            const float *__restrict__ svt,
+                                                            const int *__restrict__ evalcell,
+                                                            const int *__restrict__ counters, SvmParams p,
+                                                            float *__restrict__ dec, int8_t *__restrict__ labels,
+                                                            int *__restrict__ flag_list, int flag_cap,
+                                                            int *__restrict__ counters_rw, Dims d)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats];   // the ONLY LDS object: two SV tile images
+    const int n_evals = counters[CNT_EVALS];
+    const long base = (long)blockIdx.x * kSvmBlockEvals;
+    if (base >= n_evals) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long tile32 = (base >> 5) + wave;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;                  // LDS byte address of buffer 0
+    stage_sv_tile(svt, lds0, wave, lane);                           // tile 0 in flight while A loads
+
+    float a[kKSteps];
+    {
+        const float *xt = X + (size_t)tile32 * kTileFloats + lane;
+#pragma unroll
+        for (int s = 0; s < kKSteps; s++) a[s] = xt[s * 64];        // A[i = lane&31][k = 2s + (lane>>5)]
+    }
+    float axr[16], part[16], pabs[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);          // C/D row of register r (32x32 layout)
+        axr[r] = ax[tile32 * kTile + row];
+        part[r] = 0.0f;
+        pabs[r] = 0.0f;
+    }
+    // Pin every compiler-issued load BEFORE the main loop: the loop's LDS-DMA is invisible to hipcc's vmcnt
+    // bookkeeping, so one of its counted waits for a still-pending A/ax load would come up short once younger DMA
+    // pieces sit behind it in the queue.  An empty asm that consumes each register makes the compiler finish them here.
+#pragma unroll
+    for (int s = 0; s < kKSteps; s++) asm volatile("" : "+v"(a[s]));
+#pragma unroll
+    for (int r = 0; r < 16; r++) asm volatile("" : "+v"(axr[r]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's DMA pieces of tile 0 have landed
+    __syncthreads();
+
+    const int nt = d.n_sv_tiles;
+    for (int t = 0; t < nt; t++) {
+        float *cur = lds + (t & 1) * kTileFloats;
+        if (t + 1 < nt)
+            stage_sv_tile(svt + (size_t)(t + 1) * kTileFloats, lds0 + ((t + 1) & 1) * kTileFloats * 4, wave, lane);
+
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float *bl = cur + lane;
+#pragma unroll
+        for (int s = 0; s < kKSteps; s++) {
+            float b = bl[s * 64];                                   // B[k = 2s + (lane>>5)][j = lane&31]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc, 0, 0, 0);
+        }
+        const float as_ = cur[kKP * kTile + (lane & 31)];           // -g2*|s_j|^2
+        const float cf = cur[(kKP + 1) * kTile + (lane & 31)];      // coef_j (0 for padding SVs)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float arg = fmaf(p.two_gamma2, acc[r], axr[r] + as_);   // -g2*(|x|^2 + |s|^2 - 2 x.s)
+            float k = __builtin_amdgcn_exp2f(arg);
+            part[r] = fmaf(cf, k, part[r]);
+            pabs[r] = fmaf(fabsf(cf), k, pabs[r]);                  // sum |coef| K: scale of the rounding error
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces of tile t+1 have landed
+        __syncthreads();                                            // ... and everybody is done reading tile t
+    }
+
+    // sum the 32 SV columns held by the 32 lanes of each half
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float v = part[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        part[r] = v;
+        float w = pabs[r];
+        w += __shfl_xor(w, 16, 64);
+        w += __shfl_xor(w, 8, 64);
+        w += __shfl_xor(w, 4, 64);
+        w += __shfl_xor(w, 2, 64);
+        w += __shfl_xor(w, 1, 64);
+        pabs[r] = w;
+    }
+    if ((lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            long e = tile32 * kTile + row;
+            if (e < n_evals) {
+                float dv = part[r] - p.rho;
+                dec[e] = dv;
+                labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);      // svm.cpp:2516-2531
+                if (!(fabsf(dv) > p.guard * pabs[r] + p.guard_abs)) {            // guard band (also catches NaN)
+                    int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
+                    if (slot < flag_cap) flag_list[slot] = (int)e;
+                }
+            }
+        }
+    }
+}
+
+void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters, SvmParams p,
+                float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
+                hipStream_t s)
+{
+    long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_svm_rbf, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, X, ax, svt, evalcell, counters, p,
+                       dec, labels, flag_list, flag_cap, counters_rw, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a8 exact: guard-band evaluations re-done in libsvm's own order: d2 summed over attributes in index order in
+// fp64 without fusion (svm.cpp:327-364), K = exp(-gamma*d2), decision summed over SVs in model order (2509-2513).
+// One workgroup per flagged evaluation; rare, so simplicity over speed.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kExactChunk = 2048;
+
+__global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                 const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
+                                                 const double *__restrict__ coef64, ExactParams p,
+                                                 const int *__restrict__ flag_list, int flag_cap,
+                                                 const int *__restrict__ counters, double *__restrict__ dec_exact,
+                                                 int8_t *__restrict__ labels, Dims d)
+{
+    __shared__ double xs[kKP + 4];
+    __shared__ double terms[kExactChunk];
+    __shared__ double run_sum;
+    int n_flag = counters[CNT_FLAGGED];
+    if (n_flag > flag_cap) n_flag = flag_cap;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    for (int slot = blockIdx.x; slot < n_flag; slot += gridDim.x) {
+        const int e = flag_list[slot];
+        const int cell = evalcell[e];
+        const int br = cell / (H * W);
+        const int rem = cell - br * H * W;
+        const int i = rem / W, j = rem - i * W;
+        const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+        for (int f = threadIdx.x; f < p.kx; f += blockDim.x) {
+            double x = 0.0;
+            if (f < d.nf && !fd[f].skip) x = attribute_value(win, fd[f], p.lower, p.upper);
+            xs[f] = x;
+        }
+        if (threadIdx.x == 0) run_sum = 0.0;
+        __syncthreads();
+        for (int n0 = 0; n0 < p.n_sv; n0 += kExactChunk) {
+            for (int n = n0 + threadIdx.x; n < min(p.n_sv, n0 + kExactChunk); n += blockDim.x) {
+                double sum = 0.0;
+                for (int k = 0; k < p.kx; k++) {
+                    double dd = __dsub_rn(xs[k], sv64[(size_t)k * p.n_sv_pad + n]);
+                    sum = __dadd_rn(sum, __dmul_rn(dd, dd));
+                }
+                terms[n - n0] = __dmul_rn(coef64[n], exp(__dmul_rn(-p.gamma, sum)));
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s = run_sum;
+                int cnt = min(kExactChunk, p.n_sv - n0);
+                for (int n = 0; n < cnt; n++) s = __dadd_rn(s, terms[n]);
+                run_sum = s;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            double dv = __dsub_rn(run_sum, p.rho);
+            dec_exact[slot] = dv;
+            labels[cell] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+        }
+        __syncthreads();
+    }
+}
+
+void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
+                    ExactParams p, const int *flag_list, int flag_cap, const int *counters, double *dec_exact,
+                    int8_t *labels, Dims d, hipStream_t s)
+{
+    int blocks = flag_cap < 2048 ? flag_cap : 2048;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_recheck, dim3(blocks), dim3(256), 0, s, ii, evalcell, fd, sv64, coef64, p, flag_list, flag_cap,
+                       counters, dec_exact, labels, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a10: 29-tap weighted vote, first-wins argmax, longest-run centring; plus the 9x8 z window of a11.
+// One workgroup per (cloud, roll).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vote_at(const int8_t *__restrict__ g, int W, int row, int col)
+{
+#define G(dr, dc) ((int)g[(row + (dr)) * W + (col + (dc))])
+    return 1 * G(-2, -2) + 2 * G(-2, -1) + 3 * G(-2, 0) + 2 * G(-2, 1) + 1 * G(-2, 2) +
+           2 * G(-1, -2) + 3 * G(-1, -1) + 4 * G(-1, 0) + 3 * G(-1, 1) + 2 * G(-1, 2) +
+           2 * G(0, -4) + 2 * G(0, -3) + 3 * G(0, -2) + 4 * G(0, -1) + 55 * G(0, 0) + 4 * G(0, 1) + 3 * G(0, 2) +
+           2 * G(0, 3) + 2 * G(0, 4) +
+           2 * G(1, -2) + 3 * G(1, -1) + 4 * G(1, 0) + 3 * G(1, 1) + 2 * G(1, 2) +
+           1 * G(2, -2) + 2 * G(2, -1) + 3 * G(2, 0) + 2 * G(2, 1) + 1 * G(2, 2);       // 873-878
+#undef G
+}
+
+__global__ __launch_bounds__(256) void k_vote(const int8_t *__restrict__ labels, const float *__restrict__ heights,
+                                              const int *__restrict__ brcount, short *__restrict__ ev16,
+                                              RollRecordDev *__restrict__ rec, Dims d)
+{
+    __shared__ unsigned long long red[256];
+    __shared__ int s_top;
+    __shared__ int s_row, s_col;
+    __shared__ unsigned int zred[256];
+    const int br = blockIdx.x, t = threadIdx.x;
+    const int H = d.H, W = d.W, HW = H * W;
+    const int8_t *g = labels + (size_t)br * HW;
+    short *ev = ev16 + (size_t)br * HW;
+    unsigned long long best = 0;
+    for (int idx = t; idx < HW; idx += 256) {
+        int row = idx / W, col = idx - row * W;
+        int v = 0;
+        if (g[idx] >= 0 && row >= 2 && row < H - 2 && col >= 4 && col < W - 4) v = vote_at(g, W, row, col);   // 870-879
+        ev[idx] = (short)v;
+        unsigned long long key = ((unsigned long long)(unsigned)(v + 32768) << 32) | (unsigned)(0x7FFFFFFF - idx);
+        if (key > best) best = key;                                   // larger vote, then smaller index (first wins, 882)
+    }
+    red[t] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) s_top = (int)(red[0] >> 32) - 32768;
+    __syncthreads();
+    const int top = s_top;
+    // longest horizontal run of `top` per row (904-932): first longest run wins, column = run end - len/2
+    unsigned long long rbest = 0;
+    for (int row = t; row < H; row += 256) {
+        int cur = 0, longest = 0, endc = 0;
+        for (int col = 0; col < W; col++) {
+            if (ev[row * W + col] == top) {
+                cur++;
+                if (cur > longest) { longest = cur; endc = col; }
+            } else cur = 0;
+        }
+        if (longest > 0) {
+            int bc = endc - longest / 2;
+            unsigned long long key = ((unsigned long long)(unsigned)longest << 40) |
+                                     ((unsigned long long)(unsigned)(0xFFFF - row) << 20) | (unsigned)bc;
+            if (key > rbest) rbest = key;                             // longer run, then smaller row
+        }
+    }
+    __syncthreads();
+    red[t] = rbest;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        s_row = 0xFFFF - (int)((red[0] >> 20) & 0xFFFFF);
+        s_col = (int)(red[0] & 0xFFFFF);
+    }
+    __syncthreads();
+    const int brow = s_row, bcol = s_col;
+    // z estimate window rows brow-4..brow+4, cols bcol-4..bcol+3 (1342-1351), as an ordered-key max
+    int zk = f2key(-10.0f);
+    if (t < 72) {
+        int rr = brow + (t / 8) - 4, cc = bcol + (t % 8) - 4;
+        if (rr >= 0 && cc >= 0 && rr < H && cc < W) {
+            float h = heights[(size_t)br * HW + rr * W + cc];
+            if (-10.0f < h) zk = f2key(h);
+        }
+    }
+    zred[t] = (unsigned)(zk ^ 0x80000000);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && zred[t + o] > zred[t]) zred[t] = zred[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        RollRecordDev r;
+        r.vote = top; r.row = (short)brow; r.col = (short)bcol;
+        r.h_locmax = key2f((int)(zred[0] ^ 0x80000000));
+        r.n_evals = brcount[br];
+        rec[br] = r;
+    }
+}
+
+void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, RollRecordDev *rec, Dims d,
+                 hipStream_t s)
+{
+    hipLaunchKernelGGL(k_vote, dim3(d.B * d.R), dim3(256), 0, s, labels, heights, brcount, ev16, rec, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device-side checks of the decimal round-trip arithmetic (tests/test_engine_gpu.py)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_decq_test(const double *__restrict__ in, double *__restrict__ out, int n, int P)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hafq::decq(in[i], P);
+}
+void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decq_test, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, P);
+}
+
+__global__ void k_scale_test(const double *__restrict__ q4, const double *__restrict__ fmin, const double *__restrict__ fmax,
+                             double lower, double upper, double *__restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hafq::scale_q6(q4[i], fmin[i], fmax[i], lower, upper);
+}
+void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
+                       int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scale_test, dim3((n + 255) / 256), dim3(256), 0, s, q4, fmin, fmax, lower, upper, out, n);
+}
+
+}  // namespace haf

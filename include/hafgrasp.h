@@ -1,0 +1,167 @@
+/*
+ * hafgrasp.h -- C-ABI of the MI355X grasp-scoring engine (libhafgrasp.so).
+ *
+ * Drop-in boundary for the hot path of haf_grasping's CalcGraspPointsServer action server: the body of
+ * CCalc_Grasppoints::loop_control() (reference src/calc_grasppoints_action_server.cpp:335-402) after
+ * read_pc_cb() (250-329) has put the cloud into the base frame and before the result is published
+ * (396-401).  Plain C types only; the caller owns every input/output buffer, the engine owns device
+ * memory.  One engine handle may be used by one thread at a time (the reference runs one goal at a time on
+ * actionlib's execute thread, server.cpp:182); several handles may coexist (no global state).
+ *
+ * Every entry point returns 0 on success or a negative HAF_E_* code; haf_last_error() gives the text.
+ * The reference itself has no error convention on this path (system() failures are only logged,
+ * server.cpp:778-796); a ROS shim maps a non-zero status to setAborted().
+ *
+ * The engine REQUIRES a HIP device.  There is no CPU fallback: haf_create() fails with HAF_E_DEVICE when
+ * no gfx950 device is usable.
+ */
+#ifndef HAFGRASP_H_
+#define HAFGRASP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAF_ABI_VERSION 1
+
+enum {
+    HAF_OK = 0,
+    HAF_E_ARG = -1,        /* bad argument / unsupported configuration                         */
+    HAF_E_IO = -2,         /* cannot read or parse Features.txt / range file / model file      */
+    HAF_E_DEVICE = -3,     /* no usable HIP device, HIP runtime error                          */
+    HAF_E_CAPACITY = -4,   /* request exceeds the capacity the engine was created with         */
+    HAF_E_BUDGET = -5,     /* max_calculation_time expired before the first roll (server.cpp:371) */
+    HAF_E_INTERNAL = -6
+};
+
+/* Construction-time inputs: the four ROS params of the server (server.cpp:217-225) plus the reference's
+ * compile-time constants generalised to fields (server.cpp:92-101, 202-214). */
+typedef struct haf_config {
+    const char *feature_file;        /* feature_file_path, default <pkg>/data/Features.txt (626-628)     */
+    const char *range_file;          /* range_file_path, default <pkg>/data/range21062012_allfeatures (767-769) */
+    const char *model_file;          /* svmmodel_file_path, default <pkg>/data/all_features.txt.scale.model (771-773) */
+    int32_t nr_features_without_shaf;/* 302 (224)                                                         */
+    int32_t grid_h, grid_w;          /* HEIGHT, WIDTH = 56 cells of 1 cm (92-93); must be equal (681-682)  */
+    int32_t n_rolls;                 /* ROLL_MAX_DEGREE/ROLL_STEPS_DEGREE = 12 (101, 345)                 */
+    int32_t roll_step_deg;           /* ROLL_STEPS_DEGREE = 15 (95)                                       */
+    float   z_shift;                 /* trans_z_after_pc_transform = 0.15 (214)                           */
+    int32_t graspval_top;            /* 119 (203): early-exit threshold with show_only_best_grasp         */
+    int32_t device;                  /* HIP device ordinal                                                */
+    int32_t max_clouds;              /* capacity: clouds per batch call                                   */
+    int64_t max_points;              /* capacity: total points per batch call                             */
+    uint32_t flags;                  /* HAF_FLAG_*                                                        */
+} haf_config;
+
+#define HAF_FLAG_KEEP_DEBUG 1u       /* keep per-roll intermediates for haf_debug_fetch()                 */
+#define HAF_FLAG_PROFILE    2u       /* record HIP events per stage (haf_get_stage_ms)                    */
+
+/* GraspInput (reference msg/GraspInput.msg:3-15) minus the cloud and the frame id: the cloud is passed
+ * separately, already in the base frame (server.cpp:316). */
+typedef struct haf_grasp_input {
+    double  grasp_area_center[3];        /* geometry_msgs/Point, metres (258-260)                         */
+    float   grasp_area_length_x;         /* "in m" in the .msg, used as integer cm incl. the +14 border    */
+    float   grasp_area_length_y;         /*   (server.cpp:266-267 truncates to int; client.cpp:183-184)    */
+    double  approach_vector[3];          /* normalised by the engine as server.cpp:270-273                 */
+    double  max_calculation_time;        /* seconds (277); checked between roll batches, 1 s granularity   */
+    int32_t show_only_best_grasp;        /* changes the result: early exit at >= graspval_top (362-365)    */
+    int32_t threshold_grasp_evaluation;  /* carried for API parity; the reference server never reads it    */
+    int32_t gripper_opening_width;       /* x-scale factor (281, 433)                                      */
+} haf_grasp_input;
+
+/* GraspOutput (reference msg/GraspOutput.msg:1-7) without the header, plus the grid-space winner. */
+typedef struct haf_grasp_output {
+    int32_t eval;                   /* best vote - 20; -20 = nothing found (390, 1388, 1418)              */
+    double  grasp_point1[3];        /* 1389-1391 */
+    double  grasp_point2[3];        /* 1392-1394 */
+    double  averaged_grasp_point[3];/* 1395-1397 */
+    double  approach_vector[3];     /* 1398-1400 */
+    float   roll;                   /* radians (1401) */
+    int32_t best_row, best_col, best_roll, best_vote;   /* id_row/col_top_overall, nr_roll_top_overall, topval_gp_overall */
+    int32_t rolls_done;             /* rolls the sequential reference loop would have executed             */
+    int64_t n_evals;                /* masked (cell, roll) pairs scored = SVM evaluations                  */
+    int64_t n_rechecked;            /* evaluations re-done in exact fp64 libsvm order (guard band)         */
+} haf_grasp_output;
+
+/* One roll's outcome: what show_predicted_gps() leaves behind (server.cpp:865-932) plus the z estimate
+ * transform_gp_in_wcs_and_publish() would read from that roll's height grid (1342-1351).  16 bytes: the
+ * unit exchanged between GPUs when rolls are sharded. */
+typedef struct haf_roll_record {
+    int32_t vote;      /* topval_gp of the roll                                   */
+    int16_t row, col;  /* after longest-run centring (904-932)                    */
+    float   h_locmax;  /* max height in rows row-4..row+4, cols col-4..col+3      */
+    int32_t n_evals;   /* masked cells of this roll                               */
+} haf_roll_record;
+
+typedef struct haf_cloud {
+    const float *xyz;        /* x,y,z fp32 triples                                                        */
+    size_t       n_points;
+    size_t       stride_floats; /* 3 for packed xyz, 4 for pcl::PointXYZ                                  */
+    int32_t      on_device;  /* 0: host memory (copied over PCIe inside the call); 1: HBM resident        */
+} haf_cloud;
+
+typedef struct haf_engine haf_engine;
+
+/* defaults of the reference: 56x56, 12 rolls of 15 deg, z_shift 0.15, nshaf 302, top 119 */
+void haf_config_default(haf_config *cfg);
+void haf_grasp_input_default(haf_grasp_input *in);   /* centre 0, 32x44, av (0,0,1), 50 s, width 1 (server.cpp:191-215) */
+
+int  haf_create(const haf_config *cfg, haf_engine **out);
+void haf_destroy(haf_engine *e);
+const char *haf_last_error(const haf_engine *e);     /* e == NULL: error of the last failed haf_create in this thread */
+
+/* GraspInput -> GraspOutput for one cloud: replaces loop_control() (server.cpp:335-402). */
+int haf_score(haf_engine *e, const haf_cloud *cloud, const haf_grasp_input *in, haf_grasp_output *out);
+/* Batched clouds (BASELINE configs C4/C5): all clouds and all rolls go through the device together. */
+int haf_score_batch(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in,
+                    haf_grasp_output *out);
+
+/* Roll-sharded form for multi-GPU: score rolls [roll_first, roll_first+roll_count) only and return their
+ * records (records[c*roll_count + i]); no cross-roll rule applied.  Gather the records of all shards (one
+ * all-gather of n_rolls*16 bytes per cloud) and call haf_finalize(). */
+int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in,
+                    int32_t roll_first, int32_t roll_count, haf_roll_record *records);
+/* Sequential cross-roll rule (strict '>' keeps the lowest roll, early exit at >= graspval_top when
+ * show_only_best_grasp; server.cpp:362-365, 953-960) and the grasp pose (1274-1401) from n_rolls records. */
+int haf_finalize(haf_engine *e, const haf_grasp_input *in, const haf_roll_record *records, haf_grasp_output *out);
+
+/* Per-roll vote grid and mask of the LAST scored batch, for the marker grid the ROS shim publishes
+ * (publish_grasp_grid, server.cpp:901-902, 979-1016).  eval_grid: H*W floats, mask: H*W bytes; either may be NULL. */
+int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask);
+
+/* Intermediates of the last scored batch (needs HAF_FLAG_KEEP_DEBUG).  dst sizes per (cloud, roll):
+ * HEIGHTS H*W f32, INTEGRAL (H+1)*(W+1) f32, MASK H*W u8, LABELS H*W i8 (-1 unmasked, else label text value),
+ * DECISION H*W f64 (NaN unmasked), TRANSFORM 16 f32. */
+enum { HAF_DBG_HEIGHTS = 0, HAF_DBG_INTEGRAL = 1, HAF_DBG_MASK = 2, HAF_DBG_LABELS = 3, HAF_DBG_DECISION = 4,
+       HAF_DBG_TRANSFORM = 5 };
+int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes);
+
+/* Launch everything on this hipStream_t (default: a stream the engine creates).  The caller keeps ownership. */
+int haf_set_stream(haf_engine *e, void *hip_stream);
+void *haf_get_stream(haf_engine *e);
+
+/* Stage timings of the last call in milliseconds (HAF_FLAG_PROFILE): HIP events on the engine's stream. */
+enum { HAF_ST_UPLOAD = 0, HAF_ST_BIN, HAF_ST_INTEGRAL, HAF_ST_MASK, HAF_ST_FEATURES, HAF_ST_SVM, HAF_ST_RECHECK,
+       HAF_ST_VOTE, HAF_ST_DOWNLOAD, HAF_ST_COUNT };
+int haf_get_stage_ms(haf_engine *e, float *ms /* HAF_ST_COUNT */);
+
+/* Counters of the last scored batch: masked (cell, roll) pairs, and how many of them fell inside the guard band and
+ * were re-evaluated in exact fp64 libsvm order. */
+int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked);
+
+/* Model facts for reporting: support vectors, attribute dimension, feature rows (incl. phantom rows). */
+int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_features);
+
+/* PCD v0.7 reader (ascii / binary / binary_compressed; pcl::io::loadPCDFile in client.cpp:141).
+ * Returns a malloc'ed packed xyz array (free with haf_free) and the point count. */
+int  haf_pcd_load(const char *path, float **xyz, size_t *n_points, char *err, size_t err_cap);
+void haf_free(void *p);
+
+int haf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAFGRASP_H_ */

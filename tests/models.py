@@ -2,11 +2,13 @@
 import numpy as np
 
 
-def write_random_model(path, nsv, D=323, seed=0, gamma=None, rho=0.1, density=1.0):
+def write_random_model(path, nsv, D=323, seed=0, gamma=None, rho=0.1, density=1.0, balanced=False):
     """C-SVC / RBF model in libsvm's text format (svm.cpp:2599-2691 writer layout).
 
     SURVEY.md §8(d): SV values U(-1,1) printed %.8g, coef ~ U(0,2) with the class sign (printed %.16g),
     gamma = 1/D, rho 0.1, labels "1 -1", first half of the SVs belong to label 1.
+    balanced=True rescales the negative class so that sum(coef) = 0 (as in every real C-SVC solution) and uses
+    rho = 0.01: decision values then straddle zero and both labels occur.
     """
     rng = np.random.RandomState(seed)
     gamma = 1.0 / D if gamma is None else gamma
@@ -16,6 +18,9 @@ def write_random_model(path, nsv, D=323, seed=0, gamma=None, rho=0.1, density=1.
     keep = rng.uniform(size=(nsv, D)) < density
     coef = rng.uniform(0.0, 2.0, size=nsv)
     coef[n0:] *= -1.0
+    if balanced:
+        coef[n0:] *= coef[:n0].sum() / -coef[n0:].sum()
+        rho = 0.01
     with open(path, "w") as f:
         f.write("svm_type c_svc\nkernel_type rbf\ngamma %g\nnr_class 2\ntotal_sv %d\nrho %g\nlabel 1 -1\nnr_sv %d %d\nSV\n"
                 % (gamma, nsv, rho, n0, n1))

@@ -1,0 +1,305 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bars (north_star / SURVEY.md §8d): height grid, integral image, mask, label grid, per-roll winners, overall
+(row, col, roll) and eval BIT-EXACT / identical; decision values within 1e-4 of the fp64 oracle wherever the
+fast path is used (exact to ~1e-12 where the guard band re-evaluates); grasp points within 1e-4 m."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import models
+import pcdio
+from haf_grasping_amd import capi
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEC_TOL = 1e-4
+
+
+def _files(data_dir):
+    return os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures")
+
+
+@pytest.fixture(scope="module")
+def surrogate(golden_dir):
+    return os.path.join(golden_dir, "surrogate.model")
+
+
+@pytest.fixture(scope="module")
+def orc(data_dir, surrogate):
+    f, r = _files(data_dir)
+    return O.Oracle(f, r, surrogate)
+
+
+def make_engine(data_dir, model, **cfg):
+    f, r = _files(data_dir)
+    cfg.setdefault("flags", capi.FLAG_KEEP_DEBUG | capi.FLAG_PROFILE)
+    return capi.Engine(f, r, model, **cfg)
+
+
+def oracle_input(kw):
+    return O.make_input(center=kw.get("grasp_area_center", (0, 0, 0)), length_x=kw.get("grasp_area_length_x", 32),
+                        length_y=kw.get("grasp_area_length_y", 44), approach=kw.get("approach_vector", (0, 0, 1)),
+                        show_only_best=kw.get("show_only_best_grasp", 0), gripper_width=kw.get("gripper_opening_width", 1))
+
+
+def compare_full(eng, orc, xyz, cfg_kw, in_kw, check_dec=True):
+    ocfg = O.make_cfg(**{k: v for k, v in cfg_kw.items() if k in ("n_rolls", "roll_step_deg")},
+                      H=cfg_kw.get("grid_h", 56), W=cfg_kw.get("grid_w", 56))
+    want = orc.run(xyz, ocfg, oracle_input(in_kw))
+    got = eng.score(xyz, capi.default_input(**in_kw))
+    R = ocfg.n_rolls
+    # With show_only_best the reference stops early; the engine still computes every roll, compare the executed ones.
+    for roll in range(want["rolls_done"]):
+        h = eng.debug(capi.DBG_HEIGHTS, 0, roll)
+        assert (h.view(np.uint32) == want["heights"][roll].view(np.uint32)).all(), ("heights", roll)
+        ii = eng.debug(capi.DBG_INTEGRAL, 0, roll)
+        assert (ii.view(np.uint32) == want["integral"][roll].view(np.uint32)).all(), ("integral", roll)
+        m = eng.debug(capi.DBG_MASK, 0, roll)
+        assert (m == want["mask"][roll]).all(), ("mask", roll)
+        lab = eng.debug(capi.DBG_LABELS, 0, roll)
+        assert (lab == want["labels"][roll]).all(), ("labels", roll, int((lab != want["labels"][roll]).sum()))
+        if check_dec:
+            d = eng.debug(capi.DBG_DECISION, 0, roll)
+            msk = want["mask"][roll] == 1
+            assert np.isnan(d[~msk]).all()
+            if msk.any():
+                err = np.abs(d[msk] - want["dec"][roll][msk]).max()
+                assert err <= DEC_TOL, ("decision", roll, err)
+        ev, _ = eng.roll_grid(0, roll)
+        assert (ev == want["graspseval"][roll]).all(), ("vote grid", roll)
+    for k_e, k_o in [("eval", "eval"), ("best_row", "row"), ("best_col", "col"), ("best_roll", "roll_idx"),
+                     ("best_vote", "top"), ("rolls_done", "rolls_done"), ("n_evals", "n_evals")]:
+        assert got[k_e] == want[k_o], (k_e, got[k_e], want[k_o])
+    np.testing.assert_allclose(got["grasp_point1"], want["gp1"], atol=1e-4)
+    np.testing.assert_allclose(got["grasp_point2"], want["gp2"], atol=1e-4)
+    np.testing.assert_allclose(got["averaged_grasp_point"], want["avg"], atol=1e-4)
+    np.testing.assert_allclose(got["approach_vector"], want["av"], atol=1e-6)
+    assert got["roll"] == want["roll"]
+    assert R >= want["rolls_done"]
+    return got, want
+
+
+def test_device_decimal_roundtrip_matches_host():
+    """csrc/decq.h compiled for gfx950 gives the same bits as its host build (which test_host_cpu pins to glibc)."""
+    L = capi.lib()
+    rng = np.random.RandomState(11)
+    for digits in (4, 6):
+        parts = [rng.standard_normal(20000) * s for s in (1e-9, 1e-4, 1.0, 50.0, 1e4, 1e9, 1e-18, 1e24, 1e-30, 1e35)]
+        base = rng.randint(10 ** (digits - 1), 10 ** digits, size=4000).astype(np.float64)
+        for e in range(-6, 8):
+            t = (base + 0.5) * 10.0 ** e
+            parts += [t, np.nextafter(t, np.inf), np.nextafter(t, -np.inf)]
+        x = np.concatenate(parts + [np.array([0.0, -0.0, np.inf, -np.inf, 1e-310, 123.25, 9999.5])])
+        if digits == 4:
+            x = x.astype(np.float32).astype(np.float64)
+        out = np.empty_like(x)
+        assert L.haf_test_decq_device(x.ctypes.data, out.ctypes.data, len(x), digits) == 0
+        host = np.array([L.haf_test_decq_host(float(v), digits) for v in x])
+        assert (out.view(np.uint64) == host.view(np.uint64)).all()
+
+
+def test_device_scale_matches_host(data_dir):
+    L = capi.lib()
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, None)
+    lo, up, fmin, fmax, _ = o.range_table()
+    rng = np.random.RandomState(5)
+    n = 323 * 300
+    idx = np.tile(np.arange(1, 324), 300)
+    v = (rng.standard_normal(n) * rng.choice([0.01, 1.0, 8.0], size=n)).astype(np.float32)
+    q4 = np.array([L.haf_test_decq_host(float(x), 4) for x in v])
+    q4[::97] = fmin[idx[::97]]
+    q4[5::101] = fmax[idx[5::101]]
+    out = np.empty(n)
+    a, b = np.ascontiguousarray(fmin[idx]), np.ascontiguousarray(fmax[idx])
+    assert L.haf_test_scale_device(q4.ctypes.data, a.ctypes.data, b.ctypes.data, lo, up, out.ctypes.data, n) == 0
+    host = np.array([L.haf_test_scale_host(q4[i], a[i], b[i], lo, up) for i in range(n)])
+    assert (out.view(np.uint64) == host.view(np.uint64)).all()
+
+
+def test_c1_c2_pcd2_stage_by_stage(data_dir, surrogate, orc):
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    eng = make_engine(data_dir, surrogate, n_rolls=1)
+    compare_full(eng, orc, xyz, dict(n_rolls=1), dict(grasp_area_length_x=32, grasp_area_length_y=32))   # C1
+    eng.close()
+    eng = make_engine(data_dir, surrogate)
+    got, _ = compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))   # C2
+    assert got["eval"] == 103
+    compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32, show_only_best_grasp=1))
+    compare_full(eng, orc, xyz, dict(n_rolls=12), dict(approach_vector=(0.2, -0.1, 1.0)))
+    compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_center=(0.01, -0.02, 0.005), gripper_opening_width=2))
+    eng.close()
+
+
+def test_all_clouds_against_committed_goldens(data_dir, golden_dir, surrogate):
+    """Every data/*.pcd x configuration of tests/golden/g6_end_to_end.json: argmax-identical cell/roll, same eval."""
+    import make_fixtures as mf
+    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+        gold = json.load(f)
+    engines = {}
+    for key, g in sorted(gold.items()):
+        name, cname = key.split("/")
+        spec = mf.CONFIGS[cname]
+        ck = (spec["cfg"].get("n_rolls", 12), spec["cfg"].get("roll_step_deg", 15))
+        if ck not in engines:
+            engines[ck] = make_engine(data_dir, surrogate, n_rolls=ck[0], roll_step_deg=ck[1], max_points=1 << 18)
+        eng = engines[ck]
+        xyz = capi.load_pcd(os.path.join(data_dir, name + ".pcd"))
+        i = spec["inp"]
+        kw = dict(grasp_area_length_x=i.get("length_x", 32), grasp_area_length_y=i.get("length_y", 44))
+        if "center" in i:
+            kw["grasp_area_center"] = i["center"]
+        if "approach" in i:
+            kw["approach_vector"] = i["approach"]
+        if "show_only_best" in i:
+            kw["show_only_best_grasp"] = i["show_only_best"]
+        got = eng.score(xyz, capi.default_input(**kw))
+        assert (got["eval"], got["best_row"], got["best_col"], got["best_roll"], got["best_vote"]) == \
+               (g["eval"], g["row"], g["col"], g["roll_idx"], g["top"]), key
+        assert got["n_evals"] == g["n_evals"] and got["rolls_done"] == g["rolls_done"], key
+        np.testing.assert_allclose(got["grasp_point1"], g["gp1"], atol=1e-4, err_msg=key)
+        np.testing.assert_allclose(got["grasp_point2"], g["gp2"], atol=1e-4, err_msg=key)
+        np.testing.assert_allclose(got["approach_vector"], g["av"], atol=1e-6, err_msg=key)
+        rec = eng.score_rolls([xyz], [capi.default_input(**kw)], 0, ck[0])[0]
+        for roll in range(g["rolls_done"]):
+            assert [int(rec["row"][roll]), int(rec["col"][roll]), int(rec["vote"][roll])] == g["roll_best"][roll], (key, roll)
+            assert int(rec["n_evals"][roll]) == g["masked"][roll], (key, roll)
+    for e in engines.values():
+        e.close()
+
+
+def test_table_cloud_live_against_oracle(data_dir, surrogate, orc):
+    """C3: 102 876-point binary_compressed cloud, 56x56 area, 20 rolls of 9 degrees, full stage comparison."""
+    xyz = capi.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    eng = make_engine(data_dir, surrogate, n_rolls=20, roll_step_deg=9, max_points=1 << 18)
+    compare_full(eng, orc, xyz, dict(n_rolls=20, roll_step_deg=9),
+                 dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)))
+    eng.close()
+
+
+def test_batch_of_eight_equals_single_and_shards_compose(data_dir, surrogate):
+    """C4: pcd1..8 in one batch call == eight single calls; roll shards + haf_finalize == the unsharded call."""
+    names = ["pcd%d" % i for i in range(1, 9)]
+    clouds = [capi.load_pcd(os.path.join(data_dir, n + ".pcd")) for n in names]
+    inputs = [capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44) for _ in names]
+    inputs[6] = capi.default_input(grasp_area_center=(0.30, 0.46, 0.0))       # pcd7: centred on the object
+    eng = make_engine(data_dir, surrogate, n_rolls=20, roll_step_deg=9, max_clouds=8)
+    batch = eng.score_batch(clouds, inputs)
+    singles = [eng.score(c, i) for c, i in zip(clouds, inputs)]
+    for b, s in zip(batch, singles):
+        for k in ("eval", "best_row", "best_col", "best_roll", "best_vote", "n_evals", "grasp_point1", "roll"):
+            assert b[k] == s[k], k
+    assert batch[7]["eval"] == -20 and (batch[7]["best_row"], batch[7]["best_col"]) == (0, 27)   # pcd8 outside the grid
+    # roll shards of different sizes, gathered like ranks would
+    full = eng.score_rolls(clouds[:3], inputs[:3], 0, 20)
+    parts = [eng.score_rolls(clouds[:3], inputs[:3], a, n) for a, n in ((0, 5), (5, 5), (10, 7), (17, 3))]
+    gathered = np.concatenate(parts, axis=1)
+    assert (gathered == full).all()
+    for c in range(3):
+        assert eng.finalize(inputs[c], gathered[c])["eval"] == batch[c]["eval"]
+    eng.close()
+
+
+def test_random_models_label_order_and_guard_band(data_dir, tmp_path):
+    """Seeded random libsvm models ('label 1 -1', balanced coefficients -> decision values crowd around zero):
+    stresses the guard band; labels must still be identical to the fp64 oracle."""
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    f, r = _files(data_dir)
+    for nsv, seed in ((96, 1), (300, 2)):
+        path = str(tmp_path / ("rand%d.model" % nsv))
+        models.write_random_model(path, nsv, seed=seed, balanced=True)
+        o = O.Oracle(f, r, path)
+        eng = make_engine(data_dir, path)
+        got, want = compare_full(eng, o, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=44))
+        assert (want["labels"] > 0).sum() > 50 and ((want["labels"] == -1) & (want["mask"] == 1)).sum() > 50
+        eng.close()
+
+
+def test_generalised_grid_and_rolls(data_dir, surrogate, orc):
+    """H, W, roll step and roll count are parameters here.  96x96 grid, 8 rolls of 22 degrees."""
+    xyz = models.synthetic_cloud(grid=96, k=2, seed=3)
+    eng = make_engine(data_dir, surrogate, grid_h=96, grid_w=96, n_rolls=8, roll_step_deg=22)
+    compare_full(eng, orc, xyz, dict(n_rolls=8, roll_step_deg=22, grid_h=96, grid_w=96),
+                 dict(grasp_area_length_x=96, grasp_area_length_y=80))
+    eng.close()
+
+
+def test_edge_inputs(data_dir, surrogate, orc):
+    eng = make_engine(data_dir, surrogate)
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=32)
+    # empty cloud: nothing masked, reference answer (row 0, col 27, roll 0, eval -20)
+    got = eng.score(np.zeros((0, 3), np.float32), capi.default_input(**inp))
+    assert (got["eval"], got["best_row"], got["best_col"], got["best_roll"], got["n_evals"]) == (-20, 0, 27, 0, 0)
+    # NaN / inf coordinates never reach a cell; PCL-style stride 4
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    bad = np.concatenate([xyz, np.array([[np.nan, 0, 1], [0, np.nan, 1], [0.01, 0.01, np.nan], [np.inf, 0, 1]], np.float32)])
+    padded = np.zeros((bad.shape[0], 4), np.float32)
+    padded[:, :3] = bad
+    compare_full(eng, orc, padded, dict(n_rolls=12), inp)
+    # points exactly on cell edges and on the +-0.28 border
+    edge = np.array([[-0.28, 0, 0.1], [0.28, 0, 0.1], [0.27999997, 0.27999997, 0.2], [-0.27999997, -0.27999997, 0.2],
+                     [0.0, 0.0, 0.05], [0.01, 0.01, 0.05], [-0.01, -0.01, -0.3], [0.05, 0.05, -1.2]], np.float32)
+    compare_full(eng, orc, np.concatenate([xyz, edge]), dict(n_rolls=12), inp)
+    # search area smaller than the border: no cell can be masked
+    got = eng.score(xyz, capi.default_input(grasp_area_length_x=10, grasp_area_length_y=10))
+    assert got["n_evals"] == 0 and got["eval"] == -20
+    # capacity and argument errors are loud
+    with pytest.raises(capi.HafError) as ei:
+        eng.score_batch([xyz, xyz], [capi.default_input(), capi.default_input()])
+    assert ei.value.code == capi.HAF_E_CAPACITY
+    with pytest.raises(capi.HafError) as ei:
+        eng.score(xyz, capi.default_input(max_calculation_time=-1.0))
+    assert ei.value.code == capi.HAF_E_BUDGET
+    eng.close()
+
+
+def test_full_size_c5_properties(data_dir, tmp_path):
+    """BASELINE config C5 at full size (512x512, 36 rolls of 5 degrees, 524 288 points): size-independent properties.
+    The oracle cannot run 7.9M evaluations, so: (1) the eval count equals the pure-geometry count (all cells are
+    non-empty), (2) spot-check 300 random masked cells per sampled roll against the oracle's own feature/scale/decision
+    chain fed with the engine's integral image, (3) rolls r and r+18 (90 degrees apart, square area) mask the same number of cells,
+    (4) the same cloud scored twice gives identical records (determinism), (5) sharded == unsharded."""
+    nsv = 256
+    path = str(tmp_path / "rand256.model")
+    models.write_random_model(path, nsv, seed=4, balanced=True)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, path)
+    xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
+    assert xyz.shape == (524288, 3)
+    eng = make_engine(data_dir, path, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+    inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
+    rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
+    assert int(rec["n_evals"].sum()) == 7883478 and int(rec["n_evals"][0]) == 248004
+    assert (rec["n_evals"][:18] == rec["n_evals"][18:]).all()   # square area: rolls r and r+18 (90 degrees apart) mask alike
+    rng = np.random.RandomState(9)
+    m = o.model_arrays()
+    lo, up, fmin, fmax, _ = o.range_table()
+    skip = np.zeros(325, np.uint8)
+    skip[324] = 1
+    for roll in (0, 7, 23):
+        ii = eng.debug(capi.DBG_INTEGRAL, 0, roll)
+        lab = eng.debug(capi.DBG_LABELS, 0, roll)
+        dec = eng.debug(capi.DBG_DECISION, 0, roll)
+        msk = eng.debug(capi.DBG_MASK, 0, roll)
+        cells = np.argwhere(msk == 1)
+        assert len(cells) == rec["n_evals"][roll]
+        for i, j in cells[rng.choice(len(cells), 300, replace=False)]:
+            feats = o.feature_values(ii[i - 7:i + 8, j - 7:j + 8])
+            xs = o.scale_row(np.array([O.q4(v) for v in feats]), m["D"], skip)
+            d = o.decision(xs)
+            want = m["label"][0] if d > 0 else m["label"][1]
+            assert lab[i, j] == want, (roll, i, j, d, dec[i, j])
+            assert abs(dec[i, j] - d) <= DEC_TOL
+    rec2 = eng.score_rolls([xyz], [inp], 0, 36)[0]
+    assert (rec == rec2).all()
+    parts = np.concatenate([eng.score_rolls([xyz], [inp], a, 9)[0] for a in (0, 9, 18, 27)])
+    assert (parts == rec).all()
+    out = eng.finalize(inp, rec)
+    assert out["best_vote"] == rec["vote"].max() and out["best_roll"] == int(np.argmax(rec["vote"]))
+    eng.close()

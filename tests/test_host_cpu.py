@@ -1,0 +1,249 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports what include/hafgrasp.h declares,
+the decimal round-trip arithmetic (host build of csrc/decq.h) equals glibc printf+strtod, and the parsers, per-roll
+geometry, cross-roll rule and pose agree with the oracle.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import pcdio
+from haf_grasping_amd import capi
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    with open(os.path.join(ROOT, "include", "hafgrasp.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    names = set(re.findall(r"\b(haf_[a-z_0-9]+)\s*\(", text))
+    assert {"haf_create", "haf_score", "haf_score_batch", "haf_score_rolls", "haf_finalize", "haf_destroy",
+            "haf_last_error", "haf_get_roll_grid", "haf_pcd_load"} <= names
+    for n in sorted(names):
+        assert hasattr(L, n), n
+    assert L.haf_abi_version() == 1
+
+
+def test_struct_layouts_match_header_sizes():
+    assert C.sizeof(capi.RollRecord) == 16
+    assert C.sizeof(capi.Cloud) == 32
+    cfg = capi.default_config()
+    assert (cfg.grid_h, cfg.grid_w, cfg.n_rolls, cfg.roll_step_deg, cfg.graspval_top) == (56, 56, 12, 15, 119)
+    assert cfg.nr_features_without_shaf == 302 and abs(cfg.z_shift - 0.15) < 1e-7
+    gi = capi.default_input()
+    assert (gi.grasp_area_length_x, gi.grasp_area_length_y, gi.gripper_opening_width) == (32.0, 44.0, 1)
+    assert tuple(gi.approach_vector) == (0.0, 0.0, 1.0) and gi.max_calculation_time == 50.0
+
+
+def test_create_fails_loudly_without_gpu(data_dir, golden_dir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.HafError) as ei:
+        capi.Engine(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"),
+                    os.path.join(golden_dir, "surrogate.model"))
+    assert ei.value.code == capi.HAF_E_DEVICE and "no CPU fallback" in str(ei.value)
+
+
+def _glibc_q(x, digits):
+    return float(("%." + str(digits) + "g") % x)      # CPython: PyOS_double_to_string -> correctly rounded, == glibc
+
+
+def _bits(x):
+    return struct.pack("<d", x)
+
+
+@pytest.mark.parametrize("digits", [4, 6])
+def test_decq_host_matches_printf_strtod(digits):
+    L = capi.lib()
+    rng = np.random.RandomState(digits)
+    vals = []
+    # feature-like magnitudes, float32 inputs for %.4g, doubles for %g
+    for scale in [1e-12, 1e-9, 1e-6, 1e-3, 1.0, 30.0, 1e3, 1e5, 1e7, 1e12, 1e-17, 1e20]:
+        v = rng.standard_normal(4000) * scale
+        vals.append(v.astype(np.float32).astype(np.float64) if digits == 4 else v)
+    # exact ties and near-ties: k + 0.5 at the rounding position, +- 1 ulp
+    base = rng.randint(10 ** (digits - 1), 10 ** digits, size=3000).astype(np.float64)
+    for e in range(-8, 12):
+        t = (base + 0.5) * (10.0 ** e)
+        vals += [t, np.nextafter(t, np.inf), np.nextafter(t, -np.inf)]
+        if digits == 4:
+            vals.append(t.astype(np.float32).astype(np.float64))
+    # powers of ten and their neighbours (decimal-exponent boundary)
+    p = np.array([10.0 ** e for e in range(-22, 23)])
+    vals += [p, np.nextafter(p, np.inf), np.nextafter(p, -np.inf), p * 9.9995, p * 9.99995, p * 9.999995]
+    vals.append(np.array([0.0, -0.0, 1.0, -1.0, 0.5, 123.25, 123.75, 1234.5, 9999.5, 99999.5, 999999.5, 0.03, 2.0 ** -53 - 1.0]))
+    allv = np.concatenate(vals)
+    allv = np.concatenate([allv, -allv])
+    bad = 0
+    for x in allv:
+        x = float(x)
+        got = L.haf_test_decq_host(x, digits)
+        want = _glibc_q(x, digits)
+        if _bits(got) != _bits(want):
+            bad += 1
+            assert bad < 5, (x, got, want)
+    assert bad == 0
+
+
+def test_decq_wide_window_against_glibc():
+    """Outside 1e-19..1e26 the double-double path is used; it is expected (not proven) to agree with glibc."""
+    L = capi.lib()
+    rng = np.random.RandomState(7)
+    for digits in (4, 6):
+        for e in list(range(-300, -20, 7)) + list(range(27, 300, 7)):
+            for x in rng.uniform(1, 10, size=40) * 10.0 ** e:
+                assert _bits(L.haf_test_decq_host(float(x), digits)) == _bits(_glibc_q(float(x), digits)), (x, digits)
+    # float32 subnormals and extremes, as %.4g sees them
+    for x in np.array([1e-45, 3e-42, 1.17549435e-38, 3.4028235e38], np.float32).astype(np.float64):
+        assert _bits(L.haf_test_decq_host(float(x), 4)) == _bits(_glibc_q(float(x), 4))
+    assert np.isnan(L.haf_test_decq_host(float("nan"), 4)) and L.haf_test_decq_host(float("inf"), 6) == float("inf")
+
+
+def test_scale_host_matches_oracle(data_dir):
+    L = capi.lib()
+    orc = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"), None)
+    lo, up, fmin, fmax, present = orc.range_table()
+    rng = np.random.RandomState(3)
+    skip = np.zeros(325, np.uint8)
+    skip[324] = 1
+    for _ in range(60):
+        feats = (rng.standard_normal(324) * rng.choice([0.01, 1, 5, 30])).astype(np.float32)
+        feats[rng.randint(0, 323, 5)] = 0.0
+        q4 = np.array([O.q4(v) for v in feats])
+        q4[7] = fmin[8]
+        q4[9] = fmax[10]
+        want = orc.scale_row(q4, 323, skip)
+        got = np.array([L.haf_test_scale_host(q4[k], fmin[k + 1], fmax[k + 1], lo, up) for k in range(323)])
+        assert (got == want).all()
+
+
+def test_parsers_match_oracle(data_dir, golden_dir):
+    L = capi.lib()
+    orc = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"),
+                   os.path.join(golden_dir, "surrogate.model"))
+    n = C.c_int()
+    reg = np.zeros((400, 16), np.int32)
+    w = np.zeros((400, 4), np.float32)
+    assert L.haf_test_feature_table(os.path.join(data_dir, "Features.txt").encode(), C.byref(n), reg.ctypes.data,
+                                    w.ctypes.data, 400) == 0
+    oreg, ow = orc.feature_table()
+    assert n.value == 324 and (reg[:324] == oreg).all() and (w[:324] == ow).all()
+
+    lo, up, mi = C.c_double(), C.c_double(), C.c_int()
+    fmin, fmax, pres = np.zeros(400), np.zeros(400), np.zeros(400, np.uint8)
+    assert L.haf_test_range_table(os.path.join(data_dir, "range21062012_allfeatures").encode(), C.byref(lo), C.byref(up),
+                                  C.byref(mi), fmin.ctypes.data, fmax.ctypes.data, pres.ctypes.data, 400) == 0
+    olo, oup, ofmin, ofmax, opres = orc.range_table()
+    assert (lo.value, up.value, mi.value) == (olo, oup, 323)
+    assert (fmin[:324] == ofmin).all() and (fmax[:324] == ofmax).all() and (pres[:324] == opres).all()
+
+    om = orc.model_arrays()
+    g, r, nsv, dim = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+    cls, lab = (C.c_int * 2)(), (C.c_int * 2)()
+    coef = np.zeros(om["l"])
+    sv = np.zeros((om["l"], om["D"]))
+    assert L.haf_test_model(os.path.join(golden_dir, "surrogate.model").encode(), C.byref(g), C.byref(r), C.byref(nsv),
+                            C.byref(dim), cls, lab, coef.ctypes.data, sv.ctypes.data, sv.size) == 0
+    assert (g.value, r.value, nsv.value, dim.value) == (om["gamma"], om["rho"], om["l"], om["D"])
+    assert tuple(cls) == om["nSV"] and tuple(lab) == om["label"]
+    assert (coef == om["coef"]).all() and (sv == om["sv"]).all()
+
+
+def test_feature_file_trailing_line_quirks(tmp_path):
+    """fv.cpp:60-82: a final EMPTY line adds a phantom all-zero feature; a last line WITHOUT newline is dropped."""
+    L = capi.lib()
+    row = "\t".join(["1", "2", "3", "4"] * 4 + ["1", "-1", "2", "5"])
+    reg = np.zeros((8, 16), np.int32)
+    w = np.zeros((8, 4), np.float32)
+    n = C.c_int()
+    for text, expect in [(row + "\n" + row + "\n", 2), (row + "\n" + row + "\n\n", 3), (row + "\n" + row, 1)]:
+        p = tmp_path / "f.txt"
+        p.write_text(text)
+        assert L.haf_test_feature_table(str(p).encode(), C.byref(n), reg.ctypes.data, w.ctypes.data, 8) == 0
+        assert n.value == expect
+        oft = O.lib().hafo_features_load(str(p).encode())
+        assert oft.contents.n == expect
+    assert w[0, 3] == 0.0 and w[0, 2] == 2.0      # 4th weight dropped
+
+
+def test_pcd_reader_matches_test_reader(data_dir):
+    for name in sorted(os.listdir(data_dir)):
+        if name.endswith(".pcd"):
+            a = capi.load_pcd(os.path.join(data_dir, name))
+            b = pcdio.load_pcd(os.path.join(data_dir, name))
+            assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all(), name
+
+
+INPUTS = [dict(), dict(grasp_area_center=(0.13, 0.25, 0.02), grasp_area_length_x=56, grasp_area_length_y=56),
+          dict(approach_vector=(0.2, -0.1, 1.0)), dict(approach_vector=(0.0, 0.0, -2.0), gripper_opening_width=2),
+          dict(approach_vector=(1.0, 1.0, 0.3), grasp_area_center=(-0.05, 0.01, 0.1), grasp_area_length_x=47.9)]
+
+
+def _oracle_input(kw):
+    return O.make_input(center=kw.get("grasp_area_center", (0, 0, 0)), length_x=kw.get("grasp_area_length_x", 32),
+                        length_y=kw.get("grasp_area_length_y", 44), approach=kw.get("approach_vector", (0, 0, 1)),
+                        show_only_best=kw.get("show_only_best_grasp", 0), gripper_width=kw.get("gripper_opening_width", 1))
+
+
+@pytest.mark.parametrize("kw", INPUTS)
+@pytest.mark.parametrize("step,rolls", [(15, 12), (9, 20), (5, 36)])
+def test_roll_geometry_matches_oracle(kw, step, rolls):
+    L = capi.lib()
+    cfg = capi.default_config(n_rolls=rolls, roll_step_deg=step)
+    gi = capi.default_input(**kw)
+    ocfg = O.make_cfg(n_rolls=rolls, roll_step_deg=step)
+    oin = _oracle_input(kw)
+    for roll in range(rolls):
+        out = np.zeros(22, np.float32)
+        m16 = np.zeros(16, np.float32)
+        m16p = np.zeros(16, np.float32)
+        L.haf_test_roll_geo(C.byref(cfg), C.byref(gi), roll, out.ctypes.data, m16.ctypes.data, m16p.ctypes.data)
+        om = np.zeros(16, np.float32)
+        O.lib().hafo_transform(C.byref(ocfg), C.byref(oin), roll, 0, om.ctypes.data)
+        assert (m16.view(np.uint32) == om.view(np.uint32)).all()
+        assert (out[:12].view(np.uint32) == om[:12].view(np.uint32)).all()
+        O.lib().hafo_transform(C.byref(ocfg), C.byref(oin), roll, 1, om.ctypes.data)
+        assert (m16p.view(np.uint32) == om.view(np.uint32)).all()
+
+
+def test_finalize_matches_oracle_pose(data_dir, golden_dir):
+    """Cross-roll rule + pose (host code) from the ORACLE's per-roll winners and height grids."""
+    L = capi.lib()
+    orc = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"),
+                   os.path.join(golden_dir, "surrogate.model"))
+    cases = [("pcd2", dict(grasp_area_length_x=32, grasp_area_length_y=32)),
+             ("pcd2", dict(grasp_area_length_x=32, grasp_area_length_y=32, show_only_best_grasp=1)),
+             ("pcd2", dict(approach_vector=(0.2, -0.1, 1.0))), ("pcd6", dict()), ("pcd7", dict()),
+             ("plastic_mug2", dict(grasp_area_center=(0.02, 0.0, 0.0)))]
+    for name, kw in cases:
+        xyz = pcdio.load_pcd(os.path.join(data_dir, name + ".pcd"))
+        ocfg = O.make_cfg()
+        r = orc.run(xyz, ocfg, _oracle_input(kw))
+        rec = np.zeros(12, capi.ROLL_RECORD_DTYPE)
+        for roll in range(12):
+            row, col, val = r["roll_best"][roll]
+            if val == -1 and row == -1:         # roll not executed by the oracle (early exit): any content will do
+                continue
+            h = r["heights"][roll]
+            win = h[max(0, row - 4):row + 5, max(0, col - 4):col + 4]
+            rec[roll] = (val, row, col, max(np.float32(-10.0), win.max()), int(r["mask"][roll].sum()))
+        if kw.get("show_only_best_grasp"):
+            # rolls the oracle skipped must not matter: poison them
+            for roll in range(r["rolls_done"], 12):
+                rec[roll] = (123, 5, 5, 9.0, 0)
+        out = capi.GraspOutput()
+        assert L.haf_test_finalize(C.byref(capi.default_config()), C.byref(capi.default_input(**kw)), rec.ctypes.data,
+                                   C.byref(out)) == 0
+        assert (out.eval, out.best_row, out.best_col, out.best_roll, out.best_vote) == \
+               (r["eval"], r["row"], r["col"], r["roll_idx"], r["top"]), name
+        assert out.rolls_done == r["rolls_done"]
+        np.testing.assert_allclose(tuple(out.grasp_point1), r["gp1"], atol=1e-6)
+        np.testing.assert_allclose(tuple(out.grasp_point2), r["gp2"], atol=1e-6)
+        np.testing.assert_allclose(tuple(out.averaged_grasp_point), r["avg"], atol=1e-6)
+        np.testing.assert_allclose(tuple(out.approach_vector), r["av"], atol=1e-7)
+        assert out.roll == r["roll"]
