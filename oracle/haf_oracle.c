@@ -532,11 +532,11 @@ void hafo_scale_row(const hafo_range *rg, const unsigned char *skip, const doubl
 /* ------------------------------------------------------------------ */
 /* a8: RBF decision (svm.cpp:325-365, 2478-2532)                       */
 /* ------------------------------------------------------------------ */
-static double decision_nx(const hafo_model *m, const double *xs, int nx)
+static double decision_nx2(const hafo_model *m, const double *xs, int nx, double *sabs_out)
 {
     const int D = m->D;
     const int K = nx > D ? nx : D;
-    double dec = 0;
+    double dec = 0, sabs = 0;
     for (int i = 0; i < m->l; i++) {
         const double *sv = m->sv + (size_t)i * D;
         double sum = 0;
@@ -545,11 +545,16 @@ static double decision_nx(const hafo_model *m, const double *xs, int nx)
             double d = xv - yv;
             sum += d * d;
         }
-        dec += m->coef[i] * exp(-m->gamma * sum);   /* 2509-2512 */
+        double kv = exp(-m->gamma * sum);
+        dec += m->coef[i] * kv;                     /* 2509-2512 */
+        sabs += fabs(m->coef[i]) * kv;              /* not part of the reference: error scale for the tests */
     }
     dec -= m->rho;                                  /* 2513 */
+    if (sabs_out) *sabs_out = sabs;
     return dec;
 }
+
+static double decision_nx(const hafo_model *m, const double *xs, int nx) { return decision_nx2(m, xs, nx, NULL); }
 
 double hafo_decision(const hafo_model *m, const double *xs) { return decision_nx(m, xs, m->D); }
 
@@ -719,7 +724,9 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
         if (dbg && dbg->dec) for (int i = 0; i < H * W; i++) dbg->dec[(size_t)roll * H * W + i] = NAN;
         for (long r = 0; r < rows; r++) {
             scale_row(rg->lower, rg->upper, fmin, fmax, q4 + (size_t)r * nf, nf, cfg->skip_text, xs, nx);
-            double dec = decision_nx(m, xs, nx);
+            double sabs = 0;
+            double dec = decision_nx2(m, xs, nx, &sabs);
+            if (dbg && dbg->sabs) dbg->sabs[(size_t)roll * H * W + cells[r]] = sabs;
             int label = dec > 0 ? m->label[0] : m->label[1];       /* svm.cpp:2516-2531 */
             grid[cells[r]] = (signed char)(label == m->label[0] ? gv0 : gv1);
             if (dbg && dbg->dec) dbg->dec[(size_t)roll * H * W + cells[r]] = dec;

@@ -106,6 +106,7 @@ typedef struct {
     float         *graspseval; /* [R][H][W]    */
     int           *roll_best;  /* [R][3] row, col, val after run-centring */
     float         *M;          /* [R][16] row-major transform */
+    double        *sabs;       /* [R][H][W] sum_n |coef_n| K_n: the cancellation scale of the decision value */
 } hafo_debug;
 
 /* ---- stage functions (each cites the reference lines it follows) ---- */

@@ -36,7 +36,8 @@ class Output(C.Structure):
 
 class Debug(C.Structure):
     _fields_ = [("heights", C.c_void_p), ("integral", C.c_void_p), ("mask", C.c_void_p), ("labels", C.c_void_p),
-                ("dec", C.c_void_p), ("graspseval", C.c_void_p), ("roll_best", C.c_void_p), ("M", C.c_void_p)]
+                ("dec", C.c_void_p), ("graspseval", C.c_void_p), ("roll_best", C.c_void_p), ("M", C.c_void_p),
+                ("sabs", C.c_void_p)]
 
 
 class Features(C.Structure):
@@ -194,9 +195,10 @@ class Oracle:
             arrays = dict(heights=np.zeros((R, H, W), np.float32), integral=np.zeros((R, H + 1, W + 1), np.float32),
                           mask=np.zeros((R, H, W), np.uint8), labels=np.full((R, H, W), -1, np.int8),
                           dec=np.full((R, H, W), np.nan, np.float64), graspseval=np.zeros((R, H, W), np.float32),
-                          roll_best=np.full((R, 3), -1, np.int32), M=np.zeros((R, 16), np.float32))
+                          roll_best=np.full((R, 3), -1, np.int32), M=np.zeros((R, 16), np.float32),
+                          sabs=np.zeros((R, H, W), np.float64))
             dbg = Debug(*[_p(arrays[k]) for k in ("heights", "integral", "mask", "labels", "dec", "graspseval",
-                                                  "roll_best", "M")])
+                                                  "roll_best", "M", "sabs")])
         rc = lib().hafo_run(C.byref(cfg), self.ft, self.rg, self.m, _p(xyz), xyz.shape[0], xyz.shape[1],
                             C.byref(inp), C.byref(out), C.byref(dbg) if dbg else None)
         if rc != 0:

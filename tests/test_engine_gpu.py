@@ -1,8 +1,11 @@
 """GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle on the same inputs.
 
 Bars (north_star / SURVEY.md §8d): height grid, integral image, mask, label grid, per-roll winners, overall
-(row, col, roll) and eval BIT-EXACT / identical; decision values within 1e-4 of the fp64 oracle wherever the
-fast path is used (exact to ~1e-12 where the guard band re-evaluates); grasp points within 1e-4 m."""
+(row, col, roll) and eval BIT-EXACT / identical; grasp points within 1e-4 m.  Decision values: the fast path is an
+fp32 contraction, so its error scales with the cancellation in the sum, S = sum_n |coef_n| K_n: the bar is
+|dec - dec_oracle| <= 2^-20 * S + 1e-6 (that is <= 1e-4 whenever S <= 100, e.g. the seeded random models; the
+surrogate model trained with C = 512 has S up to 7e3), and <= 1e-12 * S where the guard band re-evaluated in fp64.
+Labels are exact in every case because |dec| <= 2^-15 * S is always re-evaluated in libsvm's own order."""
 import ctypes as C
 import json
 import os
@@ -18,7 +21,9 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-DEC_TOL = 1e-4
+DEC_REL = 2.0 ** -20      # of S = sum |coef| K
+DEC_ABS = 1e-6
+STATS = {}
 
 
 def _files(data_dir):
@@ -69,8 +74,10 @@ def compare_full(eng, orc, xyz, cfg_kw, in_kw, check_dec=True):
             msk = want["mask"][roll] == 1
             assert np.isnan(d[~msk]).all()
             if msk.any():
-                err = np.abs(d[msk] - want["dec"][roll][msk]).max()
-                assert err <= DEC_TOL, ("decision", roll, err)
+                err = np.abs(d[msk] - want["dec"][roll][msk])
+                bound = DEC_REL * want["sabs"][roll][msk] + DEC_ABS
+                assert (err <= bound).all(), ("decision", roll, float((err / bound).max()))
+                STATS["max_rel_err"] = max(STATS.get("max_rel_err", 0.0), float((err / want["sabs"][roll][msk]).max()))
         ev, _ = eng.roll_grid(0, roll)
         assert (ev == want["graspseval"][roll]).all(), ("vote grid", roll)
     for k_e, k_o in [("eval", "eval"), ("best_row", "row"), ("best_col", "col"), ("best_roll", "roll_idx"),
@@ -275,8 +282,25 @@ def test_full_size_c5_properties(data_dir, tmp_path):
     eng = make_engine(data_dir, path, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
     inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
     rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
-    assert int(rec["n_evals"].sum()) == 7883478 and int(rec["n_evals"][0]) == 248004
-    assert (rec["n_evals"][:18] == rec["n_evals"][18:]).all()   # square area: rolls r and r+18 (90 degrees apart) mask alike
+    # 7 883 478 is the pure-geometry bound (every 9x9 neighbourhood non-empty); 248 004 at 0 degrees
+    assert int(rec["n_evals"][0]) == 248004 and 7800000 < int(rec["n_evals"].sum()) <= 7883478
+    assert (rec["n_evals"][1:18] == rec["n_evals"][19:]).all()       # square area: rolls r and r+18 are 90 degrees apart
+    # stages a1-a3 for EVERY roll against the oracle's stage functions (cheap on the CPU even at this size)
+    ocfg = O.make_cfg(H=512, W=512, n_rolls=36, roll_step_deg=5)
+    oin = O.make_input(length_x=512, length_y=512)
+    M = np.zeros(16, np.float32)
+    oh = np.zeros((512, 512), np.float32)
+    oii = np.zeros((513, 513), np.float32)
+    om = np.zeros((512, 512), np.uint8)
+    for roll in range(36):
+        O.lib().hafo_transform(C.byref(ocfg), C.byref(oin), roll, 0, M.ctypes.data)
+        O.lib().hafo_height_grid(C.byref(ocfg), xyz.ctypes.data, xyz.shape[0], 3, M.ctypes.data, oh.ctypes.data)
+        O.lib().hafo_integral(C.byref(ocfg), oh.ctypes.data, oii.ctypes.data)
+        O.lib().hafo_mask(C.byref(ocfg), C.byref(oin), roll, oii.ctypes.data, om.ctypes.data)
+        assert (eng.debug(capi.DBG_HEIGHTS, 0, roll).view(np.uint32) == oh.view(np.uint32)).all(), roll
+        assert (eng.debug(capi.DBG_INTEGRAL, 0, roll).view(np.uint32) == oii.view(np.uint32)).all(), roll
+        assert (eng.debug(capi.DBG_MASK, 0, roll) == om).all(), roll
+        assert int(om.sum()) == int(rec["n_evals"][roll])
     rng = np.random.RandomState(9)
     m = o.model_arrays()
     lo, up, fmin, fmax, _ = o.range_table()
@@ -295,7 +319,7 @@ def test_full_size_c5_properties(data_dir, tmp_path):
             d = o.decision(xs)
             want = m["label"][0] if d > 0 else m["label"][1]
             assert lab[i, j] == want, (roll, i, j, d, dec[i, j])
-            assert abs(dec[i, j] - d) <= DEC_TOL
+            assert abs(dec[i, j] - d) <= 1e-4
     rec2 = eng.score_rolls([xyz], [inp], 0, 36)[0]
     assert (rec == rec2).all()
     parts = np.concatenate([eng.score_rolls([xyz], [inp], a, 9)[0] for a in (0, 9, 18, 27)])
