@@ -30,6 +30,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 D_ATTR = 323                       # algorithmic work 2*D*nSV flop per eval, D unpadded
 
 
+def pmc_traffic(args):
+    """HBM bytes per k_svm_rbf launch from the committed rocprofv3 --pmc passes (profiles/), when they were taken on
+    this exact workload; PMC counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["grid"], w["rolls"], w["n_sv"]) == (args.grid, args.rolls, args.nsv):
+            return t["kernels"]["k_svm_rbf"]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,15 +132,14 @@ def main():
     d_xyz = torch.from_numpy(xyz).cuda()                    # resident in HBM before the timed region
     cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
     inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
-    key = torch.zeros(1, dtype=torch.int64, device="cuda")
+    from haf_grasping_amd import distributed as hd
 
     def step():
         rec = eng.score_rolls([cloud], [inp], 0, args.rolls)[0]
         out = eng.finalize(inp, rec)
         if world > 1:
-            # best grasp of the batch: one all-reduce(max) of (vote, -rank) packed into 8 bytes, over xGMI
-            key[0] = (int(out["best_vote"]) + 1000) * 1024 + (1023 - rank)
-            dist.all_reduce(key, op=dist.ReduceOp.MAX)
+            # best grasp of the batch: one 8-byte all-reduce(max) over xGMI (RCCL)
+            hd.best_of_batch(out["best_vote"], tag=rank, device="cuda")
         return rec, out
 
     def fence():
@@ -177,7 +191,7 @@ def main():
                        "evals_per_cloud": int(evals_per_launch), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
                        "sharding": "clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step"},
             "roofline": {"kernel": "k_svm_rbf", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args),
                          "kernel_ms": svm_s * 1e3, "flop_per_launch": flop},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
             "rechecked_per_step": rechecked / args.steps,

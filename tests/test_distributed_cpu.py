@@ -1,0 +1,75 @@
+"""world_size-2 gloo test of the multi-GPU logic: roll shards gathered with one all-gather + the cross-roll rule /
+pose (host code of the product) reproduce the unsharded answer; one all-reduce(max) elects the best grasp of a batch.
+Roll records come from the oracle here (no GPU in this test); on the GPU box test_engine_gpu.py checks that
+haf_score_rolls shards compose to the same records."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch.multiprocessing as mp
+
+import pcdio
+from haf_grasping_amd import capi, distributed
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+def oracle_records(name, n_rolls, step, show_best):
+    orc = O.Oracle(os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_allfeatures"),
+                   os.path.join(ROOT, "tests", "golden", "surrogate.model"))
+    xyz = pcdio.load_pcd(os.path.join(DATA, name + ".pcd"))
+    full = orc.run(xyz, O.make_cfg(n_rolls=n_rolls, roll_step_deg=step), O.make_input(length_x=32, length_y=44))
+    rec = np.zeros(n_rolls, capi.ROLL_RECORD_DTYPE)
+    for roll in range(n_rolls):
+        row, col, val = full["roll_best"][roll]
+        win = full["heights"][roll][max(0, row - 4):row + 5, max(0, col - 4):col + 4]
+        rec[roll] = (val, row, col, max(np.float32(-10.0), win.max()), int(full["mask"][roll].sum()))
+    want = orc.run(xyz, O.make_cfg(n_rolls=n_rolls, roll_step_deg=step),
+                   O.make_input(length_x=32, length_y=44, show_only_best=show_best), debug=False)
+    return rec, want
+
+
+def worker(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n_rolls, step = 9, 20
+        for show_best in (0, 1):
+            rec, want = oracle_records("pcd2", n_rolls, step, show_best)
+            first, count = distributed.roll_shard(n_rolls, world, rank)
+            local = rec[None, first:first + count]                      # this rank's rolls only
+            full = distributed.gather_roll_records(local, n_rolls)
+            assert (full[0] == rec).all()
+            out = capi.GraspOutput()
+            cfg = capi.default_config(n_rolls=n_rolls, roll_step_deg=step)
+            gi = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44, show_only_best_grasp=show_best)
+            assert capi.lib().haf_test_finalize(C.byref(cfg), C.byref(gi), full[0].ctypes.data, C.byref(out)) == 0
+            assert (out.eval, out.best_row, out.best_col, out.best_roll, out.rolls_done) == \
+                   (want["eval"], want["row"], want["col"], want["roll_idx"], want["rolls_done"])
+            np.testing.assert_allclose(tuple(out.grasp_point1), want["gp1"], atol=1e-6)
+        vote, tag = distributed.best_of_batch(100 + rank, tag=rank)
+        assert (vote, tag) == (100 + world - 1, world - 1)
+        vote, tag = distributed.best_of_batch(77, tag=rank)                 # tie: smaller tag wins
+        assert (vote, tag) == (77, 0)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_roll_shards_and_batch_election_world2():
+    assert [distributed.roll_shard(36, 8, r) for r in range(8)] == \
+           [(0, 5), (5, 5), (10, 5), (15, 5), (20, 4), (24, 4), (28, 4), (32, 4)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
