@@ -461,9 +461,13 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
 // ---------------------------------------------------------------------------------------------------
 // a8 exact: guard-band evaluations re-done in libsvm's own order: d2 summed over attributes in index order in
 // fp64 without fusion (svm.cpp:327-364), K = exp(-gamma*d2), decision summed over SVs in model order (2509-2513).
-// One workgroup per flagged evaluation; rare, so simplicity over speed.
+// A workgroup takes kRB flagged evaluations at once: their attribute vectors sit in LDS (broadcast reads), each
+// thread owns one support vector of the current 256-SV chunk and streams its fp64 column ONCE for all kRB
+// evaluations (kRB-fold less L2 traffic than one evaluation per workgroup); the 256 products coef*K of a chunk go
+// to LDS and one thread per evaluation adds them in model order, carrying the running sum across chunks.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kExactChunk = 2048;
+constexpr int kRB = 16;
+constexpr int kRChunk = 256;
 
 __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                  const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
@@ -472,48 +476,66 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
                                                  const int *__restrict__ counters, double *__restrict__ dec_exact,
                                                  int8_t *__restrict__ labels, Dims d)
 {
-    __shared__ double xs[kKP + 4];
-    __shared__ double terms[kExactChunk];
-    __shared__ double run_sum;
+    __shared__ double xs[kRB][kKP];
+    __shared__ double terms[kRB][kRChunk + 1];
+    __shared__ double run_sum[kRB];
     int n_flag = counters[CNT_FLAGGED];
     if (n_flag > flag_cap) n_flag = flag_cap;
+    const int n_groups = (n_flag + kRB - 1) / kRB;
     const int H = d.H, W = d.W, W1 = W + 1;
-    for (int slot = blockIdx.x; slot < n_flag; slot += gridDim.x) {
-        const int e = flag_list[slot];
-        const int cell = evalcell[e];
-        const int br = cell / (H * W);
-        const int rem = cell - br * H * W;
-        const int i = rem / W, j = rem - i * W;
-        const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
-        for (int f = threadIdx.x; f < p.kx; f += blockDim.x) {
+    const int tid = threadIdx.x;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        for (int it = tid; it < kRB * p.kx; it += 256) {
+            const int ev = it / p.kx, f = it - ev * p.kx;
+            const int slot = g * kRB + ev;
             double x = 0.0;
-            if (f < d.nf && !fd[f].skip) x = attribute_value(win, fd[f], p.lower, p.upper);
-            xs[f] = x;
+            if (slot < n_flag && f < d.nf && !fd[f].skip) {
+                const int cell = evalcell[flag_list[slot]];
+                const int br = cell / (H * W);
+                const int rem = cell - br * H * W;
+                const int i = rem / W, j = rem - i * W;
+                const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+                x = attribute_value(win, fd[f], p.lower, p.upper);
+            }
+            xs[ev][f] = x;
         }
-        if (threadIdx.x == 0) run_sum = 0.0;
+        if (tid < kRB) run_sum[tid] = 0.0;
         __syncthreads();
-        for (int n0 = 0; n0 < p.n_sv; n0 += kExactChunk) {
-            for (int n = n0 + threadIdx.x; n < min(p.n_sv, n0 + kExactChunk); n += blockDim.x) {
-                double sum = 0.0;
+        for (int n0 = 0; n0 < p.n_sv; n0 += kRChunk) {
+            const int n = n0 + tid;
+            if (n < p.n_sv) {
+                double sum[kRB];
+#pragma unroll
+                for (int ev = 0; ev < kRB; ev++) sum[ev] = 0.0;
+                const double *col = sv64 + n;
                 for (int k = 0; k < p.kx; k++) {
-                    double dd = __dsub_rn(xs[k], sv64[(size_t)k * p.n_sv_pad + n]);
-                    sum = __dadd_rn(sum, __dmul_rn(dd, dd));
+                    const double s = col[(size_t)k * p.n_sv_pad];
+#pragma unroll
+                    for (int ev = 0; ev < kRB; ev++) {
+                        double dd = __dsub_rn(xs[ev][k], s);
+                        sum[ev] = __dadd_rn(sum[ev], __dmul_rn(dd, dd));          // svm.cpp:333-334, 342, 347
+                    }
                 }
-                terms[n - n0] = __dmul_rn(coef64[n], exp(__dmul_rn(-p.gamma, sum)));
+                const double c = coef64[n];
+#pragma unroll
+                for (int ev = 0; ev < kRB; ev++) terms[ev][tid] = __dmul_rn(c, exp(__dmul_rn(-p.gamma, sum[ev])));
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                double s = run_sum;
-                int cnt = min(kExactChunk, p.n_sv - n0);
-                for (int n = 0; n < cnt; n++) s = __dadd_rn(s, terms[n]);
-                run_sum = s;
+            if (tid < kRB) {
+                double s = run_sum[tid];
+                const int cnt = min(kRChunk, p.n_sv - n0);
+                for (int q = 0; q < cnt; q++) s = __dadd_rn(s, terms[tid][q]);    // model order (2509-2512)
+                run_sum[tid] = s;
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            double dv = __dsub_rn(run_sum, p.rho);
-            dec_exact[slot] = dv;
-            labels[cell] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+        if (tid < kRB) {
+            const int slot = g * kRB + tid;
+            if (slot < n_flag) {
+                const double dv = __dsub_rn(run_sum[tid], p.rho);                 // 2513
+                dec_exact[slot] = dv;
+                labels[evalcell[flag_list[slot]]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+            }
         }
         __syncthreads();
     }
@@ -523,7 +545,8 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, double *dec_exact,
                     int8_t *labels, Dims d, hipStream_t s)
 {
-    int blocks = flag_cap < 2048 ? flag_cap : 2048;
+    int groups = (flag_cap + kRB - 1) / kRB;
+    int blocks = groups < 2048 ? groups : 2048;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_recheck, dim3(blocks), dim3(256), 0, s, ii, evalcell, fd, sv64, coef64, p, flag_list, flag_cap,
                        counters, dec_exact, labels, d);
