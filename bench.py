@@ -55,29 +55,40 @@ def parse():
     ap.add_argument("--rolls", type=int, default=36)
     ap.add_argument("--roll-step", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-crop", type=int, default=84, help="grid size of the CPU-baseline sample (one roll)")
+    ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
     return ap.parse_args()
 
 
 def cpu_baseline(feat, rng_file, model_path, xyz, args):
-    """The oracle (scalar C port of the reference's arithmetic incl. both text round trips) on a bounded sample of the
-    same workload: the central crop x crop cells of the same cloud, one roll, same model.  1 core."""
+    """The oracle (scalar C port of the reference's arithmetic incl. both text round trips, in-process) on a bounded
+    sample of the same workload: the central crop x crop cells of the same cloud, one roll, same model.  Timed on one
+    core and on all host cores (OpenMP over feature lines / rows); `value` is the all-cores figure."""
     from oracle import oracle as O
     o = O.Oracle(feat, rng_file, model_path)
-    c = args.cpu_crop
-    half = c * 0.01 / 2
-    sel = (np.abs(xyz[:, 0]) < half) & (np.abs(xyz[:, 1]) < half)
-    pts = np.ascontiguousarray(xyz[sel])
-    cfg = O.make_cfg(H=c, W=c, n_rolls=1, roll_step_deg=args.roll_step)
-    inp = O.make_input(length_x=c, length_y=c)
-    t0 = time.perf_counter()
-    r = o.run(pts, cfg, inp, debug=False)
-    dt = time.perf_counter() - t0
-    return dict(value=r["n_evals"] / dt, unit="evals/s", cores=1, kind="port",
-                sample="oracle/haf_oracle.c end to end (features, %%.4g/%%g text round trips, svm-scale, libsvm-order fp64 RBF "
-                       "over nSV=%d, vote) on the central %dx%d crop of the same cloud, 1 roll: %d evals in %.1f s"
-                       % (args.nsv, c, c, r["n_evals"], dt))
+
+    def run(c, threads):
+        half = c * 0.01 / 2
+        sel = (np.abs(xyz[:, 0]) < half) & (np.abs(xyz[:, 1]) < half)
+        pts = np.ascontiguousarray(xyz[sel])
+        os.environ["HAFO_THREADS"] = str(threads)
+        t0 = time.perf_counter()
+        r = o.run(pts, O.make_cfg(H=c, W=c, n_rolls=1, roll_step_deg=args.roll_step), O.make_input(length_x=c, length_y=c),
+                  debug=False)
+        return r["n_evals"], time.perf_counter() - t0
+
+    cores = len(os.sched_getaffinity(0))
+    n1, t1 = run(args.cpu_crop, 1)
+    per_core = n1 / t1
+    # all cores: size the crop for roughly 10 s of work
+    c_all = int(min(args.grid, 14 + (per_core * cores * 10.0) ** 0.5))
+    na, ta = run(c_all, cores)
+    os.environ["HAFO_THREADS"] = "1"
+    return dict(value=na / ta, unit="evals/s", cores=cores, kind="port", single_core_value=per_core,
+                sample="oracle/haf_oracle.c end to end (features, %%.4g/%%g text round trips, svm-scale, libsvm-order fp64 "
+                       "RBF over nSV=%d, vote), same cloud and model, 1 roll: central %dx%d crop on 1 core (%d evals in "
+                       "%.1f s), central %dx%d crop on %d cores (%d evals in %.1f s)"
+                       % (args.nsv, args.cpu_crop, args.cpu_crop, n1, t1, c_all, c_all, cores, na, ta))
 
 
 def latency_c2(feat, rng_file, device):

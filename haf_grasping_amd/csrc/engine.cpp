@@ -337,13 +337,20 @@ int build_tables(haf_engine *e)
     e->svm.two_gamma2 = (float)(2.0 * m.gamma * log2e);
     e->svm.neg_gamma2 = (float)(-m.gamma * log2e);
     e->svm.rho = (float)m.rho;
-    // Guard band: a fast decision is trusted when |dec| > guard * sum_n |coef_n| K_n + guard_abs.  2^-15 covers the
-    // worst-case fp32 error of the contraction (324-term fma chain, fp32 attributes, v_exp_f32) per unit of
-    // sum|coef|K; DESIGN.md "Guard band" derives it and tests/test_engine_gpu.py measures the margin.
-    double guard = 1.0 / 32768.0;
+    // Guard band: a fast decision is trusted when |dec| > guard * (1 + |a_x| + max|a_s|) * sum_n |coef_n| K_n + guard_abs,
+    // a_x = gamma'*|x|^2, a_s = gamma'*|s|^2.  2^-16 is the WORST-CASE fp32 error of the contraction per unit of that
+    // product (324-term fma chain bounded through Cauchy-Schwarz by 324*2^-24*(a_x+a_s), fp32 attributes, three
+    // roundings of the exp2 argument, v_exp_f32, fp32 coefficient sum): DESIGN.md §2 derives it, tools/diag_guard.py
+    // measures the actual error (about 30x smaller).  HAF_GUARD_REL overrides it for experiments.
+    double guard = 1.0 / 65536.0;
     if (const char *g = getenv("HAF_GUARD_REL")) guard = atof(g);
     e->svm.guard = (float)guard;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
+    {
+        double as_max = 0;
+        for (int n = 0; n < m.n_sv; n++) as_max = std::max(as_max, (double)std::fabs(svt[(size_t)(n / kTile) * kTileFloats + kKP * kTile + n % kTile]));
+        e->svm.as_max1 = (float)(1.0 + as_max);
+    }
     e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
     e->exact.gamma = m.gamma; e->exact.rho = m.rho;
     e->exact.lower = e->range.lower; e->exact.upper = e->range.upper;

@@ -52,8 +52,9 @@ struct SvmParams {
     float two_gamma2;             // 2*gamma*log2(e)
     float neg_gamma2;             // -gamma*log2(e)
     float rho;
-    float guard;                  // |dec| <= guard * sum|coef|K + guard_abs -> exact fp64 recheck
+    float guard;                  // |dec| <= guard * (as_max1 + |a_x|) * sum|coef|K + guard_abs -> exact fp64 recheck
     float guard_abs;
+    float as_max1;                // 1 + max_n gamma*log2(e)*|s_n|^2
     int   gv0, gv1;               // grid values of label[0] / label[1] (atoi of the "%g" label text, server.cpp:843)
 };
 

@@ -439,7 +439,9 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
                 float dv = part[r] - p.rho;
                 dec[e] = dv;
                 labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);      // svm.cpp:2516-2531
-                if (!(fabsf(dv) > p.guard * pabs[r] + p.guard_abs)) {            // guard band (also catches NaN)
+                // guard band: the fp32 error of the sum is at most guard * (1 + |a_x| + max|a_s|) * sum|coef|K
+                // (DESIGN.md §2); inside it the evaluation is repeated in exact fp64 libsvm order.  Also catches NaN.
+                if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axr[r])) * pabs[r] + p.guard_abs)) {
                     int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                     if (slot < flag_cap) flag_list[slot] = (int)e;
                 }

@@ -613,6 +613,12 @@ void hafo_vote(const hafo_cfg *cfg, const signed char *g, float *ev, int best[3]
 /* ------------------------------------------------------------------ */
 /* whole request (loop_control 335-402, transform_gp 1274-1421)        */
 /* ------------------------------------------------------------------ */
+static int hafo_threads(void)
+{
+    const char *t = getenv("HAFO_THREADS");
+    int n = t ? atoi(t) : 1;
+    return n < 1 ? 1 : n;
+}
 
 /* 4x4 inverse: Gauss-Jordan with partial pivoting in double, rounded to float (Eigen's order is unpinned) */
 static int mat4_inverse(const float *M, float *inv)
@@ -636,28 +642,31 @@ static int mat4_inverse(const float *M, float *inv)
     return 0;
 }
 
+static int hafo_threads(void);
+
 static void roll_features_q4(const hafo_cfg *cfg, const hafo_features *ft, const float *ii, const unsigned char *mask,
                              double **q4_out, long *rows_out, int **cells_out)
 {
     const int H = cfg->H, W = cfg->W, W1 = W + 1, nf = ft->n;
-    long cap = 0, rows = 0;
-    double *q4 = NULL; int *cells = NULL;
-    float *vals = (float *)malloc(sizeof(float) * (size_t)nf);
-    for (int row = 0; row < H - 14; row++)                         /* server.cpp:637-655 */
-        for (int col = 0; col < W - 14; col++) {
-            if (!mask[(row + 7) * W + (col + 7)]) continue;
-            if (rows == cap) {
-                cap = cap ? cap * 2 : 1024;
-                q4 = (double *)realloc(q4, sizeof(double) * (size_t)cap * (size_t)nf);
-                cells = (int *)realloc(cells, sizeof(int) * (size_t)cap);
-            }
+    long rows = 0;
+    int *cells = (int *)malloc(sizeof(int) * (size_t)(H > 14 ? (H - 14) * (W - 14) : 1));
+    for (int row = 0; row < H - 14; row++)                         /* server.cpp:637-643: row-major line order */
+        for (int col = 0; col < W - 14; col++)
+            if (mask[(row + 7) * W + (col + 7)]) cells[rows++] = (row + 7) * W + (col + 7);
+    double *q4 = (double *)malloc(sizeof(double) * (size_t)(rows ? rows : 1) * (size_t)nf);
+    /* one feature line per masked cell (645-653); lines are independent, so they may be produced in parallel */
+#pragma omp parallel num_threads(hafo_threads())
+    {
+        float *vals = (float *)malloc(sizeof(float) * (size_t)nf);
+#pragma omp for schedule(dynamic, 16)
+        for (long r = 0; r < rows; r++) {
+            const int row = cells[r] / W - 7, col = cells[r] % W - 7;
             hafo_feature_values(ft, cfg->nshaf, ii + row * W1 + col, W1, vals);
             for (int k = 0; k < nf; k++)
-                q4[(size_t)rows * nf + k] = cfg->skip_text ? (double)vals[k] : hafo_q4(vals[k]);
-            cells[rows] = (row + 7) * W + (col + 7);
-            rows++;
+                q4[(size_t)r * nf + k] = cfg->skip_text ? (double)vals[k] : hafo_q4(vals[k]);
         }
-    free(vals);
+        free(vals);
+    }
     *q4_out = q4; *rows_out = rows; *cells_out = cells;
 }
 
@@ -722,14 +731,22 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
 
         for (int i = 0; i < H * W; i++) grid[i] = -1;              /* 828-829 */
         if (dbg && dbg->dec) for (int i = 0; i < H * W; i++) dbg->dec[(size_t)roll * H * W + i] = NAN;
-        for (long r = 0; r < rows; r++) {
-            scale_row(rg->lower, rg->upper, fmin, fmax, q4 + (size_t)r * nf, nf, cfg->skip_text, xs, nx);
-            double sabs = 0;
-            double dec = decision_nx2(m, xs, nx, &sabs);
-            if (dbg && dbg->sabs) dbg->sabs[(size_t)roll * H * W + cells[r]] = sabs;
-            int label = dec > 0 ? m->label[0] : m->label[1];       /* svm.cpp:2516-2531 */
-            grid[cells[r]] = (signed char)(label == m->label[0] ? gv0 : gv1);
-            if (dbg && dbg->dec) dbg->dec[(size_t)roll * H * W + cells[r]] = dec;
+        /* rows are independent: the only parallel region of the oracle (HAFO_THREADS, default 1), used by the
+         * all-cores CPU baseline of bench.py; per-row arithmetic and its order are untouched */
+#pragma omp parallel num_threads(hafo_threads())
+        {
+            double *xs_t = (double *)malloc(sizeof(double) * (size_t)nx);
+#pragma omp for schedule(dynamic, 16)
+            for (long r = 0; r < rows; r++) {
+                scale_row(rg->lower, rg->upper, fmin, fmax, q4 + (size_t)r * nf, nf, cfg->skip_text, xs_t, nx);
+                double sabs = 0;
+                double dec = decision_nx2(m, xs_t, nx, &sabs);
+                if (dbg && dbg->sabs) dbg->sabs[(size_t)roll * H * W + cells[r]] = sabs;
+                int label = dec > 0 ? m->label[0] : m->label[1];       /* svm.cpp:2516-2531 */
+                grid[cells[r]] = (signed char)(label == m->label[0] ? gv0 : gv1);
+                if (dbg && dbg->dec) dbg->dec[(size_t)roll * H * W + cells[r]] = dec;
+            }
+            free(xs_t);
         }
         n_evals += rows;
         free(q4); free(cells); free(fmin); free(fmax);
