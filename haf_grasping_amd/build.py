@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhafgrasp.so")
 SOURCES = ["kernels.hip", "engine.cpp", "parsers.cpp"]
-HEADERS = ["kernels.h", "parsers.h", "decq.h", os.path.join("..", "..", "include", "hafgrasp.h")]
+HEADERS = ["kernels.h", "parsers.h", "decq.h", os.path.join("..", "..", "include", "hafgrasp.h"),
+           os.path.join("..", "cli", "haf_grasp_cli.cpp")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-Wno-inline-asm"]
@@ -34,6 +35,13 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    # ROS-free command line front end (C++ host code over the C-ABI)
+    cli = os.path.join(HERE, "haf_grasp_cli")
+    cmd = [hipcc, "-O2", "-std=c++17", os.path.join(HERE, "cli", "haf_grasp_cli.cpp"), "-o", cli, "-L" + HERE, "-lhafgrasp",
+           "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -327,3 +327,26 @@ def test_full_size_c5_properties(data_dir, tmp_path):
     out = eng.finalize(inp, rec)
     assert out["best_vote"] == rec["vote"].max() and out["best_roll"] == int(np.argmax(rec["vote"]))
     eng.close()
+
+
+def test_cli_and_server_mirror(data_dir, golden_dir, surrogate):
+    """The C++ command-line front end (client parameter surface, client.cpp:79-118) and the Python mirror of the action
+    interface give the golden answer for the README demo cloud."""
+    import subprocess
+    from haf_grasping_amd import CalcGraspPointsServer, GraspInputMsg
+    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+        g = json.load(f)["pcd2/C2"]
+    f_, r_ = _files(data_dir)
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "haf_grasp_cli")
+    out = subprocess.run([cli, "--features", f_, "--range", r_, "--model", surrogate, "--search-size", "18", "18",
+                          os.path.join(data_dir, "pcd2.pcd")], check=True, capture_output=True, text=True)
+    tok = out.stdout.split()
+    assert int(tok[0]) == g["eval"] and int(tok[13]) == g["roll_idx"] * 15          # 18 + 14 = 32 cm search area
+    np.testing.assert_allclose([float(t) for t in tok[1:4]], g["gp1"], atol=1e-4)
+    srv = CalcGraspPointsServer(f_, r_, surrogate)
+    res = srv.execute(GraspInputMsg(input_pc=capi.load_pcd(os.path.join(data_dir, "pcd2.pcd")),
+                                    grasp_area_length_x=32, grasp_area_length_y=32))
+    assert res.eval == g["eval"] and res.frame_id == "/base_link"
+    np.testing.assert_allclose(res.graspPoint2, g["gp2"], atol=1e-4)
+    assert res.hypothesis_string().split()[0] == str(g["eval"])
+    srv.close()
