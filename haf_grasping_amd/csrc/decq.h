@@ -5,17 +5,23 @@
 // "%g" (svm-scale.c:350) and svm-predict re-reads it with strtod (svm-predict.c:108).  Each round trip is
 //      x  ->  N * 10^q   (N = the P most significant decimal digits of x, round-half-even on the EXACT
 //                         binary value, as glibc printf does)  ->  nearest double to N * 10^q (strtod).
-// haf_decq(x, P) computes that double without ever forming text:
+// decq(x, P) computes that double without ever forming text:
 //   * N comes from an exact product/quotient: x*10^k as an unevaluated sum hi+lo (one multiply + one fma)
 //     or x/10^j as quotient + exact fma remainder, so ties and near-ties are decided exactly;
-//   * the result N*10^j or N/10^k is ONE IEEE operation on exactly representable operands, hence correctly
-//     rounded, which is what strtod returns.
+//   * the result N*10^j or N/10^k is ONE correctly rounded IEEE operation on exactly representable operands,
+//     which is what strtod returns.
 // This is exact whenever |k|, |j| <= 22 (10^22 is the largest exact power of ten in binary64), i.e. for
 // 1e-19 <= |x| < 1e26 (P=4) and 1e-17 <= |x| < 1e28 (P=6).  Outside that window (never reached by height
 // data in metres) a double-double evaluation is used whose decision can differ from glibc only when x lies
-// within ~1e-30 relative of a rounding boundary; tests/test_decq.py exercises both windows against glibc.
+// within ~1e-30 relative of a rounding boundary; tests/test_host_cpu.py exercises both windows against glibc.
 //
-// The same source is compiled for the device (kernels.hip) and for the host (decq_host.cpp -> unit tests).
+// Two code paths, same results: a branch-light FAST path for 10^(P-23) <= ... the common magnitudes
+// (1 <= k <= 22: both candidate decimal exponents evaluated, no loop, no per-lane-divergent switch, the final
+// division N/10^k done as q = N*y, q += fma(-q, T, N)*y with y = RN(10^-k) -- verified EXHAUSTIVELY equal to
+// IEEE division for every N in [10^3,10^4] U [10^5,10^6] and k in 0..22, tools/divtest.c), and the general SLOW path
+// (loops, true divisions) for everything else.
+//
+// The same source is compiled for the device (kernels.hip) and for the host (engine.cpp -> unit tests).
 #pragma once
 
 #include <math.h>
@@ -24,36 +30,55 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HAF_HD __host__ __device__ __forceinline__
+#define HAF_HD_NOINLINE static __host__ __device__ __attribute__((noinline))
 #else
 #define HAF_HD inline
+#define HAF_HD_NOINLINE inline
 #endif
 
 namespace hafq {
 
+#define HAFQ_P10_LIST                                                                                              \
+    1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, \
+        1e20, 1e21, 1e22
+#define HAFQ_P10INV_LIST                                                                                                 \
+    1e-0, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9, 1e-10, 1e-11, 1e-12, 1e-13, 1e-14, 1e-15, 1e-16, 1e-17, \
+        1e-18, 1e-19, 1e-20, 1e-21, 1e-22
+// 10^k exactly (k <= 22) and RN(10^-k): a decimal literal IS the correctly rounded double of its value
+static const double kP10_host[23] = {HAFQ_P10_LIST};
+static const double kP10inv_host[23] = {HAFQ_P10INV_LIST};
+#if defined(__HIP__)
+__device__ static const double kP10_dev[23] = {HAFQ_P10_LIST};
+__device__ static const double kP10inv_dev[23] = {HAFQ_P10INV_LIST};
+#endif
+
 HAF_HD double pow10_exact(int k)   // 0 <= k <= 22
 {
-    // switch keeps the constants in the instruction stream on the device (no constant-memory table needed)
-    switch (k) {
-        case 0: return 1e0;   case 1: return 1e1;   case 2: return 1e2;   case 3: return 1e3;
-        case 4: return 1e4;   case 5: return 1e5;   case 6: return 1e6;   case 7: return 1e7;
-        case 8: return 1e8;   case 9: return 1e9;   case 10: return 1e10; case 11: return 1e11;
-        case 12: return 1e12; case 13: return 1e13; case 14: return 1e14; case 15: return 1e15;
-        case 16: return 1e16; case 17: return 1e17; case 18: return 1e18; case 19: return 1e19;
-        case 20: return 1e20; case 21: return 1e21; default: return 1e22;
-    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kP10_dev[k];
+#else
+    return kP10_host[k];
+#endif
+}
+HAF_HD double pow10_inv(int k)     // RN(10^-k), 0 <= k <= 22
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kP10inv_dev[k];
+#else
+    return kP10inv_host[k];
+#endif
 }
 
-// round-half-even of the exact positive value hi+lo (|lo| <= ulp(hi)/2, hi < 2^52)
+// round-half-even of the exact positive value hi+lo (|lo| <= ulp(hi)/2, hi < 2^52), branch-free
 HAF_HD double rhe(double hi, double lo)
 {
     double fl = floor(hi);
     double frac = hi - fl;                 // exact
-    if (frac > 0.5) return fl + 1.0;
-    if (frac < 0.5) return fl;             // also covers frac == 0 with lo < 0: nearest integer is still fl
-    if (lo > 0.0) return fl + 1.0;
-    if (lo < 0.0) return fl;
-    double half = fl * 0.5;                // exact tie: to even
-    return (floor(half) == half) ? fl : fl + 1.0;
+    double half = fl * 0.5;
+    bool odd = floor(half) != half;
+    // frac < 0.5 (incl. frac == 0 with lo < 0): nearest integer is fl; exact tie only when frac == 0.5 and lo == 0
+    bool up = (frac > 0.5) || ((frac == 0.5) && ((lo > 0.0) || ((lo == 0.0) && odd)));
+    return up ? fl + 1.0 : fl;
 }
 
 struct dd { double hi, lo; };
@@ -79,7 +104,7 @@ HAF_HD dd dd_div_d(dd a, double b)        // (a.hi + a.lo) / b, double-double
     return o;
 }
 
-// Slow path: |k| > 22.  Scales by 10^22 repeatedly in double-double.
+// |k| > 22: scales by 10^22 repeatedly in double-double (not proven exact, see header)
 HAF_HD double decq_wide(double a, int P, int e)
 {
     const double lo_bound = pow10_exact(P - 1), hi_bound = pow10_exact(P);
@@ -103,12 +128,11 @@ HAF_HD double decq_wide(double a, int P, int e)
     return a;
 }
 
-// |x| -> nearest double to the P-significant-digit decimal nearest to |x| (see file header).
-HAF_HD double decq_abs(double a, int P)
+// General (slow) path: any positive finite a.
+HAF_HD_NOINLINE double decq_abs_slow(double a, int P)
 {
-    // decimal exponent estimate from the binary exponent: floor(log10(a)) is e0 or e0+1
     int b = ilogb(a);
-    int e = (b * 1233) >> 12;              // floor(b*log10(2)) for |b| < 1100 (checked in tests)
+    int e = (b * 1233) >> 12;              // floor(b*log10(2)) for |b| < 1100; floor(log10(a)) is e or e+1
     const double lo_bound = pow10_exact(P - 1), hi_bound = pow10_exact(P);
     for (int iter = 0; iter < 3; iter++) {
         int k = P - 1 - e;                 // t = a * 10^k in [10^(P-1), 10^P)
@@ -134,6 +158,33 @@ HAF_HD double decq_abs(double a, int P)
     return a;
 }
 
+// |x| -> nearest double to the P-significant-digit decimal nearest to |x| (see file header); P is 4 or 6.
+HAF_HD double decq_abs(double a, int P)
+{
+    const int b = ilogb(a);
+    const int e = (b * 1233) >> 12;
+    const int k0 = P - 1 - e;              // the true scale exponent is k0 or k0 - 1
+    if (k0 >= 1 && k0 <= 22) {
+        const double lo_bound = pow10_exact(P - 1), hi_bound = pow10_exact(P);
+        const double T0 = pow10_exact(k0), T1 = pow10_exact(k0 - 1);
+        const double h0 = a * T0, l0 = fma(a, T0, -h0);      // exact: a*T0 = h0 + l0
+        const double h1 = a * T1, l1 = fma(a, T1, -h1);
+        const bool up = (h0 > hi_bound) || ((h0 == hi_bound) && (l0 >= 0.0));    // a*10^k0 >= 10^P: one decade up
+        const double hi = up ? h1 : h0, lo = up ? l1 : l0;
+        const int k = up ? k0 - 1 : k0;
+        const bool below = (hi < lo_bound) || ((hi == lo_bound) && (lo < 0.0));
+        const bool above = (hi > hi_bound) || ((hi == hi_bound) && (lo >= 0.0));
+        if (!(below || above)) {
+            const double N = rhe(hi, lo);
+            const double T = pow10_exact(k), y = pow10_inv(k);
+            double q = N * y;                                  // N / 10^k, correctly rounded (exhaustively verified):
+            q = fma(fma(-q, T, N), y, q);                      //   q + (N - q*T) * RN(1/T)
+            return q;
+        }
+    }
+    return decq_abs_slow(a, P);
+}
+
 // strtod(sprintf("%.{P}g", x)) for any x; zeros, infinities and NaNs pass through like the text forms do.
 HAF_HD double decq(double x, int P)
 {
@@ -143,15 +194,30 @@ HAF_HD double decq(double x, int P)
     return x < 0.0 ? -r : r;
 }
 
-// svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed.
-// Returns the attribute value svm-predict parses (0.0 when the attribute is omitted from the text).
-HAF_HD double scale_q6(double q4, double fmin, double fmax, double lower, double upper)
+// svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed; range = fmax - fmin
+// and inv_range = RN(1/range) are per-attribute constants.  Returns the attribute value svm-predict parses
+// (0.0 when the attribute is omitted from the text).
+HAF_HD double scale_q6(double q4, double fmin, double fmax, double range, double inv_range, double lower, double upper)
 {
     double value;
     if (q4 == fmin) value = lower;
     else if (q4 == fmax) value = upper;
-    else value = lower + (upper - lower) * (q4 - fmin) / (fmax - fmin);   // no contraction: built with -ffp-contract=off
-    if (value == 0.0) return 0.0;          // "if(value != 0)" attribute omitted
+    else {
+        const double num = (upper - lower) * (q4 - fmin);     // svm-scale.c:344-346, unfused (-ffp-contract=off)
+        const double an = fabs(num);
+        double q;
+        if ((an < 1e290) && ((an > 1e-290) || (num == 0.0))) {
+            // num / range, correctly rounded without a hardware division: y = RN(1/range); two Markstein steps
+            // (q1 is a faithful quotient, so q2 = RN(q1 + r1*y) is the correctly rounded one)
+            double q0 = num * inv_range;
+            double q1 = fma(fma(-q0, range, num), inv_range, q0);
+            q = fma(fma(-q1, range, num), inv_range, q1);
+        } else {
+            q = num / range;
+        }
+        value = lower + q;
+    }
+    if (value == 0.0) return 0.0;          // "if(value != 0)": attribute omitted
     return decq(value, 6);
 }
 

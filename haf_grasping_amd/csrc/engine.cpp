@@ -282,6 +282,8 @@ int build_tables(haf_engine *e)
             d.fmin = e->range.fmin[(size_t)idx];
             d.fmax = e->range.fmax[(size_t)idx];
             d.skip = (d.fmin == d.fmax) ? 1 : 0;      // svm-scale.c:336
+            d.range = d.fmax - d.fmin;                // svm-scale.c:346 denominator
+            d.inv_range = d.skip ? 0.0 : 1.0 / d.range;
         } else {
             // Attribute not listed in the range file: svm-scale would take min/max from the rows of each roll's
             // file (svm-scale.c:165-198).  That is data-independent only for a structurally constant feature
@@ -883,7 +885,11 @@ int haf_test_finalize(const haf_config *cfg, const haf_grasp_input *in, const ha
 
 // ---- test hooks (host and device builds of the decimal round-trip arithmetic; see tests/) ----
 double haf_test_decq_host(double x, int digits) { return hafq::decq(x, digits); }
-double haf_test_scale_host(double q4, double fmin, double fmax, double lower, double upper) { return hafq::scale_q6(q4, fmin, fmax, lower, upper); }
+double haf_test_scale_host(double q4, double fmin, double fmax, double lower, double upper)
+{
+    const double range = fmax - fmin;
+    return hafq::scale_q6(q4, fmin, fmax, range, 1.0 / range, lower, upper);
+}
 
 int haf_test_decq_device(const double *in, double *out, int n, int digits)
 {

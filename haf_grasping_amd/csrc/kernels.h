@@ -40,6 +40,7 @@ struct FeatDesc {
     int   skip;                   // attribute dropped by svm-scale (feature_max == feature_min, svm-scale.c:336)
     int   pad;
     double fmin, fmax;
+    double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
 };
 
 struct Dims {

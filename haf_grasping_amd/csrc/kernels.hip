@@ -273,7 +273,7 @@ __device__ __forceinline__ double attribute_value(const float *__restrict__ win,
 {
     float v = feature_value(win, f);
     double q4 = hafq::decq((double)v, 4);
-    return hafq::scale_q6(q4, f.fmin, f.fmax, lower, upper);
+    return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper);
 }
 
 // X image: tiles of 32 evals, k-major inside a tile ([tile][kDP][32] fp32) -- the exact register image of the MFMA
@@ -677,7 +677,10 @@ __global__ void k_scale_test(const double *__restrict__ q4, const double *__rest
                              double lower, double upper, double *__restrict__ out, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = hafq::scale_q6(q4[i], fmin[i], fmax[i], lower, upper);
+    if (i < n) {
+        const double range = fmax[i] - fmin[i];
+        out[i] = hafq::scale_q6(q4[i], fmin[i], fmax[i], range, 1.0 / range, lower, upper);
+    }
 }
 void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
                        int n, hipStream_t s)
