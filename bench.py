@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense
 D_ATTR = 323                       # algorithmic work 2*D*nSV flop per eval, D unpadded
 
 
@@ -54,6 +55,8 @@ def parse():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rolls", type=int, default=36)
     ap.add_argument("--roll-step", type=int, default=5)
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+                    help="RBF contraction: one fp32 MFMA pass, or three fp16 MFMA passes on hi/lo halves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
@@ -138,7 +141,8 @@ def main():
 
     G = args.grid
     eng = capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
-                      roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2, flags=capi.FLAG_PROFILE)
+                      roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2,
+                      flags=capi.FLAG_PROFILE | (capi.FLAG_SPLIT_F16 if args.precision == "f16x3" else 0))
     xyz = models.synthetic_cloud(grid=G, k=2, seed=rank)
     d_xyz = torch.from_numpy(xyz).cuda()                    # resident in HBM before the timed region
     cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
@@ -188,6 +192,7 @@ def main():
         svm_s = float(np.mean(svm_ms)) * 1e-3
         flop = evals_per_launch * 2.0 * D_ATTR * args.nsv           # algorithmic: 646*nSV per eval, one pass
         achieved = flop / svm_s / 1e12
+        peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         line = {
             "metric": "grid-cell x rotation SVM evals/sec",
             "value": total_evals / elapsed,
@@ -195,14 +200,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "f16x3 (fp32 operands split into fp16 hi+lo, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "C5: synthetic %dx%d heightmap (%d points), %d rolls x %d deg, %dx%d cm area, seeded random "
                                    "libsvm RBF model nSV=%d D=323 gamma=1/323, one cloud per GPU per step, cloud resident in HBM"
                                    % (G, G, xyz.shape[0], args.rolls, args.roll_step, G, G, args.nsv),
                        "evals_per_cloud": int(evals_per_launch), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
                        "sharding": "clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step"},
-            "roofline": {"kernel": "k_svm_rbf", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args),
+            "roofline": {"kernel": "k_svm_rbf" if args.precision == "f32" else "k_svm_rbf_h", "bound": "mfma",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": pmc_traffic(args) if args.precision == "f32" else None,
                          "kernel_ms": svm_s * 1e3, "flop_per_launch": flop},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
             "rechecked_per_step": rechecked / args.steps,

@@ -204,6 +204,7 @@ struct haf_engine {
     DevBuf<uint8_t> d_mask;
     DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list;
     DevBuf<float> d_X, d_ax, d_dec, d_svt;
+    DevBuf<char> d_svt_h;            // split-fp16 SV tile images
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_sv64, d_coef64;
     DevBuf<short> d_ev16;
@@ -322,6 +323,31 @@ int build_tables(haf_engine *e)
     if (hipSuccess != e->d_svt.alloc(svt.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(sv tiles)");
     HIPCHK(e, hipMemcpy(e->d_svt.p, svt.data(), svt.size() * sizeof(float), hipMemcpyHostToDevice));
 
+    if (e->cfg.flags & HAF_FLAG_SPLIT_F16) {
+        // split-fp16 images: s = sh + sl (fp16 each), [k-step][k-half][SV][8] for hi then lo, then 32 a_s and 32 coef
+        std::vector<char> img((size_t)e->n_sv_tiles * kHSvTileBytes, 0);
+        for (int n = 0; n < m.n_sv; n++) {
+            const int t = n / kTile, j = n % kTile;
+            char *tile = img.data() + (size_t)t * kHSvTileBytes;
+            double ss = 0;
+            for (int k = 0; k < m.dim; k++) {
+                const float s = (float)m.sv[(size_t)n * m.dim + k];
+                const _Float16 h = (_Float16)s;
+                const _Float16 l = (_Float16)(s - (float)h);
+                const size_t off = ((size_t)((k / 16) * 2 + (k % 16) / 8) * kTile + j) * 16 + (size_t)(k % 8) * 2;
+                memcpy(tile + off, &h, 2);
+                memcpy(tile + kHMatBytes + off, &l, 2);
+                const double se = (double)((float)h + (float)l);      // what the three passes multiply
+                ss += se * se;
+            }
+            float *tail = reinterpret_cast<float *>(tile + 2 * kHMatBytes);
+            tail[j] = (float)(-m.gamma * log2e * ss);
+            tail[kTile + j] = (float)m.coef[(size_t)n];
+        }
+        if (hipSuccess != e->d_svt_h.alloc(img.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(split sv tiles)");
+        HIPCHK(e, hipMemcpy(e->d_svt_h.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    }
+
     std::vector<double> sv64((size_t)e->kx * e->n_sv_pad, 0.0), coef64((size_t)e->n_sv_pad, 0.0);
     for (int n = 0; n < m.n_sv; n++) {
         for (int k = 0; k < m.dim; k++) sv64[(size_t)k * e->n_sv_pad + n] = m.sv[(size_t)n * m.dim + k];
@@ -383,7 +409,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_counters.alloc(CNT_COUNT);
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->flag_cap);
-    ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * kTileFloats);
+    ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * (size_t)std::max<int>(kTileFloats, kHXTileBytes / 4));
     ok &= hipSuccess == e->d_ax.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
@@ -447,7 +473,7 @@ void haf_destroy(haf_engine *e)
     e->d_clouds.release(); e->d_points.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
-    e->d_dec.release(); e->d_svt.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_sv64.release();
+    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_sv64.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_fd.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -596,11 +622,16 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
     launch_compact(e->d_mask.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
     mark(e, HAF_ST_FEATURES);
+    const bool split = (c.flags & HAF_FLAG_SPLIT_F16) != 0;
     launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower, e->range.upper,
-                    e->svm.neg_gamma2, evals_cap, s);
+                    e->svm.neg_gamma2, evals_cap, split, s);
     mark(e, HAF_ST_SVM);
-    launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-               e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
+    if (split)
+        launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                     e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
+    else
+        launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                   e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
     mark(e, HAF_ST_RECHECK);
     launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag_list.p, e->flag_cap,
                    e->d_counters.p, e->d_dec_exact.p, e->d_labels.p, d, s);

@@ -16,6 +16,15 @@ constexpr int kTileFloats = kDP * kTile;          // 10496 floats = 41 KiB: 41 L
 constexpr int kSvmBlockEvals = 256; // 8 waves x 32 evals
 constexpr int kSvmThreads = 512;
 
+// ---- split-fp16 variant of the contraction (three v_mfma_f32_32x32x16_f16 passes: hi*hi + lo*hi + hi*lo) ----
+constexpr int kHK = 336;                              // attributes padded to 21 k-steps of 16
+constexpr int kHSteps = kHK / 16;                     // 21
+constexpr int kHMatBytes = kHSteps * 1024;            // one 32 x 336 fp16 operand image: [step][k-half][row][8] = 21 KiB
+constexpr int kHXTileBytes = 2 * kHMatBytes;          // X tile: hi image + lo image = 42 KiB per 32 evals
+constexpr int kHSvTileBytes = 44032;                  // SV tile: hi + lo + 32 a_s + 32 coef (43264 B) padded to 43 KiB
+constexpr int kHSvPieces = kHSvTileBytes / 1024;      // 43 LDS-DMA wave instructions
+constexpr int kHBuffers = 3;                          // LDS ring: two tiles in flight behind the one being computed
+
 struct CloudDev {
     const float *xyz;
     int n;
@@ -78,10 +87,13 @@ void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
 void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
-                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, hipStream_t s);
+                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, bool split_f16, hipStream_t s);
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);
+void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
+                  SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
+                  long max_evals, hipStream_t s);
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, double *dec_exact,
                     int8_t *labels, Dims d, hipStream_t s);

@@ -276,8 +276,13 @@ __device__ __forceinline__ double attribute_value(const float *__restrict__ win,
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper);
 }
 
-// X image: tiles of 32 evals, k-major inside a tile ([tile][kDP][32] fp32) -- the exact register image of the MFMA
-// A operand, so the contraction kernel fills its A fragments with fully coalesced 256-byte loads.
+// X image, fp32 form: tiles of 32 evals, k-major inside a tile ([tile][kDP][32] fp32) -- the exact register image of
+// the fp32 MFMA A operand, so the contraction kernel fills its A fragments with fully coalesced 256-byte loads.
+// X image, split-fp16 form: per tile of 32 evals two operand images (hi, lo) of [21 k-steps][2 k-halves][32 evals][8 fp16];
+// a thread finishes 8 attributes, then stores them as one 16-byte vector per image (512 contiguous bytes per 32 lanes).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
@@ -288,8 +293,17 @@ __global__ __launch_bounds__(256) void k_features(const float *__restrict__ ii, 
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if ((long)blockIdx.x * 256 >= n_pad) return;
     float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
+    char *xh = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * kHXTileBytes + (e & 31) * 16;
     if (e >= n_evals) {                       // padding rows of the last 256-eval block: zeros
-        for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
+        if (SPLIT) {
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int g = 0; g < 2 * kHSteps; g++) {
+                *reinterpret_cast<half8 *>(xh + g * 512) = z;
+                *reinterpret_cast<half8 *>(xh + kHMatBytes + g * 512) = z;
+            }
+        } else {
+            for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
+        }
         ax[e] = 0.0f;
         return;
     }
@@ -300,24 +314,51 @@ __global__ __launch_bounds__(256) void k_features(const float *__restrict__ ii, 
     const int i = rem / W, j = rem - i * W;
     const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
     double xx = 0.0;
-    for (int f = 0; f < d.nf; f++) {
-        const FeatDesc &F = fd[f];
-        float xf = 0.0f;
-        if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
-        xcol[f * kTile] = xf;
-        xx = fma((double)xf, (double)xf, xx);
+    if (SPLIT) {
+        for (int g = 0; g < 2 * kHSteps; g++) {           // 42 groups of 8 attributes
+            half8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int f = g * 8 + q;
+                float xf = 0.0f;
+                if (f < d.nf) {
+                    const FeatDesc &F = fd[f];
+                    if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+                }
+                const _Float16 h = (_Float16)xf;                       // RN
+                const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
+                hi[q] = h;
+                lo[q] = l;
+                const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
+                xx = fma((double)xe, (double)xe, xx);
+            }
+            *reinterpret_cast<half8 *>(xh + g * 512) = hi;
+            *reinterpret_cast<half8 *>(xh + kHMatBytes + g * 512) = lo;
+        }
+    } else {
+        for (int f = 0; f < d.nf; f++) {
+            const FeatDesc &F = fd[f];
+            float xf = 0.0f;
+            if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+            xcol[f * kTile] = xf;
+            xx = fma((double)xf, (double)xf, xx);
+        }
+        for (int k = d.nf; k < kKP; k++) xcol[k * kTile] = 0.0f;
     }
-    for (int k = d.nf; k < kKP; k++) xcol[k * kTile] = 0.0f;
     ax[e] = neg_gamma2 * (float)xx;           // -gamma*log2(e)*|x|^2, folded into the exp2 argument
 }
 
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
-                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, hipStream_t s)
+                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, bool split_f16, hipStream_t s)
 {
     long blocks = (max_evals + 255) / 256;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_features, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
-                       upper, neg_gamma2);
+    if (split_f16)
+        hipLaunchKernelGGL(k_features<true>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
+                           upper, neg_gamma2);
+    else
+        hipLaunchKernelGGL(k_features<false>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
+                           upper, neg_gamma2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -458,6 +499,148 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_svm_rbf, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, X, ax, svt, evalcell, counters, p,
                        dec, labels, flag_list, flag_cap, counters_rw, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a8, split-fp16 form of the same contraction: x = xh + xl, s = sh + sl with fp16 halves (22 significant bits, i.e. the
+// fp32 operand to within one ulp), x.s = xh.sh + xl.sh + xh.sl as three v_mfma_f32_32x32x16_f16 passes into ONE fp32
+// accumulator (the dropped xl.sl term is 2^-22 relative).  Every fp16 x fp16 product is exact in fp32, so the error
+// budget is the fp32 kernel's (accumulation) plus 2^-22 per term, covered by the same guard band; the MFMA work per
+// output tile drops from 162 x 64 to 63 x 32 cycles.  Same structure as k_svm_rbf: 8 waves x 32 evals, A fragments
+// (hi and lo: 168 VGPRs) loaded once, SV tile images streamed by LDS-DMA -- here through a 3-deep LDS ring with a
+// counted vmcnt, because a tile is consumed in ~4k cycles, about the latency of one DMA round trip.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int stage_sv_tile_h(const char *__restrict__ gtile, unsigned lds_byte_off, int wave, int lane)
+{
+    int issued = 0;
+    for (int p = wave; p < kHSvPieces; p += 8) {
+        const char *g = gtile + p * 1024 + lane * 16;
+        unsigned l = __builtin_amdgcn_readfirstlane(lds_byte_off + p * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
+        issued++;
+    }
+    return issued;
+}
+
+__global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__restrict__ X, const float *__restrict__ ax,
+                                                              const char *__restrict__ svt,
+                                                              const int *__restrict__ evalcell,
+                                                              const int *__restrict__ counters, SvmParams p,
+                                                              float *__restrict__ dec, int8_t *__restrict__ labels,
+                                                              int *__restrict__ flag_list, int flag_cap,
+                                                              int *__restrict__ counters_rw, Dims d)
+{
+    // the ONLY LDS object: 3 SV tile images + one row of a_x per wave
+    __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 8 * kTile * 4];
+    const int n_evals = counters[CNT_EVALS];
+    const long base = (long)blockIdx.x * kSvmBlockEvals;
+    if (base >= n_evals) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long tile32 = (base >> 5) + wave;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    const int nt = d.n_sv_tiles;
+    float *axs = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + wave * kTile;
+
+    stage_sv_tile_h(svt, lds0, wave, lane);                                              // tile 0
+    if (nt > 1) stage_sv_tile_h(svt + (size_t)kHSvTileBytes, lds0 + kHSvTileBytes, wave, lane);   // tile 1
+
+    half8 ah[kHSteps], al[kHSteps];
+    {
+        const char *xt = X + (size_t)tile32 * kHXTileBytes + lane * 16;
+#pragma unroll
+        for (int s = 0; s < kHSteps; s++) {
+            ah[s] = *reinterpret_cast<const half8 *>(xt + s * 1024);                 // A[i = lane&31][k = 16s + 8(lane>>5) + j]
+            al[s] = *reinterpret_cast<const half8 *>(xt + kHMatBytes + s * 1024);
+        }
+    }
+    if (lane < kTile) axs[lane] = ax[tile32 * kTile + lane];
+    float part[16], pabs[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { part[r] = 0.0f; pabs[r] = 0.0f; }
+    // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
+#pragma unroll
+    for (int s = 0; s < kHSteps; s++) {
+        asm volatile("" : "+v"(ah[s]));
+        asm volatile("" : "+v"(al[s]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tiles 0 and 1 (this wave's pieces) have landed
+    __syncthreads();
+
+    const int my_pieces = (kHSvPieces - wave + 7) / 8;              // DMA instructions this wave issues per tile (6 or 5)
+    for (int t = 0; t < nt; t++) {
+        const char *cur = lds + (t % kHBuffers) * kHSvTileBytes;
+        const bool more = t + 2 < nt;
+        if (more)
+            stage_sv_tile_h(svt + (size_t)(t + 2) * kHSvTileBytes, lds0 + ((t + 2) % kHBuffers) * kHSvTileBytes, wave, lane);
+
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const char *bl = cur + lane * 16;
+#pragma unroll
+        for (int s = 0; s < kHSteps; s++) {
+            const half8 bh = *reinterpret_cast<const half8 *>(bl + s * 1024);                // B[k = 16s + 8(lane>>5) + j][col lane&31]
+            const half8 bq = *reinterpret_cast<const half8 *>(bl + kHMatBytes + s * 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq, acc, 0, 0, 0);
+        }
+        const float *tail = reinterpret_cast<const float *>(cur + 2 * kHMatBytes);
+        const float as_ = tail[lane & 31];                          // -g2*|s_j|^2
+        const float cf = tail[kTile + (lane & 31)];                 // coef_j (0 for padding SVs)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float arg = fmaf(p.two_gamma2, acc[r], axs[row] + as_);
+            float k = __builtin_amdgcn_exp2f(arg);
+            part[r] = fmaf(cf, k, part[r]);
+            pabs[r] = fmaf(fabsf(cf), k, pabs[r]);
+        }
+        // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
+        if (more) {
+            if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                              // no LDS read of the next tile may move above the barrier
+    }
+
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float v = part[r], w = pabs[r];
+        v += __shfl_xor(v, 16, 64); w += __shfl_xor(w, 16, 64);
+        v += __shfl_xor(v, 8, 64);  w += __shfl_xor(w, 8, 64);
+        v += __shfl_xor(v, 4, 64);  w += __shfl_xor(w, 4, 64);
+        v += __shfl_xor(v, 2, 64);  w += __shfl_xor(w, 2, 64);
+        v += __shfl_xor(v, 1, 64);  w += __shfl_xor(w, 1, 64);
+        part[r] = v; pabs[r] = w;
+    }
+    if ((lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            long e = tile32 * kTile + row;
+            if (e < n_evals) {
+                float dv = part[r] - p.rho;
+                dec[e] = dv;
+                labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
+                if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axs[row])) * pabs[r] + p.guard_abs)) {
+                    int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
+                    if (slot < flag_cap) flag_list[slot] = (int)e;
+                }
+            }
+        }
+    }
+}
+
+void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters, SvmParams p,
+                  float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
+                  hipStream_t s)
+{
+    long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_svm_rbf_h, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
+                       evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -57,6 +57,8 @@ typedef struct haf_config {
 
 #define HAF_FLAG_KEEP_DEBUG 1u       /* keep per-roll intermediates for haf_debug_fetch()                 */
 #define HAF_FLAG_PROFILE    2u       /* record HIP events per stage (haf_get_stage_ms)                    */
+#define HAF_FLAG_SPLIT_F16  4u       /* RBF contraction as three fp16 MFMA passes on hi/lo halves of the fp32 operands
+                                        instead of one fp32 MFMA pass: same guard band, same labels, ~3-4x the rate   */
 
 /* GraspInput (reference msg/GraspInput.msg:3-15) minus the cloud and the frame id: the cloud is passed
  * separately, already in the base frame (server.cpp:316). */

@@ -41,9 +41,13 @@ def orc(data_dir, surrogate):
     return O.Oracle(f, r, surrogate)
 
 
-def make_engine(data_dir, model, **cfg):
+MODES = [pytest.param(0, id="f32mfma"), pytest.param(capi.FLAG_SPLIT_F16, id="splitf16")]
+
+
+def make_engine(data_dir, model, mode=0, **cfg):
     f, r = _files(data_dir)
     cfg.setdefault("flags", capi.FLAG_KEEP_DEBUG | capi.FLAG_PROFILE)
+    cfg["flags"] |= mode
     return capi.Engine(f, r, model, **cfg)
 
 
@@ -130,12 +134,13 @@ def test_device_scale_matches_host(data_dir):
     assert (out.view(np.uint64) == host.view(np.uint64)).all()
 
 
-def test_c1_c2_pcd2_stage_by_stage(data_dir, surrogate, orc):
+@pytest.mark.parametrize("mode", MODES)
+def test_c1_c2_pcd2_stage_by_stage(data_dir, surrogate, orc, mode):
     xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
-    eng = make_engine(data_dir, surrogate, n_rolls=1)
+    eng = make_engine(data_dir, surrogate, mode, n_rolls=1)
     compare_full(eng, orc, xyz, dict(n_rolls=1), dict(grasp_area_length_x=32, grasp_area_length_y=32))   # C1
     eng.close()
-    eng = make_engine(data_dir, surrogate)
+    eng = make_engine(data_dir, surrogate, mode)
     got, _ = compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))   # C2
     assert got["eval"] == 103
     compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32, show_only_best_grasp=1))
@@ -144,7 +149,8 @@ def test_c1_c2_pcd2_stage_by_stage(data_dir, surrogate, orc):
     eng.close()
 
 
-def test_all_clouds_against_committed_goldens(data_dir, golden_dir, surrogate):
+@pytest.mark.parametrize("mode", MODES)
+def test_all_clouds_against_committed_goldens(data_dir, golden_dir, surrogate, mode):
     """Every data/*.pcd x configuration of tests/golden/g6_end_to_end.json: argmax-identical cell/roll, same eval."""
     import make_fixtures as mf
     with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
@@ -155,7 +161,7 @@ def test_all_clouds_against_committed_goldens(data_dir, golden_dir, surrogate):
         spec = mf.CONFIGS[cname]
         ck = (spec["cfg"].get("n_rolls", 12), spec["cfg"].get("roll_step_deg", 15))
         if ck not in engines:
-            engines[ck] = make_engine(data_dir, surrogate, n_rolls=ck[0], roll_step_deg=ck[1], max_points=1 << 18)
+            engines[ck] = make_engine(data_dir, surrogate, mode, n_rolls=ck[0], roll_step_deg=ck[1], max_points=1 << 18)
         eng = engines[ck]
         xyz = capi.load_pcd(os.path.join(data_dir, name + ".pcd"))
         i = spec["inp"]
@@ -181,10 +187,11 @@ def test_all_clouds_against_committed_goldens(data_dir, golden_dir, surrogate):
         e.close()
 
 
-def test_table_cloud_live_against_oracle(data_dir, surrogate, orc):
+@pytest.mark.parametrize("mode", MODES)
+def test_table_cloud_live_against_oracle(data_dir, surrogate, orc, mode):
     """C3: 102 876-point binary_compressed cloud, 56x56 area, 20 rolls of 9 degrees, full stage comparison."""
     xyz = capi.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
-    eng = make_engine(data_dir, surrogate, n_rolls=20, roll_step_deg=9, max_points=1 << 18)
+    eng = make_engine(data_dir, surrogate, mode, n_rolls=20, roll_step_deg=9, max_points=1 << 18)
     compare_full(eng, orc, xyz, dict(n_rolls=20, roll_step_deg=9),
                  dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)))
     eng.close()
@@ -213,7 +220,8 @@ def test_batch_of_eight_equals_single_and_shards_compose(data_dir, surrogate):
     eng.close()
 
 
-def test_random_models_label_order_and_guard_band(data_dir, tmp_path):
+@pytest.mark.parametrize("mode", MODES)
+def test_random_models_label_order_and_guard_band(data_dir, tmp_path, mode):
     """Seeded random libsvm models ('label 1 -1', balanced coefficients -> decision values crowd around zero):
     stresses the guard band; labels must still be identical to the fp64 oracle."""
     xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
@@ -222,16 +230,17 @@ def test_random_models_label_order_and_guard_band(data_dir, tmp_path):
         path = str(tmp_path / ("rand%d.model" % nsv))
         models.write_random_model(path, nsv, seed=seed, balanced=True)
         o = O.Oracle(f, r, path)
-        eng = make_engine(data_dir, path)
+        eng = make_engine(data_dir, path, mode)
         got, want = compare_full(eng, o, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=44))
         assert (want["labels"] > 0).sum() > 50 and ((want["labels"] == -1) & (want["mask"] == 1)).sum() > 50
         eng.close()
 
 
-def test_generalised_grid_and_rolls(data_dir, surrogate, orc):
+@pytest.mark.parametrize("mode", MODES)
+def test_generalised_grid_and_rolls(data_dir, surrogate, orc, mode):
     """H, W, roll step and roll count are parameters here.  96x96 grid, 8 rolls of 22 degrees."""
     xyz = models.synthetic_cloud(grid=96, k=2, seed=3)
-    eng = make_engine(data_dir, surrogate, grid_h=96, grid_w=96, n_rolls=8, roll_step_deg=22)
+    eng = make_engine(data_dir, surrogate, mode, grid_h=96, grid_w=96, n_rolls=8, roll_step_deg=22)
     compare_full(eng, orc, xyz, dict(n_rolls=8, roll_step_deg=22, grid_h=96, grid_w=96),
                  dict(grasp_area_length_x=96, grasp_area_length_y=80))
     eng.close()
@@ -266,7 +275,8 @@ def test_edge_inputs(data_dir, surrogate, orc):
     eng.close()
 
 
-def test_full_size_c5_properties(data_dir, tmp_path):
+@pytest.mark.parametrize("mode", MODES)
+def test_full_size_c5_properties(data_dir, tmp_path, mode):
     """BASELINE config C5 at full size (512x512, 36 rolls of 5 degrees, 524 288 points): size-independent properties.
     The oracle cannot run 7.9M evaluations, so: (1) the eval count equals the pure-geometry count (all cells are
     non-empty), (2) spot-check 300 random masked cells per sampled roll against the oracle's own feature/scale/decision
@@ -279,7 +289,7 @@ def test_full_size_c5_properties(data_dir, tmp_path):
     o = O.Oracle(f, r, path)
     xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
     assert xyz.shape == (524288, 3)
-    eng = make_engine(data_dir, path, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+    eng = make_engine(data_dir, path, mode, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
     inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
     rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
     # 7 883 478 is the pure-geometry bound (every 9x9 neighbourhood non-empty); 248 004 at 0 degrees
