@@ -179,7 +179,7 @@ struct haf_engine {
     std::vector<FeatureRow> features;
     RangeTable range;
     SvmModel model;
-    int nf = 0, kx = 0, n_sv_tiles = 0, n_sv_pad = 0;
+    int nf = 0, kx = 0, n_sv_tiles = 0, n_sv_pad = 0, sv_tile_neg = 0;
     int gv0 = 0, gv1 = 0;
     double sum_abs_coef = 0;
     SvmParams svm{};
@@ -303,12 +303,24 @@ int build_tables(haf_engine *e)
     // ---- SVM images ----
     const SvmModel &m = e->model;
     const double log2e = 1.4426950408889634;
-    e->n_sv_tiles = (m.n_sv + kTile - 1) / kTile;
-    e->n_sv_pad = e->n_sv_tiles * kTile;
+    // Tile images carry the support vectors with coefficient >= 0 first (padded to whole tiles), then the negative ones:
+    // the fast path's fp32 sum may take any order, and the split lets one accumulator deliver both the decision value
+    // and the guard scale sum|coef|K.  The exact recheck keeps libsvm's model order (sv64 below).
+    std::vector<int> slot_of((size_t)m.n_sv);
+    {
+        int npos = 0;
+        for (int n = 0; n < m.n_sv; n++) if (m.coef[(size_t)n] >= 0) slot_of[(size_t)n] = npos++;
+        const int pos_tiles = (npos + kTile - 1) / kTile;
+        int nneg = 0;
+        for (int n = 0; n < m.n_sv; n++) if (!(m.coef[(size_t)n] >= 0)) slot_of[(size_t)n] = pos_tiles * kTile + nneg++;
+        e->n_sv_tiles = pos_tiles + (nneg + kTile - 1) / kTile;
+        e->sv_tile_neg = nneg ? pos_tiles : e->n_sv_tiles;
+    }
+    e->n_sv_pad = ((m.n_sv + kTile - 1) / kTile) * kTile;
     std::vector<float> svt((size_t)e->n_sv_tiles * kTileFloats, 0.0f);
     e->sum_abs_coef = 0;
     for (int n = 0; n < m.n_sv; n++) {
-        const int t = n / kTile, j = n % kTile;
+        const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
         float *tile = svt.data() + (size_t)t * kTileFloats;
         double ss = 0;
         for (int k = 0; k < m.dim; k++) {
@@ -327,7 +339,7 @@ int build_tables(haf_engine *e)
         // split-fp16 images: s = sh + sl (fp16 each), [k-step][k-half][SV][8] for hi then lo, then 32 a_s and 32 coef
         std::vector<char> img((size_t)e->n_sv_tiles * kHSvTileBytes, 0);
         for (int n = 0; n < m.n_sv; n++) {
-            const int t = n / kTile, j = n % kTile;
+            const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
             char *tile = img.data() + (size_t)t * kHSvTileBytes;
             double ss = 0;
             for (int k = 0; k < m.dim; k++) {
@@ -376,7 +388,8 @@ int build_tables(haf_engine *e)
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
         double as_max = 0;
-        for (int n = 0; n < m.n_sv; n++) as_max = std::max(as_max, (double)std::fabs(svt[(size_t)(n / kTile) * kTileFloats + kKP * kTile + n % kTile]));
+        for (int t = 0; t < e->n_sv_tiles; t++)
+            for (int j = 0; j < kTile; j++) as_max = std::max(as_max, (double)std::fabs(svt[(size_t)t * kTileFloats + kKP * kTile + j]));
         e->svm.as_max1 = (float)(1.0 + as_max);
     }
     e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
@@ -605,7 +618,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     mark(e, HAF_ST_BIN);
 
     Dims d;
-    d.H = H; d.W = W; d.R = R; d.B = B; d.nf = e->nf; d.n_sv = e->model.n_sv; d.n_sv_tiles = e->n_sv_tiles;
+    d.H = H; d.W = W; d.R = R; d.B = B; d.nf = e->nf; d.n_sv = e->model.n_sv; d.n_sv_tiles = e->n_sv_tiles; d.sv_tile_neg = e->sv_tile_neg;
     const float r_row = (float)((0.5 * (float)H) / 100.0), r_col = (float)((0.5 * (float)W) / 100.0);   // server.cpp:410-411
     const long evals_cap = (long)B * R * (H - 14) * (W - 14);
 

@@ -55,7 +55,8 @@ struct FeatDesc {
 struct Dims {
     int H, W, R, B;               // grid, rolls in this launch, clouds
     int nf;                       // feature rows (324)
-    int n_sv, n_sv_tiles;
+    int n_sv, n_sv_tiles;         // SV tile images: coefficients >= 0 first, padded to whole tiles, then the negative ones
+    int sv_tile_neg;              // first tile of the negative-coefficient group (== n_sv_tiles when there is none)
 };
 
 struct SvmParams {

@@ -530,8 +530,8 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                                                               int *__restrict__ flag_list, int flag_cap,
                                                               int *__restrict__ counters_rw, Dims d)
 {
-    // the ONLY LDS object: 3 SV tile images + one row of a_x per wave
-    __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 8 * kTile * 4];
+    // the ONLY LDS object: 3 SV tile images + per wave one row of a_x and one row of positive-group sums
+    __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 2 * 8 * kTile * 4];
     const int n_evals = counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kSvmBlockEvals;
     if (base >= n_evals) return;
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
     const int nt = d.n_sv_tiles;
     float *axs = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + wave * kTile;
+    float *pos = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + 8 * kTile + wave * kTile;
 
     stage_sv_tile_h(svt, lds0, wave, lane);                                              // tile 0
     if (nt > 1) stage_sv_tile_h(svt + (size_t)kHSvTileBytes, lds0 + kHSvTileBytes, wave, lane);   // tile 1
@@ -553,10 +554,10 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             al[s] = *reinterpret_cast<const half8 *>(xt + kHMatBytes + s * 1024);
         }
     }
-    if (lane < kTile) axs[lane] = ax[tile32 * kTile + lane];
-    float part[16], pabs[16];
+    if (lane < kTile) { axs[lane] = ax[tile32 * kTile + lane]; pos[lane] = 0.0f; }
+    float part[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) { part[r] = 0.0f; pabs[r] = 0.0f; }
+    for (int r = 0; r < 16; r++) part[r] = 0.0f;
     // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
 #pragma unroll
     for (int s = 0; s < kHSteps; s++) {
@@ -572,16 +573,41 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
         const bool more = t + 2 < nt;
         if (more)
             stage_sv_tile_h(svt + (size_t)(t + 2) * kHSvTileBytes, lds0 + ((t + 2) % kHBuffers) * kHSvTileBytes, wave, lane);
+        if (t == d.sv_tile_neg) {
+            // The tile images hold the non-negative coefficients first: what has been summed so far is
+            // P = sum_{coef>0} coef*K, what follows is N = sum_{coef<0} coef*K.  dec = P + N - rho and the guard scale
+            // sum|coef|K = P - N come from the same accumulator; P is parked in LDS (once per workgroup).
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = part[r];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 1, 64);
+                if ((lane & 31) == 0) pos[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = v;
+                part[r] = 0.0f;
+            }
+        }
 
+        // B fragments run two k-steps ahead of the MFMAs that consume them (LDS latency ~ one step of 3 MFMAs)
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const char *bl = cur + lane * 16;
+        half8 bh[3], bq[3];
+        bh[0] = *reinterpret_cast<const half8 *>(bl);
+        bq[0] = *reinterpret_cast<const half8 *>(bl + kHMatBytes);
+        bh[1] = *reinterpret_cast<const half8 *>(bl + 1024);
+        bq[1] = *reinterpret_cast<const half8 *>(bl + kHMatBytes + 1024);
 #pragma unroll
         for (int s = 0; s < kHSteps; s++) {
-            const half8 bh = *reinterpret_cast<const half8 *>(bl + s * 1024);                // B[k = 16s + 8(lane>>5) + j][col lane&31]
-            const half8 bq = *reinterpret_cast<const half8 *>(bl + kHMatBytes + s * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq, acc, 0, 0, 0);
+            if (s + 2 < kHSteps) {
+                bh[(s + 2) % 3] = *reinterpret_cast<const half8 *>(bl + (s + 2) * 1024);     // B[k = 16s + 8(lane>>5) + j][col lane&31]
+                bq[(s + 2) % 3] = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s + 2) * 1024);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s % 3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s % 3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq[s % 3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keep the two-step read-ahead: hipcc otherwise sinks the reads to their use
         }
         const float *tail = reinterpret_cast<const float *>(cur + 2 * kHMatBytes);
         const float as_ = tail[lane & 31];                          // -g2*|s_j|^2
@@ -592,7 +618,6 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             float arg = fmaf(p.two_gamma2, acc[r], axs[row] + as_);
             float k = __builtin_amdgcn_exp2f(arg);
             part[r] = fmaf(cf, k, part[r]);
-            pabs[r] = fmaf(fabsf(cf), k, pabs[r]);
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
         if (more) {
@@ -607,24 +632,28 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
 
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        float v = part[r], w = pabs[r];
-        v += __shfl_xor(v, 16, 64); w += __shfl_xor(w, 16, 64);
-        v += __shfl_xor(v, 8, 64);  w += __shfl_xor(w, 8, 64);
-        v += __shfl_xor(v, 4, 64);  w += __shfl_xor(w, 4, 64);
-        v += __shfl_xor(v, 2, 64);  w += __shfl_xor(w, 2, 64);
-        v += __shfl_xor(v, 1, 64);  w += __shfl_xor(w, 1, 64);
-        part[r] = v; pabs[r] = w;
+        float v = part[r];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        part[r] = v;
     }
     if ((lane & 31) == 0) {
+        const bool has_neg = d.sv_tile_neg < nt;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             long e = tile32 * kTile + row;
             if (e < n_evals) {
-                float dv = part[r] - p.rho;
+                const float P = has_neg ? pos[row] : part[r];
+                const float N = has_neg ? part[r] : 0.0f;
+                const float dv = (P + N) - p.rho;
+                const float sabs = P - N;                           // sum |coef| K
                 dec[e] = dv;
                 labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-                if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axs[row])) * pabs[r] + p.guard_abs)) {
+                if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axs[row])) * sabs + p.guard_abs)) {
                     int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                     if (slot < flag_cap) flag_list[slot] = (int)e;
                 }
