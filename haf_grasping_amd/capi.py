@@ -86,7 +86,7 @@ def lib():
         L.haf_get_stream.argtypes = [E]
         L.haf_get_stage_ms.argtypes = [E, C.POINTER(C.c_float)]
         L.haf_model_info.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                    C.c_size_t]
         L.haf_free.argtypes = [C.c_void_p]
@@ -192,9 +192,9 @@ class Engine:
         return dict(n_sv=a.value, dim=b.value, n_features=c.value)
 
     def last_counts(self):
-        a, b = C.c_int64(), C.c_int64()
-        self._check(self._L.haf_last_counts(self._h, C.byref(a), C.byref(b)))
-        return dict(n_evals=a.value, n_rechecked=b.value)
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._L.haf_last_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_evals=a.value, n_rechecked=b.value, n_strict=c.value)
 
     def score(self, xyz, grasp_input):
         return self.score_batch([xyz], [grasp_input])[0]

@@ -192,7 +192,7 @@ struct haf_engine {
     float stage_ms[HAF_ST_COUNT] = {};
 
     long max_evals = 0, max_evals_pad = 0;
-    int flag_cap = 0;
+    int flag_cap = 0, flag2_cap = 0;
     size_t cells_cap = 0;   // B*R*H*W
 
     DevBuf<CloudDev> d_clouds;
@@ -202,11 +202,11 @@ struct haf_engine {
     DevBuf<double> d_rowsum;
     DevBuf<float> d_ii;
     DevBuf<uint8_t> d_mask;
-    DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list;
+    DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list, d_flag2_list;
     DevBuf<float> d_X, d_ax, d_dec, d_svt;
     DevBuf<char> d_svt_h;            // split-fp16 SV tile images
     DevBuf<int8_t> d_labels;
-    DevBuf<double> d_dec_exact, d_sv64, d_coef64;
+    DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64;
     DevBuf<short> d_ev16;
     DevBuf<RollRecordDev> d_rec;
     DevBuf<FeatDesc> d_fd;
@@ -220,7 +220,7 @@ struct haf_engine {
 
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
-    int last_evals = 0, last_flagged = 0;
+    int last_evals = 0, last_flagged = 0, last_flagged2 = 0;
     std::vector<haf_grasp_input> last_inputs;
 };
 
@@ -360,15 +360,30 @@ int build_tables(haf_engine *e)
         HIPCHK(e, hipMemcpy(e->d_svt_h.p, img.data(), img.size(), hipMemcpyHostToDevice));
     }
 
-    std::vector<double> sv64((size_t)e->kx * e->n_sv_pad, 0.0), coef64((size_t)e->n_sv_pad, 0.0);
+    // fp64 image for both recheck tiers, SVs in MODEL order: rows 0..323 attributes, row 324 |s|^2, row 325 coef
+    std::vector<double> sv64((size_t)kM64Rows * e->n_sv_pad, 0.0), coef64((size_t)e->n_sv_pad, 0.0);
+    double ss_max = 0;
     for (int n = 0; n < m.n_sv; n++) {
-        for (int k = 0; k < m.dim; k++) sv64[(size_t)k * e->n_sv_pad + n] = m.sv[(size_t)n * m.dim + k];
+        double ss = 0;
+        for (int k = 0; k < m.dim; k++) {
+            const double v = m.sv[(size_t)n * m.dim + k];
+            sv64[(size_t)k * e->n_sv_pad + n] = v;
+            ss += v * v;
+        }
+        sv64[(size_t)kKP * e->n_sv_pad + n] = ss;
+        sv64[(size_t)(kKP + 1) * e->n_sv_pad + n] = m.coef[(size_t)n];
         coef64[(size_t)n] = m.coef[(size_t)n];
+        ss_max = std::max(ss_max, ss);
     }
     if (hipSuccess != e->d_sv64.alloc(sv64.size()) || hipSuccess != e->d_coef64.alloc(coef64.size()))
         return fail(e, HAF_E_DEVICE, "hipMalloc(fp64 model)");
     HIPCHK(e, hipMemcpy(e->d_sv64.p, sv64.data(), sv64.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->d_coef64.p, coef64.data(), coef64.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->exact.gamma2 = m.gamma * log2e;
+    e->exact.as_max1 = 1.0 + m.gamma * log2e * ss_max;
+    // fp64 GEMM-form tier: worst-case error ~ 324 * 2^-53 per unit of (a_x + a_s) * sum|coef|K, i.e. < 2^-44; 2^-40 leaves 16x
+    e->exact.guard2 = std::ldexp(1.0, -40);
+    if (const char *g = getenv("HAF_GUARD2_REL")) e->exact.guard2 = atof(g);
 
     e->gv0 = label_grid_value(m.label[0]);
     e->gv1 = label_grid_value(m.label[1]);
@@ -408,6 +423,7 @@ int alloc_buffers(haf_engine *e)
     e->max_evals = (long)(B * R * (H - 14) * (W - 14));
     e->max_evals_pad = (e->max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
     e->flag_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 4), 1L << 24);
+    e->flag2_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 64), 1L << 20);
     bool ok = true;
     ok &= hipSuccess == e->d_clouds.alloc(B);
     ok &= hipSuccess == e->d_points.alloc((size_t)c.max_points * 3);
@@ -427,6 +443,8 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->flag_cap);
+    ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->flag2_cap);
+    ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->flag2_cap);
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rec.alloc(B * R);
     if (!ok) return fail(e, HAF_E_DEVICE, std::string("hipMalloc of working buffers failed: ") + hipGetErrorString(hipGetLastError()));
@@ -486,7 +504,7 @@ void haf_destroy(haf_engine *e)
     e->d_clouds.release(); e->d_points.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
-    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_sv64.release();
+    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_sv64.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_fd.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -545,11 +563,12 @@ int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_
     return HAF_OK;
 }
 
-int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked)
+int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked, int64_t *n_strict)
 {
     if (!e) return HAF_E_ARG;
     if (n_evals) *n_evals = e->last_evals;
     if (n_rechecked) *n_rechecked = e->last_flagged;
+    if (n_strict) *n_strict = e->last_flagged2;
     return HAF_OK;
 }
 
@@ -646,8 +665,12 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
         launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                    e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
     mark(e, HAF_ST_RECHECK);
-    launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag_list.p, e->flag_cap,
-                   e->d_counters.p, e->d_dec_exact.p, e->d_labels.p, d, s);
+    // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
+    // is still within 2^-40 of zero (practically nothing)
+    launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, e->d_counters.p,
+                        e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->flag2_cap, d, s);
+    launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->flag2_cap,
+                   e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
     mark(e, HAF_ST_VOTE);
     launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_rec.p, d, s);
     mark(e, HAF_ST_DOWNLOAD);
@@ -663,6 +686,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     e->last_B = B; e->last_R = R; e->last_roll_first = roll_first;
     e->last_evals = e->h_counters[CNT_EVALS];
     e->last_flagged = e->h_counters[CNT_FLAGGED];
+    e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_inputs.assign(in, in + B);
     if (e->last_flagged > e->flag_cap) {
         char msg[200];
@@ -670,6 +694,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
                  e->last_evals, e->flag_cap);
         return fail(e, HAF_E_CAPACITY, msg);
     }
+    if (e->last_flagged2 > e->flag2_cap) return fail(e, HAF_E_CAPACITY, "strict-order recheck list overflow");
     for (int i = 0; i < B * R; i++) {
         records[i].vote = e->h_rec[i].vote;
         records[i].row = e->h_rec[i].row;
@@ -827,6 +852,14 @@ int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, vo
             }
             std::vector<double> d64(dec.begin(), dec.end());
             for (size_t k = 0; k < nfl; k++) d64[(size_t)fl[k]] = ex[k];
+            const size_t nf2 = (size_t)std::min(e->last_flagged2, e->flag2_cap);
+            if (nf2) {
+                std::vector<int> fl2(nf2);
+                std::vector<double> ex2(nf2);
+                HIPCHK(e, hipMemcpy(fl2.data(), e->d_flag2_list.p, nf2 * 4, hipMemcpyDeviceToHost));
+                HIPCHK(e, hipMemcpy(ex2.data(), e->d_dec_exact2.p, nf2 * 8, hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < nf2; k++) d64[(size_t)fl2[k]] = ex2[k];
+            }
             for (size_t k = 0; k < ne; k++) {
                 size_t cb = (size_t)cell[k] / HW;
                 if (cb == br) g[(size_t)cell[k] - cb * HW] = d64[k];

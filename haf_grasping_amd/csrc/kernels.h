@@ -71,12 +71,18 @@ struct SvmParams {
 
 struct ExactParams {
     double gamma, rho, lower, upper;
+    double guard2, as_max1;       // fp64 GEMM-form guard: |dec| <= guard2 * (as_max1 + gamma'|x|^2) * sum|coef|K -> strict order
+    double gamma2;                // gamma * log2(e)
     int n_sv, n_sv_pad, kx;       // kx = rows of the fp64 k-major SV image
     int gv0, gv1;
 };
 
 // counters[] slots in device memory
-enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_COUNT = 8 };
+enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_COUNT = 8 };
+
+// fp64 model image for the rechecks: attribute-major [kM64Rows][n_sv_pad]; rows 0..323 attributes (model order of SVs),
+// row 324 |s|^2, row 325 coef
+constexpr int kM64Rows = 326;
 
 struct RollRecordDev { int vote; short row, col; float h_locmax; int n_evals; };
 
@@ -96,8 +102,11 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                   long max_evals, hipStream_t s);
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
-                    ExactParams p, const int *flag_list, int flag_cap, const int *counters, double *dec_exact,
-                    int8_t *labels, Dims d, hipStream_t s);
+                    ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
+                    double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
+void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
+                         const int *flag_list, int flag_cap, int *counters, double *dec_exact, int8_t *labels,
+                         int *flag2_list, int flag2_cap, Dims d, hipStream_t s);
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, RollRecordDev *rec, Dims d,
                  hipStream_t s);
 void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s);

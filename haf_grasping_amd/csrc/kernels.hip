@@ -687,13 +687,13 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
                                                  const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
                                                  const double *__restrict__ coef64, ExactParams p,
                                                  const int *__restrict__ flag_list, int flag_cap,
-                                                 const int *__restrict__ counters, double *__restrict__ dec_exact,
-                                                 int8_t *__restrict__ labels, Dims d)
+                                                 const int *__restrict__ counters, int counter_slot,
+                                                 double *__restrict__ dec_exact, int8_t *__restrict__ labels, Dims d)
 {
     __shared__ double xs[kRB][kKP];
     __shared__ double terms[kRB][kRChunk + 1];
     __shared__ double run_sum[kRB];
-    int n_flag = counters[CNT_FLAGGED];
+    int n_flag = counters[counter_slot];
     if (n_flag > flag_cap) n_flag = flag_cap;
     const int n_groups = (n_flag + kRB - 1) / kRB;
     const int H = d.H, W = d.W, W1 = W + 1;
@@ -756,14 +756,168 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
 }
 
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
-                    ExactParams p, const int *flag_list, int flag_cap, const int *counters, double *dec_exact,
-                    int8_t *labels, Dims d, hipStream_t s)
+                    ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
+                    double *dec_exact, int8_t *labels, Dims d, hipStream_t s)
 {
     int groups = (flag_cap + kRB - 1) / kRB;
     int blocks = groups < 2048 ? groups : 2048;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_recheck, dim3(blocks), dim3(256), 0, s, ii, evalcell, fd, sv64, coef64, p, flag_list, flag_cap,
-                       counters, dec_exact, labels, d);
+                       counters, counter_slot, dec_exact, labels, d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a8, middle tier: the guard-band evaluations of the fp32/fp16 contraction re-done as an fp64 MFMA contraction
+// (v_mfma_f64_16x16x4_f64, GEMM form, fp64 exp).  Its error is ~2^-44 of sum|coef|K, so only evaluations with
+// |dec| <= 2^-40 * T * sum|coef|K (practically none) still need libsvm's strict summation order (k_recheck).
+// Workgroup = 4 waves x 16 flagged evaluations; each wave keeps its 16 x 324 fp64 attributes as the A operand in 162
+// VGPRs (computed in place: a lane evaluates exactly the attributes its A fragment holds), the fp64 SV tile
+// (326 x 16: attributes, |s|^2, coef) is shared through LDS, double buffered with a register-staged prefetch.
+// ---------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kMWaves = 4;
+constexpr int kMEvals = 16 * kMWaves;
+constexpr int kMSteps = kKP / 4;                 // 81 k-steps of 4
+constexpr int kMChunk = 27;                      // A staging chunk (k-steps); 81 = 3 x 27
+constexpr int kMTileDoubles = kM64Rows * 16;     // 5216 doubles = 41728 B
+constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per thread per tile (11)
+
+__global__ __launch_bounds__(256) void k_recheck_mfma(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                      const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
+                                                      ExactParams p, const int *__restrict__ flag_list, int flag_cap,
+                                                      int *__restrict__ counters, double *__restrict__ dec_exact,
+                                                      int8_t *__restrict__ labels, int *__restrict__ flag2_list,
+                                                      int flag2_cap, Dims d)
+{
+    __shared__ __attribute__((aligned(16))) double bt[2][kMTileDoubles];
+    __shared__ double stage[kMWaves][kMChunk][64];
+    __shared__ double xxs[kMWaves][16];
+    int n_flag = counters[CNT_FLAGGED];
+    if (n_flag > flag_cap) n_flag = flag_cap;
+    const int n_groups = (n_flag + kMEvals - 1) / kMEvals;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    const int n_tiles = p.n_sv_pad / 16;
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, computed in place ----
+        const int slot = g * kMEvals + wave * 16 + (lane & 15);
+        const bool valid = slot < n_flag;
+        const float *win = ii;
+        int cell = 0;
+        if (valid) {
+            cell = evalcell[flag_list[slot]];
+            const int br = cell / (H * W);
+            const int rem = cell - br * H * W;
+            const int i = rem / W, j = rem - i * W;
+            win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+        }
+        double a[kMSteps];
+        double xxp = 0.0;
+#pragma unroll
+        for (int c = 0; c < kMSteps / kMChunk; c++) {
+            for (int j = 0; j < kMChunk; j++) {
+                const int k = 4 * (c * kMChunk + j) + (lane >> 4);
+                double v = 0.0;
+                if (valid && k < d.nf && !fd[k].skip) v = attribute_value(win, fd[k], p.lower, p.upper);
+                stage[wave][j][lane] = v;
+                xxp = fma(v, v, xxp);
+            }
+#pragma unroll
+            for (int j = 0; j < kMChunk; j++) a[c * kMChunk + j] = stage[wave][j][lane];
+        }
+        xxp += __shfl_xor(xxp, 16, 64);
+        xxp += __shfl_xor(xxp, 32, 64);
+        if ((lane >> 4) == 0) xxs[wave][lane & 15] = xxp;
+
+        // ---- SV tiles ----
+        double2_t pre[kMLoads];
+        auto tile_load = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < kMLoads; q++) {
+                const int idx = tid + q * 256;               // pair index: row = idx / 8, column pair = idx % 8
+                if (idx < kMTileDoubles / 2)
+                    pre[q] = *reinterpret_cast<const double2_t *>(sv64 + (size_t)(idx >> 3) * p.n_sv_pad + t * 16 + (idx & 7) * 2);
+            }
+        };
+        auto tile_store = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < kMLoads; q++) {
+                const int idx = tid + q * 256;
+                if (idx < kMTileDoubles / 2) *reinterpret_cast<double2_t *>(&bt[buf][idx * 2]) = pre[q];
+            }
+        };
+        tile_load(0);
+        tile_store(0);
+        __syncthreads();
+
+        double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
+        for (int t = 0; t < n_tiles; t++) {
+            const double *B = bt[t & 1];
+            if (t + 1 < n_tiles) tile_load(t + 1);
+            f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < kMSteps; s++) {
+                const double b = B[(4 * s + (lane >> 4)) * 16 + (lane & 15)];      // B[k = 4s + (lane>>4)][j = lane&15]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
+            }
+            const double ss = B[kKP * 16 + (lane & 15)];
+            const double cf = B[(kKP + 1) * 16 + (lane & 15)];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = (lane >> 4) + 4 * r;                               // f64 C/D layout: row = (lane>>4) + 4*reg
+                const double d2 = fma(-2.0, acc[r], xxs[wave][row] + ss);
+                const double kv = exp(-p.gamma * d2);
+                part[r] = fma(cf, kv, part[r]);
+                pabs[r] = fma(fabs(cf), kv, pabs[r]);
+            }
+            __syncthreads();                          // everyone is done reading buffer (t+1)&1 of the previous round
+            if (t + 1 < n_tiles) tile_store((t + 1) & 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = part[r], w = pabs[r];
+            v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
+            v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
+            v += __shfl_xor(v, 2, 64); w += __shfl_xor(w, 2, 64);
+            v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
+            part[r] = v; pabs[r] = w;
+        }
+        // lane with (lane&15)==0 of 16-lane group q holds rows q + 4r; evaluation (lane&15)=e lives in every group:
+        // let the lane whose own evaluation index equals one of its rows write it
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = (lane >> 4) + 4 * r;
+                const int sl = g * kMEvals + wave * 16 + row;
+                if (sl < n_flag) {
+                    const double dv = part[r] - p.rho;
+                    dec_exact[sl] = dv;
+                    const int e = flag_list[sl];
+                    labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+                    const double T = p.as_max1 + p.gamma2 * xxs[wave][row];
+                    if (!(fabs(dv) > p.guard2 * T * pabs[r])) {
+                        int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
+                        if (s2 < flag2_cap) flag2_list[s2] = e;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
+                         const int *flag_list, int flag_cap, int *counters, double *dec_exact, int8_t *labels,
+                         int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
+{
+    int groups = (flag_cap + kMEvals - 1) / kMEvals;
+    int blocks = groups < 1024 ? groups : 1024;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_recheck_mfma, dim3(blocks), dim3(256), 0, s, ii, evalcell, fd, sv64, p, flag_list, flag_cap, counters,
+                       dec_exact, labels, flag2_list, flag2_cap, d);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -84,7 +84,7 @@ typedef struct haf_grasp_output {
     int32_t best_row, best_col, best_roll, best_vote;   /* id_row/col_top_overall, nr_roll_top_overall, topval_gp_overall */
     int32_t rolls_done;             /* rolls the sequential reference loop would have executed             */
     int64_t n_evals;                /* masked (cell, roll) pairs scored = SVM evaluations                  */
-    int64_t n_rechecked;            /* evaluations re-done in exact fp64 libsvm order (guard band)         */
+    int64_t n_rechecked;            /* evaluations re-done in fp64 (guard band of the fast contraction)     */
 } haf_grasp_output;
 
 /* One roll's outcome: what show_predicted_gps() leaves behind (server.cpp:865-932) plus the z estimate
@@ -149,9 +149,10 @@ enum { HAF_ST_UPLOAD = 0, HAF_ST_BIN, HAF_ST_INTEGRAL, HAF_ST_MASK, HAF_ST_FEATU
        HAF_ST_VOTE, HAF_ST_DOWNLOAD, HAF_ST_COUNT };
 int haf_get_stage_ms(haf_engine *e, float *ms /* HAF_ST_COUNT */);
 
-/* Counters of the last scored batch: masked (cell, roll) pairs, and how many of them fell inside the guard band and
- * were re-evaluated in exact fp64 libsvm order. */
-int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked);
+/* Counters of the last scored batch: masked (cell, roll) pairs; how many fell inside the guard band of the fast
+ * contraction and were re-evaluated by the fp64 MFMA tier; how many of those were still too close to zero and were
+ * re-evaluated in libsvm's strict fp64 summation order. */
+int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked, int64_t *n_strict);
 
 /* Model facts for reporting: support vectors, attribute dimension, feature rows (incl. phantom rows). */
 int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_features);

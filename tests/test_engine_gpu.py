@@ -360,3 +360,34 @@ def test_cli_and_server_mirror(data_dir, golden_dir, surrogate):
     np.testing.assert_allclose(res.graspPoint2, g["gp2"], atol=1e-4)
     assert res.hypothesis_string().split()[0] == str(g["eval"])
     srv.close()
+
+
+def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
+    """Guard tiers: fast contraction -> fp64 MFMA (GEMM form) -> libsvm's strict fp64 order.  Forcing wide bands sends
+    every evaluation through tier 2, then through tier 3; labels stay identical and the decision values of tier 3 are
+    the oracle's to 1e-12 of the cancellation scale (same order, same arithmetic; only exp may differ in the last bit)."""
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
+    want = orc.run(xyz, O.make_cfg(), oracle_input(inp))
+    for g1, g2, tol in (("1e30", None, 2.0 ** -40), ("1e30", "1e30", 1e-13)):
+        monkeypatch.setenv("HAF_GUARD_REL", g1)
+        if g2:
+            monkeypatch.setenv("HAF_GUARD2_REL", g2)
+        eng = make_engine(data_dir, surrogate)
+        got = eng.score(xyz, capi.default_input(**inp))
+        cnt = eng.last_counts()
+        assert cnt["n_rechecked"] == cnt["n_evals"] == want["n_evals"]
+        assert cnt["n_strict"] == (cnt["n_evals"] if g2 else 0) or (not g2 and cnt["n_strict"] < 5)
+        for roll in range(12):
+            assert (eng.debug(capi.DBG_LABELS, 0, roll) == want["labels"][roll]).all()
+            m = want["mask"][roll] == 1
+            if m.any():
+                d = eng.debug(capi.DBG_DECISION, 0, roll)
+                rel = np.abs(d[m] - want["dec"][roll][m]) / want["sabs"][roll][m]
+                assert rel.max() <= tol, (g2, roll, rel.max())
+        assert (got["eval"], got["best_row"], got["best_col"], got["best_roll"]) == \
+               (want["eval"], want["row"], want["col"], want["roll_idx"])
+        eng.close()
+        monkeypatch.delenv("HAF_GUARD_REL")
+        if g2:
+            monkeypatch.delenv("HAF_GUARD2_REL")
