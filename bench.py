@@ -8,7 +8,7 @@ per GPU per step (weak scaling: rolls x cells of independent clouds shard across
 the only exchange is one 8-byte RCCL all-reduce(max) per step that elects the best grasp of the batch).
 
 A step = one pass of the whole hot path (bin -> integral -> mask -> features+text round trips+scale -> RBF decision
--> guard-band recheck -> vote/argmax -> pose) over one cloud per rank, inputs already resident in HBM.
+-> fp64 recheck tiers -> vote/argmax -> pose) over one cloud per rank, inputs already resident in HBM.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -31,21 +31,6 @@ PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense
 D_ATTR = 323                       # algorithmic work 2*D*nSV flop per eval, D unpadded
 
 
-def pmc_traffic(args):
-    """HBM bytes per k_svm_rbf launch from the committed rocprofv3 --pmc passes (profiles/), when they were taken on
-    this exact workload; PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        w = t["workload"]
-        if (w["grid"], w["rolls"], w["n_sv"]) == (args.grid, args.rolls, args.nsv):
-            return t["kernels"]["k_svm_rbf"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,12 +40,29 @@ def parse():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rolls", type=int, default=36)
     ap.add_argument("--roll-step", type=int, default=5)
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
-                    help="RBF contraction: one fp32 MFMA pass, or three fp16 MFMA passes on hi/lo halves")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
+                    help="RBF contraction: one fp32 MFMA pass, or three fp16 MFMA passes on the hi/lo halves of the "
+                         "same fp32 operands (same guard band, identical labels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-f32-side", action="store_true", help="skip the side measurement of the fp32-MFMA mode")
     return ap.parse_args()
+
+
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), when they
+    were taken on this exact workload; PMC counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["grid"], w["rolls"], w["n_sv"]) == (args.grid, args.rolls, args.nsv):
+            return t["kernels"][kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(feat, rng_file, model_path, xyz, args):
@@ -94,13 +96,13 @@ def cpu_baseline(feat, rng_file, model_path, xyz, args):
                        % (args.nsv, args.cpu_crop, args.cpu_crop, n1, t1, c_all, c_all, cores, na, ta))
 
 
-def latency_c2(feat, rng_file, device):
+def latency_c2(feat, rng_file, device, flags):
     """BASELINE config C2 (pcd2.pcd, 32x32 cm area, 12 rolls, surrogate model), host-resident cloud: wall time of one
     haf_score call including the PCIe copies -- the second half of the metric."""
     from haf_grasping_amd import capi
     model = os.path.join(ROOT, "tests", "golden", "surrogate.model")
     xyz = capi.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "pcd2.pcd"))
-    eng = capi.Engine(feat, rng_file, model, device=device)
+    eng = capi.Engine(feat, rng_file, model, device=device, flags=flags)
     inp = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32)
     for _ in range(3):
         out = eng.score(xyz, inp)
@@ -127,11 +129,13 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
 
     import models
     from haf_grasping_amd import capi
+    from haf_grasping_amd import distributed as hd
 
     data = os.path.join(ROOT, "tests", "golden", "data")
     feat, rng_file = os.path.join(data, "Features.txt"), os.path.join(data, "range21062012_allfeatures")
@@ -140,59 +144,81 @@ def main():
     models.write_random_model(model_path, args.nsv, D=D_ATTR, seed=1234, balanced=True)
 
     G = args.grid
-    eng = capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
-                      roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2,
-                      flags=capi.FLAG_PROFILE | (capi.FLAG_SPLIT_F16 if args.precision == "f16x3" else 0))
     xyz = models.synthetic_cloud(grid=G, k=2, seed=rank)
     d_xyz = torch.from_numpy(xyz).cuda()                    # resident in HBM before the timed region
     cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
     inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
-    from haf_grasping_amd import distributed as hd
 
-    def step():
-        rec = eng.score_rolls([cloud], [inp], 0, args.rolls)[0]
-        out = eng.finalize(inp, rec)
-        if world > 1:
-            # best grasp of the batch: one 8-byte all-reduce(max) over xGMI (RCCL)
-            hd.best_of_batch(out["best_vote"], tag=rank, device="cuda")
-        return rec, out
+    def make_engine(precision):
+        return capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
+                           roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2,
+                           flags=capi.FLAG_PROFILE | (capi.FLAG_SPLIT_F16 if precision == "f16x3" else 0))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    svm_ms, stage_acc, evals_rank, rechecked = [], {}, 0, 0
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec, out = step()
-        evals_rank += int(rec["n_evals"].sum())
-        rechecked += eng.last_counts()["n_rechecked"]
-        st = eng.stage_ms()
-        svm_ms.append(st["svm"])
-        for k, v in st.items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-    fence()
-    elapsed = time.perf_counter() - t0
+    def run(eng, steps, warmup, collective):
+        def step():
+            rec = eng.score_rolls([cloud], [inp], 0, args.rolls)[0]
+            out = eng.finalize(inp, rec)
+            if collective:
+                hd.best_of_batch(out["best_vote"], tag=rank, device="cuda")   # one 8-byte all-reduce(max) over xGMI (RCCL)
+            return rec, out
+        for _ in range(warmup):
+            step()
+        svm_ms, stage_acc, evals, rechecked, strict = [], {}, 0, 0, 0
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rec, out = step()
+            evals += int(rec["n_evals"].sum())
+            c = eng.last_counts()
+            rechecked += c["n_rechecked"]
+            strict += c["n_strict"]
+            st = eng.stage_ms()
+            svm_ms.append(st["svm"])
+            for k, v in st.items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+        fence()
+        return dict(elapsed=time.perf_counter() - t0, evals=evals, steps=steps, svm_s=float(np.mean(svm_ms)) * 1e-3,
+                    stage_ms={k: v / steps for k, v in stage_acc.items()}, rechecked=rechecked / steps,
+                    strict=strict / steps, out=out)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    ev = torch.tensor([evals_rank], dtype=torch.int64, device="cuda")
-    if world > 1:
+    eng = make_engine(args.precision)
+    res = run(eng, args.steps, args.warmup, use_dist)
+    eng.close()
+
+    t = torch.tensor([res["elapsed"]], dtype=torch.float64, device="cuda")
+    ev = torch.tensor([res["evals"]], dtype=torch.int64, device="cuda")
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(ev, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_evals = int(ev.item())
 
+    def roofline(r, precision):
+        evals_per_launch = r["evals"] / r["steps"]
+        flop = evals_per_launch * 2.0 * D_ATTR * args.nsv           # algorithmic: 646*nSV per eval, ONE pass
+        achieved = flop / r["svm_s"] / 1e12
+        peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+        kernel = "k_svm_rbf_h" if precision == "f16x3" else "k_svm_rbf"
+        o = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+             "frac": achieved / peak, "traffic": pmc_traffic(args, kernel), "kernel_ms": r["svm_s"] * 1e3,
+             "flop_per_launch": flop}
+        if precision == "f16x3":
+            # three fp16 passes over K padded to 336 execute 3*336/323 = 3.12 times the algorithmic flop: the ceiling
+            # of `frac` for this split-precision contraction is 0.32, not 1
+            executed = flop * 3.0 * 336.0 / D_ATTR
+            o.update({"passes": 3, "executed_tflops": executed / r["svm_s"] / 1e12,
+                      "mfma_busy_frac": executed / r["svm_s"] / 1e12 / peak,
+                      "note": "fp32 operands split into fp16 hi+lo; x.s = xh.sh + xl.sh + xh.sl (3 MFMA passes, fp32 "
+                              "accumulate); algorithmic flop counted once, per SURVEY.md 8(d)"})
+        return o
+
     if rank == 0:
-        evals_per_launch = evals_rank / args.steps
-        svm_s = float(np.mean(svm_ms)) * 1e-3
-        flop = evals_per_launch * 2.0 * D_ATTR * args.nsv           # algorithmic: 646*nSV per eval, one pass
-        achieved = flop / svm_s / 1e12
-        peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         line = {
             "metric": "grid-cell x rotation SVM evals/sec",
             "value": total_evals / elapsed,
@@ -200,30 +226,38 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16x3 (fp32 operands split into fp16 hi+lo, fp32 accumulate)",
+            "dtype": "f32" if args.precision == "f32" else "f16x3",
             "data": "synthetic",
             "config": {"workload": "C5: synthetic %dx%d heightmap (%d points), %d rolls x %d deg, %dx%d cm area, seeded random "
                                    "libsvm RBF model nSV=%d D=323 gamma=1/323, one cloud per GPU per step, cloud resident in HBM"
                                    % (G, G, xyz.shape[0], args.rolls, args.roll_step, G, G, args.nsv),
-                       "evals_per_cloud": int(evals_per_launch), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
+                       "evals_per_cloud": int(res["evals"] / args.steps), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
+                       "contraction": args.precision,
                        "sharding": "clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step"},
-            "roofline": {"kernel": "k_svm_rbf" if args.precision == "f32" else "k_svm_rbf_h", "bound": "mfma",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(args) if args.precision == "f32" else None,
-                         "kernel_ms": svm_s * 1e3, "flop_per_launch": flop},
-            "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
-            "rechecked_per_step": rechecked / args.steps,
-            "best": {"eval": out["eval"], "row": out["best_row"], "col": out["best_col"], "roll": out["best_roll"]},
+            "roofline": roofline(res, args.precision),
+            "stage_ms_per_step": res["stage_ms"],
+            "rechecked_per_step": {"fp64_mfma_tier": res["rechecked"], "strict_order_tier": res["strict"]},
+            "best": {"eval": res["out"]["eval"], "row": res["out"]["best_row"], "col": res["out"]["best_col"],
+                     "roll": res["out"]["best_roll"]},
         }
+        if world == 1 and args.precision == "f16x3" and not args.no_f32_side:
+            e2 = make_engine("f32")
+            r2 = run(e2, 2, 1, False)
+            e2.close()
+            line["f32_mode"] = {"value": r2["evals"] / r2["elapsed"], "ms_per_step": 1e3 * r2["elapsed"] / 2,
+                                "roofline": roofline(r2, "f32"), "stage_ms_per_step": r2["stage_ms"],
+                                "same_best": bool(r2["out"]["eval"] == res["out"]["eval"] and
+                                                  r2["out"]["best_row"] == res["out"]["best_row"] and
+                                                  r2["out"]["best_col"] == res["out"]["best_col"])}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(feat, rng_file, model_path, xyz, args)
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_latency:
-            eng.close()
-            line["grasp_latency"] = latency_c2(feat, rng_file, local_rank)
+            line["grasp_latency"] = latency_c2(feat, rng_file, local_rank,
+                                               capi.FLAG_SPLIT_F16 if args.precision == "f16x3" else 0)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
