@@ -105,7 +105,7 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
-                         const int *flag_list, int flag_cap, int *counters, double *dec_exact, int8_t *labels,
+                         const int *flag_list, int flag_cap, int *counters, double *x64, double *dec_exact, int8_t *labels,
                          int *flag2_list, int flag2_cap, Dims d, hipStream_t s);
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, RollRecordDev *rec, Dims d,
                  hipStream_t s);

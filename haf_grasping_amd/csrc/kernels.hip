@@ -282,8 +282,10 @@ __device__ __forceinline__ double attribute_value(const float *__restrict__ win,
 // a thread finishes 8 attributes, then stores them as one 16-byte vector per image (512 contiguous bytes per 32 lanes).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
+// workgroups for C5).  Small requests use k_features below.
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
+__global__ __launch_bounds__(256) void k_features_serial(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2)
@@ -348,16 +350,96 @@ __global__ __launch_bounds__(256) void k_features(const float *__restrict__ ii, 
     ax[e] = neg_gamma2 * (float)xx;           // -gamma*log2(e)*|x|^2, folded into the exp2 argument
 }
 
+// Workgroup = 64 evals x 8 waves: wave w evaluates the groups of 8 attributes w, w+8, ... (42 groups of 8 = 336
+// attribute slots) for the same 64 evals, so the attribute index stays wave-uniform (feature descriptors by scalar
+// loads, no divergence), a small request (a few thousand evals) still fills the chip, and a single evaluation is
+// never one long serial chain of 324 attributes.
+constexpr int kFeatEvals = 64;
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                  const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
+                                                  float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
+                                                  double upper, float neg_gamma2)
+{
+    __shared__ double red[8][kFeatEvals];
+    const int n_evals = counters[CNT_EVALS];
+    const long n_pad = ((long)n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+    if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
+    const int ev = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * kFeatEvals + ev;
+    const long tile = e >> 5;
+    float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
+    char *xh = reinterpret_cast<char *>(X) + (size_t)tile * kHXTileBytes + (e & 31) * 16;
+    const int n_groups = SPLIT ? 2 * kHSteps : (kKP + 7) / 8;          // 42 / 41
+    const bool live = e < n_evals;
+    const float *win = ii;
+    if (live) {
+        const int H = d.H, W = d.W, W1 = W + 1;
+        const int cell = evalcell[e];
+        const int br = cell / (H * W);
+        const int rem = cell - br * H * W;
+        const int i = rem / W, j = rem - i * W;
+        win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+    }
+    double xx = 0.0;
+    for (int g = gl; g < n_groups; g += 8) {
+        half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int f = g * 8 + q;
+            float xf = 0.0f;
+            if (live && f < d.nf) {
+                const FeatDesc &F = fd[f];
+                if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+            }
+            if (SPLIT) {
+                const _Float16 h = (_Float16)xf;                       // RN
+                const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
+                hi[q] = h;
+                lo[q] = l;
+                const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
+                xx = fma((double)xe, (double)xe, xx);
+            } else {
+                if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
+                xx = fma((double)xf, (double)xf, xx);
+            }
+        }
+        if (SPLIT) {
+            *reinterpret_cast<half8 *>(xh + g * 512) = hi;
+            *reinterpret_cast<half8 *>(xh + kHMatBytes + g * 512) = lo;
+        }
+    }
+    red[gl][ev] = xx;
+    __syncthreads();
+    if (gl == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t += red[k][ev];                  // fixed order: deterministic
+        ax[e] = neg_gamma2 * (float)t;                                 // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+    }
+}
+
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, bool split_f16, hipStream_t s)
 {
-    long blocks = (max_evals + 255) / 256;
-    if (blocks <= 0) return;
+    if (max_evals <= 0) return;
+    if (max_evals >= (1L << 20)) {
+        // enough evaluations to fill the chip with one thread each
+        long blocks = (max_evals + 255) / 256;
+        if (split_f16)
+            hipLaunchKernelGGL(k_features_serial<true>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                               lower, upper, neg_gamma2);
+        else
+            hipLaunchKernelGGL(k_features_serial<false>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                               lower, upper, neg_gamma2);
+        return;
+    }
+    long blocks = ((max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals) * (kSvmBlockEvals / kFeatEvals);
     if (split_f16)
-        hipLaunchKernelGGL(k_features<true>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
+        hipLaunchKernelGGL(k_features<true>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
                            upper, neg_gamma2);
     else
-        hipLaunchKernelGGL(k_features<false>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
+        hipLaunchKernelGGL(k_features<false>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
                            upper, neg_gamma2);
 }
 
@@ -771,61 +853,73 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
 // (v_mfma_f64_16x16x4_f64, GEMM form, fp64 exp).  Its error is ~2^-44 of sum|coef|K, so only evaluations with
 // |dec| <= 2^-40 * T * sum|coef|K (practically none) still need libsvm's strict summation order (k_recheck).
 // Workgroup = 4 waves x 16 flagged evaluations; each wave keeps its 16 x 324 fp64 attributes as the A operand in 162
-// VGPRs (computed in place: a lane evaluates exactly the attributes its A fragment holds), the fp64 SV tile
+// VGPRs (loaded from the image k_recheck_x writes with one thread per attribute), the fp64 SV tile
 // (326 x 16: attributes, |s|^2, coef) is shared through LDS, double buffered with a register-staged prefetch.
 // ---------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kMWaves = 4;
 constexpr int kMEvals = 16 * kMWaves;
 constexpr int kMSteps = kKP / 4;                 // 81 k-steps of 4
-constexpr int kMChunk = 27;                      // A staging chunk (k-steps); 81 = 3 x 27
 constexpr int kMTileDoubles = kM64Rows * 16;     // 5216 doubles = 41728 B
 constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per thread per tile (11)
 
-__global__ __launch_bounds__(256) void k_recheck_mfma(const float *__restrict__ ii, const int *__restrict__ evalcell,
-                                                      const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
+// fp64 attribute vectors of the flagged evaluations, one thread per (evaluation, attribute): [group of 16][324][16],
+// the register image of the fp64 MFMA A operand (64 consecutive doubles per k-step).
+__global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                   const FeatDesc *__restrict__ fd, ExactParams p,
+                                                   const int *__restrict__ flag_list, int flag_cap,
+                                                   const int *__restrict__ counters, double *__restrict__ x64, Dims d)
+{
+    int n_flag = counters[CNT_FLAGGED];
+    if (n_flag > flag_cap) n_flag = flag_cap;
+    const int n_grp = (n_flag + 15) / 16;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    for (int grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        for (int it = threadIdx.x; it < 16 * kKP; it += 256) {
+            const int k = it >> 4, ev = it & 15;
+            const int slot = grp * 16 + ev;
+            double v = 0.0;
+            if (slot < n_flag && k < d.nf && !fd[k].skip) {
+                const int cell = evalcell[flag_list[slot]];
+                const int br = cell / (H * W);
+                const int rem = cell - br * H * W;
+                const int i = rem / W, j = rem - i * W;
+                const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+                v = attribute_value(win, fd[k], p.lower, p.upper);
+            }
+            x64[(size_t)grp * kKP * 16 + it] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__ x64, const int *__restrict__ evalcell,
+                                                      const double *__restrict__ sv64,
                                                       ExactParams p, const int *__restrict__ flag_list, int flag_cap,
                                                       int *__restrict__ counters, double *__restrict__ dec_exact,
                                                       int8_t *__restrict__ labels, int *__restrict__ flag2_list,
                                                       int flag2_cap, Dims d)
 {
     __shared__ __attribute__((aligned(16))) double bt[2][kMTileDoubles];
-    __shared__ double stage[kMWaves][kMChunk][64];
     __shared__ double xxs[kMWaves][16];
     int n_flag = counters[CNT_FLAGGED];
     if (n_flag > flag_cap) n_flag = flag_cap;
     const int n_groups = (n_flag + kMEvals - 1) / kMEvals;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int H = d.H, W = d.W, W1 = W + 1;
     const int n_tiles = p.n_sv_pad / 16;
     typedef double double2_t __attribute__((ext_vector_type(2)));
 
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, computed in place ----
-        const int slot = g * kMEvals + wave * 16 + (lane & 15);
-        const bool valid = slot < n_flag;
-        const float *win = ii;
-        int cell = 0;
-        if (valid) {
-            cell = evalcell[flag_list[slot]];
-            const int br = cell / (H * W);
-            const int rem = cell - br * H * W;
-            const int i = rem / W, j = rem - i * W;
-            win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
-        }
+        // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, from k_recheck_x's image ----
+        const int grp = g * kMWaves + wave;                          // 16 flagged evaluations
         double a[kMSteps];
         double xxp = 0.0;
+        {
+            const double *xg = x64 + (size_t)grp * kKP * 16 + lane;  // [(grp*324 + 4s + (lane>>4))*16 + (lane&15)]
 #pragma unroll
-        for (int c = 0; c < kMSteps / kMChunk; c++) {
-            for (int j = 0; j < kMChunk; j++) {
-                const int k = 4 * (c * kMChunk + j) + (lane >> 4);
-                double v = 0.0;
-                if (valid && k < d.nf && !fd[k].skip) v = attribute_value(win, fd[k], p.lower, p.upper);
-                stage[wave][j][lane] = v;
-                xxp = fma(v, v, xxp);
+            for (int s = 0; s < kMSteps; s++) {
+                a[s] = xg[s * 64];
+                xxp = fma(a[s], a[s], xxp);
             }
-#pragma unroll
-            for (int j = 0; j < kMChunk; j++) a[c * kMChunk + j] = stage[wave][j][lane];
         }
         xxp += __shfl_xor(xxp, 16, 64);
         xxp += __shfl_xor(xxp, 32, 64);
@@ -910,13 +1004,14 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const float *__restrict__ 
 }
 
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
-                         const int *flag_list, int flag_cap, int *counters, double *dec_exact, int8_t *labels,
+                         const int *flag_list, int flag_cap, int *counters, double *x64, double *dec_exact, int8_t *labels,
                          int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
 {
     int groups = (flag_cap + kMEvals - 1) / kMEvals;
-    int blocks = groups < 1024 ? groups : 1024;
+    int blocks = groups < 2048 ? groups : 2048;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_recheck_mfma, dim3(blocks), dim3(256), 0, s, ii, evalcell, fd, sv64, p, flag_list, flag_cap, counters,
+    hipLaunchKernelGGL(k_recheck_x, dim3(blocks * 2), dim3(256), 0, s, ii, evalcell, fd, p, flag_list, flag_cap, counters, x64, d);
+    hipLaunchKernelGGL(k_recheck_mfma, dim3(blocks), dim3(256), 0, s, x64, evalcell, sv64, p, flag_list, flag_cap, counters,
                        dec_exact, labels, flag2_list, flag2_cap, d);
 }
 
