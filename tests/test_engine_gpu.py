@@ -391,3 +391,14 @@ def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
         monkeypatch.delenv("HAF_GUARD_REL")
         if g2:
             monkeypatch.delenv("HAF_GUARD2_REL")
+
+
+def test_guard_list_overflow_is_loud(data_dir, surrogate, monkeypatch):
+    """More guard-band evaluations than the recheck capacity must fail the call, never silently keep fast-tier labels."""
+    monkeypatch.setenv("HAF_GUARD_REL", "1e30")            # every evaluation lands in the band
+    xyz = models.synthetic_cloud(grid=56, k=3, seed=1)     # dense: all 42x42 cells x 12 rolls masked (>= 4x the capacity)
+    eng = make_engine(data_dir, surrogate)
+    with pytest.raises(capi.HafError) as ei:
+        eng.score(xyz, capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56))
+    assert ei.value.code == capi.HAF_E_CAPACITY and "guard band" in str(ei.value)
+    eng.close()
