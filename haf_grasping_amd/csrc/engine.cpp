@@ -395,7 +395,7 @@ int build_tables(haf_engine *e)
     // Guard band: a fast decision is trusted when |dec| > guard * (1 + |a_x| + max|a_s|) * sum_n |coef_n| K_n + guard_abs,
     // a_x = gamma'*|x|^2, a_s = gamma'*|s|^2.  2^-16 is the WORST-CASE fp32 error of the contraction per unit of that
     // product (324-term fma chain bounded through Cauchy-Schwarz by 324*2^-24*(a_x+a_s), fp32 attributes, three
-    // roundings of the exp2 argument, v_exp_f32, fp32 coefficient sum): DESIGN.md §2 derives it, tools/diag_guard.py
+    // roundings of the exp2 argument, v_exp_f32, fp32 coefficient sum): DESIGN.md §2 derives it, tests/diag_guard.py
     // measures the actual error (about 30x smaller).  HAF_GUARD_REL overrides it for experiments.
     double guard = 1.0 / 65536.0;
     if (const char *g = getenv("HAF_GUARD_REL")) guard = atof(g);
