@@ -402,3 +402,42 @@ def test_guard_list_overflow_is_loud(data_dir, surrogate, monkeypatch):
         eng.score(xyz, capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56))
     assert ei.value.code == capi.HAF_E_CAPACITY and "guard band" in str(ei.value)
     eng.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_randomised_requests_against_oracle(data_dir, tmp_path, mode):
+    """Seeded random requests: random clouds (blobs, planes, outliers, duplicates, points on cell edges), centres,
+    approach vectors, gripper widths, search areas, roll counts/steps; stage-by-stage bit parity with the oracle."""
+    f, r = _files(data_dir)
+    path = str(tmp_path / "rand128.model")
+    models.write_random_model(path, 128, seed=77, balanced=True)
+    o = O.Oracle(f, r, path)
+    rng = np.random.RandomState(2024)
+    engines = {}
+    for case in range(24):
+        n_rolls, step = [(12, 15), (5, 36), (7, 25), (3, 60)][case % 4]
+        n = int(rng.choice([50, 500, 4000, 20000]))
+        pts = []
+        for _ in range(rng.randint(1, 5)):                       # blobs
+            c = rng.uniform(-0.15, 0.15, 3) * [1, 1, 0.3] + [0, 0, 0.05]
+            pts.append(c + rng.standard_normal((n // 4 + 1, 3)) * rng.uniform(0.005, 0.05, 3))
+        xy = rng.uniform(-0.3, 0.3, (n // 2, 2))                  # a tilted plane
+        pts.append(np.column_stack([xy, 0.02 + 0.1 * xy[:, 0] - 0.05 * xy[:, 1]]))
+        grid_pts = np.round(rng.uniform(-0.28, 0.28, (64, 3)), 2)  # exactly on centimetre edges
+        grid_pts[:, 2] = rng.uniform(0, 0.1, 64)
+        pts.append(grid_pts)
+        xyz = np.concatenate(pts).astype(np.float32)
+        xyz = np.concatenate([xyz, xyz[:17]])                     # duplicates
+        kw = dict(grasp_area_center=tuple(rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]),
+                  grasp_area_length_x=float(rng.choice([20, 28.9, 32, 44, 56])),
+                  grasp_area_length_y=float(rng.choice([18, 32, 44, 56, 70])),
+                  gripper_opening_width=int(rng.choice([1, 1, 1, 2, 3])),
+                  show_only_best_grasp=int(rng.rand() < 0.3))
+        if rng.rand() < 0.5:
+            kw["approach_vector"] = tuple(rng.standard_normal(3) * [0.3, 0.3, 1.0] + [0, 0, 1.0])
+        key = (n_rolls, step)
+        if key not in engines:
+            engines[key] = make_engine(data_dir, path, mode, n_rolls=n_rolls, roll_step_deg=step, max_points=1 << 16)
+        compare_full(engines[key], o, xyz, dict(n_rolls=n_rolls, roll_step_deg=step), kw)
+    for e in engines.values():
+        e.close()
