@@ -15,10 +15,10 @@
 // data in metres) a double-double evaluation is used whose decision can differ from glibc only when x lies
 // within ~1e-30 relative of a rounding boundary; tests/test_host_cpu.py exercises both windows against glibc.
 //
-// Two code paths, same results: a branch-light FAST path for 10^(P-23) <= ... the common magnitudes
-// (1 <= k <= 22: both candidate decimal exponents evaluated, no loop, no per-lane-divergent switch, the final
-// division N/10^k done as q = N*y, q += fma(-q, T, N)*y with y = RN(10^-k) -- verified EXHAUSTIVELY equal to
-// IEEE division for every N in [10^3,10^4] U [10^5,10^6] and k in 0..22, tools/divtest.c), and the general SLOW path
+// Two code paths, same results: a branch-light FAST path for the common magnitudes (0 <= k <= 22: the decimal exponent
+// is decided exactly by ONE comparison against a table of "smallest double >= 10^e", no loop, no per-lane-divergent
+// switch; the final division N/10^k is q = N*y, q += fma(-q, T, N)*y with y = RN(10^-k) -- verified EXHAUSTIVELY equal
+// to IEEE division for every N in [10^3,10^4] U [10^5,10^6] and k in 0..22, tools/divtest.c), and the general SLOW path
 // (loops, true divisions) for everything else.
 //
 // The same source is compiled for the device (kernels.hip) and for the host (engine.cpp -> unit tests).
@@ -44,12 +44,30 @@ namespace hafq {
 #define HAFQ_P10INV_LIST                                                                                                 \
     1e-0, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9, 1e-10, 1e-11, 1e-12, 1e-13, 1e-14, 1e-15, 1e-16, 1e-17, \
         1e-18, 1e-19, 1e-20, 1e-21, 1e-22
+// kBnd[e + 24] = the smallest double >= 10^e, e = -24..24 (generated with exact rational arithmetic): for a double a,
+// a >= 10^e  <=>  a >= kBnd[e + 24], exactly, also where 10^e itself is not representable.
+#define HAFQ_BND_LIST                                                                                              \
+    0x1.357c299a88ea8p-80, 0x1.82db34012b252p-77, 0x1.e392010175ee6p-74, 0x1.2e3b40a0e9b50p-70, \
+    0x1.79ca10c924224p-67, 0x1.d83c94fb6d2adp-64, 0x1.2725dd1d243acp-60, 0x1.70ef54646d497p-57, \
+    0x1.cd2b297d889bdp-54, 0x1.203af9ee75616p-50, 0x1.6849b86a12b9cp-47, 0x1.c25c268497682p-44, \
+    0x1.19799812dea12p-40, 0x1.5fd7fe1796496p-37, 0x1.b7cdfd9d7bdbbp-34, 0x1.12e0be826d695p-30, \
+    0x1.5798ee2308c3ap-27, 0x1.ad7f29abcaf49p-24, 0x1.0c6f7a0b5ed8ep-20, 0x1.4f8b588e368f1p-17, \
+    0x1.a36e2eb1c432dp-14, 0x1.0624dd2f1a9fcp-10, 0x1.47ae147ae147bp-7, 0x1.999999999999ap-4, \
+    0x1.0000000000000p+0, 0x1.4000000000000p+3, 0x1.9000000000000p+6, 0x1.f400000000000p+9, \
+    0x1.3880000000000p+13, 0x1.86a0000000000p+16, 0x1.e848000000000p+19, 0x1.312d000000000p+23, \
+    0x1.7d78400000000p+26, 0x1.dcd6500000000p+29, 0x1.2a05f20000000p+33, 0x1.74876e8000000p+36, \
+    0x1.d1a94a2000000p+39, 0x1.2309ce5400000p+43, 0x1.6bcc41e900000p+46, 0x1.c6bf526340000p+49, \
+    0x1.1c37937e08000p+53, 0x1.6345785d8a000p+56, 0x1.bc16d674ec800p+59, 0x1.158e460913d00p+63, \
+    0x1.5af1d78b58c40p+66, 0x1.b1ae4d6e2ef50p+69, 0x1.0f0cf064dd592p+73, 0x1.52d02c7e14af7p+76, \
+    0x1.a784379d99db5p+79
 // 10^k exactly (k <= 22) and RN(10^-k): a decimal literal IS the correctly rounded double of its value
 static const double kP10_host[23] = {HAFQ_P10_LIST};
 static const double kP10inv_host[23] = {HAFQ_P10INV_LIST};
+static const double kBnd_host[49] = {HAFQ_BND_LIST};
 #if defined(__HIP__)
 __device__ static const double kP10_dev[23] = {HAFQ_P10_LIST};
 __device__ static const double kP10inv_dev[23] = {HAFQ_P10INV_LIST};
+__device__ static const double kBnd_dev[49] = {HAFQ_BND_LIST};
 #endif
 
 HAF_HD double pow10_exact(int k)   // 0 <= k <= 22
@@ -66,6 +84,15 @@ HAF_HD double pow10_inv(int k)     // RN(10^-k), 0 <= k <= 22
     return kP10inv_dev[k];
 #else
     return kP10inv_host[k];
+#endif
+}
+
+HAF_HD double pow10_bound(int e)   // smallest double >= 10^e, -24 <= e <= 24
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kBnd_dev[e + 24];
+#else
+    return kBnd_host[e + 24];
 #endif
 }
 
@@ -162,24 +189,20 @@ HAF_HD_NOINLINE double decq_abs_slow(double a, int P)
 HAF_HD double decq_abs(double a, int P)
 {
     const int b = ilogb(a);
-    const int e = (b * 1233) >> 12;
-    const int k0 = P - 1 - e;              // the true scale exponent is k0 or k0 - 1
-    if (k0 >= 1 && k0 <= 22) {
-        const double lo_bound = pow10_exact(P - 1), hi_bound = pow10_exact(P);
-        const double T0 = pow10_exact(k0), T1 = pow10_exact(k0 - 1);
-        const double h0 = a * T0, l0 = fma(a, T0, -h0);      // exact: a*T0 = h0 + l0
-        const double h1 = a * T1, l1 = fma(a, T1, -h1);
-        const bool up = (h0 > hi_bound) || ((h0 == hi_bound) && (l0 >= 0.0));    // a*10^k0 >= 10^P: one decade up
-        const double hi = up ? h1 : h0, lo = up ? l1 : l0;
-        const int k = up ? k0 - 1 : k0;
-        const bool below = (hi < lo_bound) || ((hi == lo_bound) && (lo < 0.0));
-        const bool above = (hi > hi_bound) || ((hi == hi_bound) && (lo >= 0.0));
-        if (!(below || above)) {
-            const double N = rhe(hi, lo);
+    const int e0 = (b * 1233) >> 12;       // floor(b*log10(2)); for -80 <= b <= 80 (checked exhaustively with exact
+                                           // rationals) the decimal exponent floor(log10(a)) is e0 or e0 + 1
+    if (e0 >= -24 && e0 <= 23) {
+        const int e = e0 + ((a >= pow10_bound(e0 + 1)) ? 1 : 0);     // exact decision, see kBnd
+        const int k = P - 1 - e;                                      // a * 10^k lies in [10^(P-1), 10^P)
+        if (k >= 0 && k <= 22) {
             const double T = pow10_exact(k), y = pow10_inv(k);
-            double q = N * y;                                  // N / 10^k, correctly rounded (exhaustively verified):
-            q = fma(fma(-q, T, N), y, q);                      //   q + (N - q*T) * RN(1/T)
-            return q;
+            const double hi = a * T, lo = fma(a, T, -hi);             // exact: a*T = hi + lo
+            if (hi >= pow10_exact(P - 1) && hi < pow10_exact(P)) {     // always true here; anything else goes the slow way
+                const double N = rhe(hi, lo);
+                double q = N * y;                                      // N / 10^k, correctly rounded (exhaustively verified):
+                q = fma(fma(-q, T, N), y, q);                          //   q + (N - q*T) * RN(1/T)
+                return q;
+            }
         }
     }
     return decq_abs_slow(a, P);
