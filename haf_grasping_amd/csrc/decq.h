@@ -217,6 +217,36 @@ HAF_HD double decq(double x, int P)
     return x < 0.0 ? -r : r;
 }
 
+// "%.4g" round trip of an fp32 value (what fv.cpp:133 prints).  A float has 24 significant bits and 5^12 < 2^28, so for
+// k <= 12 the product a * 10^k is EXACT in binary64 and round-half-even of it is a single v_rndne_f64.
+HAF_HD double decq4_float(float v)
+{
+    const double x = (double)v;
+    const double a = fabs(x);
+    if (!(a > 0.0) || !(a < INFINITY)) return x;
+    const int b = ilogb(a);
+    const int e0 = (b * 1233) >> 12;
+    double r;
+    bool done = false;
+    if (e0 >= -24 && e0 <= 23) {
+        const int e = e0 + ((a >= pow10_bound(e0 + 1)) ? 1 : 0);
+        const int k = 3 - e;
+        if (k >= 0 && k <= 12) {
+            const double T = pow10_exact(k), y = pow10_inv(k);
+            const double t = a * T;                                    // exact
+            if (t >= 1e3 && t < 1e4) {
+                const double N = rint(t);                              // round-half-even, like glibc on the exact value
+                double q = N * y;
+                q = fma(fma(-q, T, N), y, q);                          // N / 10^k, correctly rounded
+                r = q;
+                done = true;
+            }
+        }
+    }
+    if (!done) r = decq_abs(a, 4);
+    return x < 0.0 ? -r : r;
+}
+
 // svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed; range = fmax - fmin
 // and inv_range = RN(1/range) are per-attribute constants.  Returns the attribute value svm-predict parses
 // (0.0 when the attribute is omitted from the text).

@@ -962,7 +962,7 @@ int haf_test_finalize(const haf_config *cfg, const haf_grasp_input *in, const ha
 }
 
 // ---- test hooks (host and device builds of the decimal round-trip arithmetic; see tests/) ----
-double haf_test_decq_host(double x, int digits) { return hafq::decq(x, digits); }
+double haf_test_decq_host(double x, int digits) { return digits == 40 ? hafq::decq4_float((float)x) : hafq::decq(x, digits); }
 double haf_test_scale_host(double q4, double fmin, double fmax, double lower, double upper)
 {
     const double range = fmax - fmin;

@@ -272,7 +272,7 @@ __device__ __forceinline__ float feature_value(const float *__restrict__ win, co
 __device__ __forceinline__ double attribute_value(const float *__restrict__ win, const FeatDesc &f, double lower, double upper)
 {
     float v = feature_value(win, f);
-    double q4 = hafq::decq((double)v, 4);
+    double q4 = hafq::decq4_float(v);
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper);
 }
 
@@ -1127,7 +1127,7 @@ void launch_vote(const int8_t *labels, const float *heights, const int *brcount,
 __global__ void k_decq_test(const double *__restrict__ in, double *__restrict__ out, int n, int P)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = hafq::decq(in[i], P);
+    if (i < n) out[i] = (P == 40) ? hafq::decq4_float((float)in[i]) : hafq::decq(in[i], P);   // 40: the fp32 "%.4g" entry
 }
 void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s)
 {

@@ -113,6 +113,10 @@ def test_device_decimal_roundtrip_matches_host():
         assert L.haf_test_decq_device(x.ctypes.data, out.ctypes.data, len(x), digits) == 0
         host = np.array([L.haf_test_decq_host(float(v), digits) for v in x])
         assert (out.view(np.uint64) == host.view(np.uint64)).all()
+        if digits == 4:     # the fp32 entry the feature kernel calls
+            out40 = np.empty_like(x)
+            assert L.haf_test_decq_device(x.ctypes.data, out40.ctypes.data, len(x), 40) == 0
+            assert (out40.view(np.uint64) == host.view(np.uint64)).all()
 
 
 def test_device_scale_matches_host(data_dir):

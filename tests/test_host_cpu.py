@@ -90,6 +90,25 @@ def test_decq_host_matches_printf_strtod(digits):
     assert bad == 0
 
 
+def test_decq4_float_entry_matches_printf_strtod():
+    """The fp32 "%.4g" entry the kernels use (digits code 40): exact-product shortcut for k <= 12, general path beyond."""
+    L = capi.lib()
+    rng = np.random.RandomState(40)
+    parts = [(rng.standard_normal(30000) * s).astype(np.float32) for s in (1e-12, 1e-9, 1e-7, 1e-4, 1e-2, 1.0, 30.0, 1e3, 1e5, 1e9)]
+    base = rng.randint(1000, 10000, size=4000).astype(np.float64)
+    for e in range(-10, 8):                       # exact ties representable in fp32 and their fp32 neighbours
+        t = ((base + 0.5) * 10.0 ** e).astype(np.float32)
+        parts += [t, np.nextafter(t, np.float32(np.inf)), np.nextafter(t, np.float32(-np.inf))]
+    p10 = np.array([10.0 ** e for e in range(-20, 21)], np.float32)
+    parts += [p10, np.nextafter(p10, np.float32(np.inf)), np.nextafter(p10, np.float32(-np.inf)),
+              np.array([0.0, -0.0, 123.25, 123.75, 1234.5, 9999.5, 99995.0, 1e-45, 3.4e38], np.float32)]
+    x = np.concatenate(parts)
+    x = np.concatenate([x, -x])
+    for v in x:
+        v = float(v)
+        assert _bits(L.haf_test_decq_host(v, 40)) == _bits(_glibc_q(v, 4)), v
+
+
 def test_decq_wide_window_against_glibc():
     """Outside 1e-19..1e26 the double-double path is used; it is expected (not proven) to agree with glibc."""
     L = capi.lib()
