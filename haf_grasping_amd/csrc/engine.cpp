@@ -209,6 +209,7 @@ struct haf_engine {
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64;
     DevBuf<short> d_ev16;
     DevBuf<RollRecordDev> d_rec;
+    DevBuf<unsigned long long> d_topkey;
     DevBuf<FeatDesc> d_fd;
 
     // pinned host staging
@@ -448,6 +449,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->flag2_cap);
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rec.alloc(B * R);
+    ok &= hipSuccess == e->d_topkey.alloc(B * R);
     if (!ok) return fail(e, HAF_E_DEVICE, std::string("hipMalloc of working buffers failed: ") + hipGetErrorString(hipGetLastError()));
     HIPCHK(e, hipHostMalloc((void **)&e->h_clouds, B * sizeof(CloudDev)));
     HIPCHK(e, hipHostMalloc((void **)&e->h_geo, B * R * sizeof(RollGeo)));
@@ -506,7 +508,7 @@ void haf_destroy(haf_engine *e)
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
-    e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_fd.release();
+    e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
     if (e->h_rec) (void)hipHostFree(e->h_rec);
@@ -673,7 +675,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->flag2_cap,
                    e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
     mark(e, HAF_ST_VOTE);
-    launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_rec.p, d, s);
+    launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rec.p, d, s);
     mark(e, HAF_ST_DOWNLOAD);
     HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
     HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -10,7 +10,7 @@
 //   k_svm_rbf        svm_predict_values / Kernel::k_function RBF (libsvm svm.cpp:325-365, 2478-2532) as an
 //                    fp32 MFMA contraction with an exp epilogue and a guard band
 //   k_recheck        the same decision in libsvm's exact fp64 order for guard-band evaluations
-//   k_vote           show_predicted_gps 865-932 (29-tap vote, first-wins argmax, longest-run centring) and the
+//   k_vote_cells / k_vote_pick   show_predicted_gps 865-932 (29-tap vote, first-wins argmax, longest-run centring) and the
 //                    z window of transform_gp_in_wcs_and_publish 1342-1351
 //
 // Built with -ffp-contract=off: every fp32/fp64 expression that must match the CPU restatement bit for bit is
@@ -96,7 +96,7 @@ void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkey
 // fp64 partial sums and the fp32 narrowing (599-601) are bit-identical for any input, not only when the
 // sums happen to be exact.  One workgroup per (cloud, roll): thread-per-row pass, then thread-per-column pass.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_integral(int *__restrict__ hk, double *__restrict__ rowsum, float *__restrict__ ii,
+__global__ __launch_bounds__(512) void k_integral(int *hk, double *__restrict__ rowsum, float *__restrict__ ii,
                                                   Dims d)
 {
     const int br = blockIdx.x;
@@ -107,12 +107,22 @@ __global__ __launch_bounds__(512) void k_integral(int *__restrict__ hk, double *
     float *I = ii + (size_t)br * (H + 1) * W1;
     for (int row = threadIdx.x; row < H; row += blockDim.x) {
         double s = 0.0;
-        for (int c = 0; c < W; c++) {
-            float h = key2f(keys[row * W + c]);
-            if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare)
-            hts[row * W + c] = h;
-            s = __dadd_rn(s, (double)h);              // 589: widened before the integral
-            rs[row * W + c] = s;
+        // the running sum is sequential by definition; the loads are not: fetch 8 keys ahead of the dependent chain
+        // (keys and heights share storage, so the compiler cannot hoist the loads itself)
+        for (int c0 = 0; c0 < W; c0 += 8) {
+            int kreg[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) kreg[q] = (c0 + q < W) ? keys[row * W + c0 + q] : 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (c0 + q < W) {
+                    float h = key2f(kreg[q]);
+                    if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare)
+                    hts[row * W + c0 + q] = h;
+                    s = __dadd_rn(s, (double)h);              // 589: widened before the integral
+                    rs[row * W + c0 + q] = s;
+                }
+            }
         }
     }
     __syncthreads();
@@ -122,6 +132,7 @@ __global__ __launch_bounds__(512) void k_integral(int *__restrict__ hk, double *
             for (int r = 0; r < H; r++) I[(r + 1) * W1] = 0.0f;
         } else {
             double acc = 0.0;
+#pragma unroll 8
             for (int r = 0; r < H; r++) {
                 acc = __dadd_rn(acc, rs[r * W + (c - 1)]);
                 I[(r + 1) * W1 + c] = (float)acc;     // 601
@@ -1031,20 +1042,21 @@ __device__ __forceinline__ int vote_at(const int8_t *__restrict__ g, int W, int 
 #undef G
 }
 
-__global__ __launch_bounds__(256) void k_vote(const int8_t *__restrict__ labels, const float *__restrict__ heights,
-                                              const int *__restrict__ brcount, short *__restrict__ ev16,
-                                              RollRecordDev *__restrict__ rec, Dims d)
+// pass 1: vote grid + per-roll maximum.  Many workgroups per (cloud, roll); the roll's top is an atomicMax on a 64-bit
+// key (vote, then smallest linear index): max is order independent, so the result is deterministic.
+constexpr int kVoteCellsPerBlock = 2048;
+
+__global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ labels, short *__restrict__ ev16,
+                                                    unsigned long long *__restrict__ topkey, Dims d)
 {
     __shared__ unsigned long long red[256];
-    __shared__ int s_top;
-    __shared__ int s_row, s_col;
-    __shared__ unsigned int zred[256];
-    const int br = blockIdx.x, t = threadIdx.x;
+    const int br = blockIdx.y, t = threadIdx.x;
     const int H = d.H, W = d.W, HW = H * W;
     const int8_t *g = labels + (size_t)br * HW;
     short *ev = ev16 + (size_t)br * HW;
     unsigned long long best = 0;
-    for (int idx = t; idx < HW; idx += 256) {
+    const int lo = blockIdx.x * kVoteCellsPerBlock, hi = min(HW, lo + kVoteCellsPerBlock);
+    for (int idx = lo + t; idx < hi; idx += 256) {
         int row = idx / W, col = idx - row * W;
         int v = 0;
         if (g[idx] >= 0 && row >= 2 && row < H - 2 && col >= 4 && col < W - 4) v = vote_at(g, W, row, col);   // 870-879
@@ -1058,13 +1070,27 @@ __global__ __launch_bounds__(256) void k_vote(const int8_t *__restrict__ labels,
         if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
         __syncthreads();
     }
-    if (t == 0) s_top = (int)(red[0] >> 32) - 32768;
-    __syncthreads();
-    const int top = s_top;
+    if (t == 0 && red[0]) atomicMax(&topkey[br], red[0]);
+}
+
+// pass 2: longest-run centring on the roll's top value, z window, roll record.  One workgroup per (cloud, roll).
+__global__ __launch_bounds__(256) void k_vote_pick(const float *__restrict__ heights, const int *__restrict__ brcount,
+                                                   const short *__restrict__ ev16,
+                                                   const unsigned long long *__restrict__ topkey,
+                                                   RollRecordDev *__restrict__ rec, Dims d)
+{
+    __shared__ unsigned long long red[256];
+    __shared__ int s_row, s_col;
+    __shared__ unsigned int zred[256];
+    const int br = blockIdx.x, t = threadIdx.x;
+    const int H = d.H, W = d.W, HW = H * W;
+    const short *ev = ev16 + (size_t)br * HW;
+    const int top = (int)(topkey[br] >> 32) - 32768;
     // longest horizontal run of `top` per row (904-932): first longest run wins, column = run end - len/2
     unsigned long long rbest = 0;
     for (int row = t; row < H; row += 256) {
         int cur = 0, longest = 0, endc = 0;
+#pragma unroll 8
         for (int col = 0; col < W; col++) {
             if (ev[row * W + col] == top) {
                 cur++;
@@ -1078,7 +1104,6 @@ __global__ __launch_bounds__(256) void k_vote(const int8_t *__restrict__ labels,
             if (key > rbest) rbest = key;                             // longer run, then smaller row
         }
     }
-    __syncthreads();
     red[t] = rbest;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1115,10 +1140,14 @@ __global__ __launch_bounds__(256) void k_vote(const int8_t *__restrict__ labels,
     }
 }
 
-void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, RollRecordDev *rec, Dims d,
-                 hipStream_t s)
+void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
+                 RollRecordDev *rec, Dims d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_vote, dim3(d.B * d.R), dim3(256), 0, s, labels, heights, brcount, ev16, rec, d);
+    (void)hipMemsetAsync(topkey, 0, (size_t)d.B * d.R * sizeof(unsigned long long), s);
+    const int HW = d.H * d.W;
+    hipLaunchKernelGGL(k_vote_cells, dim3((HW + kVoteCellsPerBlock - 1) / kVoteCellsPerBlock, d.B * d.R), dim3(256), 0, s, labels, ev16,
+                       topkey, d);
+    hipLaunchKernelGGL(k_vote_pick, dim3(d.B * d.R), dim3(256), 0, s, heights, brcount, ev16, topkey, rec, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
