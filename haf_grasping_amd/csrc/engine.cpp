@@ -337,7 +337,7 @@ int build_tables(haf_engine *e)
     HIPCHK(e, hipMemcpy(e->d_svt.p, svt.data(), svt.size() * sizeof(float), hipMemcpyHostToDevice));
 
     if (e->cfg.flags & HAF_FLAG_SPLIT_F16) {
-        // split-fp16 images: s = sh + sl (fp16 each), [k-step][k-half][SV][8] for hi then lo, then 32 a_s and 32 coef
+        // split-fp16 images: s = sh + sl (fp16 each), hi image then lo image (h_image_offset), then 32 a_s and 32 coef
         std::vector<char> img((size_t)e->n_sv_tiles * kHSvTileBytes, 0);
         for (int n = 0; n < m.n_sv; n++) {
             const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
@@ -347,7 +347,7 @@ int build_tables(haf_engine *e)
                 const float s = (float)m.sv[(size_t)n * m.dim + k];
                 const _Float16 h = (_Float16)s;
                 const _Float16 l = (_Float16)(s - (float)h);
-                const size_t off = ((size_t)((k / 16) * 2 + (k % 16) / 8) * kTile + j) * 16 + (size_t)(k % 8) * 2;
+                const size_t off = (size_t)h_image_offset(j, k);
                 memcpy(tile + off, &h, 2);
                 memcpy(tile + kHMatBytes + off, &l, 2);
                 const double se = (double)((float)h + (float)l);      // what the three passes multiply

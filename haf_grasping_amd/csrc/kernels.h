@@ -16,14 +16,30 @@ constexpr int kTileFloats = kDP * kTile;          // 10496 floats = 41 KiB: 41 L
 constexpr int kSvmBlockEvals = 256; // 8 waves x 32 evals
 constexpr int kSvmThreads = 512;
 
-// ---- split-fp16 variant of the contraction (three v_mfma_f32_32x32x16_f16 passes: hi*hi + lo*hi + hi*lo) ----
-constexpr int kHK = 336;                              // attributes padded to 21 k-steps of 16
-constexpr int kHSteps = kHK / 16;                     // 21
-constexpr int kHMatBytes = kHSteps * 1024;            // one 32 x 336 fp16 operand image: [step][k-half][row][8] = 21 KiB
+// ---- split-fp16 variant of the contraction (three fp16 MFMA passes: hi*hi + lo*hi + hi*lo) ----
+// MFMA shape 16x16x32 (+ one 16x16x16 step for the K tail): on MI355X the chip sustains ~15 % more FLOP/s on this
+// shape than on 32x32x16 under DVFS (tools/ubench/mfma_shape.hip: 1.92 vs 1.67 PFLOP/s), at equal cycles per FLOP.
+constexpr int kHK = 336;                              // attributes padded to 10 k-steps of 32 + one of 16
+constexpr int kHFull = 10;                            // 16x16x32 steps
+constexpr int kHSteps = kHK / 16;                     // 21 groups of 16 attributes (layout bookkeeping)
+constexpr int kHMatBytes = kHSteps * 1024;            // one 32 x 336 fp16 operand image = 21 KiB, see h_image_offset()
+constexpr int kHTailOff = kHFull * 2048;              // byte offset of the 16-wide K tail inside an operand image
 constexpr int kHXTileBytes = 2 * kHMatBytes;          // X tile: hi image + lo image = 42 KiB per 32 evals
 constexpr int kHSvTileBytes = 44032;                  // SV tile: hi + lo + 32 a_s + 32 coef (43264 B) padded to 43 KiB
 constexpr int kHSvPieces = kHSvTileBytes / 1024;      // 43 LDS-DMA wave instructions
 constexpr int kHBuffers = 3;                          // LDS ring: two tiles in flight behind the one being computed
+
+// Byte offset of element (row r of 32, attribute k of 336) inside one fp16 operand image.  The image is the register
+// image of the MFMA operands: for k-step s (32 attributes) and row block m (16 rows) the 64 lanes of a wave hold
+// 8 consecutive attributes each, lane = ((k%32)/8)*16 + r%16  ->  [s][m][lane][8 halfs]; the K tail (k >= 320) is the
+// 16x16x16 form with 4 attributes per lane -> [m][lane][4 halfs].
+__host__ __device__ inline int h_image_offset(int r, int k)
+{
+    const int m = r >> 4, row = r & 15;
+    if (k < kHFull * 32) return (((k >> 5) * 2 + m) * 64 + ((k >> 3) & 3) * 16 + row) * 16 + (k & 7) * 2;
+    const int kk = k - kHFull * 32;
+    return kHTailOff + (m * 64 + (kk >> 2) * 16 + row) * 8 + (kk & 3) * 2;
+}
 
 struct CloudDev {
     const float *xyz;

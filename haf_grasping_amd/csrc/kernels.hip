@@ -292,6 +292,26 @@ __device__ __forceinline__ double attribute_value(const float *__restrict__ win,
 // X image, split-fp16 form: per tile of 32 evals two operand images (hi, lo) of [21 k-steps][2 k-halves][32 evals][8 fp16];
 // a thread finishes 8 attributes, then stores them as one 16-byte vector per image (512 contiguous bytes per 32 lanes).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// stores attributes 8g..8g+7 of tile row r into the hi and lo operand images (h_image_offset): one 16-byte vector per
+// image for the 16x16x32 steps, two 8-byte vectors for the 16-wide K tail
+__device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 hi, half8 lo)
+{
+    if (g < kHFull * 4) {
+        const int off = h_image_offset(r, g * 8);
+        *reinterpret_cast<half8 *>(xtile + off) = hi;
+        *reinterpret_cast<half8 *>(xtile + kHMatBytes + off) = lo;
+    } else {
+        const int o0 = h_image_offset(r, g * 8), o1 = h_image_offset(r, g * 8 + 4);
+        const half4 h0 = {hi[0], hi[1], hi[2], hi[3]}, h1 = {hi[4], hi[5], hi[6], hi[7]};
+        const half4 l0 = {lo[0], lo[1], lo[2], lo[3]}, l1 = {lo[4], lo[5], lo[6], lo[7]};
+        *reinterpret_cast<half4 *>(xtile + o0) = h0;
+        *reinterpret_cast<half4 *>(xtile + o1) = h1;
+        *reinterpret_cast<half4 *>(xtile + kHMatBytes + o0) = l0;
+        *reinterpret_cast<half4 *>(xtile + kHMatBytes + o1) = l1;
+    }
+}
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
 // workgroups for C5).  Small requests use k_features below.
@@ -306,14 +326,11 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if ((long)blockIdx.x * 256 >= n_pad) return;
     float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
-    char *xh = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * kHXTileBytes + (e & 31) * 16;
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * kHXTileBytes;
     if (e >= n_evals) {                       // padding rows of the last 256-eval block: zeros
         if (SPLIT) {
             const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int g = 0; g < 2 * kHSteps; g++) {
-                *reinterpret_cast<half8 *>(xh + g * 512) = z;
-                *reinterpret_cast<half8 *>(xh + kHMatBytes + g * 512) = z;
-            }
+            for (int g = 0; g < 2 * kHSteps; g++) store_group_h(xtile, (int)(e & 31), g, z, z);
         } else {
             for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
         }
@@ -345,8 +362,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
                 xx = fma((double)xe, (double)xe, xx);
             }
-            *reinterpret_cast<half8 *>(xh + g * 512) = hi;
-            *reinterpret_cast<half8 *>(xh + kHMatBytes + g * 512) = lo;
+            store_group_h(xtile, (int)(e & 31), g, hi, lo);
         }
     } else {
         for (int f = 0; f < d.nf; f++) {
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
     const long e = (long)blockIdx.x * kFeatEvals + ev;
     const long tile = e >> 5;
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
-    char *xh = reinterpret_cast<char *>(X) + (size_t)tile * kHXTileBytes + (e & 31) * 16;
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * kHXTileBytes;
     const int n_groups = SPLIT ? 2 * kHSteps : (kKP + 7) / 8;          // 42 / 41
     const bool live = e < n_evals;
     const float *win = ii;
@@ -415,10 +431,7 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
                 xx = fma((double)xf, (double)xf, xx);
             }
         }
-        if (SPLIT) {
-            *reinterpret_cast<half8 *>(xh + g * 512) = hi;
-            *reinterpret_cast<half8 *>(xh + kHMatBytes + g * 512) = lo;
-        }
+        if (SPLIT) store_group_h(xtile, (int)(e & 31), g, hi, lo);
     }
     red[gl][ev] = xx;
     __syncthreads();
@@ -596,13 +609,17 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
 
 // ---------------------------------------------------------------------------------------------------
 // a8, split-fp16 form of the same contraction: x = xh + xl, s = sh + sl with fp16 halves (22 significant bits, i.e. the
-// fp32 operand to within one ulp), x.s = xh.sh + xl.sh + xh.sl as three v_mfma_f32_32x32x16_f16 passes into ONE fp32
-// accumulator (the dropped xl.sl term is 2^-22 relative).  Every fp16 x fp16 product is exact in fp32, so the error
-// budget is the fp32 kernel's (accumulation) plus 2^-22 per term, covered by the same guard band; the MFMA work per
-// output tile drops from 162 x 64 to 63 x 32 cycles.  Same structure as k_svm_rbf: 8 waves x 32 evals, A fragments
-// (hi and lo: 168 VGPRs) loaded once, SV tile images streamed by LDS-DMA -- here through a 3-deep LDS ring with a
-// counted vmcnt, because a tile is consumed in ~4k cycles, about the latency of one DMA round trip.
+// fp32 operand to within one ulp), x.s = xh.sh + xl.sh + xh.sl as three fp16 MFMA passes into ONE fp32 accumulator (the
+// dropped xl.sl term is 2^-22 relative).  Every fp16 x fp16 product is exact in fp32, so the error budget is the fp32
+// kernel's (accumulation) plus 2^-22 per term, covered by the same guard band; the MFMA work per 32x32 output tile
+// drops from 162 x 64 to 2016 cycles.  MFMA shape: v_mfma_f32_16x16x32_f16 (10 k-steps) + v_mfma_f32_16x16x16_f16
+// (K tail), 2x2 sub-tiles per wave: same cycles per FLOP as 32x32x16 but the chip holds a ~15 % higher clock on it.
+// Same structure as k_svm_rbf: 8 waves x 32 evals, A fragments (hi and lo: 168 VGPRs) loaded once, SV tile images
+// streamed by LDS-DMA -- here through a 3-deep LDS ring with a counted vmcnt, because a tile is consumed in ~4k cycles,
+// about the latency of one DMA round trip.
 // ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ int stage_sv_tile_h(const char *__restrict__ gtile, unsigned lds_byte_off, int wave, int lane)
 {
     int issued = 0;
@@ -638,24 +655,42 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     stage_sv_tile_h(svt, lds0, wave, lane);                                              // tile 0
     if (nt > 1) stage_sv_tile_h(svt + (size_t)kHSvTileBytes, lds0 + kHSvTileBytes, wave, lane);   // tile 1
 
-    half8 ah[kHSteps], al[kHSteps];
+    // A fragments: [k-step][row block m][hi|lo]; lane holds A[row 16m + (lane&15)][k = 32s + 8(lane>>4) + j]
+    half8 ah[kHFull][2], al[kHFull][2];
+    half4 aht[2], alt[2];                                            // K tail: A[row][k = 320 + 4(lane>>4) + j]
     {
-        const char *xt = X + (size_t)tile32 * kHXTileBytes + lane * 16;
+        const char *xt = X + (size_t)tile32 * kHXTileBytes;
 #pragma unroll
-        for (int s = 0; s < kHSteps; s++) {
-            ah[s] = *reinterpret_cast<const half8 *>(xt + s * 1024);                 // A[i = lane&31][k = 16s + 8(lane>>5) + j]
-            al[s] = *reinterpret_cast<const half8 *>(xt + kHMatBytes + s * 1024);
+        for (int s = 0; s < kHFull; s++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                ah[s][m] = *reinterpret_cast<const half8 *>(xt + (s * 2 + m) * 1024 + lane * 16);
+                al[s][m] = *reinterpret_cast<const half8 *>(xt + kHMatBytes + (s * 2 + m) * 1024 + lane * 16);
+            }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            aht[m] = *reinterpret_cast<const half4 *>(xt + kHTailOff + m * 512 + lane * 8);
+            alt[m] = *reinterpret_cast<const half4 *>(xt + kHMatBytes + kHTailOff + m * 512 + lane * 8);
         }
     }
     if (lane < kTile) { axs[lane] = ax[tile32 * kTile + lane]; pos[lane] = 0.0f; }
-    float part[16];
+    float part[2][4];                                                // rows 16m + 4(lane>>4) + r, summed over this lane's columns
 #pragma unroll
-    for (int r = 0; r < 16; r++) part[r] = 0.0f;
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[m][r] = 0.0f;
     // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
 #pragma unroll
-    for (int s = 0; s < kHSteps; s++) {
-        asm volatile("" : "+v"(ah[s]));
-        asm volatile("" : "+v"(al[s]));
+    for (int s = 0; s < kHFull; s++)
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            asm volatile("" : "+v"(ah[s][m]));
+            asm volatile("" : "+v"(al[s][m]));
+        }
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        asm volatile("" : "+v"(aht[m]));
+        asm volatile("" : "+v"(alt[m]));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tiles 0 and 1 (this wave's pieces) have landed
     __syncthreads();
@@ -671,46 +706,82 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             // P = sum_{coef>0} coef*K, what follows is N = sum_{coef<0} coef*K.  dec = P + N - rho and the guard scale
             // sum|coef|K = P - N come from the same accumulator; P is parked in LDS (once per workgroup).
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float v = part[r];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 8, 64);
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 1, 64);
-                if ((lane & 31) == 0) pos[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = v;
-                part[r] = 0.0f;
-            }
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = part[m][r];
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 1, 64);
+                    if ((lane & 15) == 0) pos[16 * m + 4 * (lane >> 4) + r] = v;
+                    part[m][r] = 0.0f;
+                }
         }
 
-        // B fragments run two k-steps ahead of the MFMAs that consume them (LDS latency ~ one step of 3 MFMAs)
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const char *bl = cur + lane * 16;
-        half8 bh[3], bq[3];
-        bh[0] = *reinterpret_cast<const half8 *>(bl);
-        bq[0] = *reinterpret_cast<const half8 *>(bl + kHMatBytes);
-        bh[1] = *reinterpret_cast<const half8 *>(bl + 1024);
-        bq[1] = *reinterpret_cast<const half8 *>(bl + kHMatBytes + 1024);
+        // 2x2 sub-tiles of 16x16; B fragments run one k-step (12 MFMAs) ahead of the MFMAs that consume them
+        f32x4 acc[2][2];
 #pragma unroll
-        for (int s = 0; s < kHSteps; s++) {
-            if (s + 2 < kHSteps) {
-                bh[(s + 2) % 3] = *reinterpret_cast<const half8 *>(bl + (s + 2) * 1024);     // B[k = 16s + 8(lane>>5) + j][col lane&31]
-                bq[(s + 2) % 3] = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s + 2) * 1024);
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const char *bl = cur + lane * 16;
+        half8 bh[2][2], bq[2][2];                                    // [ring][column block n]
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            bh[0][n] = *reinterpret_cast<const half8 *>(bl + n * 1024);                  // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
+            bq[0][n] = *reinterpret_cast<const half8 *>(bl + kHMatBytes + n * 1024);
+        }
+#pragma unroll
+        for (int s = 0; s < kHFull; s++) {
+            const int c = s & 1, nx = c ^ 1;
+            if (s + 1 < kHFull) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    bh[nx][n] = *reinterpret_cast<const half8 *>(bl + ((s + 1) * 2 + n) * 1024);
+                    bq[nx][n] = *reinterpret_cast<const half8 *>(bl + kHMatBytes + ((s + 1) * 2 + n) * 1024);
+                }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s % 3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s % 3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bq[s % 3], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);      // keep the two-step read-ahead: hipcc otherwise sinks the reads to their use
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bh[c][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], bh[c][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bq[c][n], acc[m][n], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead: hipcc otherwise sinks the reads to their use
+        }
+        {   // K tail: attributes 320..335, 16x16x16 form (4 halfs per lane)
+            half4 bht[2], bqt[2];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                bht[n] = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
+                bqt[n] = *reinterpret_cast<const half4 *>(cur + kHMatBytes + kHTailOff + n * 512 + lane * 8);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bht[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt[n], acc[m][n], 0, 0, 0);
+                }
         }
         const float *tail = reinterpret_cast<const float *>(cur + 2 * kHMatBytes);
-        const float as_ = tail[lane & 31];                          // -g2*|s_j|^2
-        const float cf = tail[kTile + (lane & 31)];                 // coef_j (0 for padding SVs)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float arg = fmaf(p.two_gamma2, acc[r], axs[row] + as_);
-            float k = __builtin_amdgcn_exp2f(arg);
-            part[r] = fmaf(cf, k, part[r]);
+        for (int n = 0; n < 2; n++) {
+            const float as_ = tail[16 * n + (lane & 15)];            // -g2*|s_j|^2
+            const float cf = tail[kTile + 16 * n + (lane & 15)];     // coef_j (0 for padding SVs)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * m + 4 * (lane >> 4) + r;     // 16x16 C/D layout: col = lane&15, row = 4(lane>>4) + reg
+                    float arg = fmaf(p.two_gamma2, acc[m][n][r], axs[row] + as_);
+                    float k = __builtin_amdgcn_exp2f(arg);
+                    part[m][r] = fmaf(cf, k, part[m][r]);
+                }
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
         if (more) {
@@ -724,34 +795,37 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     }
 
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float v = part[r];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 1, 64);
-        part[r] = v;
-    }
-    if ((lane & 31) == 0) {
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = part[m][r];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 1, 64);
+            part[m][r] = v;
+        }
+    if ((lane & 15) == 0) {
         const bool has_neg = d.sv_tile_neg < nt;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            long e = tile32 * kTile + row;
-            if (e < n_evals) {
-                const float P = has_neg ? pos[row] : part[r];
-                const float N = has_neg ? part[r] : 0.0f;
-                const float dv = (P + N) - p.rho;
-                const float sabs = P - N;                           // sum |coef| K
-                dec[e] = dv;
-                labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-                if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axs[row])) * sabs + p.guard_abs)) {
-                    int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
-                    if (slot < flag_cap) flag_list[slot] = (int)e;
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * m + 4 * (lane >> 4) + r;
+                const long e = tile32 * kTile + row;
+                if (e < n_evals) {
+                    const float P = has_neg ? pos[row] : part[m][r];
+                    const float N = has_neg ? part[m][r] : 0.0f;
+                    const float dv = (P + N) - p.rho;
+                    const float sabs = P - N;                       // sum |coef| K
+                    dec[e] = dv;
+                    labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
+                    if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axs[row])) * sabs + p.guard_abs)) {
+                        int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
+                        if (slot < flag_cap) flag_list[slot] = (int)e;
+                    }
                 }
             }
-        }
     }
 }
 
