@@ -532,7 +532,8 @@ int haf_create(const haf_config *cfg, haf_engine **out)
     if (cfg->grid_h != cfg->grid_w) { e->error = "grid_h must equal grid_w (the reference's mask geometry assumes a square grid, server.cpp:681-682, 705)"; return bail(HAF_E_ARG); }
     if (cfg->grid_h < 15 || cfg->grid_h > 4096) { e->error = "grid size must be in [15, 4096]"; return bail(HAF_E_ARG); }
     if (cfg->n_rolls < 1 || cfg->n_rolls > 4096 || cfg->max_clouds < 1 || cfg->max_points < 1) { e->error = "n_rolls, max_clouds and max_points must be positive"; return bail(HAF_E_ARG); }
-    if ((double)cfg->max_clouds * cfg->n_rolls * cfg->grid_h * cfg->grid_w > 2.0e9) { e->error = "max_clouds*n_rolls*grid cells exceeds 2^31"; return bail(HAF_E_CAPACITY); }
+    // integral images are read through a buffer descriptor (32-bit byte offsets): all of them must fit 4 GiB
+    if ((double)cfg->max_clouds * cfg->n_rolls * (cfg->grid_h + 1) * (cfg->grid_w + 1) * 4.0 >= 4294967296.0) { e->error = "max_clouds*n_rolls*grid cells exceeds 2^30"; return bail(HAF_E_CAPACITY); }
 
     if (!load_features(e->feature_file, e->features, e->error)) return bail(HAF_E_IO);
     if (!load_range(e->range_file, e->range, e->error)) return bail(HAF_E_IO);

@@ -252,26 +252,46 @@ void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims 
 // ---------------------------------------------------------------------------------------------------
 // a5/a6: one feature value from the 15x15 integral window (fv.cpp:141-199).  fp32, strict order, unfused.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float region_sum(const float *__restrict__ win, const int *off)
+// Integral-image reads go through a buffer descriptor: address = descriptor base + 32-bit VGPR byte offset (the window
+// origin of the lane's cell) + SGPR byte offset (the region corner from the wave-uniform feature descriptor), i.e.
+// `buffer_load_dword v, v_off, s[rsrc], s_off offen` with NO vector address arithmetic per load.  UNI = false (feature
+// index differs per lane: recheck kernels) folds the corner offset into the VGPR instead.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_ii_rsrc(const float *ii, Dims d)
 {
-    float s = __fsub_rn(win[off[0]], win[off[1]]);
-    s = __fsub_rn(s, win[off[2]]);
-    return __fadd_rn(s, win[off[3]]);                                    // fv.cpp:161-162 / 183-184
+    const unsigned bytes = (unsigned)d.B * (unsigned)d.R * (unsigned)((d.H + 1) * (d.W + 1)) * 4u;   // < 2^32, checked in haf_create
+    return __builtin_amdgcn_make_buffer_rsrc((void *)ii, 0, (int)bytes, 0x00020000);
 }
 
-__device__ __forceinline__ float feature_value(const float *__restrict__ win, const FeatDesc &f)
+template <bool UNI>
+__device__ __forceinline__ float ii_load(rsrc_t r, unsigned w0b, int off)
+{
+    if (UNI) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)w0b, off * 4, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(w0b + (unsigned)off * 4u), 0, 0));
+}
+
+template <bool UNI>
+__device__ __forceinline__ float region_sum(rsrc_t ii, unsigned w0b, const int *off)
+{
+    float s = __fsub_rn(ii_load<UNI>(ii, w0b, off[0]), ii_load<UNI>(ii, w0b, off[1]));
+    s = __fsub_rn(s, ii_load<UNI>(ii, w0b, off[2]));
+    return __fadd_rn(s, ii_load<UNI>(ii, w0b, off[3]));                  // fv.cpp:161-162 / 183-184
+}
+
+template <bool UNI>
+__device__ __forceinline__ float feature_value(rsrc_t ii, unsigned w0b, const FeatDesc &f)
 {
     if (!f.shaf) {
         float rv = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            if (f.active & (1 << k)) rv = __fadd_rn(rv, __fmul_rn(f.w[k], region_sum(win, f.off[k])));
+            if (f.active & (1 << k)) rv = __fadd_rn(rv, __fmul_rn(f.w[k], region_sum<UNI>(ii, w0b, f.off[k])));
         return rv;
     }
     float r[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        if (f.active & (1 << k)) r[k] = __fmul_rn(f.w[k], region_sum(win, f.off[k]));
+        if (f.active & (1 << k)) r[k] = __fmul_rn(f.w[k], region_sum<UNI>(ii, w0b, f.off[k]));
     if (r[1] > r[0] && r[1] > r[2]) {                                    // fv.cpp:187-191
         float a = __fsub_rn(r[1], r[0]), b = __fsub_rn(r[1], r[2]);
         return (b < a) ? b : a;
@@ -280,11 +300,21 @@ __device__ __forceinline__ float feature_value(const float *__restrict__ win, co
 }
 
 // fp32 feature -> attribute value svm-predict would parse (both decimal text round trips emulated exactly)
-__device__ __forceinline__ double attribute_value(const float *__restrict__ win, const FeatDesc &f, double lower, double upper)
+template <bool UNI>
+__device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper)
 {
-    float v = feature_value(win, f);
+    float v = feature_value<UNI>(ii, w0b, f);
     double q4 = hafq::decq4_float(v);
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper);
+}
+
+// BYTE offset of the 15x15 window origin II[i-7][j-7] of a cell id (br*H + i)*W + j inside the integral-image buffer
+__device__ __forceinline__ unsigned window_origin(int cell, int H, int W)
+{
+    const int br = cell / (H * W);
+    const int rem = cell - br * H * W;
+    const int i = rem / W, j = rem - i * W;
+    return ((unsigned)br * (unsigned)((H + 1) * (W + 1)) + (unsigned)((i - 7) * (W + 1) + (j - 7))) * 4u;
 }
 
 // X image, fp32 form: tiles of 32 evals, k-major inside a tile ([tile][kDP][32] fp32) -- the exact register image of
@@ -337,12 +367,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         ax[e] = 0.0f;
         return;
     }
-    const int H = d.H, W = d.W, W1 = W + 1;
-    const int cell = evalcell[e];
-    const int br = cell / (H * W);
-    const int rem = cell - br * H * W;
-    const int i = rem / W, j = rem - i * W;
-    const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
+    const rsrc_t iir = make_ii_rsrc(ii, d);
+    const unsigned w0 = window_origin(evalcell[e], d.H, d.W);
     double xx = 0.0;
     if (SPLIT) {
         for (int g = 0; g < 2 * kHSteps; g++) {           // 42 groups of 8 attributes
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 float xf = 0.0f;
                 if (f < d.nf) {
                     const FeatDesc &F = fd[f];
-                    if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+                    if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper);
                 }
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         for (int f = 0; f < d.nf; f++) {
             const FeatDesc &F = fd[f];
             float xf = 0.0f;
-            if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+            if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper);
             xcol[f * kTile] = xf;
             xx = fma((double)xf, (double)xf, xx);
         }
@@ -399,15 +425,8 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
     char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * kHXTileBytes;
     const int n_groups = SPLIT ? 2 * kHSteps : (kKP + 7) / 8;          // 42 / 41
     const bool live = e < n_evals;
-    const float *win = ii;
-    if (live) {
-        const int H = d.H, W = d.W, W1 = W + 1;
-        const int cell = evalcell[e];
-        const int br = cell / (H * W);
-        const int rem = cell - br * H * W;
-        const int i = rem / W, j = rem - i * W;
-        win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
-    }
+    const rsrc_t iir = make_ii_rsrc(ii, d);
+    const unsigned w0 = live ? window_origin(evalcell[e], d.H, d.W) : 0u;
     double xx = 0.0;
     for (int g = gl; g < n_groups; g += 8) {
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -417,7 +436,7 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
             float xf = 0.0f;
             if (live && f < d.nf) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xf = (float)attribute_value(win, F, lower, upper);
+                if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper);
             }
             if (SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
@@ -863,21 +882,16 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
     int n_flag = counters[counter_slot];
     if (n_flag > flag_cap) n_flag = flag_cap;
     const int n_groups = (n_flag + kRB - 1) / kRB;
-    const int H = d.H, W = d.W, W1 = W + 1;
+    const int H = d.H, W = d.W;
+    const rsrc_t iir = make_ii_rsrc(ii, d);
     const int tid = threadIdx.x;
     for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
         for (int it = tid; it < kRB * p.kx; it += 256) {
             const int ev = it / p.kx, f = it - ev * p.kx;
             const int slot = g * kRB + ev;
             double x = 0.0;
-            if (slot < n_flag && f < d.nf && !fd[f].skip) {
-                const int cell = evalcell[flag_list[slot]];
-                const int br = cell / (H * W);
-                const int rem = cell - br * H * W;
-                const int i = rem / W, j = rem - i * W;
-                const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
-                x = attribute_value(win, fd[f], p.lower, p.upper);
-            }
+            if (slot < n_flag && f < d.nf && !fd[f].skip)
+                x = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[f], p.lower, p.upper);
             xs[ev][f] = x;
         }
         if (tid < kRB) run_sum[tid] = 0.0;
@@ -958,20 +972,15 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
     int n_flag = counters[CNT_FLAGGED];
     if (n_flag > flag_cap) n_flag = flag_cap;
     const int n_grp = (n_flag + 15) / 16;
-    const int H = d.H, W = d.W, W1 = W + 1;
+    const int H = d.H, W = d.W;
+    const rsrc_t iir = make_ii_rsrc(ii, d);
     for (int grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
         for (int it = threadIdx.x; it < 16 * kKP; it += 256) {
             const int k = it >> 4, ev = it & 15;
             const int slot = grp * 16 + ev;
             double v = 0.0;
-            if (slot < n_flag && k < d.nf && !fd[k].skip) {
-                const int cell = evalcell[flag_list[slot]];
-                const int br = cell / (H * W);
-                const int rem = cell - br * H * W;
-                const int i = rem / W, j = rem - i * W;
-                const float *win = ii + (size_t)br * (H + 1) * W1 + (i - 7) * W1 + (j - 7);
-                v = attribute_value(win, fd[k], p.lower, p.upper);
-            }
+            if (slot < n_flag && k < d.nf && !fd[k].skip)
+                v = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[k], p.lower, p.upper);
             x64[(size_t)grp * kKP * 16 + it] = v;
         }
     }
