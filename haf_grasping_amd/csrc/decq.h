@@ -96,6 +96,26 @@ HAF_HD double pow10_bound(int e)   // smallest double >= 10^e, -24 <= e <= 24
 #endif
 }
 
+// Table providers: the default reads the constant arrays above (host: static data, device: global memory through L1);
+// kernels that evaluate millions of values copy the 95 doubles into LDS once per workgroup and pass a PtrTabs, which
+// turns three dependent global loads per round trip into LDS reads.
+struct GlobalTabs {
+    HAF_HD double p10(int k) const { return pow10_exact(k); }
+    HAF_HD double p10inv(int k) const { return pow10_inv(k); }
+    HAF_HD double bnd(int e) const { return pow10_bound(e); }
+};
+constexpr int kTabDoubles = 23 + 23 + 49;
+struct PtrTabs {
+    const double *t;      // [0,23): 10^k   [23,46): RN(10^-k)   [46,95): smallest double >= 10^(e), e = -24..24
+    HAF_HD double p10(int k) const { return t[k]; }
+    HAF_HD double p10inv(int k) const { return t[23 + k]; }
+    HAF_HD double bnd(int e) const { return t[46 + 24 + e]; }
+};
+HAF_HD double tab_entry(int i)    // the value PtrTabs expects at index i
+{
+    return i < 23 ? pow10_exact(i) : (i < 46 ? pow10_inv(i - 23) : pow10_bound(i - 46 - 24));
+}
+
 // round-half-even of the exact positive value hi+lo (|lo| <= ulp(hi)/2, hi < 2^52), branch-free
 HAF_HD double rhe(double hi, double lo)
 {
@@ -186,18 +206,20 @@ HAF_HD_NOINLINE double decq_abs_slow(double a, int P)
 }
 
 // |x| -> nearest double to the P-significant-digit decimal nearest to |x| (see file header); P is 4 or 6.
-HAF_HD double decq_abs(double a, int P)
+template <class Tabs>
+HAF_HD double decq_abs(double a, int P, const Tabs &tb)
 {
     const int b = ilogb(a);
     const int e0 = (b * 1233) >> 12;       // floor(b*log10(2)); for -80 <= b <= 80 (checked exhaustively with exact
                                            // rationals) the decimal exponent floor(log10(a)) is e0 or e0 + 1
     if (e0 >= -24 && e0 <= 23) {
-        const int e = e0 + ((a >= pow10_bound(e0 + 1)) ? 1 : 0);     // exact decision, see kBnd
+        const int e = e0 + ((a >= tb.bnd(e0 + 1)) ? 1 : 0);          // exact decision, see kBnd
         const int k = P - 1 - e;                                      // a * 10^k lies in [10^(P-1), 10^P)
         if (k >= 0 && k <= 22) {
-            const double T = pow10_exact(k), y = pow10_inv(k);
+            const double T = tb.p10(k), y = tb.p10inv(k);
             const double hi = a * T, lo = fma(a, T, -hi);             // exact: a*T = hi + lo
-            if (hi >= pow10_exact(P - 1) && hi < pow10_exact(P)) {     // always true here; anything else goes the slow way
+            const double lo_b = (P == 4) ? 1e3 : 1e5, hi_b = (P == 4) ? 1e4 : 1e6;
+            if (hi >= lo_b && hi < hi_b) {                             // always true here; anything else goes the slow way
                 const double N = rhe(hi, lo);
                 double q = N * y;                                      // N / 10^k, correctly rounded (exhaustively verified):
                 q = fma(fma(-q, T, N), y, q);                          //   q + (N - q*T) * RN(1/T)
@@ -208,18 +230,21 @@ HAF_HD double decq_abs(double a, int P)
     return decq_abs_slow(a, P);
 }
 
-// strtod(sprintf("%.{P}g", x)) for any x; zeros, infinities and NaNs pass through like the text forms do.
-HAF_HD double decq(double x, int P)
+// strtod(sprintf("%.{P}g", x)) for any x (P = 4 or 6); zeros, infinities and NaNs pass through like the text forms do.
+template <class Tabs>
+HAF_HD double decq(double x, int P, const Tabs &tb)
 {
     double a = fabs(x);
     if (!(a > 0.0) || !(a < INFINITY)) return x;
-    double r = decq_abs(a, P);
+    double r = decq_abs(a, P, tb);
     return x < 0.0 ? -r : r;
 }
+HAF_HD double decq(double x, int P) { return decq(x, P, GlobalTabs()); }
 
 // "%.4g" round trip of an fp32 value (what fv.cpp:133 prints).  A float has 24 significant bits and 5^12 < 2^28, so for
 // k <= 12 the product a * 10^k is EXACT in binary64 and round-half-even of it is a single v_rndne_f64.
-HAF_HD double decq4_float(float v)
+template <class Tabs>
+HAF_HD double decq4_float(float v, const Tabs &tb)
 {
     const double x = (double)v;
     const double a = fabs(x);
@@ -229,10 +254,10 @@ HAF_HD double decq4_float(float v)
     double r;
     bool done = false;
     if (e0 >= -24 && e0 <= 23) {
-        const int e = e0 + ((a >= pow10_bound(e0 + 1)) ? 1 : 0);
+        const int e = e0 + ((a >= tb.bnd(e0 + 1)) ? 1 : 0);
         const int k = 3 - e;
         if (k >= 0 && k <= 12) {
-            const double T = pow10_exact(k), y = pow10_inv(k);
+            const double T = tb.p10(k), y = tb.p10inv(k);
             const double t = a * T;                                    // exact
             if (t >= 1e3 && t < 1e4) {
                 const double N = rint(t);                              // round-half-even, like glibc on the exact value
@@ -243,14 +268,17 @@ HAF_HD double decq4_float(float v)
             }
         }
     }
-    if (!done) r = decq_abs(a, 4);
+    if (!done) r = decq_abs(a, 4, tb);
     return x < 0.0 ? -r : r;
 }
+HAF_HD double decq4_float(float v) { return decq4_float(v, GlobalTabs()); }
 
 // svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed; range = fmax - fmin
 // and inv_range = RN(1/range) are per-attribute constants.  Returns the attribute value svm-predict parses
 // (0.0 when the attribute is omitted from the text).
-HAF_HD double scale_q6(double q4, double fmin, double fmax, double range, double inv_range, double lower, double upper)
+template <class Tabs>
+HAF_HD double scale_q6(double q4, double fmin, double fmax, double range, double inv_range, double lower, double upper,
+                       const Tabs &tb)
 {
     double value;
     if (q4 == fmin) value = lower;
@@ -271,7 +299,11 @@ HAF_HD double scale_q6(double q4, double fmin, double fmax, double range, double
         value = lower + q;
     }
     if (value == 0.0) return 0.0;          // "if(value != 0)": attribute omitted
-    return decq(value, 6);
+    return decq(value, 6, tb);
+}
+HAF_HD double scale_q6(double q4, double fmin, double fmax, double range, double inv_range, double lower, double upper)
+{
+    return scale_q6(q4, fmin, fmax, range, inv_range, lower, upper, GlobalTabs());
 }
 
 }  // namespace hafq

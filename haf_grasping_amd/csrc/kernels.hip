@@ -300,12 +300,23 @@ __device__ __forceinline__ float feature_value(rsrc_t ii, unsigned w0b, const Fe
 }
 
 // fp32 feature -> attribute value svm-predict would parse (both decimal text round trips emulated exactly)
-template <bool UNI>
-__device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper)
+template <bool UNI, class Tabs>
+__device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper,
+                                                  const Tabs &tb)
 {
     float v = feature_value<UNI>(ii, w0b, f);
-    double q4 = hafq::decq4_float(v);
-    return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper);
+    double q4 = hafq::decq4_float(v, tb);
+    return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper, tb);
+}
+
+// the decimal tables (95 doubles) in LDS: call from every thread of the workgroup before any divergent return
+__device__ __forceinline__ hafq::PtrTabs load_decimal_tables(double *lds_tab)
+{
+    if (threadIdx.x < hafq::kTabDoubles) lds_tab[threadIdx.x] = hafq::tab_entry((int)threadIdx.x);
+    __syncthreads();
+    hafq::PtrTabs tb;
+    tb.t = lds_tab;
+    return tb;
 }
 
 // BYTE offset of the 15x15 window origin II[i-7][j-7] of a cell id (br*H + i)*W + j inside the integral-image buffer
@@ -355,6 +366,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     const long n_pad = ((long)n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if ((long)blockIdx.x * 256 >= n_pad) return;
+    __shared__ double s_tab[hafq::kTabDoubles];
+    const hafq::PtrTabs tb = load_decimal_tables(s_tab);
     float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * kHXTileBytes;
     if (e >= n_evals) {                       // padding rows of the last 256-eval block: zeros
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 float xf = 0.0f;
                 if (f < d.nf) {
                     const FeatDesc &F = fd[f];
-                    if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper);
+                    if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper, tb);
                 }
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         for (int f = 0; f < d.nf; f++) {
             const FeatDesc &F = fd[f];
             float xf = 0.0f;
-            if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper);
+            if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper, tb);
             xcol[f * kTile] = xf;
             xx = fma((double)xf, (double)xf, xx);
         }
@@ -418,6 +431,8 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
     const int n_evals = counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
+    __shared__ double s_tab[hafq::kTabDoubles];
+    const hafq::PtrTabs tb = load_decimal_tables(s_tab);
     const int ev = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const long e = (long)blockIdx.x * kFeatEvals + ev;
     const long tile = e >> 5;
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
             float xf = 0.0f;
             if (live && f < d.nf) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper);
+                if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper, tb);
             }
             if (SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
@@ -891,7 +906,7 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
             const int slot = g * kRB + ev;
             double x = 0.0;
             if (slot < n_flag && f < d.nf && !fd[f].skip)
-                x = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[f], p.lower, p.upper);
+                x = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[f], p.lower, p.upper, hafq::GlobalTabs());
             xs[ev][f] = x;
         }
         if (tid < kRB) run_sum[tid] = 0.0;
@@ -980,7 +995,7 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
             const int slot = grp * 16 + ev;
             double v = 0.0;
             if (slot < n_flag && k < d.nf && !fd[k].skip)
-                v = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[k], p.lower, p.upper);
+                v = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[k], p.lower, p.upper, hafq::GlobalTabs());
             x64[(size_t)grp * kKP * 16 + it] = v;
         }
     }
