@@ -248,6 +248,12 @@ def test_generalised_grid_and_rolls(data_dir, surrogate, orc, mode):
     compare_full(eng, orc, xyz, dict(n_rolls=8, roll_step_deg=22, grid_h=96, grid_w=96),
                  dict(grasp_area_length_x=96, grasp_area_length_y=80))
     eng.close()
+    # odd grid size, roll step that does not divide 180
+    xyz = models.synthetic_cloud(grid=61, k=3, seed=5)
+    eng = make_engine(data_dir, surrogate, mode, grid_h=61, grid_w=61, n_rolls=3, roll_step_deg=37)
+    compare_full(eng, orc, xyz, dict(n_rolls=3, roll_step_deg=37, grid_h=61, grid_w=61),
+                 dict(grasp_area_length_x=61, grasp_area_length_y=45, grasp_area_center=(0.004, -0.003, 0.0)))
+    eng.close()
 
 
 def test_edge_inputs(data_dir, surrogate, orc):
@@ -445,3 +451,15 @@ def test_randomised_requests_against_oracle(data_dir, tmp_path, mode):
         compare_full(engines[key], o, xyz, dict(n_rolls=n_rolls, roll_step_deg=step), kw)
     for e in engines.values():
         e.close()
+
+
+def test_range_file_must_cover_non_constant_attributes(data_dir, surrogate, tmp_path):
+    """svm-scale derives the range of an attribute missing from the range file from each roll's data (svm-scale.c:165-198);
+    the engine refuses such a configuration instead of silently scaling differently."""
+    f, r = _files(data_dir)
+    lines = open(r).read().splitlines()
+    short = tmp_path / "range_short"
+    short.write_text("\n".join(l for l in lines if not l.startswith("17 ")) + "\n")
+    with pytest.raises(capi.HafError) as ei:
+        capi.Engine(f, str(short), surrogate)
+    assert ei.value.code == capi.HAF_E_ARG and "attribute 17" in str(ei.value)

@@ -266,3 +266,32 @@ def test_finalize_matches_oracle_pose(data_dir, golden_dir):
         np.testing.assert_allclose(tuple(out.averaged_grasp_point), r["avg"], atol=1e-6)
         np.testing.assert_allclose(tuple(out.approach_vector), r["av"], atol=1e-7)
         assert out.roll == r["roll"]
+
+
+def test_create_reports_file_errors_before_touching_a_device(data_dir, golden_dir, tmp_path):
+    """Unreadable / unsupported construction files fail with HAF_E_IO and a message, on any machine."""
+    f = os.path.join(data_dir, "Features.txt")
+    r = os.path.join(data_dir, "range21062012_allfeatures")
+    m = os.path.join(golden_dir, "surrogate.model")
+    bad_kernel = tmp_path / "lin.model"
+    bad_kernel.write_text(open(m).read().replace("kernel_type rbf", "kernel_type linear", 1))
+    three = tmp_path / "three.model"
+    three.write_text(open(m).read().replace("nr_class 2", "nr_class 3", 1))
+    trunc = tmp_path / "trunc.model"
+    trunc.write_text("".join(open(m).readlines()[:20]))
+    norange = tmp_path / "norange"
+    norange.write_text("y\n-1 1\n0 1\n")
+    cases = [((str(tmp_path / "nope.txt"), r, m), "cannot open feature file"),
+             ((f, str(tmp_path / "nope"), m), "cannot open range file"),
+             ((f, str(norange), m), "no x section"),
+             ((f, r, str(tmp_path / "nope.model")), "cannot open model file"),
+             ((f, r, str(bad_kernel)), "kernel_type rbf"),
+             ((f, r, str(three)), "nr_class must be 2"),
+             ((f, r, str(trunc)), "fewer SV lines")]
+    for args, msg in cases:
+        with pytest.raises(capi.HafError) as ei:
+            capi.Engine(*args)
+        assert ei.value.code == capi.HAF_E_IO and msg in str(ei.value), (args, str(ei.value))
+    with pytest.raises(capi.HafError) as ei:
+        capi.Engine(f, r, m, grid_h=56, grid_w=64)
+    assert ei.value.code == capi.HAF_E_ARG and "square" in str(ei.value)
