@@ -236,6 +236,14 @@ def main():
                        "sharding": "clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step"},
             "roofline": roofline(res, args.precision),
             "stage_ms_per_step": res["stage_ms"],
+            "prestages_hbm": (lambda ms, b: {"kernels": "k_bin + k_integral + k_mask_count/k_scan/k_compact + k_vote_cells/k_vote_pick",
+                                             "algorithmic_bytes": b, "ms": ms, "GBps": b / ms / 1e6, "peak_GBps": 8000.0,
+                                             "frac": b / ms / 1e6 / 8000.0,
+                                             "note": "SURVEY 8(d): 12 B per cell per roll + 12 B per point per roll; these launches are "
+                                                     "latency-bound (36 workgroup-rows of sequential sums, 19 M scattered atomics), "
+                                                     "2 % of the step"})(
+                res["stage_ms"]["bin"] + res["stage_ms"]["integral"] + res["stage_ms"]["mask"] + res["stage_ms"]["vote"],
+                12.0 * args.rolls * (G * G + xyz.shape[0])),
             "rechecked_per_step": {"fp64_mfma_tier": res["rechecked"], "strict_order_tier": res["strict"]},
             "best": {"eval": res["out"]["eval"], "row": res["out"]["best_row"], "col": res["out"]["best_col"],
                      "roll": res["out"]["best_roll"]},
