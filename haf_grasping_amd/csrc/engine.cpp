@@ -444,7 +444,8 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->flag_cap);
-    ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 15) / 16 * 16 * kKP);
+    // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
+    ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->flag2_cap);
     ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->flag2_cap);
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);

@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
 {
     int n_flag = counters[CNT_FLAGGED];
     if (n_flag > flag_cap) n_flag = flag_cap;
-    const int n_grp = (n_flag + 15) / 16;
+    const int n_grp = (n_flag + 63) / 64 * 4;          // whole k_recheck_mfma workgroups (64 evaluations): unused slots get zeros
     const int H = d.H, W = d.W;
     const rsrc_t iir = make_ii_rsrc(ii, d);
     for (int grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
