@@ -152,7 +152,7 @@ def main():
     def make_engine(precision):
         return capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
                            roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2,
-                           flags=capi.FLAG_PROFILE | (capi.FLAG_SPLIT_F16 if precision == "f16x3" else 0))
+                           flags=capi.FLAG_PROFILE | (capi.FLAG_FP32_MFMA if precision == "f32" else 0))
 
     def fence():
         torch.cuda.synchronize()
@@ -263,7 +263,7 @@ def main():
             line["cpu_baseline"] = None
         if world == 1 and not args.no_latency:
             line["grasp_latency"] = latency_c2(feat, rng_file, local_rank,
-                                               capi.FLAG_SPLIT_F16 if args.precision == "f16x3" else 0)
+                                               capi.FLAG_FP32_MFMA if args.precision == "f32" else 0)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhafgrasp.so")
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
-FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_SPLIT_F16 = 1, 2, 4
+FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA = 1, 2, 4
 DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM = range(6)
 STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "recheck", "vote", "download"]
 

@@ -336,7 +336,7 @@ int build_tables(haf_engine *e)
     if (hipSuccess != e->d_svt.alloc(svt.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(sv tiles)");
     HIPCHK(e, hipMemcpy(e->d_svt.p, svt.data(), svt.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    if (e->cfg.flags & HAF_FLAG_SPLIT_F16) {
+    if (!(e->cfg.flags & HAF_FLAG_FP32_MFMA)) {
         // split-fp16 images: s = sh + sl (fp16 each), hi image then lo image (h_image_offset), then 32 a_s and 32 coef
         std::vector<char> img((size_t)e->n_sv_tiles * kHSvTileBytes, 0);
         for (int n = 0; n < m.n_sv; n++) {
@@ -659,7 +659,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
     launch_compact(e->d_mask.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
     mark(e, HAF_ST_FEATURES);
-    const bool split = (c.flags & HAF_FLAG_SPLIT_F16) != 0;
+    const bool split = (c.flags & HAF_FLAG_FP32_MFMA) == 0;
     launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower, e->range.upper,
                     e->svm.neg_gamma2, evals_cap, split, s);
     mark(e, HAF_ST_SVM);

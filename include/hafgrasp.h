@@ -57,8 +57,9 @@ typedef struct haf_config {
 
 #define HAF_FLAG_KEEP_DEBUG 1u       /* keep per-roll intermediates for haf_debug_fetch()                 */
 #define HAF_FLAG_PROFILE    2u       /* record HIP events per stage (haf_get_stage_ms)                    */
-#define HAF_FLAG_SPLIT_F16  4u       /* RBF contraction as three fp16 MFMA passes on hi/lo halves of the fp32 operands
-                                        instead of one fp32 MFMA pass: same guard band, same labels, ~3-4x the rate   */
+#define HAF_FLAG_FP32_MFMA  4u       /* RBF contraction as ONE fp32 MFMA pass instead of the default three fp16 MFMA passes
+                                        on the hi/lo halves of the same fp32 operands: same guard band, same labels,
+                                        about a third of the rate                                                  */
 
 /* GraspInput (reference msg/GraspInput.msg:3-15) minus the cloud and the frame id: the cloud is passed
  * separately, already in the base frame (server.cpp:316). */

@@ -20,7 +20,7 @@ F, R = os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_all
 
 def run(model, names, tag):
     o = O.Oracle(F, R, model)
-    eng = capi.Engine(F, R, model, flags=capi.FLAG_KEEP_DEBUG | (capi.FLAG_SPLIT_F16 if os.environ.get('HAF_DIAG_SPLIT') else 0), max_points=1 << 18)
+    eng = capi.Engine(F, R, model, flags=capi.FLAG_KEEP_DEBUG | (capi.FLAG_FP32_MFMA if os.environ.get('HAF_DIAG_F32') else 0), max_points=1 << 18)
     worst, errs = 0.0, []
     for name in names:
         xyz = capi.load_pcd(os.path.join(DATA, name + ".pcd"))

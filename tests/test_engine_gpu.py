@@ -41,7 +41,7 @@ def orc(data_dir, surrogate):
     return O.Oracle(f, r, surrogate)
 
 
-MODES = [pytest.param(0, id="f32mfma"), pytest.param(capi.FLAG_SPLIT_F16, id="splitf16")]
+MODES = [pytest.param(capi.FLAG_FP32_MFMA, id="f32mfma"), pytest.param(0, id="splitf16")]
 
 
 def make_engine(data_dir, model, mode=0, **cfg):

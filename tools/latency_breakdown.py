@@ -16,7 +16,7 @@ MODEL = os.path.join(ROOT, "tests", "golden", "surrogate.model")
 
 
 def bench(name, clouds, inputs, **cfg):
-    eng = capi.Engine(F, R, MODEL, flags=capi.FLAG_PROFILE | capi.FLAG_SPLIT_F16, max_clouds=len(clouds), max_points=1 << 20, **cfg)
+    eng = capi.Engine(F, R, MODEL, flags=capi.FLAG_PROFILE, max_clouds=len(clouds), max_points=1 << 20, **cfg)
     for _ in range(3):
         out = eng.score_batch(clouds, inputs)
     ts, acc = [], {}
