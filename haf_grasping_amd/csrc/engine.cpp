@@ -809,6 +809,7 @@ int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, vo
 {
     if (!e) return HAF_E_ARG;
     if (!dst) return fail(e, HAF_E_ARG, "haf_debug_fetch: null dst");
+    if (!(e->cfg.flags & HAF_FLAG_KEEP_DEBUG)) return fail(e, HAF_E_ARG, "haf_debug_fetch: engine was created without HAF_FLAG_KEEP_DEBUG");
     const int rl = roll - e->last_roll_first;
     if (cloud < 0 || cloud >= e->last_B || rl < 0 || rl >= e->last_R) return fail(e, HAF_E_ARG, "haf_debug_fetch: (cloud, roll) not in the last scored batch");
     const size_t H = (size_t)e->cfg.grid_h, W = (size_t)e->cfg.grid_w, HW = H * W;
