@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
                     help="RBF contraction: one fp32 MFMA pass, or three fp16 MFMA passes on the hi/lo halves of the "
                          "same fp32 operands (same guard band, identical labels)")
+    ap.add_argument("--shard", choices=["clouds", "rolls"], default="clouds",
+                    help="clouds (default, weak scaling): one cloud per GPU per step; rolls (strong scaling): ONE cloud per "
+                         "step, its rolls split over the GPUs, roll records all-gathered (16 B each) and finalised on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
@@ -144,7 +147,7 @@ def main():
     models.write_random_model(model_path, args.nsv, D=D_ATTR, seed=1234, balanced=True)
 
     G = args.grid
-    xyz = models.synthetic_cloud(grid=G, k=2, seed=rank)
+    xyz = models.synthetic_cloud(grid=G, k=2, seed=rank if args.shard == "clouds" else 0)
     d_xyz = torch.from_numpy(xyz).cuda()                    # resident in HBM before the timed region
     cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
     inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
@@ -162,6 +165,11 @@ def main():
 
     def run(eng, steps, warmup, collective):
         def step():
+            if args.shard == "rolls" and collective:
+                first, count = hd.roll_shard(args.rolls, world, rank)
+                local = eng.score_rolls([cloud], [inp], first, count)
+                full = hd.gather_roll_records(local, args.rolls, device="cuda")[0]   # one all-gather of 16 B per roll
+                return local[0], eng.finalize(inp, full)
             rec = eng.score_rolls([cloud], [inp], 0, args.rolls)[0]
             out = eng.finalize(inp, rec)
             if collective:
@@ -225,7 +233,7 @@ def main():
             "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.shard == "clouds" else "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f16x3",
             "data": "synthetic",
             "config": {"workload": "C5: synthetic %dx%d heightmap (%d points), %d rolls x %d deg, %dx%d cm area, seeded random "
@@ -233,7 +241,8 @@ def main():
                                    % (G, G, xyz.shape[0], args.rolls, args.roll_step, G, G, args.nsv),
                        "evals_per_cloud": int(res["evals"] / args.steps), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
                        "contraction": args.precision,
-                       "sharding": "clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step"},
+                       "sharding": ("clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step" if args.shard == "clouds"
+                                    else "rolls of one cloud split over the GPUs; all-gather of the 16-byte roll records per step")},
             "roofline": roofline(res, args.precision),
             "stage_ms_per_step": res["stage_ms"],
             "prestages_hbm": (lambda ms, b: {"kernels": "k_bin + k_integral + k_mask_count/k_scan/k_compact + k_vote_cells/k_vote_pick",
