@@ -393,20 +393,25 @@ int build_tables(haf_engine *e)
     e->svm.two_gamma2 = (float)(2.0 * m.gamma * log2e);
     e->svm.neg_gamma2 = (float)(-m.gamma * log2e);
     e->svm.rho = (float)m.rho;
-    // Guard band: a fast decision is trusted when |dec| > guard * (1 + |a_x| + max|a_s|) * sum_n |coef_n| K_n + guard_abs,
-    // a_x = gamma'*|x|^2, a_s = gamma'*|s|^2.  2^-16 is the WORST-CASE fp32 error of the contraction per unit of that
-    // product (324-term fma chain bounded through Cauchy-Schwarz by 324*2^-24*(a_x+a_s), fp32 attributes, three
-    // roundings of the exp2 argument, v_exp_f32, fp32 coefficient sum): DESIGN.md §2 derives it, tests/diag_guard.py
-    // measures the actual error (about 30x smaller).  HAF_GUARD_REL overrides it for experiments.
-    double guard = 1.0 / 65536.0;
-    if (const char *g = getenv("HAF_GUARD_REL")) guard = atof(g);
-    e->svm.guard = (float)guard;
+    // Guard band: a fast decision is trusted when
+    //     |dec| > (guard_acc + guard_dot * (a_x + max a_s)) * sum_n |coef_n| K_n + guard_abs,   a = gamma'*|.|^2.
+    // Both constants are WORST-CASE fp32 error bounds per unit of sum|coef|K:
+    //   guard_dot: the 324-term fp32 fma chain of x.s, bounded through Cauchy-Schwarz (324 * 2^-24 * ln2 in K), the fp32
+    //              rounding of the attributes (2 * 2^-24; 2^-22 for the fp16 hi+lo split) and the roundings of the argument;
+    //   guard_acc: the sequential fp32 sum of coef*K over the SV tiles plus the 5-step lane reduction ((tiles + 8) * 2^-24),
+    //              v_exp_f32 and the coefficient product (3 * 2^-23).
+    // tests/diag_guard.py measures the actual error with the band disabled: 20-30x smaller.  HAF_GUARD_REL scales the band.
+    double guard_scale = 1.0;
+    if (const char *g = getenv("HAF_GUARD_REL")) guard_scale = atof(g);
+    const double u = std::ldexp(1.0, -24);
+    e->svm.guard_dot = (float)(guard_scale * (0.6932 * 324.0 * u + 8.0 * u));
+    e->svm.guard_acc = (float)(guard_scale * ((e->n_sv_tiles + 8) * u + 6.0 * u));
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
         double as_max = 0;
         for (int t = 0; t < e->n_sv_tiles; t++)
             for (int j = 0; j < kTile; j++) as_max = std::max(as_max, (double)std::fabs(svt[(size_t)t * kTileFloats + kKP * kTile + j]));
-        e->svm.as_max1 = (float)(1.0 + as_max);
+        e->svm.as_max = (float)as_max;
     }
     e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
     e->exact.gamma = m.gamma; e->exact.rho = m.rho;

@@ -79,9 +79,11 @@ struct SvmParams {
     float two_gamma2;             // 2*gamma*log2(e)
     float neg_gamma2;             // -gamma*log2(e)
     float rho;
-    float guard;                  // |dec| <= guard * (as_max1 + |a_x|) * sum|coef|K + guard_abs -> exact fp64 recheck
+    // |dec| <= (guard_acc + guard_dot * (|a_x| + as_max)) * sum|coef|K + guard_abs  ->  fp64 recheck tier
+    float guard_acc;              // fp32 accumulation of the coefficient sum over the SV tiles, exp2, argument roundings
+    float guard_dot;              // 324-term fp32 dot-product chain, per unit of (a_x + a_s)
     float guard_abs;
-    float as_max1;                // 1 + max_n gamma*log2(e)*|s_n|^2
+    float as_max;                 // max_n gamma*log2(e)*|s_n|^2
     int   gv0, gv1;               // grid values of label[0] / label[1] (atoi of the "%g" label text, server.cpp:843)
 };
 

@@ -622,9 +622,9 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
                 float dv = part[r] - p.rho;
                 dec[e] = dv;
                 labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);      // svm.cpp:2516-2531
-                // guard band: the fp32 error of the sum is at most guard * (1 + |a_x| + max|a_s|) * sum|coef|K
-                // (DESIGN.md §2); inside it the evaluation is repeated in exact fp64 libsvm order.  Also catches NaN.
-                if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axr[r])) * pabs[r] + p.guard_abs)) {
+                // guard band: the fp32 error of the sum is at most (guard_acc + guard_dot*(|a_x| + max|a_s|)) * sum|coef|K
+                // (DESIGN.md §2); inside it the evaluation goes to the fp64 tiers.  Also catches NaN.
+                if (!(fabsf(dv) > (p.guard_acc + p.guard_dot * (p.as_max + fabsf(axr[r]))) * pabs[r] + p.guard_abs)) {
                     int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                     if (slot < flag_cap) flag_list[slot] = (int)e;
                 }
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     const float sabs = P - N;                       // sum |coef| K
                     dec[e] = dv;
                     labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-                    if (!(fabsf(dv) > p.guard * (p.as_max1 + fabsf(axs[row])) * sabs + p.guard_abs)) {
+                    if (!(fabsf(dv) > (p.guard_acc + p.guard_dot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
                         int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                         if (slot < flag_cap) flag_list[slot] = (int)e;
                     }
