@@ -629,7 +629,8 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
             float *dst = e->h_points + off * 3;
             const float *src = clouds[b].xyz;
             const size_t st = clouds[b].stride_floats;
-            if (st == 3) memcpy(dst, src, clouds[b].n_points * 3 * sizeof(float));
+            if (clouds[b].n_points == 0) { /* nothing to stage */ }
+            else if (st == 3) memcpy(dst, src, clouds[b].n_points * 3 * sizeof(float));
             else for (size_t i = 0; i < clouds[b].n_points; i++) { dst[i * 3] = src[i * st]; dst[i * 3 + 1] = src[i * st + 1]; dst[i * 3 + 2] = src[i * st + 2]; }
             cd.xyz = e->d_points.p + off * 3;
             cd.stride = 3;
