@@ -14,6 +14,14 @@ DATA = os.path.join(GOLDEN, "data")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The product library and the checker are built in-tree; build them when the suite runs on a fresh checkout
+    # (hipcc cross-compiles gfx950 without a GPU, ~15 s).  Nothing here falls back to another implementation.
+    from haf_grasping_amd import build as _b
+    if not os.path.exists(_b.LIB):
+        _b.build()
+    from oracle import oracle as _o
+    if not os.path.exists(os.path.join(os.path.dirname(_o.__file__), "libhaforacle.so")):
+        _o.build()
 
 
 @pytest.fixture(scope="session")
