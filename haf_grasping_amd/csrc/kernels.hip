@@ -732,6 +732,11 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     __syncthreads();
 
     const int my_pieces = (kHSvPieces - wave + 7) / 8;              // DMA instructions this wave issues per tile (6 or 5)
+    float axr[2][4];                                                // a_x of this lane's 8 rows (LDS reads cannot be hoisted
+#pragma unroll                                                      //  over the asm DMA by the compiler, so do it by hand)
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) axr[m][r] = axs[16 * m + 4 * (lane >> 4) + r];
     for (int t = 0; t < nt; t++) {
         const char *cur = lds + (t % kHBuffers) * kHSvTileBytes;
         const bool more = t + 2 < nt;
@@ -813,8 +818,8 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = 16 * m + 4 * (lane >> 4) + r;     // 16x16 C/D layout: col = lane&15, row = 4(lane>>4) + reg
-                    float arg = fmaf(p.two_gamma2, acc[m][n][r], axs[row] + as_);
+                    // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
+                    float arg = fmaf(p.two_gamma2, acc[m][n][r], axr[m][r] + as_);
                     float k = __builtin_amdgcn_exp2f(arg);
                     part[m][r] = fmaf(cf, k, part[m][r]);
                 }
