@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhafgrasp.so")
+LIB_PATH = os.environ.get("HAF_LIB", os.path.join(HERE, "libhafgrasp.so"))   # HAF_LIB: A/B another build of the same ABI
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA = 1, 2, 4

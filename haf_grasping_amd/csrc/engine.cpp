@@ -405,7 +405,11 @@ int build_tables(haf_engine *e)
     if (const char *g = getenv("HAF_GUARD_REL")) guard_scale = atof(g);
     const double u = std::ldexp(1.0, -24);
     e->svm.guard_dot = (float)(guard_scale * (0.6932 * 324.0 * u + 8.0 * u));
-    e->svm.guard_acc = (float)(guard_scale * ((e->n_sv_tiles + 8) * u + 6.0 * u));
+    // coefficient sum: sequential over the tiles (fp32 kernel) or two-level, 8 tiles per inner sum (split-fp16 kernel);
+    // +2 for the class split (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product
+    const bool split_mode = !(e->cfg.flags & HAF_FLAG_FP32_MFMA);
+    const double acc_adds = split_mode ? (8.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0) : (e->n_sv_tiles + 5.0);
+    e->svm.guard_acc = (float)(guard_scale * ((acc_adds + 6.0) * u));
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
         double as_max = 0;

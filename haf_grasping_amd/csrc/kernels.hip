@@ -710,11 +710,13 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
         }
     }
     if (lane < kTile) { axs[lane] = ax[tile32 * kTile + lane]; pos[lane] = 0.0f; }
-    float part[2][4];                                                // rows 16m + 4(lane>>4) + r, summed over this lane's columns
+    // rows 16m + 4(lane>>4) + r, summed over this lane's columns.  Two levels: `lo` takes the products of up to 8 tiles,
+    // then folds into `part`, so the fp32 error of the coefficient sum grows with tiles/8 + 8 instead of tiles
+    float part[2][4], lo[2][4];
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) part[m][r] = 0.0f;
+        for (int r = 0; r < 4; r++) { part[m][r] = 0.0f; lo[m][r] = 0.0f; }
     // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
 #pragma unroll
     for (int s = 0; s < kHFull; s++)
@@ -750,13 +752,14 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float v = part[m][r];
+                    float v = part[m][r] + lo[m][r];
                     v += __shfl_xor(v, 8, 64);
                     v += __shfl_xor(v, 4, 64);
                     v += __shfl_xor(v, 2, 64);
                     v += __shfl_xor(v, 1, 64);
                     if ((lane & 15) == 0) pos[16 * m + 4 * (lane >> 4) + r] = v;
                     part[m][r] = 0.0f;
+                    lo[m][r] = 0.0f;
                 }
         }
 
@@ -821,8 +824,14 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
                     float arg = fmaf(p.two_gamma2, acc[m][n][r], axr[m][r] + as_);
                     float k = __builtin_amdgcn_exp2f(arg);
-                    part[m][r] = fmaf(cf, k, part[m][r]);
+                    lo[m][r] = fmaf(cf, k, lo[m][r]);
                 }
+        }
+        if ((t & 7) == 7) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { part[m][r] += lo[m][r]; lo[m][r] = 0.0f; }
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
         if (more) {
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            float v = part[m][r];
+            float v = part[m][r] + lo[m][r];
             v += __shfl_xor(v, 8, 64);
             v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 2, 64);
