@@ -794,7 +794,6 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], bh[c][n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bq[c][n], acc[m][n], 0, 0, 0);
                 }
-            __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead: hipcc otherwise sinks the reads to their use
         }
         {   // K tail: attributes 320..335, 16x16x16 form (4 halfs per lane)
             half4 bht[2], bqt[2];
