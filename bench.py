@@ -92,11 +92,41 @@ def cpu_baseline(feat, rng_file, model_path, xyz, args):
     c_all = int(min(args.grid, 14 + (per_core * cores * 10.0) ** 0.5))
     na, ta = run(c_all, cores)
     os.environ["HAFO_THREADS"] = "1"
-    return dict(value=na / ta, unit="evals/s", cores=cores, kind="port", single_core_value=per_core,
+    ref = reference_tools_baseline(o, O, rng_file, model_path, xyz, args)
+    return dict(value=na / ta, unit="evals/s", cores=cores, kind="port", single_core_value=per_core, reference_tools=ref,
                 sample="oracle/haf_oracle.c end to end (features, %%.4g/%%g text round trips, svm-scale, libsvm-order fp64 "
                        "RBF over nSV=%d, vote), same cloud and model, 1 roll: central %dx%d crop on 1 core (%d evals in "
                        "%.1f s), central %dx%d crop on %d cores (%d evals in %.1f s)"
                        % (args.nsv, args.cpu_crop, args.cpu_crop, n1, t1, c_all, c_all, cores, na, ta))
+
+
+def reference_tools_baseline(o, O, rng_file, model_path, xyz, args):
+    """The reference's own SVM stage as the server runs it (server.cpp:775-788): the REAL svm-scale and svm-predict
+    binaries (built from /root/reference/libsvm-3.12 into oracle/_ref) on the feature text file of one roll of a
+    40x40 crop, through temp files, 1 core.  None when oracle/_ref is not present."""
+    import subprocess
+    ref = O.ref_dir()
+    if not (os.path.exists(os.path.join(ref, "svm-scale")) and os.path.exists(os.path.join(ref, "svm-predict"))):
+        return None
+    c = 40
+    half = c * 0.01 / 2
+    sel = (np.abs(xyz[:, 0]) < half) & (np.abs(xyz[:, 1]) < half)
+    pts = np.ascontiguousarray(xyz[sel])
+    tmp = tempfile.mkdtemp(prefix="hafref_")
+    f = os.path.join(tmp, "features.txt")
+    t0 = time.perf_counter()
+    n = o.dump_feature_file(pts, O.make_cfg(H=c, W=c, n_rolls=1, roll_step_deg=args.roll_step), O.make_input(length_x=c, length_y=c), 0, f)
+    t_feat = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with open(f + ".scale", "w") as out:
+        subprocess.run([os.path.join(ref, "svm-scale"), "-r", rng_file, f], stdout=out, check=True)
+    t_scale = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    subprocess.run([os.path.join(ref, "svm-predict"), f + ".scale", model_path, f + ".out"], stdout=subprocess.DEVNULL, check=True)
+    t_pred = time.perf_counter() - t0
+    return dict(kind="reference", value=n / (t_feat + t_scale + t_pred), unit="evals/s", cores=1,
+                sample="real svm-scale + svm-predict (oracle/_ref) on the oracle's feature file of a %dx%d crop, 1 roll, nSV=%d: "
+                       "%d evals; features+text %.2f s, svm-scale %.2f s, svm-predict %.2f s" % (c, c, args.nsv, n, t_feat, t_scale, t_pred))
 
 
 def latency_c2(feat, rng_file, device, flags):
