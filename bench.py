@@ -8,7 +8,7 @@ per GPU per step (weak scaling: rolls x cells of independent clouds shard across
 the only exchange is one 8-byte RCCL all-reduce(max) per step that elects the best grasp of the batch).
 
 A step = one pass of the whole hot path (bin -> integral -> mask -> features+text round trips+scale -> RBF decision
--> fp64 recheck tiers -> vote/argmax -> pose) over one cloud per rank, inputs already resident in HBM.
+(fp16 screening pass -> three-pass kernel on its guard band) -> fp64 recheck tiers -> vote/argmax -> pose) over one cloud per rank, inputs already resident in HBM.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -40,16 +40,17 @@ def parse():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rolls", type=int, default=36)
     ap.add_argument("--roll-step", type=int, default=5)
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
-                    help="RBF contraction: one fp32 MFMA pass, or three fp16 MFMA passes on the hi/lo halves of the "
-                         "same fp32 operands (same guard band, identical labels)")
+    ap.add_argument("--precision", choices=["f32", "f16x3", "f16s"], default="f16s",
+                    help="RBF contraction: f16s (default) = one fp16 MFMA screening pass over every evaluation, the three-pass "
+                         "kernel only on what falls inside its rigorous guard band; f16x3 = three fp16 MFMA passes on the "
+                         "hi/lo halves of the fp32 operands for every evaluation; f32 = one fp32 MFMA pass.  Identical labels.")
     ap.add_argument("--shard", choices=["clouds", "rolls"], default="clouds",
                     help="clouds (default, weak scaling): one cloud per GPU per step; rolls (strong scaling): ONE cloud per "
                          "step, its rolls split over the GPUs, roll records all-gathered (16 B each) and finalised on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--no-f32-side", action="store_true", help="skip the side measurement of the fp32-MFMA mode")
+    ap.add_argument("--no-f32-side", action="store_true", help="skip the side measurements of the other contraction modes")
     return ap.parse_args()
 
 
@@ -185,7 +186,7 @@ def main():
     def make_engine(precision):
         return capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
                            roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2,
-                           flags=capi.FLAG_PROFILE | (capi.FLAG_FP32_MFMA if precision == "f32" else 0))
+                           flags=capi.FLAG_PROFILE | {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[precision])
 
     def fence():
         torch.cuda.synchronize()
@@ -207,7 +208,7 @@ def main():
             return rec, out
         for _ in range(warmup):
             step()
-        svm_ms, stage_acc, evals, rechecked, strict = [], {}, 0, 0, 0
+        svm_ms, stage_acc, evals, rechecked, strict, refined = [], {}, 0, 0, 0, 0
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -216,6 +217,7 @@ def main():
             c = eng.last_counts()
             rechecked += c["n_rechecked"]
             strict += c["n_strict"]
+            refined += c["n_refined"]
             st = eng.stage_ms()
             svm_ms.append(st["svm"])
             for k, v in st.items():
@@ -223,7 +225,7 @@ def main():
         fence()
         return dict(elapsed=time.perf_counter() - t0, evals=evals, steps=steps, svm_s=float(np.mean(svm_ms)) * 1e-3,
                     stage_ms={k: v / steps for k, v in stage_acc.items()}, rechecked=rechecked / steps,
-                    strict=strict / steps, out=out)
+                    strict=strict / steps, refined=refined / steps, out=out)
 
     eng = make_engine(args.precision)
     res = run(eng, args.steps, args.warmup, use_dist)
@@ -241,8 +243,8 @@ def main():
         evals_per_launch = r["evals"] / r["steps"]
         flop = evals_per_launch * 2.0 * D_ATTR * args.nsv           # algorithmic: 646*nSV per eval, ONE pass
         achieved = flop / r["svm_s"] / 1e12
-        peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-        kernel = "k_svm_rbf_h" if precision == "f16x3" else "k_svm_rbf"
+        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+        kernel = {"f16s": "k_svm_screen", "f16x3": "k_svm_rbf_h", "f32": "k_svm_rbf"}[precision]
         o = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
              "frac": achieved / peak, "traffic": pmc_traffic(args, kernel), "kernel_ms": r["svm_s"] * 1e3,
              "flop_per_launch": flop}
@@ -254,6 +256,14 @@ def main():
                       "mfma_busy_frac": executed / r["svm_s"] / 1e12 / peak,
                       "note": "fp32 operands split into fp16 hi+lo; x.s = xh.sh + xl.sh + xh.sl (3 MFMA passes, fp32 "
                               "accumulate); algorithmic flop counted once, per SURVEY.md 8(d)"})
+        if precision == "f16s":
+            executed = flop * 336.0 / D_ATTR
+            o.update({"passes": 1, "executed_tflops": executed / r["svm_s"] / 1e12,
+                      "note": "single fp16 MFMA pass over every evaluation (K padded 323 -> 336, the padding carries the norm "
+                              "terms); evaluations inside its rigorous guard band are re-done by the three-pass kernel "
+                              "(stage 'refine') and the fp64 tiers, so the labels are libsvm's",
+                      "refined_per_launch": r["refined"], "refined_share": r["refined"] / max(1.0, evals_per_launch),
+                      "refine_ms": r["stage_ms"].get("refine")})
         return o
 
     if rank == 0:
@@ -264,7 +274,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak" if args.shard == "clouds" else "strong", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16x3",
+            "dtype": {"f32": "f32", "f16x3": "f16x3", "f16s": "f16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "C5: synthetic %dx%d heightmap (%d points), %d rolls x %d deg, %dx%d cm area, seeded random "
                                    "libsvm RBF model nSV=%d D=323 gamma=1/323, one cloud per GPU per step, cloud resident in HBM"
@@ -283,26 +293,29 @@ def main():
                                                      "2 % of the step"})(
                 res["stage_ms"]["bin"] + res["stage_ms"]["integral"] + res["stage_ms"]["mask"] + res["stage_ms"]["vote"],
                 12.0 * args.rolls * (G * G + xyz.shape[0])),
-            "rechecked_per_step": {"fp64_mfma_tier": res["rechecked"], "strict_order_tier": res["strict"]},
+            "rechecked_per_step": {"three_pass_tier": res["refined"], "fp64_mfma_tier": res["rechecked"],
+                                   "strict_order_tier": res["strict"]},
             "best": {"eval": res["out"]["eval"], "row": res["out"]["best_row"], "col": res["out"]["best_col"],
                      "roll": res["out"]["best_roll"]},
         }
-        if world == 1 and args.precision == "f16x3" and not args.no_f32_side:
-            e2 = make_engine("f32")
-            r2 = run(e2, 2, 1, False)
-            e2.close()
-            line["f32_mode"] = {"value": r2["evals"] / r2["elapsed"], "ms_per_step": 1e3 * r2["elapsed"] / 2,
-                                "roofline": roofline(r2, "f32"), "stage_ms_per_step": r2["stage_ms"],
-                                "same_best": bool(r2["out"]["eval"] == res["out"]["eval"] and
-                                                  r2["out"]["best_row"] == res["out"]["best_row"] and
-                                                  r2["out"]["best_col"] == res["out"]["best_col"])}
+        if world == 1 and not args.no_f32_side:
+            for other in [m for m in ("f16x3", "f32") if m != args.precision]:
+                e2 = make_engine(other)
+                r2 = run(e2, 2, 1, False)
+                e2.close()
+                line[other + "_mode"] = {"value": r2["evals"] / r2["elapsed"], "ms_per_step": 1e3 * r2["elapsed"] / 2,
+                                         "roofline": roofline(r2, other), "stage_ms_per_step": r2["stage_ms"],
+                                         "same_best": bool(r2["out"]["eval"] == res["out"]["eval"] and
+                                                           r2["out"]["best_row"] == res["out"]["best_row"] and
+                                                           r2["out"]["best_col"] == res["out"]["best_col"] and
+                                                           r2["out"]["best_roll"] == res["out"]["best_roll"])}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(feat, rng_file, model_path, xyz, args)
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_latency:
             line["grasp_latency"] = latency_c2(feat, rng_file, local_rank,
-                                               capi.FLAG_FP32_MFMA if args.precision == "f32" else 0)
+                                               {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision])
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -6,7 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhafgrasp.so")
-SOURCES = ["kernels.hip", "engine.cpp", "parsers.cpp"]
+SOURCES = ["kernels.hip", "screen.hip", "engine.cpp", "parsers.cpp"]
+# per-file extra flags (screen.hip: see its header)
+EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["kernels.h", "parsers.h", "decq.h", os.path.join("..", "..", "include", "hafgrasp.h"),
            os.path.join("..", "cli", "haf_grasp_cli.cpp")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
@@ -29,7 +31,7 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

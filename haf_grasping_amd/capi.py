@@ -9,9 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAF_LIB", os.path.join(HERE, "libhafgrasp.so"))   # HAF_LIB: A/B another build of the same ABI
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
-FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA = 1, 2, 4
+FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16 = 1, 2, 4, 8
 DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM = range(6)
-STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "recheck", "vote", "download"]
+STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "refine", "recheck", "vote", "download"]
 
 
 class Config(C.Structure):
@@ -87,6 +87,7 @@ def lib():
         L.haf_get_stage_ms.argtypes = [E, C.POINTER(C.c_float)]
         L.haf_model_info.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.haf_last_tiers.argtypes = [E] + [C.POINTER(C.c_int64)] * 4
         L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                    C.c_size_t]
         L.haf_free.argtypes = [C.c_void_p]
@@ -192,9 +193,9 @@ class Engine:
         return dict(n_sv=a.value, dim=b.value, n_features=c.value)
 
     def last_counts(self):
-        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
-        self._check(self._L.haf_last_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(n_evals=a.value, n_rechecked=b.value, n_strict=c.value)
+        a, r, b, c = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._L.haf_last_tiers(self._h, C.byref(a), C.byref(r), C.byref(b), C.byref(c)))
+        return dict(n_evals=a.value, n_refined=r.value, n_rechecked=b.value, n_strict=c.value)
 
     def score(self, xyz, grasp_input):
         return self.score_batch([xyz], [grasp_input])[0]

@@ -193,6 +193,10 @@ struct haf_engine {
 
     long max_evals = 0, max_evals_pad = 0;
     int flag_cap = 0, flag2_cap = 0;
+    int flag0_cap = 0;      // screening pass: evaluations that go on to the three-pass kernel
+    bool screen_active = true;   // default mode only: cleared (for good) once more than 60 % of a call's evaluations fell inside
+                                 // the screening band -- for such a model the single pass is wasted work
+    ScreenParams screen{};
     size_t cells_cap = 0;   // B*R*H*W
 
     DevBuf<CloudDev> d_clouds;
@@ -205,6 +209,9 @@ struct haf_engine {
     DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list, d_flag2_list;
     DevBuf<float> d_X, d_ax, d_dec, d_svt;
     DevBuf<char> d_svt_h;            // split-fp16 SV tile images
+    DevBuf<char> d_svt0;             // screening-pass SV tile images
+    DevBuf<float> d_X1, d_ax1, d_gband;   // three-pass operand images / a_x of the screened-out rest; per-evaluation guard band
+    DevBuf<int> d_flag0_list;
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64;
     DevBuf<short> d_ev16;
@@ -221,7 +228,7 @@ struct haf_engine {
 
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
-    int last_evals = 0, last_flagged = 0, last_flagged2 = 0;
+    int last_evals = 0, last_flagged = 0, last_flagged2 = 0, last_flagged0 = 0;
     std::vector<haf_grasp_input> last_inputs;
 };
 
@@ -235,6 +242,16 @@ namespace {
             return HAF_E_DEVICE;                                                                          \
         }                                                                                                 \
     } while (0)
+
+// contraction mode: default = screening pass + three-pass refinement; HAF_FLAG_SPLIT_F16 = three passes for everything;
+// HAF_FLAG_FP32_MFMA = one fp32 MFMA pass for everything
+enum { MODE_SCREEN = 0, MODE_SPLIT = 1, MODE_F32 = 2 };
+int contraction_mode(const haf_config &c)
+{
+    if (c.flags & HAF_FLAG_FP32_MFMA) return MODE_F32;
+    if (c.flags & HAF_FLAG_SPLIT_F16) return MODE_SPLIT;
+    return MODE_SCREEN;
+}
 
 int fail(haf_engine *e, int code, const std::string &msg)
 {
@@ -361,6 +378,46 @@ int build_tables(haf_engine *e)
         HIPCHK(e, hipMemcpy(e->d_svt_h.p, img.data(), img.size(), hipMemcpyHostToDevice));
     }
 
+    if (contraction_mode(e->cfg) == MODE_SCREEN) {
+        // screening images: v^ = fp16(c*s) with c = sqrt(2*gamma*log2 e), the norm slots (kernels.h) and 32 coefficients;
+        // the bounds the per-evaluation guard band needs are taken over the model here (ScreenParams)
+        ScreenParams &sp = e->screen;
+        sp.c = std::sqrt(2.0 * m.gamma * log2e);
+        sp.v_max = sp.dv_max = sp.das_max = sp.as_max = 0.0;
+        std::vector<char> img((size_t)e->n_sv_tiles * kS0SvTileBytes, 0);
+        for (int n = 0; n < m.n_sv; n++) {
+            const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
+            char *tile = img.data() + (size_t)t * kS0SvTileBytes;
+            double vv = 0, hh = 0, dd = 0;
+            for (int k = 0; k < m.dim; k++) {
+                const double v = m.sv[(size_t)n * m.dim + k] * sp.c;
+                _Float16 h = (_Float16)(float)v;
+                if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+                memcpy(tile + h_image_offset(j, k), &h, 2);
+                const double hd = (double)(float)h;
+                vv += v * v; hh += hd * hd; dd += (hd - v) * (hd - v);
+            }
+            const double a_s = 0.5 * vv;
+            _Float16 s3[3];
+            const double rep = split3_f16(-a_s, s3);
+            for (int q = 0; q < 3; q++) memcpy(tile + h_image_offset(j, kAugS + q), &s3[q], 2);
+            const _Float16 one = (_Float16)1.0f, tiny = (_Float16)(1.0f / kAugScale);
+            memcpy(tile + h_image_offset(j, kAugX), &one, 2);
+            memcpy(tile + h_image_offset(j, kAugX + 1), &tiny, 2);
+            memcpy(tile + h_image_offset(j, kAugX + 2), &tiny, 2);
+            reinterpret_cast<float *>(tile + kHMatBytes)[j] = (float)m.coef[(size_t)n];
+            sp.v_max = std::max(sp.v_max, std::sqrt(hh));
+            sp.dv_max = std::max(sp.dv_max, std::sqrt(dd));
+            sp.das_max = std::max(sp.das_max, std::fabs(rep + a_s));
+            sp.as_max = std::max(sp.as_max, a_s);
+        }
+        // the bounds feed a rigorous band: round them up past their own fp64 rounding
+        sp.v_max *= 1.0 + 1e-12; sp.dv_max *= 1.0 + 1e-12; sp.das_max = sp.das_max * (1.0 + 1e-12) + 1e-300;
+        if (!(sp.v_max < 60000.0)) return fail(e, HAF_E_ARG, "support vectors too large for the fp16 screening pass; use HAF_FLAG_SPLIT_F16");
+        if (hipSuccess != e->d_svt0.alloc(img.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening sv tiles)");
+        HIPCHK(e, hipMemcpy(e->d_svt0.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    }
+
     // fp64 image for both recheck tiers, SVs in MODEL order: rows 0..323 attributes, row 324 |s|^2, row 325 coef
     std::vector<double> sv64((size_t)kM64Rows * e->n_sv_pad, 0.0), coef64((size_t)e->n_sv_pad, 0.0);
     double ss_max = 0;
@@ -410,6 +467,13 @@ int build_tables(haf_engine *e)
     const bool split_mode = !(e->cfg.flags & HAF_FLAG_FP32_MFMA);
     const double acc_adds = split_mode ? (8.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0) : (e->n_sv_tiles + 5.0);
     e->svm.guard_acc = (float)(guard_scale * ((acc_adds + 6.0) * u));
+    // screening pass: one sequential fp32 sum per lane over two column blocks per tile, the 4-step lane reduction, the
+    // class split, v_exp_f32 and the coefficient product; the band is ~3e-4, so nothing is gained by a two-level sum.
+    // HAF_GUARD0_REL scales the whole screening band (this term and the per-evaluation one) for experiments.
+    double guard0_scale = 1.0;
+    if (const char *g = getenv("HAF_GUARD0_REL")) guard0_scale = atof(g);
+    e->svm.guard_acc0 = (float)(guard0_scale * ((2.0 * e->n_sv_tiles + 4.0 + 2.0 + 6.0) * u));
+    e->screen.scale = 1.001 * guard0_scale;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
         double as_max = 0;
@@ -431,8 +495,12 @@ int alloc_buffers(haf_engine *e)
     const size_t B = (size_t)c.max_clouds, R = (size_t)c.n_rolls, H = (size_t)c.grid_h, W = (size_t)c.grid_w;
     e->cells_cap = B * R * H * W;
     e->max_evals = (long)(B * R * (H - 14) * (W - 14));
-    e->max_evals_pad = (e->max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+    e->max_evals_pad = (e->max_evals + kS0BlockEvals - 1) / kS0BlockEvals * kS0BlockEvals;
     e->flag_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 4), 1L << 22);
+    const int mode = contraction_mode(c);
+    // screening pass: up to half of the evaluations may go on to the three-pass kernel before the call fails loudly
+    e->flag0_cap = mode == MODE_SCREEN ? (int)std::min<long>(std::max<long>(4096, (e->max_evals / 2 + 255) / 256 * 256), 1L << 23) : 0;
+    if (mode == MODE_SCREEN) e->flag_cap = std::min(e->flag_cap, e->flag0_cap);
     e->flag2_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 64), 1L << 20);
     bool ok = true;
     ok &= hipSuccess == e->d_clouds.alloc(B);
@@ -448,7 +516,18 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_counters.alloc(CNT_COUNT);
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->flag_cap);
-    ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * (size_t)std::max<int>(kTileFloats, kHXTileBytes / 4));
+    if (mode == MODE_SCREEN) {
+        // sized for the three-pass form as well: a model whose decisions crowd inside the screening band is served by
+        // the three-pass kernel alone (screen_active)
+        ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * (size_t)(kHXTileBytes / 4));
+        const size_t slots = ((size_t)e->flag0_cap + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+        ok &= hipSuccess == e->d_X1.alloc(slots / kTile * (size_t)(kHXTileBytes / 4));
+        ok &= hipSuccess == e->d_ax1.alloc(slots);
+        ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad);
+        ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
+    } else {
+        ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * (size_t)std::max<int>(kTileFloats, kHXTileBytes / 4));
+    }
     ok &= hipSuccess == e->d_ax.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
@@ -518,6 +597,7 @@ void haf_destroy(haf_engine *e)
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
+    e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -581,6 +661,16 @@ int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked,
 {
     if (!e) return HAF_E_ARG;
     if (n_evals) *n_evals = e->last_evals;
+    if (n_rechecked) *n_rechecked = e->last_flagged;
+    if (n_strict) *n_strict = e->last_flagged2;
+    return HAF_OK;
+}
+
+int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, int64_t *n_rechecked, int64_t *n_strict)
+{
+    if (!e) return HAF_E_ARG;
+    if (n_evals) *n_evals = e->last_evals;
+    if (n_refined) *n_refined = e->last_flagged0;
     if (n_rechecked) *n_rechecked = e->last_flagged;
     if (n_strict) *n_strict = e->last_flagged2;
     return HAF_OK;
@@ -668,32 +758,73 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     launch_mask_count(e->d_ii.p, e->d_geo.p, e->d_mask.p, e->d_rowcount.p, d, s);
     launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
     launch_compact(e->d_mask.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
-    mark(e, HAF_ST_FEATURES);
-    const bool split = (c.flags & HAF_FLAG_FP32_MFMA) == 0;
-    launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower, e->range.upper,
-                    e->svm.neg_gamma2, evals_cap, split, s);
-    mark(e, HAF_ST_SVM);
-    if (split)
-        launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                     e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
-    else
-        launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                   e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
-    mark(e, HAF_ST_RECHECK);
-    // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
-    // is still within 2^-40 of zero (practically nothing)
-    launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, e->d_counters.p,
-                        e->d_x64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->flag2_cap, d, s);
-    launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->flag2_cap,
-                   e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
-    mark(e, HAF_ST_VOTE);
-    launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rec.p, d, s);
-    mark(e, HAF_ST_DOWNLOAD);
-    HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
-    HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
-    mark(e, HAF_ST_COUNT);
-    HIPCHK(e, hipStreamSynchronize(s));
-    HIPCHK(e, hipGetLastError());
+    // features -> decision tiers -> vote -> records on the host, for one contraction mode
+    auto decide = [&](int mode) -> int {
+        mark(e, HAF_ST_FEATURES);
+        const bool large = evals_cap >= (1L << 20);          // enough evaluations to fill the chip with one thread each
+        if (mode == MODE_SCREEN) {
+            // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
+            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, s);
+            mark(e, HAF_ST_SVM);
+            launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                              e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
+            mark(e, HAF_ST_REFINE);
+            const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
+            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
+                            e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
+                            e->flag0_cap, large, s);
+            launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap, s);
+        } else if (mode == MODE_SPLIT) {
+            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, s);
+            mark(e, HAF_ST_SVM);
+            launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, s);
+            mark(e, HAF_ST_REFINE);
+        } else {
+            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, s);
+            mark(e, HAF_ST_SVM);
+            launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                       e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
+            mark(e, HAF_ST_REFINE);
+        }
+        mark(e, HAF_ST_RECHECK);
+        // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
+        // is still within 2^-40 of zero (practically nothing)
+        launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, e->d_counters.p,
+                            e->d_x64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->flag2_cap, d, s);
+        launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->flag2_cap,
+                       e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+        mark(e, HAF_ST_VOTE);
+        launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rec.p, d, s);
+        mark(e, HAF_ST_DOWNLOAD);
+        HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+        mark(e, HAF_ST_COUNT);
+        HIPCHK(e, hipStreamSynchronize(s));
+        HIPCHK(e, hipGetLastError());
+        return HAF_OK;
+    };
+    int mode = contraction_mode(c);
+    if (mode == MODE_SCREEN && !e->screen_active) mode = MODE_SPLIT;
+    int rc = decide(mode);
+    if (rc != HAF_OK) return rc;
+    if (mode == MODE_SCREEN) {
+        const int f0 = e->h_counters[CNT_FLAGGED0], ne = e->h_counters[CNT_EVALS];
+        if (f0 > e->flag0_cap) {
+            // more undecided evaluations than the refinement list holds: this pass's labels are incomplete.  Redo the decision
+            // stage with the three-pass kernel for every evaluation (same labels by construction) and stay with it.
+            e->screen_active = false;
+            HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
+            rc = decide(MODE_SPLIT);
+            if (rc != HAF_OK) return rc;
+        } else if (ne >= 256 && (double)f0 > 0.6 * (double)ne) {
+            e->screen_active = false;
+        }
+    }
 
     if (c.flags & HAF_FLAG_PROFILE)
         for (int i = 0; i < HAF_ST_COUNT; i++) (void)hipEventElapsedTime(&e->stage_ms[i], e->ev[i], e->ev[i + 1]);
@@ -702,6 +833,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     e->last_evals = e->h_counters[CNT_EVALS];
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
+    e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
     e->last_inputs.assign(in, in + B);
     if (e->last_flagged > e->flag_cap) {
         char msg[200];

@@ -41,6 +41,49 @@ __host__ __device__ inline int h_image_offset(int r, int k)
     return kHTailOff + (m * 64 + (kk >> 2) * 16 + row) * 8 + (kk & 3) * 2;
 }
 
+// ---- screening pass (tier 0): ONE fp16 MFMA pass on operands pre-scaled by c = sqrt(2*gamma*log2 e) ----
+// u = c*x, v = c*s  =>  exp2 argument = u.v - |u|^2/2 - |v|^2/2.  The two norm terms ride in spare K slots of the
+// 336-wide operand images (attributes use slots 0..323), each as a three-term fp16 split against constants
+// (1, 2^-12, 2^-12), so the accumulator IS the exp2 argument and the epilogue is v_exp_f32 + one fma per element.
+// A wave keeps 64 evals (two 32-eval hi images) in registers; a workgroup is 8 waves = 512 evals.
+constexpr int kS0WaveEvals = 64;
+constexpr int kS0BlockEvals = 512;
+constexpr int kS0SvTileBytes = 22528;                 // fp16 image (21504 B) + 32 coef floats, padded to 22 KiB
+constexpr int kS0Pieces = kS0SvTileBytes / 1024;      // 22 LDS-DMA wave instructions
+constexpr int kS0Buffers = 3;
+constexpr int kAugS = 324;                            // slots 324..326: x = (1, 2^-12, 2^-12), s = split3(-|v|^2/2)
+constexpr int kAugX = 327;                            // slots 327..329: x = split3(-|u|^2/2), s = (1, 2^-12, 2^-12)
+constexpr float kAugScale = 4096.0f;                  // 2^12
+constexpr float kF16MinNormal = 6.103515625e-05f;     // 2^-14: smaller fp16 magnitudes are flushed in software
+
+// a = h + (m + l) * 2^-12 with fp16 h, m, l (subnormal halves flushed to 0, so the value is the same whether or not the
+// matrix core honours fp16 denormals); returns the value the three products actually add up to
+__host__ __device__ inline double split3_f16(double a, _Float16 out[3])
+{
+    auto rn = [](double v) {
+        _Float16 h = (_Float16)(float)v;
+        float f = (float)h;
+        if ((f < 0 ? -f : f) < kF16MinNormal) h = (_Float16)0.0f;
+        return h;
+    };
+    out[0] = rn(a);
+    const double r1 = a - (double)(float)out[0];
+    out[1] = rn(r1 * 4096.0);
+    const double r2 = r1 - (double)(float)out[1] / 4096.0;
+    out[2] = rn(r2 * 4096.0);
+    return (double)(float)out[0] + ((double)(float)out[1] + (double)(float)out[2]) / 4096.0;
+}
+
+// constants of the screening pass that the feature kernel needs to write the per-evaluation guard band
+struct ScreenParams {
+    double c;                     // sqrt(2*gamma*log2 e)
+    double v_max;                 // max_n |v^_n|  (stored fp16 operand)
+    double dv_max;                // max_n |v^_n - v_n|
+    double das_max;               // max_n |split3(-a_s) - (-a_s)|
+    double as_max;                // max_n |v_n|^2/2
+    double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
+};
+
 struct CloudDev {
     const float *xyz;
     int n;
@@ -84,6 +127,7 @@ struct SvmParams {
     float guard_dot;              // 324-term fp32 dot-product chain, per unit of (a_x + a_s)
     float guard_abs;
     float as_max;                 // max_n gamma*log2(e)*|s_n|^2
+    float guard_acc0;             // screening pass: single-level fp32 coefficient sum + exp2 + product, per unit of sum|coef|K
     int   gv0, gv1;               // grid values of label[0] / label[1] (atoi of the "%g" label text, server.cpp:843)
 };
 
@@ -96,7 +140,7 @@ struct ExactParams {
 };
 
 // counters[] slots in device memory
-enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_COUNT = 8 };
+enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAGGED0 = 4, CNT_COUNT = 8 };
 
 // fp64 model image for the rechecks: attribute-major [kM64Rows][n_sv_pad]; rows 0..323 attributes (model order of SVs),
 // row 324 |s|^2, row 325 coef
@@ -111,14 +155,22 @@ void launch_integral(int *hkeys_heights, double *rowsum, float *ii, Dims d, hipS
 void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s);
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
 void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
+// operand image the feature kernels write
+enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2 };
+// idx_list == nullptr: evaluations 0..counters[CNT_EVALS]; otherwise slot j takes evaluation idx_list[j],
+// j < min(counters[list_counter], list_cap) (the screened evaluations that go on to the three-pass kernel)
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
-                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, bool split_f16, hipStream_t s);
+                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
+                     const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s);
+void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
+                       SvmParams p, float *dec, int8_t *labels, int *flag0_list, int flag0_cap, int *counters_rw, Dims d,
+                       long max_evals, hipStream_t s);
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
-                  long max_evals, hipStream_t s);
+                  long max_evals, const int *idx_list, int list_counter, int list_cap, hipStream_t s);
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);

@@ -334,48 +334,89 @@ __device__ __forceinline__ unsigned window_origin(int cell, int H, int W)
 // the fp32 MFMA A operand, so the contraction kernel fills its A fragments with fully coalesced 256-byte loads.
 // X image, split-fp16 form: per tile of 32 evals two operand images (hi, lo) of [21 k-steps][2 k-halves][32 evals][8 fp16];
 // a thread finishes 8 attributes, then stores them as one 16-byte vector per image (512 contiguous bytes per 32 lanes).
+// X image, screening form: per tile of 32 evals ONE operand image of the same layout holding fp16(c*x) plus the norm
+// slots (kernels.h); the per-evaluation guard band goes where the other forms keep a_x.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-// stores attributes 8g..8g+7 of tile row r into the hi and lo operand images (h_image_offset): one 16-byte vector per
-// image for the 16x16x32 steps, two 8-byte vectors for the 16-wide K tail
-__device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 hi, half8 lo)
+// stores attributes 8g..8g+7 of tile row r into one operand image (h_image_offset): one 16-byte vector for the 16x16x32
+// steps, two 8-byte vectors for the 16-wide K tail
+__device__ __forceinline__ void store_group_img(char *img, int r, int g, half8 v)
 {
     if (g < kHFull * 4) {
-        const int off = h_image_offset(r, g * 8);
-        *reinterpret_cast<half8 *>(xtile + off) = hi;
-        *reinterpret_cast<half8 *>(xtile + kHMatBytes + off) = lo;
+        *reinterpret_cast<half8 *>(img + h_image_offset(r, g * 8)) = v;
     } else {
-        const int o0 = h_image_offset(r, g * 8), o1 = h_image_offset(r, g * 8 + 4);
-        const half4 h0 = {hi[0], hi[1], hi[2], hi[3]}, h1 = {hi[4], hi[5], hi[6], hi[7]};
-        const half4 l0 = {lo[0], lo[1], lo[2], lo[3]}, l1 = {lo[4], lo[5], lo[6], lo[7]};
-        *reinterpret_cast<half4 *>(xtile + o0) = h0;
-        *reinterpret_cast<half4 *>(xtile + o1) = h1;
-        *reinterpret_cast<half4 *>(xtile + kHMatBytes + o0) = l0;
-        *reinterpret_cast<half4 *>(xtile + kHMatBytes + o1) = l1;
+        const half4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<half4 *>(img + h_image_offset(r, g * 8)) = v0;
+        *reinterpret_cast<half4 *>(img + h_image_offset(r, g * 8 + 4)) = v1;
     }
+}
+__device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 hi, half8 lo)
+{
+    store_group_img(xtile, r, g, hi);
+    store_group_img(xtile + kHMatBytes, r, g, lo);
+}
+
+// screening operand of one attribute: u = c*x in fp64 (the reference value), u^ = fp16(u) with subnormals flushed;
+// accumulates |u|^2 and |u^ - u|^2, the two norms the guard band of the screening pass is made of
+__device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &su2, double &sd2)
+{
+    const double ud = xd * c;
+    _Float16 h = (_Float16)(float)ud;
+    if (fabsf((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+    const double du = (double)(float)h - ud;
+    su2 = fma(ud, ud, su2);
+    sd2 = fma(du, du, sd2);
+    return h;
+}
+
+// norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band, per unit of sum|coef|K:
+//   | u^.v^ - u.v | <= |u^-u| |v^| + |u| |v^-v|   (u^.v^ - u.v = (u^-u).v^ + u.(v^-v), Cauchy-Schwarz on each term)
+//   + what the fp16 splits of the two norm terms miss + the fp32 accumulation inside the matrix core
+//   (11 accumulating instructions, a few ulp of the largest partial sum each: 2^-18 of |u||v^| + a_x + a_s is generous),
+// times ln 2 (d exp2(t) = ln2 exp2(t) dt); DESIGN.md §2.
+__device__ __forceinline__ float screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41)
+{
+    const double a_x = 0.5 * su2;
+    _Float16 s3[3];
+    const double rep = split3_f16(-a_x, s3);
+    const double dax = fabs(rep + a_x);
+    g40[4] = (_Float16)1.0f;
+    g40[5] = (_Float16)(1.0f / kAugScale);
+    g40[6] = (_Float16)(1.0f / kAugScale);
+    g40[7] = s3[0];
+    g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
+    const double un = sqrt(su2), dn = sqrt(sd2);
+    const double gb = 0.69314718056 * (dn * sp.v_max + (un + dn) * sp.dv_max + dax + sp.das_max +
+                                       3.814697265625e-06 * (un * sp.v_max + a_x + sp.as_max));
+    return (float)(gb * sp.scale);           // scale = 1.001: rounding of this expression and of the cast are far inside 0.1 %
 }
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
 // workgroups for C5).  Small requests use k_features below.
-template <bool SPLIT>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
-                                                  double upper, float neg_gamma2)
+                                                  double upper, float neg_gamma2, ScreenParams sp,
+                                                  const int *__restrict__ idx_list, int list_counter, int list_cap)
 {
-    const int n_evals = counters[CNT_EVALS];
-    const long n_pad = ((long)n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
+    const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
+    const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if ((long)blockIdx.x * 256 >= n_pad) return;
     __shared__ double s_tab[hafq::kTabDoubles];
     const hafq::PtrTabs tb = load_decimal_tables(s_tab);
     float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
-    char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * kHXTileBytes;
-    if (e >= n_evals) {                       // padding rows of the last 256-eval block: zeros
-        if (SPLIT) {
-            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int g = 0; g < 2 * kHSteps; g++) store_group_h(xtile, (int)(e & 31), g, z, z);
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
+    const int r = (int)(e & 31);
+    if (e >= n_evals) {                       // padding rows of the last block: zeros
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (MODE == XMODE_SPLIT) {
+            for (int g = 0; g < 2 * kHSteps; g++) store_group_h(xtile, r, g, z, z);
+        } else if (MODE == XMODE_SCREEN) {
+            for (int g = 0; g < 2 * kHSteps; g++) store_group_img(xtile, r, g, z);
         } else {
             for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
         }
@@ -383,9 +424,32 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         return;
     }
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    const unsigned w0 = window_origin(evalcell[e], d.H, d.W);
+    const unsigned w0 = window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W);
     double xx = 0.0;
-    if (SPLIT) {
+    if (MODE == XMODE_SCREEN) {
+        double sd2 = 0.0;
+        half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0}, g41;
+        for (int g = 0; g <= kAugS / 8; g++) {           // groups 0..40: attribute slots 0..327, of which 0..323 are attributes
+            half8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int f = g * 8 + q;
+                double xd = 0.0;
+                if (f < d.nf && f < kAugS) {
+                    const FeatDesc &F = fd[f];
+                    if (!F.skip) xd = attribute_value<true>(iir, w0, F, lower, upper, tb);
+                }
+                hi[q] = screen_operand(xd, sp.c, xx, sd2);
+            }
+            if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
+            else g40 = hi;
+        }
+        ax[e] = screen_finish(xx, sd2, sp, g40, g41);
+        store_group_img(xtile, r, 40, g40);
+        store_group_img(xtile, r, 41, g41);
+        return;
+    }
+    if (MODE == XMODE_SPLIT) {
         for (int g = 0; g < 2 * kHSteps; g++) {           // 42 groups of 8 attributes
             half8 hi, lo;
 #pragma unroll
@@ -403,7 +467,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
                 xx = fma((double)xe, (double)xe, xx);
             }
-            store_group_h(xtile, (int)(e & 31), g, hi, lo);
+            store_group_h(xtile, r, g, hi, lo);
         }
     } else {
         for (int f = 0; f < d.nf; f++) {
@@ -423,39 +487,48 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
 // loads, no divergence), a small request (a few thousand evals) still fills the chip, and a single evaluation is
 // never one long serial chain of 324 attributes.
 constexpr int kFeatEvals = 64;
-template <bool SPLIT>
+template <int MODE>
 __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
-                                                  double upper, float neg_gamma2)
+                                                  double upper, float neg_gamma2, ScreenParams sp,
+                                                  const int *__restrict__ idx_list, int list_counter, int list_cap)
 {
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     __shared__ double red[8][kFeatEvals];
-    const int n_evals = counters[CNT_EVALS];
-    const long n_pad = ((long)n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
+    __shared__ double red2[(MODE == XMODE_SCREEN) ? 8 : 1][kFeatEvals];
+    const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
+    const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
     __shared__ double s_tab[hafq::kTabDoubles];
     const hafq::PtrTabs tb = load_decimal_tables(s_tab);
     const int ev = threadIdx.x & 63, gl = threadIdx.x >> 6;
     const long e = (long)blockIdx.x * kFeatEvals + ev;
     const long tile = e >> 5;
+    const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
-    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * kHXTileBytes;
-    const int n_groups = SPLIT ? 2 * kHSteps : (kKP + 7) / 8;          // 42 / 41
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
+    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : 2 * kHSteps;          // 41 / 42
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    const unsigned w0 = live ? window_origin(evalcell[e], d.H, d.W) : 0u;
-    double xx = 0.0;
+    const unsigned w0 = live ? window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W) : 0u;
+    double xx = 0.0, sd2 = 0.0;
+    half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = gl; g < n_groups; g += 8) {
+        if (MODE == XMODE_SCREEN && g > kAugS / 8) break;              // group 41 holds norm slots only
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int f = g * 8 + q;
-            float xf = 0.0f;
-            if (live && f < d.nf) {
+            double xd = 0.0;
+            if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper, tb);
+                if (!F.skip) xd = attribute_value<true>(iir, w0, F, lower, upper, tb);
             }
-            if (SPLIT) {
+            const float xf = (float)xd;
+            if (MODE == XMODE_SCREEN) {
+                hi[q] = screen_operand(xd, sp.c, xx, sd2);
+            } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
                 hi[q] = h;
@@ -467,40 +540,67 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
                 xx = fma((double)xf, (double)xf, xx);
             }
         }
-        if (SPLIT) store_group_h(xtile, (int)(e & 31), g, hi, lo);
+        if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
+        if (MODE == XMODE_SCREEN) {
+            if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
+            else g40 = hi;                                             // wave 0 keeps group 40 until the norms are known
+        }
     }
     red[gl][ev] = xx;
+    if (MODE == XMODE_SCREEN) red2[gl][ev] = sd2;
     __syncthreads();
     if (gl == 0) {
-        double t = 0.0;
+        double t = 0.0, t2 = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; k++) t += red[k][ev];                  // fixed order: deterministic
-        ax[e] = neg_gamma2 * (float)t;                                 // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+        if (MODE == XMODE_SCREEN) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) t2 += red2[k][ev];
+            half8 g41;
+            float gb = 0.0f;
+            if (live) gb = screen_finish(t, t2, sp, g40, g41);
+            else g41 = g40;                                            // padding rows: all zero
+            ax[e] = gb;
+            store_group_img(xtile, r, 40, g40);
+            store_group_img(xtile, r, 41, g41);
+        } else {
+            ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+        }
     }
 }
 
-void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
-                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, bool split_f16, hipStream_t s)
+template <int MODE>
+static void launch_features_mode(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
+                                 Dims d, double lower, double upper, float neg_gamma2, long max_evals, ScreenParams sp,
+                                 const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s)
 {
-    if (max_evals <= 0) return;
-    if (max_evals >= (1L << 20)) {
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
+    if (large) {
         // enough evaluations to fill the chip with one thread each
-        long blocks = (max_evals + 255) / 256;
-        if (split_f16)
-            hipLaunchKernelGGL(k_features_serial<true>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                               lower, upper, neg_gamma2);
-        else
-            hipLaunchKernelGGL(k_features_serial<false>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                               lower, upper, neg_gamma2);
+        long blocks = (max_evals + kBlock - 1) / kBlock * (kBlock / 256);
+        hipLaunchKernelGGL(k_features_serial<MODE>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
         return;
     }
-    long blocks = ((max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals) * (kSvmBlockEvals / kFeatEvals);
-    if (split_f16)
-        hipLaunchKernelGGL(k_features<true>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
-                           upper, neg_gamma2);
+    long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
+    hipLaunchKernelGGL(k_features<MODE>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
+                       upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
+}
+
+void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
+                     Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
+                     const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s)
+{
+    if (max_evals <= 0) return;
+    if (xmode == XMODE_SCREEN)
+        launch_features_mode<XMODE_SCREEN>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
+                                           list_counter, list_cap, large, s);
+    else if (xmode == XMODE_SPLIT)
+        launch_features_mode<XMODE_SPLIT>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
+                                          list_counter, list_cap, large, s);
     else
-        hipLaunchKernelGGL(k_features<false>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
-                           upper, neg_gamma2);
+        launch_features_mode<XMODE_F32>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
+                                        list_counter, list_cap, large, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -584,12 +684,18 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
         }
         const float as_ = cur[kKP * kTile + (lane & 31)];           // -g2*|s_j|^2
         const float cf = cur[(kKP + 1) * kTile + (lane & 31)];      // coef_j (0 for padding SVs)
+        // HAZARD (measured on gfx950, two waves per SIMD; screen.hip has the details): a VALU instruction that reads a
+        // v_exp_f32 result within a few instructions of the v_exp_f32 can read the register before it is written.  All
+        // sixteen exps are issued first and pinned there; their consumers follow.
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            acc[r] = __builtin_amdgcn_exp2f(fmaf(p.two_gamma2, acc[r], axr[r] + as_));   // -g2*(|x|^2 + |s|^2 - 2 x.s)
+#pragma unroll
+        for (int r = 0; r < 16; r++) asm volatile("" : "+v"(acc[r]));
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            float arg = fmaf(p.two_gamma2, acc[r], axr[r] + as_);   // -g2*(|x|^2 + |s|^2 - 2 x.s)
-            float k = __builtin_amdgcn_exp2f(arg);
-            part[r] = fmaf(cf, k, part[r]);
-            pabs[r] = fmaf(fabsf(cf), k, pabs[r]);                  // sum |coef| K: scale of the rounding error
+            part[r] = fmaf(cf, acc[r], part[r]);
+            pabs[r] = fmaf(fabsf(cf), acc[r], pabs[r]);              // sum |coef| K: scale of the rounding error
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces of tile t+1 have landed
         __syncthreads();                                            // ... and everybody is done reading tile t
@@ -674,11 +780,13 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                                                               const int *__restrict__ counters, SvmParams p,
                                                               float *__restrict__ dec, int8_t *__restrict__ labels,
                                                               int *__restrict__ flag_list, int flag_cap,
-                                                              int *__restrict__ counters_rw, Dims d)
+                                                              int *__restrict__ counters_rw, Dims d,
+                                                              const int *__restrict__ idx_list, int list_counter, int list_cap)
 {
     // the ONLY LDS object: 3 SV tile images + per wave one row of a_x and one row of positive-group sums
     __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 2 * 8 * kTile * 4];
-    const int n_evals = counters[CNT_EVALS];
+    // list mode (behind the screening pass): slot j of X / ax holds evaluation idx_list[j]
+    const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kSvmBlockEvals;
     if (base >= n_evals) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -812,20 +920,32 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                 }
         }
         const float *tail = reinterpret_cast<const float *>(cur + 2 * kHMatBytes);
+        float cfn[2];
+        // HAZARD (measured on gfx950, two waves per SIMD; screen.hip has the details): a VALU instruction that reads a
+        // v_exp_f32 result within a few instructions of the v_exp_f32 can read the register before it is written.  All
+        // sixteen exps are issued first and pinned there; the coefficient fmas follow.
 #pragma unroll
         for (int n = 0; n < 2; n++) {
             const float as_ = tail[16 * n + (lane & 15)];            // -g2*|s_j|^2
-            const float cf = tail[kTile + 16 * n + (lane & 15)];     // coef_j (0 for padding SVs)
+            cfn[n] = tail[kTile + 16 * n + (lane & 15)];             // coef_j (0 for padding SVs)
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
-                    float arg = fmaf(p.two_gamma2, acc[m][n][r], axr[m][r] + as_);
-                    float k = __builtin_amdgcn_exp2f(arg);
-                    lo[m][r] = fmaf(cf, k, lo[m][r]);
-                }
+                for (int r = 0; r < 4; r++)                          // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
+                    acc[m][n][r] = __builtin_amdgcn_exp2f(fmaf(p.two_gamma2, acc[m][n][r], axr[m][r] + as_));
         }
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) asm volatile("" : "+v"(acc[m][n][r]));
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) lo[m][r] = fmaf(cfn[n], acc[m][n][r], lo[m][r]);
         if ((t & 7) == 7) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
@@ -861,8 +981,9 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 16 * m + 4 * (lane >> 4) + r;
-                const long e = tile32 * kTile + row;
-                if (e < n_evals) {
+                const long es = tile32 * kTile + row;
+                if (es < n_evals) {
+                    const int e = idx_list ? idx_list[es] : (int)es;
                     const float P = has_neg ? pos[row] : part[m][r];
                     const float N = has_neg ? part[m][r] : 0.0f;
                     const float dv = (P + N) - p.rho;
@@ -871,7 +992,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
                     if (!(fabsf(dv) > (p.guard_acc + p.guard_dot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
                         int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
-                        if (slot < flag_cap) flag_list[slot] = (int)e;
+                        if (slot < flag_cap) flag_list[slot] = e;
                     }
                 }
             }
@@ -880,12 +1001,12 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
 
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters, SvmParams p,
                   float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
-                  hipStream_t s)
+                  const int *idx_list, int list_counter, int list_cap, hipStream_t s)
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_svm_rbf_h, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
-                       evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d);
+                       evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,237 @@
+// screen.hip -- the screening pass (tier 0) of the RBF decision: k_svm_screen.  Its own translation unit because it is
+// built with -fno-slp-vectorize: hipcc's SLP pass packs pairs of the epilogue's fp32 FMAs into v_pk_fma_f32, which
+// cannot be placed one by one between the MFMAs (and measured wrong sums on gfx950 when fed straight from v_exp_f32).
+#include "kernels.h"
+
+namespace haf {
+
+#ifndef SCREEN_VARIANT
+#define SCREEN_VARIANT 0
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// a8, screening pass (tier 0): the same decision function as ONE fp16 MFMA pass.  Operands are pre-scaled by
+// c = sqrt(2*gamma*log2 e) and rounded to fp16 (u^ = fp16(c x), v^ = fp16(c s)); the norm terms -|u|^2/2 and -|v|^2/2
+// ride in spare K slots (kernels.h), so the 16x16 accumulator IS the exp2 argument and the epilogue is one v_exp_f32
+// and one fma per (evaluation, SV).  The result is only trusted outside a rigorous per-evaluation band
+//     |dec| > (guard_acc0 + g_e) * sum|coef|K + guard_abs,     g_e from k_features (screen_finish),
+// which is ~20x wider than the three-pass kernel's, so a few per cent of the evaluations go on to that kernel (in list
+// mode) and from there to the fp64 tiers as before: the labels stay those of libsvm, the bulk costs a third.
+//   * a wave keeps 64 evals x 336 slots in 168 VGPRs (twice the rows of the three-pass kernel: every B fragment read
+//     from LDS feeds 4 MFMAs), workgroup = 8 waves = 512 evals;
+//   * SV tiles (32 SVs, 22 KiB) stream through a 3-deep LDS ring by LDS-DMA exactly as in k_svm_rbf_h;
+//   * the exp/fma epilogue of a 16-SV column block is issued BETWEEN the MFMAs of the next block (two accumulator
+//     sets in ping-pong), so it overlaps the matrix pipe inside one wave instead of relying on the partner wave.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_sv_tile_s0(const char *__restrict__ gtile, unsigned lds_byte_off, int wave, unsigned lane16)
+{
+    // scalar base + one VGPR offset (lane*16): no per-piece vector address arithmetic, no address VGPRs kept alive
+#pragma unroll
+    for (int q = 0; q < 3; q++) {                                    // 22 pieces over 8 waves x 3: pieces 0 and 1 go twice
+        int p = wave + 8 * q;
+        if (p >= kS0Pieces) p -= kS0Pieces;
+        const uintptr_t ga = (uintptr_t)(gtile + p * 1024);          // readfirstlane returns int: widen as unsigned
+        const unsigned long long g = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) << 32);
+        const unsigned l = __builtin_amdgcn_readfirstlane(lds_byte_off + p * 1024);
+        // s_nop 4: an SGPR base fresh from v_readfirstlane needs 5 wait states before a vector-memory instruction reads it
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane16), "s"(g) : "memory", "m0");
+    }
+}
+
+// MFMAs of column block n (16 SVs) of the tile at `cur` into acc, with the epilogue of the PREVIOUS block (old, cf_old)
+// spread over the k-steps: behind the four MFMAs of step s come the two v_exp_f32 of element pair s-1 and the two fmas of
+// pair s-2.
+// HAZARD (measured on gfx950, two waves per SIMD): a VALU instruction that reads a v_exp_f32 result within ~4 instructions
+// of the v_exp_f32 -- an MFMA in between does not help -- can read the register BEFORE the transcendental unit has written
+// it (wrong sums on some waves of some launches; hipcc pads one wait state, which is not enough).  Every exp result
+// here is consumed one whole k-step (>= 4 MFMAs, >= 8 instructions) after it was issued.
+__device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], const half4 (&at)[4],
+                                             f32x4 (&acc)[4], const f32x4 (&old)[4], float cf_old, float (&sum)[4][4])
+{
+    const char *bl = cur + n * 1024 + lane * 16;
+    __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
+#pragma unroll
+    for (int m = 0; m < 4; m++) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    half8 b = *reinterpret_cast<const half8 *>(bl);                  // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
+    // The issue order of every k-step is pinned instruction by instruction (a scheduling barrier after each): B read of the
+    // next step, then MFMA | exp | MFMA | exp | MFMA | fma | MFMA | fma, where the exps belong to pair s-1 and the fmas to
+    // pair s-2.  hipcc's own scheduling (also with sched_group_barrier hints) pulls an fma right behind its exp.
+#define HAF_SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int s = 0; s < kHFull; s++) {
+        half8 bn = b;
+        if (s + 1 < kHFull) bn = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
+        HAF_SB();
+        const bool ex = s >= 1 && s < 9, fm = s >= 2;
+        const int e0 = 2 * (s - 1), e1 = e0 + 1, f0 = 2 * (s - 2), f1 = f0 + 1;
+        float q0 = 0.0f, q1 = 0.0f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, acc[0], 0, 0, 0);
+        HAF_SB();
+        if (ex) { q0 = __builtin_amdgcn_exp2f(old[e0 >> 2][e0 & 3]); HAF_SB(); }
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, acc[1], 0, 0, 0);
+        HAF_SB();
+        if (ex) { q1 = __builtin_amdgcn_exp2f(old[e1 >> 2][e1 & 3]); HAF_SB(); }
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, acc[2], 0, 0, 0);
+        HAF_SB();
+        if (fm) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, acc[3], 0, 0, 0);
+        HAF_SB();
+        if (fm) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
+        k0 = q0;
+        k1 = q1;
+        b = bn;
+    }
+#undef HAF_SB
+    const half4 bt = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
+#pragma unroll
+    for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(at[m], bt, acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
+}
+
+__global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
+                                                               const char *__restrict__ svt0,
+                                                               const int *__restrict__ evalcell,
+                                                               const int *__restrict__ counters, SvmParams p,
+                                                               float *__restrict__ dec, int8_t *__restrict__ labels,
+                                                               int *__restrict__ flag0_list, int flag0_cap,
+                                                               int *__restrict__ counters_rw, Dims d)
+{
+    // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
+    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 2 * 8 * kS0WaveEvals * 4];
+    const int n_evals = counters[CNT_EVALS];
+    const long base = (long)blockIdx.x * kS0BlockEvals;
+    if (base >= n_evals) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long tile32 = (base >> 5) + 2 * wave;                      // this wave's two 32-eval operand images
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    const int nt = d.n_sv_tiles;
+    float *pos = reinterpret_cast<float *>(lds + kS0Buffers * kS0SvTileBytes) + wave * kS0WaveEvals;
+    float *fin = pos + 8 * kS0WaveEvals;
+
+    const unsigned lane16 = (unsigned)lane * 16u;
+    stage_sv_tile_s0(svt0, lds0, wave, lane16);                                                      // tile 0
+    if (nt > 1) stage_sv_tile_s0(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, wave, lane16);   // tile 1
+
+    // A fragments: row block m = 0..3 (rows 16m..16m+15 of the wave's 64); lane holds A[16m + (lane&15)][32s + 8(lane>>4) + j]
+    half8 a[kHFull][4];
+    half4 at[4];                                                     // K tail: A[row][320 + 4(lane>>4) + j]
+    {
+        const char *xt = X0 + (size_t)tile32 * kHMatBytes;
+#pragma unroll
+        for (int s = 0; s < kHFull; s++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                a[s][m] = *reinterpret_cast<const half8 *>(xt + (m >> 1) * kHMatBytes + (s * 2 + (m & 1)) * 1024 + lane * 16);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            at[m] = *reinterpret_cast<const half4 *>(xt + (m >> 1) * kHMatBytes + kHTailOff + (m & 1) * 512 + lane * 8);
+    }
+    // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
+#pragma unroll
+    for (int s = 0; s < kHFull; s++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) asm volatile("" : "+v"(a[s][m]));
+#pragma unroll
+    for (int m = 0; m < 4; m++) asm volatile("" : "+v"(at[m]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tiles 0 and 1 (this wave's pieces) have landed
+    __syncthreads();
+
+    float sum[4][4];                                                 // rows 16m + 4(lane>>4) + r, this lane's columns
+    f32x4 acc0[4], acc1[4];
+    // Two sweeps: the tile images hold the non-negative coefficients first, so the first sweep yields
+    // P = sum_{coef>0} coef*K and the second N = sum_{coef<0} coef*K; dec = P + N - rho and the guard scale
+    // sum|coef|K = P - N come from the same registers.  The DMA ring runs on across the two sweeps.
+    for (int ph = 0; ph < 2; ph++) {
+        const int t_end = ph ? nt : d.sv_tile_neg;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            acc1[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; r++) sum[m][r] = 0.0f;
+        }
+        float cf_prev = 0.0f;                                        // the first deferred epilogue adds 0 * exp2(0)
+        for (int t = ph ? d.sv_tile_neg : 0; t < t_end; t++) {
+            const char *cur = lds + (t % kS0Buffers) * kS0SvTileBytes;
+            // always three DMA pieces per wave and tile, so the wait below is one constant: past the last tile the ring
+            // slot that nobody reads any more is refilled with tile (t+2) mod nt
+            const int tn = (t + 2) % nt;
+            stage_sv_tile_s0(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, wave, lane16);
+            const float *cft = reinterpret_cast<const float *>(cur + kHMatBytes);
+            const float cf0 = cft[lane & 15], cf1 = cft[16 + (lane & 15)];   // coef of this lane's column in either block
+            screen_block(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum);     // block 0 | epilogue of the previous tile's block 1
+            screen_block(cur, 1, lane, a, at, acc1, acc0, cf0, sum);         // block 1 | epilogue of block 0
+            cf_prev = cf1;
+            // tile t+1 must have landed before anyone reads it; the three pieces just issued may stay in flight
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");                          // no LDS read of the next tile may move above the barrier
+        }
+        // epilogue of the sweep's last block, then the sum over the 16 column lanes
+        float *dst = ph ? fin : pos;
+        // (all sixteen v_exp_f32 first, their consumers behind a scheduling barrier: see the hazard note at screen_block)
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc1[m][r] = __builtin_amdgcn_exp2f(acc1[m][r]);
+#pragma unroll
+        for (int m = 0; m < 4; m++)                                  // keeps hipcc from sinking each exp next to its use
+#pragma unroll
+            for (int r = 0; r < 4; r++) asm volatile("" : "+v"(acc1[m][r]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = fmaf(cf_prev, acc1[m][r], sum[m][r]);
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 1, 64);
+                if ((lane & 15) == 0) dst[16 * m + 4 * (lane >> 4) + r] = v;
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the refills past the last tile
+    __syncthreads();
+    // one evaluation per lane from here: coalesced stores, one list reservation per wave
+    const long e = base + wave * kS0WaveEvals + lane;
+    const bool live = e < n_evals;
+    const float P = pos[lane], N = fin[lane];
+    const float dv = (P + N) - p.rho;
+    const float sabs = P - N;                                       // sum |coef| K
+    bool flagged = false;
+    if (live) {
+        dec[e] = dv;
+        labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
+        flagged = !(fabsf(dv) > (p.guard_acc0 + gband[e]) * sabs + p.guard_abs);   // also catches NaN
+    }
+    const unsigned long long bal = __ballot(flagged);
+    if (bal) {
+        int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&counters_rw[CNT_FLAGGED0], __popcll(bal));
+        slot0 = __shfl(slot0, 0, 64);
+        if (flagged) {
+            const int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < flag0_cap) flag0_list[slot] = (int)e;
+        }
+    }
+}
+
+void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
+                       SvmParams p, float *dec, int8_t *labels, int *flag0_list, int flag0_cap, int *counters_rw, Dims d,
+                       long max_evals, hipStream_t s)
+{
+    long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)X0, gband, (const char *)svt0,
+                       evalcell, counters, p, dec, labels, flag0_list, flag0_cap, counters_rw, d);
+}
+
+
+
+}  // namespace haf

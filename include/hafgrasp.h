@@ -57,9 +57,12 @@ typedef struct haf_config {
 
 #define HAF_FLAG_KEEP_DEBUG 1u       /* keep per-roll intermediates for haf_debug_fetch()                 */
 #define HAF_FLAG_PROFILE    2u       /* record HIP events per stage (haf_get_stage_ms)                    */
-#define HAF_FLAG_FP32_MFMA  4u       /* RBF contraction as ONE fp32 MFMA pass instead of the default three fp16 MFMA passes
-                                        on the hi/lo halves of the same fp32 operands: same guard band, same labels,
-                                        about a third of the rate                                                  */
+#define HAF_FLAG_FP32_MFMA  4u       /* RBF contraction as ONE fp32 MFMA pass for every evaluation: same labels, slowest   */
+#define HAF_FLAG_SPLIT_F16  8u       /* three fp16 MFMA passes on the hi/lo halves of the fp32 operands for EVERY evaluation
+                                        (fp32-grade decision values everywhere).  Default (neither flag): a single-pass fp16
+                                        screening kernel decides every evaluation outside a rigorous guard band and only
+                                        the rest goes through the three-pass kernel and the fp64 tiers: same labels, same
+                                        grasps, about 2.5x the rate                                                       */
 
 /* GraspInput (reference msg/GraspInput.msg:3-15) minus the cloud and the frame id: the cloud is passed
  * separately, already in the base frame (server.cpp:316). */
@@ -146,14 +149,18 @@ int haf_set_stream(haf_engine *e, void *hip_stream);
 void *haf_get_stream(haf_engine *e);
 
 /* Stage timings of the last call in milliseconds (HAF_FLAG_PROFILE): HIP events on the engine's stream. */
-enum { HAF_ST_UPLOAD = 0, HAF_ST_BIN, HAF_ST_INTEGRAL, HAF_ST_MASK, HAF_ST_FEATURES, HAF_ST_SVM, HAF_ST_RECHECK,
-       HAF_ST_VOTE, HAF_ST_DOWNLOAD, HAF_ST_COUNT };
+enum { HAF_ST_UPLOAD = 0, HAF_ST_BIN, HAF_ST_INTEGRAL, HAF_ST_MASK, HAF_ST_FEATURES, HAF_ST_SVM, HAF_ST_REFINE,
+       HAF_ST_RECHECK, HAF_ST_VOTE, HAF_ST_DOWNLOAD, HAF_ST_COUNT };   /* REFINE: three-pass kernel on the screened-out rest */
 int haf_get_stage_ms(haf_engine *e, float *ms /* HAF_ST_COUNT */);
 
 /* Counters of the last scored batch: masked (cell, roll) pairs; how many fell inside the guard band of the fast
  * contraction and were re-evaluated by the fp64 MFMA tier; how many of those were still too close to zero and were
  * re-evaluated in libsvm's strict fp64 summation order. */
 int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked, int64_t *n_strict);
+
+/* The same with the screening tier of the default mode: evaluations the single-pass screening kernel could not decide
+ * (they went through the three-pass kernel; 0 in the other modes), then the fp64 MFMA tier, then the strict tier. */
+int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, int64_t *n_rechecked, int64_t *n_strict);
 
 /* Model facts for reporting: support vectors, attribute dimension, feature rows (incl. phantom rows). */
 int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_features);

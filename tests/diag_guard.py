@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Measures the fast (fp32 MFMA) decision error relative to S = sum|coef|K against the fp64 oracle, with the guard band
-disabled (HAF_GUARD_REL=0), to calibrate the band.  GPU box only."""
+"""Measures the decision error of a fast tier relative to S = sum|coef|K against the fp64 oracle, with its guard band
+disabled, to calibrate the band.  HAF_DIAG_MODE = screen (default: the single-pass fp16 screening kernel,
+HAF_GUARD0_REL=0), split (three-pass kernel) or f32 (fp32 MFMA kernel), both with HAF_GUARD_REL=0.  GPU box only."""
 import os
 import sys
 
 os.environ["HAF_GUARD_REL"] = "0"
+os.environ["HAF_GUARD0_REL"] = "0"
+MODE = os.environ.get("HAF_DIAG_MODE", "screen")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,7 +23,8 @@ F, R = os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_all
 
 def run(model, names, tag):
     o = O.Oracle(F, R, model)
-    eng = capi.Engine(F, R, model, flags=capi.FLAG_KEEP_DEBUG | (capi.FLAG_FP32_MFMA if os.environ.get('HAF_DIAG_F32') else 0), max_points=1 << 18)
+    eng = capi.Engine(F, R, model, flags=capi.FLAG_KEEP_DEBUG | {"screen": 0, "split": capi.FLAG_SPLIT_F16, "f32": capi.FLAG_FP32_MFMA}[MODE],
+                      max_points=1 << 18)
     worst, errs = 0.0, []
     for name in names:
         xyz = capi.load_pcd(os.path.join(DATA, name + ".pcd"))
