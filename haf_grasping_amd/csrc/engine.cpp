@@ -411,6 +411,57 @@ int build_tables(haf_engine *e)
             sp.das_max = std::max(sp.das_max, std::fabs(rep + a_s));
             sp.as_max = std::max(sp.as_max, a_s);
         }
+        // spectral norms of V^ and dV = V^ - V (n_sv x dim) for the sqrt(S) form of the band: sigma^2 = lambda_max(M'M),
+        // bounded from ABOVE by (trace (M'M)^(2^j))^(1/2^j), j = 7 (at most dim^(1/128) = 4.6 % above the true value)
+        {
+            const int D = m.dim;
+            auto sigma_upper = [&](bool delta) {
+                std::vector<double> G((size_t)D * D, 0.0), row((size_t)D);
+                for (int n = 0; n < m.n_sv; n++) {
+                    for (int k = 0; k < D; k++) {
+                        const double v = m.sv[(size_t)n * D + k] * sp.c;
+                        _Float16 h = (_Float16)(float)v;
+                        if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+                        row[(size_t)k] = delta ? (double)(float)h - v : (double)(float)h;
+                    }
+                    for (int k = 0; k < D; k++) {
+                        const double rk = row[(size_t)k];
+                        if (rk == 0.0) continue;
+                        double *g = G.data() + (size_t)k * D;
+                        for (int l = k; l < D; l++) g[l] += rk * row[(size_t)l];
+                    }
+                }
+                for (int k = 0; k < D; k++) for (int l = 0; l < k; l++) G[(size_t)k * D + l] = G[(size_t)l * D + k];
+                double log_scale = 0.0, pw = 1.0;
+                std::vector<double> T((size_t)D * D);
+                for (int it = 0; it < 7; it++) {
+                    double tr = 0.0;
+                    for (int k = 0; k < D; k++) tr += G[(size_t)k * D + k];
+                    if (!(tr > 0.0)) return 0.0;
+                    for (auto &x : G) x /= tr;
+                    log_scale += std::log(tr) / pw;
+                    std::fill(T.begin(), T.end(), 0.0);
+                    for (int i = 0; i < D; i++)
+                        for (int k = 0; k < D; k++) {
+                            const double a = G[(size_t)i * D + k];
+                            if (a == 0.0) continue;
+                            const double *gk = G.data() + (size_t)k * D;
+                            double *ti = T.data() + (size_t)i * D;
+                            for (int j = 0; j < D; j++) ti[j] += a * gk[j];
+                        }
+                    G.swap(T);
+                    pw *= 2.0;
+                }
+                double tr = 0.0;
+                for (int k = 0; k < D; k++) tr += G[(size_t)k * D + k];
+                return std::sqrt(std::exp(log_scale + std::log(tr) / pw)) * (1.0 + 1e-9);
+            };
+            sp.sigma_v = sigma_upper(false);
+            sp.sigma_dv = sigma_upper(true);
+            double cmax = 0.0;
+            for (int n = 0; n < m.n_sv; n++) cmax = std::max(cmax, std::fabs(m.coef[(size_t)n]));
+            sp.sqrt_cmax = std::sqrt(cmax) * (1.0 + 1e-12);
+        }
         // the bounds feed a rigorous band: round them up past their own fp64 rounding
         sp.v_max *= 1.0 + 1e-12; sp.dv_max *= 1.0 + 1e-12; sp.das_max = sp.das_max * (1.0 + 1e-12) + 1e-300;
         if (!(sp.v_max < 60000.0)) return fail(e, HAF_E_ARG, "support vectors too large for the fp16 screening pass; use HAF_FLAG_SPLIT_F16");
@@ -523,7 +574,7 @@ int alloc_buffers(haf_engine *e)
         const size_t slots = ((size_t)e->flag0_cap + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
         ok &= hipSuccess == e->d_X1.alloc(slots / kTile * (size_t)(kHXTileBytes / 4));
         ok &= hipSuccess == e->d_ax1.alloc(slots);
-        ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad);
+        ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad * kBandFloats);
         ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
     } else {
         ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * (size_t)std::max<int>(kTileFloats, kHXTileBytes / 4));

@@ -81,8 +81,14 @@ struct ScreenParams {
     double dv_max;                // max_n |v^_n - v_n|
     double das_max;               // max_n |split3(-a_s) - (-a_s)|
     double as_max;                // max_n |v_n|^2/2
+    double sigma_v;               // upper bound of the largest singular value of the N x D matrix of the v^_n
+    double sigma_dv;              // the same for the matrix of the v^_n - v_n
+    double sqrt_cmax;             // sqrt(max_n |coef_n|)
     double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
 };
+// per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
+//   |dec^ - dec| <= min(gA * sqrt(S), gC * S) + (guard_acc0 + gB) * S + guard_abs,   S = sum|coef|K   
+constexpr int kBandFloats = 4;
 
 struct CloudDev {
     const float *xyz;

@@ -370,12 +370,17 @@ __device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &
     return h;
 }
 
-// norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band, per unit of sum|coef|K:
-//   | u^.v^ - u.v | <= |u^-u| |v^| + |u| |v^-v|   (u^.v^ - u.v = (u^-u).v^ + u.(v^-v), Cauchy-Schwarz on each term)
-//   + what the fp16 splits of the two norm terms miss + the fp32 accumulation inside the matrix core
-//   (11 accumulating instructions, a few ulp of the largest partial sum each: 2^-18 of |u||v^| + a_x + a_s is generous),
-// times ln 2 (d exp2(t) = ln2 exp2(t) dt); DESIGN.md §2.
-__device__ __forceinline__ float screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41)
+// norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band.  With e_n the error of the
+// exp2 argument of SV n, dec^ - dec = sum_n c_n K_n (2^e_n - 1) = ln2 * sum_n c_n K_n e_n + second order, and
+//   e_n = (u^-u).v^_n + u.(v^_n - v_n) + [what the fp16 splits of the norm terms miss + fp32 accumulation in the matrix core].
+// The bilinear part sums to (u^-u).(V^' w) + u.(dV' w) with w_n = c_n K_n, so it is bounded TWICE:
+//   (a) per SV by Cauchy-Schwarz:   <= (|u^-u| max|v^_n| + |u| max|v^_n - v_n|) * S                          =: d_max * S
+//   (b) through the spectral norms: <= (|u^-u| sigma(V^) + |u| sigma(dV)) * |w|_2,  |w|_2^2 <= max|c_n| * S   (K_n <= 1)
+// (b) grows with sqrt(S) only and is ~7x tighter on a 4096-SV model; the kernel takes the smaller of the two.
+// Second order: |2^e - 1 - ln2 e| <= 0.6 (ln2 e)^2 for |e| <= d_max < 0.1.  The bracket is bounded per unit of S:
+// norm splits exactly (dax, das_max), matrix-core accumulation generously (11 accumulating instructions, a few ulp of the
+// largest partial sum each: 2^-18 of |u||v^| + a_x + a_s).  Output: {gA, gB, gC} of kernels.h, scaled by sp.scale.
+__device__ __forceinline__ void screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41, float *band)
 {
     const double a_x = 0.5 * su2;
     _Float16 s3[3];
@@ -387,9 +392,18 @@ __device__ __forceinline__ float screen_finish(double su2, double sd2, const Scr
     g40[7] = s3[0];
     g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
     const double un = sqrt(su2), dn = sqrt(sd2);
-    const double gb = 0.69314718056 * (dn * sp.v_max + (un + dn) * sp.dv_max + dax + sp.das_max +
-                                       3.814697265625e-06 * (un * sp.v_max + a_x + sp.as_max));
-    return (float)(gb * sp.scale);           // scale = 1.001: rounding of this expression and of the cast are far inside 0.1 %
+    const double ln2 = 0.69314718056;
+    const double d_max = dn * sp.v_max + (un + dn) * sp.dv_max;
+    const double gA = ln2 * (dn * sp.sigma_v + (un + dn) * sp.sigma_dv) * sp.sqrt_cmax;
+    const double gB = ln2 * (dax + sp.das_max + 3.814697265625e-06 * (un * sp.v_max + a_x + sp.as_max)) +
+                      0.6 * (ln2 * d_max) * (ln2 * d_max);
+    // the kernel measures S^ = sum|c_n| K^_n; the true S is at most S^ * 2^(max |e_n|)
+    const double e_max = d_max + dax + sp.das_max + 3.814697265625e-06 * (un * sp.v_max + a_x + sp.as_max);
+    band[0] = (float)(gA * sp.scale);        // scale = 1.001: the roundings of these expressions and of the casts are far inside 0.1 %
+    band[1] = (float)(gB * sp.scale);
+    band[2] = (float)(ln2 * d_max * sp.scale);
+    band[3] = (float)(exp2(e_max) * 1.000001);
+    if (!(e_max < 0.05)) band[1] = __builtin_inff();     // outside the range the second-order bound was derived for: never trusted
 }
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
@@ -420,7 +434,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         } else {
             for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
         }
-        ax[e] = 0.0f;
+        if (MODE == XMODE_SCREEN) *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        else ax[e] = 0.0f;
         return;
     }
     const rsrc_t iir = make_ii_rsrc(ii, d);
@@ -444,7 +459,9 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
             else g40 = hi;
         }
-        ax[e] = screen_finish(xx, sd2, sp, g40, g41);
+        float band[kBandFloats];
+        screen_finish(xx, sd2, sp, g40, g41, band);
+        *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
         store_group_img(xtile, r, 40, g40);
         store_group_img(xtile, r, 41, g41);
         return;
@@ -557,10 +574,10 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
 #pragma unroll
             for (int k = 0; k < 8; k++) t2 += red2[k][ev];
             half8 g41;
-            float gb = 0.0f;
-            if (live) gb = screen_finish(t, t2, sp, g40, g41);
+            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (live) screen_finish(t, t2, sp, g40, g41, band);
             else g41 = g40;                                            // padding rows: all zero
-            ax[e] = gb;
+            *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
             store_group_img(xtile, r, 40, g40);
             store_group_img(xtile, r, 41, g41);
         } else {
