@@ -822,9 +822,11 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
                               e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
             mark(e, HAF_ST_REFINE);
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
+            // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
+            // workgroups beyond the list's end exit at once)
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
-                            e->flag0_cap, large, s);
+                            e->flag0_cap, false, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap, s);
         } else if (mode == MODE_SPLIT) {

@@ -8,6 +8,11 @@ namespace haf {
 #ifndef SCREEN_VARIANT
 #define SCREEN_VARIANT 0
 #endif
+// SCREEN_ABL: timing experiments only (results are wrong): 1 = no v_exp_f32, 2 = no epilogue VALU at all,
+// 3 = no LDS-DMA inside the loop, 4 = no tile barrier, 5 = no B-fragment LDS reads inside the k loop, 6 = exps but no fmas
+#ifndef SCREEN_ABL
+#define SCREEN_ABL 0
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -26,20 +31,31 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 //   * the exp/fma epilogue of a 16-SV column block is issued BETWEEN the MFMAs of the next block (two accumulator
 //     sets in ping-pong), so it overlaps the matrix pipe inside one wave instead of relying on the partner wave.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_sv_tile_s0(const char *__restrict__ gtile, unsigned lds_byte_off, int wave, unsigned lane16)
+// One LDS-DMA piece (1 KiB): wave-uniform global base + lane*16, LDS destination M0 + lane*16.  Base and M0 must come out
+// of SALU arithmetic (kernel arguments, readfirstlane results computed long before): an SGPR fresh from v_readfirstlane
+// needs 5 wait states before a vector-memory instruction reads it, and nothing inside an asm string is padded.
+__device__ __forceinline__ void dma_piece(const char *gbase, unsigned lds_dst, unsigned lane16)
 {
-    // scalar base + one VGPR offset (lane*16): no per-piece vector address arithmetic, no address VGPRs kept alive
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(lane16), "s"(gbase) : "memory", "m0");
+}
+
+// the three pieces of one SV tile this wave stages (22 pieces over 8 waves x 3: pieces 0 and 1 go twice)
+struct TileDma {
+    const char *g[3];
+    unsigned l[3];
+};
+__device__ __forceinline__ TileDma tile_dma(const char *gtile, unsigned lds_slot, const int (&poff)[3])
+{
+    TileDma d;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {                                    // 22 pieces over 8 waves x 3: pieces 0 and 1 go twice
-        int p = wave + 8 * q;
-        if (p >= kS0Pieces) p -= kS0Pieces;
-        const uintptr_t ga = (uintptr_t)(gtile + p * 1024);          // readfirstlane returns int: widen as unsigned
-        const unsigned long long g = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga) |
-                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) << 32);
-        const unsigned l = __builtin_amdgcn_readfirstlane(lds_byte_off + p * 1024);
-        // s_nop 4: an SGPR base fresh from v_readfirstlane needs 5 wait states before a vector-memory instruction reads it
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane16), "s"(g) : "memory", "m0");
-    }
+    for (int q = 0; q < 3; q++) { d.g[q] = gtile + poff[q]; d.l[q] = lds_slot + (unsigned)poff[q]; }
+    return d;
+}
+__device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane16)
+{
+    asm volatile("s_nop 4");                                         // prologue only: the bases may be fresh from v_readfirstlane
+#pragma unroll
+    for (int q = 0; q < 3; q++) dma_piece(d.g[q], d.l[q], lane16);
 }
 
 // MFMAs of column block n (16 SVs) of the tile at `cur` into acc, with the epilogue of the PREVIOUS block (old, cf_old)
@@ -49,15 +65,20 @@ __device__ __forceinline__ void stage_sv_tile_s0(const char *__restrict__ gtile,
 // of the v_exp_f32 -- an MFMA in between does not help -- can read the register BEFORE the transcendental unit has written
 // it (wrong sums on some waves of some launches; hipcc pads one wait state, which is not enough).  Every exp result
 // here is consumed one whole k-step (>= 4 MFMAs, >= 8 instructions) after it was issued.
+// DMA = true: the wave's three LDS-DMA pieces of the tile two ahead are issued behind the first three MFMAs of k-step 0
+// (which carries no epilogue work).  The two waves of a SIMD do this in different column blocks, so the ~60 issue cycles
+// of a piece always sit beside the partner's MFMAs instead of every wave paying them together behind the tile barrier.
+template <bool DMA>
 __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], const half4 (&at)[4],
-                                             f32x4 (&acc)[4], const f32x4 (&old)[4], float cf_old, float (&sum)[4][4])
+                                             f32x4 (&acc)[4], const f32x4 (&old)[4], float cf_old, float (&sum)[4][4],
+                                             const TileDma &dma, unsigned lane16)
 {
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
 #pragma unroll
     for (int m = 0; m < 4; m++) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     half8 b = *reinterpret_cast<const half8 *>(bl);                  // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    half8 b1 = *reinterpret_cast<const half8 *>(bl + 2048);          // fragments are read two k-steps ahead of their MFMAs
     float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
     // The issue order of every k-step is pinned instruction by instruction (a scheduling barrier after each): B read of the
     // next step, then MFMA | exp | MFMA | exp | MFMA | fma | MFMA | fma, where the exps belong to pair s-1 and the fmas to
@@ -65,27 +86,51 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
 #define HAF_SB() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int s = 0; s < kHFull; s++) {
-        half8 bn = b;
-        if (s + 1 < kHFull) bn = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
+        half8 b2 = b1;
+        if (s + 2 < kHFull && SCREEN_ABL != 5) b2 = *reinterpret_cast<const half8 *>(bl + (s + 2) * 2048);
         HAF_SB();
         const bool ex = s >= 1 && s < 9, fm = s >= 2;
         const int e0 = 2 * (s - 1), e1 = e0 + 1, f0 = 2 * (s - 2), f1 = f0 + 1;
         float q0 = 0.0f, q1 = 0.0f;
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, acc[0], 0, 0, 0);
         HAF_SB();
+        if (DMA && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[0], dma.l[0], lane16); HAF_SB(); }
+#if SCREEN_ABL == 1
+        if (ex) { q0 = old[e0 >> 2][e0 & 3] + 1.0f; HAF_SB(); }
+#elif SCREEN_ABL == 2
+        if (ex) { asm volatile("" ::"v"(old[e0 >> 2][e0 & 3])); HAF_SB(); }
+#else
         if (ex) { q0 = __builtin_amdgcn_exp2f(old[e0 >> 2][e0 & 3]); HAF_SB(); }
+#endif
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, acc[1], 0, 0, 0);
         HAF_SB();
+        if (DMA && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[1], dma.l[1], lane16); HAF_SB(); }
+#if SCREEN_ABL == 1
+        if (ex) { q1 = old[e1 >> 2][e1 & 3] + 1.0f; HAF_SB(); }
+#elif SCREEN_ABL == 2
+        if (ex) { asm volatile("" ::"v"(old[e1 >> 2][e1 & 3])); HAF_SB(); }
+#else
         if (ex) { q1 = __builtin_amdgcn_exp2f(old[e1 >> 2][e1 & 3]); HAF_SB(); }
+#endif
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, acc[2], 0, 0, 0);
         HAF_SB();
+        if (DMA && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[2], dma.l[2], lane16); HAF_SB(); }
+#if SCREEN_ABL != 2 && SCREEN_ABL != 6
         if (fm) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
+#elif SCREEN_ABL == 6
+        if (fm) { asm volatile("" ::"v"(k0)); HAF_SB(); }
+#endif
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, acc[3], 0, 0, 0);
         HAF_SB();
+#if SCREEN_ABL != 2 && SCREEN_ABL != 6
         if (fm) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
+#elif SCREEN_ABL == 6
+        if (fm) { asm volatile("" ::"v"(k1)); HAF_SB(); }
+#endif
         k0 = q0;
         k1 = q1;
-        b = bn;
+        b = b1;
+        b1 = b2;
     }
 #undef HAF_SB
     const half4 bt = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
@@ -115,8 +160,16 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
     float *fin = pos + 8 * kS0WaveEvals;
 
     const unsigned lane16 = (unsigned)lane * 16u;
-    stage_sv_tile_s0(svt0, lds0, wave, lane16);                                                      // tile 0
-    if (nt > 1) stage_sv_tile_s0(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, wave, lane16);   // tile 1
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int poff[3];                                                     // byte offsets of this wave's three pieces inside a tile
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        int pq = wave_u + 8 * q;
+        if (pq >= kS0Pieces) pq -= kS0Pieces;
+        poff[q] = pq * 1024;
+    }
+    stage_sv_tile_s0(tile_dma(svt0, lds0, poff), lane16);                                                      // tile 0
+    if (nt > 1) stage_sv_tile_s0(tile_dma(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, poff), lane16);   // tile 1
 
     // A fragments: row block m = 0..3 (rows 16m..16m+15 of the wave's 64); lane holds A[16m + (lane&15)][32s + 8(lane>>4) + j]
     half8 a[kHFull][4];
@@ -161,15 +214,28 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
             // always three DMA pieces per wave and tile, so the wait below is one constant: past the last tile the ring
             // slot that nobody reads any more is refilled with tile (t+2) mod nt
             const int tn = (t + 2) % nt;
-            stage_sv_tile_s0(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, wave, lane16);
+            const TileDma dma = tile_dma(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, poff);
             const float *cft = reinterpret_cast<const float *>(cur + kHMatBytes);
             const float cf0 = cft[lane & 15], cf1 = cft[16 + (lane & 15)];   // coef of this lane's column in either block
-            screen_block(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum);     // block 0 | epilogue of the previous tile's block 1
-            screen_block(cur, 1, lane, a, at, acc1, acc0, cf0, sum);         // block 1 | epilogue of block 0
+            // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0; waves 0-3 stage the next
+            // tile inside block 0, their SIMD partners (waves 4-7) inside block 1
+            if (wave_u < 4) {
+                screen_block<true>(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum, dma, lane16);
+                screen_block<false>(cur, 1, lane, a, at, acc1, acc0, cf0, sum, dma, lane16);
+            } else {
+                screen_block<false>(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum, dma, lane16);
+                screen_block<true>(cur, 1, lane, a, at, acc1, acc0, cf0, sum, dma, lane16);
+            }
             cf_prev = cf1;
             // tile t+1 must have landed before anyone reads it; the three pieces just issued may stay in flight
+#if SCREEN_ABL == 3
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
+#if SCREEN_ABL != 4
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");                          // no LDS read of the next tile may move above the barrier
         }
         // epilogue of the sweep's last block, then the sum over the 16 column lanes

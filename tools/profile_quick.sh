@@ -1,0 +1,21 @@
+# quick per-kernel profile of the default bench workload (GPU box): kernel trace + SQ counters of the dominant kernel
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/quick
+rm -rf $O; mkdir -p $O
+B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/kt.log 2>&1
+B1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-f32-side"
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_ANY --output-format csv -d $O/sq -- python3 $B1 > $O/sq.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/sq2 -- python3 $B1 > $O/sq2.log 2>&1
+find $O -name "*kernel_stats.csv" | head -1 | xargs cat | cut -d, -f1-8 | head -20
+python3 - <<'PY'
+import csv,glob,collections
+for d in ("sq","sq2"):
+    for f in glob.glob("/root/repo/gpurun_out/quick/%s/**/*counter_collection.csv"%d, recursive=True):
+        acc=collections.defaultdict(float)
+        for r in csv.DictReader(open(f)):
+            if "k_svm_screen" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]]+=float(r["Counter_Value"])
+        print(d, dict(acc))
+PY
