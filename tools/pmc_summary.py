@@ -2,7 +2,7 @@
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_traffic.json.
 
     python tools/pmc_summary.py --fetch A_counter_collection.csv --write B_counter_collection.csv \
-        [--fetch-f32 C.csv --write-f32 D.csv] --grid 512 --rolls 36 --nsv 4096 -o profiles/pmc_traffic.json
+        [--fetch-f32 C.csv --write-f32 D.csv] [--fetch-f16x3 E.csv --write-f16x3 F.csv] --grid 512 --rolls 36 --nsv 4096 -o profiles/pmc_traffic.json
 
 Per kernel the value is the AVERAGE over that kernel's launches in the pass (KiB, as the counter reports it).
 hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts wide coalesced reads at half their size
@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--write", required=True)
     ap.add_argument("--fetch-f32")
     ap.add_argument("--write-f32")
+    ap.add_argument("--fetch-f16x3")
+    ap.add_argument("--write-f16x3")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rolls", type=int, default=36)
     ap.add_argument("--nsv", type=int, default=4096)
@@ -62,7 +64,9 @@ def main():
     kernels = {}
     if a.fetch_f32 and a.write_f32:
         kernels.update(fold(a.fetch_f32, a.write_f32, "f32 mode"))
-    kernels.update(fold(a.fetch, a.write, "f16x3 mode"))
+    if a.fetch_f16x3 and a.write_f16x3:
+        kernels.update(fold(a.fetch_f16x3, a.write_f16x3, "f16x3 mode"))
+    kernels.update(fold(a.fetch, a.write, "default (screened) mode"))
     doc = {
         "workload": {"grid": a.grid, "rolls": a.rolls, "n_sv": a.nsv},
         "note": "FETCH_SIZE/WRITE_SIZE in KiB per launch (average over the pass) from separate rocprofv3 --pmc passes; "

@@ -1,17 +1,22 @@
+# Reproduces profiles/ for one round on the GPU box: bash tools/profile_round.sh   (about 4 GPU-minutes)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final
 rm -rf $O; mkdir -p $O
-timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 700 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/kt.log 2>&1
 B1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-f32-side"
+# default (screened) mode: kernel trace + PMC passes (counters in their own runs)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/kt.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $B1 > $O/fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $B1 > $O/write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_ANY --output-format csv -d $O/sq -- python3 $B1 > $O/sq.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/lds -- python3 $B1 > $O/lds.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt32 -- python3 $B --precision f32 > $O/kt32.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch32 -- python3 $B1 --precision f32 > $O/fetch32.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write32 -- python3 $B1 --precision f32 > $O/write32.log 2>&1
+# the other two contraction modes: kernel trace + traffic
+for M in f16x3 f32; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$M -- python3 $B --precision $M > $O/kt_$M.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$M -- python3 $B1 --precision $M > $O/fetch_$M.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$M -- python3 $B1 --precision $M > $O/write_$M.log 2>&1
+done
 find $O -name "*.csv" | xargs ls -la | awk '{print $5, $9}'
-cat $O/bench_default.json | cut -c1-600
+cut -c1-600 $O/bench_default.json
