@@ -267,6 +267,47 @@ int label_grid_value(int label)
     return atoi(buf);
 }
 
+// Upper bound of the largest singular value of the n x d matrix M (row-major): sigma^2 = lambda_max(M'M) <=
+// (trace (M'M)^(2^j))^(1/2^j) with j = 7 squarings, i.e. at most d^(1/128) (4.6 % for d = 324) above the true value.  Each
+// squaring is normalised by its trace; the fp64 roundings of the products (~1e-13 relative) are covered by the final 1e-9.
+double sigma_upper_bound(const double *M, int n, int d)
+{
+    std::vector<double> G((size_t)d * d, 0.0), T((size_t)d * d);
+    for (int r = 0; r < n; r++) {
+        const double *row = M + (size_t)r * d;
+        for (int k = 0; k < d; k++) {
+            const double rk = row[k];
+            if (rk == 0.0) continue;
+            double *g = G.data() + (size_t)k * d;
+            for (int l = k; l < d; l++) g[l] += rk * row[l];
+        }
+    }
+    for (int k = 0; k < d; k++) for (int l = 0; l < k; l++) G[(size_t)k * d + l] = G[(size_t)l * d + k];
+    double log_scale = 0.0, pw = 1.0;
+    for (int it = 0; it < 7; it++) {
+        double tr = 0.0;
+        for (int k = 0; k < d; k++) tr += G[(size_t)k * d + k];
+        if (!(tr > 0.0)) return 0.0;
+        for (auto &x : G) x /= tr;
+        log_scale += std::log(tr) / pw;
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int i = 0; i < d; i++)
+            for (int k = 0; k < d; k++) {
+                const double a = G[(size_t)i * d + k];
+                if (a == 0.0) continue;
+                const double *gk = G.data() + (size_t)k * d;
+                double *ti = T.data() + (size_t)i * d;
+                for (int j = 0; j < d; j++) ti[j] += a * gk[j];
+            }
+        G.swap(T);
+        pw *= 2.0;
+    }
+    double tr = 0.0;
+    for (int k = 0; k < d; k++) tr += G[(size_t)k * d + k];
+    if (!(tr > 0.0)) return 0.0;
+    return std::sqrt(std::exp(log_scale + std::log(tr) / pw)) * (1.0 + 1e-9);
+}
+
 int build_tables(haf_engine *e)
 {
     const haf_config &c = e->cfg;
@@ -416,45 +457,15 @@ int build_tables(haf_engine *e)
         {
             const int D = m.dim;
             auto sigma_upper = [&](bool delta) {
-                std::vector<double> G((size_t)D * D, 0.0), row((size_t)D);
-                for (int n = 0; n < m.n_sv; n++) {
+                std::vector<double> M((size_t)m.n_sv * D);
+                for (int n = 0; n < m.n_sv; n++)
                     for (int k = 0; k < D; k++) {
                         const double v = m.sv[(size_t)n * D + k] * sp.c;
                         _Float16 h = (_Float16)(float)v;
                         if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
-                        row[(size_t)k] = delta ? (double)(float)h - v : (double)(float)h;
+                        M[(size_t)n * D + k] = delta ? (double)(float)h - v : (double)(float)h;
                     }
-                    for (int k = 0; k < D; k++) {
-                        const double rk = row[(size_t)k];
-                        if (rk == 0.0) continue;
-                        double *g = G.data() + (size_t)k * D;
-                        for (int l = k; l < D; l++) g[l] += rk * row[(size_t)l];
-                    }
-                }
-                for (int k = 0; k < D; k++) for (int l = 0; l < k; l++) G[(size_t)k * D + l] = G[(size_t)l * D + k];
-                double log_scale = 0.0, pw = 1.0;
-                std::vector<double> T((size_t)D * D);
-                for (int it = 0; it < 7; it++) {
-                    double tr = 0.0;
-                    for (int k = 0; k < D; k++) tr += G[(size_t)k * D + k];
-                    if (!(tr > 0.0)) return 0.0;
-                    for (auto &x : G) x /= tr;
-                    log_scale += std::log(tr) / pw;
-                    std::fill(T.begin(), T.end(), 0.0);
-                    for (int i = 0; i < D; i++)
-                        for (int k = 0; k < D; k++) {
-                            const double a = G[(size_t)i * D + k];
-                            if (a == 0.0) continue;
-                            const double *gk = G.data() + (size_t)k * D;
-                            double *ti = T.data() + (size_t)i * D;
-                            for (int j = 0; j < D; j++) ti[j] += a * gk[j];
-                        }
-                    G.swap(T);
-                    pw *= 2.0;
-                }
-                double tr = 0.0;
-                for (int k = 0; k < D; k++) tr += G[(size_t)k * D + k];
-                return std::sqrt(std::exp(log_scale + std::log(tr) / pw)) * (1.0 + 1e-9);
+                return sigma_upper_bound(M.data(), m.n_sv, D);
             };
             sp.sigma_v = sigma_upper(false);
             sp.sigma_dv = sigma_upper(true);
@@ -1167,6 +1178,16 @@ double haf_test_scale_host(double q4, double fmin, double fmax, double lower, do
 {
     const double range = fmax - fmin;
     return hafq::scale_q6(q4, fmin, fmax, range, 1.0 / range, lower, upper);
+}
+
+// host-side pieces of the screening band (tests/test_host_cpu.py)
+double haf_test_sigma_upper(const double *M, int n, int d) { return sigma_upper_bound(M, n, d); }
+double haf_test_split3(double a, float *parts)
+{
+    _Float16 h[3];
+    const double rep = split3_f16(a, h);
+    for (int i = 0; i < 3; i++) parts[i] = (float)h[i];
+    return rep;
 }
 
 int haf_test_decq_device(const double *in, double *out, int n, int digits)

@@ -295,3 +295,29 @@ def test_create_reports_file_errors_before_touching_a_device(data_dir, golden_di
     with pytest.raises(capi.HafError) as ei:
         capi.Engine(f, r, m, grid_h=56, grid_w=64)
     assert ei.value.code == capi.HAF_E_ARG and "square" in str(ei.value)
+
+
+def test_screening_band_host_pieces():
+    """Host arithmetic behind the screening pass's guard band: the spectral-norm bound is an UPPER bound of
+    numpy's largest singular value and at most d^(1/128) above it; the three-term fp16 split reports exactly what its three
+    products add up to and misses at most 2^-25 + 2^-33 |a|."""
+    L = capi.lib()
+    rng = np.random.RandomState(5)
+    for n, d, kind in ((300, 40, "uniform"), (64, 324, "uniform"), (500, 324, "lowrank"), (10, 7, "zero")):
+        if kind == "uniform":
+            M = rng.uniform(-1, 1, size=(n, d))
+        elif kind == "lowrank":
+            M = np.outer(rng.uniform(-1, 1, n), rng.uniform(-1, 1, d)) + 1e-3 * rng.standard_normal((n, d))
+        else:
+            M = np.zeros((n, d))
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        got = L.haf_test_sigma_upper(M.ctypes.data, n, d)
+        want = np.linalg.svd(M, compute_uv=False)[0] if kind != "zero" else 0.0
+        assert want <= got <= want * d ** (1.0 / 128.0) * (1 + 1e-6) + 1e-300, (kind, got, want)
+    parts = np.zeros(3, np.float32)
+    for a in list(-rng.uniform(0, 40, 200)) + [0.0, -1e-9, -0.5, -1.0, -65000.0, 3.25]:
+        rep = L.haf_test_split3(float(a), parts.ctypes.data)
+        assert rep == float(parts[0]) + (float(parts[1]) + float(parts[2])) / 4096.0
+        assert abs(rep - a) <= 2.0 ** -25 + 2.0 ** -33 * abs(a), (a, rep)
+        for v in parts:                                     # every part is an fp16 value, none of them subnormal
+            assert float(np.float16(v)) == float(v) and (v == 0 or abs(v) >= 2.0 ** -14)
