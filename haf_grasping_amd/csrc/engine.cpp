@@ -212,6 +212,8 @@ struct haf_engine {
     DevBuf<char> d_svt0;             // screening-pass SV tile images
     DevBuf<float> d_X1, d_ax1, d_gband;   // three-pass operand images / a_x of the screened-out rest; per-evaluation guard band
     DevBuf<int> d_flag0_list;
+    DevBuf<unsigned long long> d_flag0_words;   // one bit per evaluation: undecided by the screening pass
+    DevBuf<int> d_flag0_wgcount;                // popcounts per 256 words, for the ordered compaction
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64;
     DevBuf<short> d_ev16;
@@ -587,6 +589,8 @@ int alloc_buffers(haf_engine *e)
         ok &= hipSuccess == e->d_ax1.alloc(slots);
         ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad * kBandFloats);
         ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
+        ok &= hipSuccess == e->d_flag0_words.alloc((size_t)e->max_evals_pad / 64);
+        ok &= hipSuccess == e->d_flag0_wgcount.alloc((size_t)e->max_evals_pad / 64 / 256 + 1);
     } else {
         ok &= hipSuccess == e->d_X.alloc((size_t)(e->max_evals_pad / kTile) * (size_t)std::max<int>(kTileFloats, kHXTileBytes / 4));
     }
@@ -659,7 +663,7 @@ void haf_destroy(haf_engine *e)
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
-    e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release();
+    e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -830,7 +834,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
                             e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, s);
             mark(e, HAF_ST_SVM);
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                              e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
+                              e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
             mark(e, HAF_ST_REFINE);
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose

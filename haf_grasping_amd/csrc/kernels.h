@@ -169,8 +169,8 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
                      const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s);
 void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
-                       SvmParams p, float *dec, int8_t *labels, int *flag0_list, int flag0_cap, int *counters_rw, Dims d,
-                       long max_evals, hipStream_t s);
+                       SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s);
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);

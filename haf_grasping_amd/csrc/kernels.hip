@@ -520,7 +520,10 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
     __shared__ double s_tab[hafq::kTabDoubles];
     const hafq::PtrTabs tb = load_decimal_tables(s_tab);
     const int ev = threadIdx.x & 63, gl = threadIdx.x >> 6;
-    const long e = (long)blockIdx.x * kFeatEvals + ev;
+    // grid-stride over blocks of 64 evaluations: a list launch is sized for a few thousand workgroups, not for the list's
+    // capacity (tens of thousands of workgroups that would only find out that there is nothing for them)
+    for (long blk = blockIdx.x; blk * kFeatEvals < n_pad; blk += gridDim.x) {
+    const long e = blk * kFeatEvals + ev;
     const long tile = e >> 5;
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
@@ -584,6 +587,8 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
     }
+    __syncthreads();                                                   // red / red2 are reused by the next block
+    }
 }
 
 template <int MODE>
@@ -600,6 +605,7 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
         return;
     }
     long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
+    if (idx_list && blocks > 4096) blocks = 4096;                      // grid-stride inside the kernel
     hipLaunchKernelGGL(k_features<MODE>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
                        upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
 }

@@ -144,8 +144,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
                                                                const int *__restrict__ evalcell,
                                                                const int *__restrict__ counters, SvmParams p,
                                                                float *__restrict__ dec, int8_t *__restrict__ labels,
-                                                               int *__restrict__ flag0_list, int flag0_cap,
-                                                               int *__restrict__ counters_rw, Dims d)
+                                                               unsigned long long *__restrict__ flag0_words, Dims d)
 {
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
     __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 2 * 8 * kS0WaveEvals * 4];
@@ -280,28 +279,106 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
         const float lin = fminf(g.x * sqrtf(s1), g.z * s1);
         flagged = !(fabsf(dv) > lin + (p.guard_acc0 + g.y) * s1 + p.guard_abs);   // also catches NaN
     }
+    // one 64-bit word per wave (64 consecutive evaluations): k_screen_compact turns the words into the ORDERED list of
+    // undecided evaluations -- neighbours in the list are neighbours on the grid, so the feature kernel that follows reads
+    // overlapping windows, and the list (hence every later tile) is the same from run to run
     const unsigned long long bal = __ballot(flagged);
-    if (bal) {
-        int slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(&counters_rw[CNT_FLAGGED0], __popcll(bal));
-        slot0 = __shfl(slot0, 0, 64);
-        if (flagged) {
-            const int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
-            if (slot < flag0_cap) flag0_list[slot] = (int)e;
+    if (lane == 0) flag0_words[(base >> 6) + wave] = bal;
+}
+
+// Ordered compaction of the screening pass's flag words in two small launches: k_screen_count sums the popcounts of
+// 256 words per workgroup; k_screen_compact gives every word its slot (sum of the preceding workgroups' counts + a
+// workgroup scan) and writes the set bits in ascending order.  counters[CNT_FLAGGED0] receives the total, which may exceed
+// the list's capacity (the host then falls back to the three-pass kernel for everything).
+constexpr int kCompactWords = 256;
+
+__device__ __forceinline__ int screen_words(const int *counters)
+{
+    return (counters[CNT_EVALS] + kS0BlockEvals - 1) / kS0BlockEvals * (kS0BlockEvals / 64);
+}
+
+__global__ __launch_bounds__(kCompactWords) void k_screen_count(const unsigned long long *__restrict__ words,
+                                                                int *__restrict__ wgcount, const int *__restrict__ counters)
+{
+    __shared__ int red[kCompactWords / 64];
+    const int n_words = screen_words(counters);
+    const int w = blockIdx.x * kCompactWords + threadIdx.x;
+    int c = (w < n_words) ? __popcll(words[w]) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) wgcount[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned long long *__restrict__ words,
+                                                                  const int *__restrict__ wgcount, int n_wg,
+                                                                  int *__restrict__ list, int cap, int *__restrict__ counters)
+{
+    __shared__ int part[kCompactWords];
+    __shared__ int s_base;
+    const int n_words = screen_words(counters);
+    const int t = threadIdx.x;
+    // slots taken by the preceding workgroups (the last workgroup also publishes the total)
+    int before = 0;
+    const int upto = (blockIdx.x == gridDim.x - 1) ? n_wg : blockIdx.x;
+    int total = 0;
+    for (int j = t; j < upto; j += kCompactWords) {
+        const int c = wgcount[j];
+        total += c;
+        if (j < (int)blockIdx.x) before += c;
+    }
+    part[t] = before;
+    __syncthreads();
+    for (int o = kCompactWords / 2; o > 0; o >>= 1) {
+        if (t < o) part[t] += part[t + o];
+        __syncthreads();
+    }
+    if (t == 0) s_base = part[0];
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1) {
+        part[t] = total;
+        __syncthreads();
+        for (int o = kCompactWords / 2; o > 0; o >>= 1) {
+            if (t < o) part[t] += part[t + o];
+            __syncthreads();
         }
+        if (t == 0) counters[CNT_FLAGGED0] = part[0];
+        __syncthreads();
+    }
+    const int w = blockIdx.x * kCompactWords + t;
+    unsigned long long m = (w < n_words) ? words[w] : 0ull;
+    const int cnt = __popcll(m);
+    part[t] = cnt;
+    __syncthreads();
+    for (int o = 1; o < kCompactWords; o <<= 1) {
+        int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int slot = s_base + part[t] - cnt;
+    while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (slot < cap) list[slot] = w * 64 + b;
+        slot++;
     }
 }
 
 void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
-                       SvmParams p, float *dec, int8_t *labels, int *flag0_list, int flag0_cap, int *counters_rw, Dims d,
-                       long max_evals, hipStream_t s)
+                       SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)X0, gband, (const char *)svt0,
-                       evalcell, counters, p, dec, labels, flag0_list, flag0_cap, counters_rw, d);
+                       evalcell, counters, p, dec, labels, flag0_words, d);
+    // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
+    const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters);
+    hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
+                       counters_rw);
 }
-
-
 
 }  // namespace haf
