@@ -87,7 +87,8 @@ struct ScreenParams {
     double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
 };
 // per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
-//   |dec^ - dec| <= min(gA * sqrt(S), gC * S) + (guard_acc0 + gB) * S + guard_abs,   S = sum|coef|K   
+//   |dec^ - dec| <= min(gA * sqrt(S), gC * S) + (guard_acc0 + gB) * S + cm * (|dec^| + |rho|) + guard_abs,  S = sum|coef|K
+// with {gA, gB, gC, cm} per evaluation
 constexpr int kBandFloats = 4;
 
 struct CloudDev {

@@ -311,6 +311,22 @@ __device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper, tb);
 }
 
+// Attribute value for the SCREENING pass only: the "%.4g" round trip exactly, svm-scale's formula in plain fp64, and NO
+// "%g" round trip.  The value svm-predict would parse, x, differs from the result x' by at most 5e-6 |x'| + 1e-12 (six
+// significant decimal digits: half a unit of the sixth digit is <= 5e-6 relative; the fp64 roundings of the formula, the
+// exact-zero omission and the min/max shortcuts are inside the 1e-12).  screen_finish() carries that difference through
+// the guard band; evaluations the screening pass cannot decide get the exact attributes in the three-pass tier.
+constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6);
+constexpr double kScreenEtaAbs = 1e-12;
+template <bool UNI, class Tabs>
+__device__ __forceinline__ double attribute_value_screen(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper,
+                                                         const Tabs &tb)
+{
+    const float v = feature_value<UNI>(ii, w0b, f);
+    const double q4 = hafq::decq4_float(v, tb);
+    return lower + ((upper - lower) * (q4 - f.fmin)) * f.inv_range;
+}
+
 // the decimal tables (95 doubles) in LDS: call from every thread of the workgroup before any divergent return
 __device__ __forceinline__ hafq::PtrTabs load_decimal_tables(double *lds_tab)
 {
@@ -357,8 +373,8 @@ __device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 h
     store_group_img(xtile + kHMatBytes, r, g, lo);
 }
 
-// screening operand of one attribute: u = c*x in fp64 (the reference value), u^ = fp16(u) with subnormals flushed;
-// accumulates |u|^2 and |u^ - u|^2, the two norms the guard band of the screening pass is made of
+// screening operand of one attribute: u' = c*x' in fp64 (x' from attribute_value_screen), u^ = fp16(u') with subnormals
+// flushed; accumulates |u'|^2 and |u^ - u'|^2, the two norms the guard band of the screening pass is made of
 __device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &su2, double &sd2)
 {
     const double ud = xd * c;
@@ -370,19 +386,28 @@ __device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &
     return h;
 }
 
-// norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band.  With e_n the error of the
-// exp2 argument of SV n, dec^ - dec = sum_n c_n K_n (2^e_n - 1) = ln2 * sum_n c_n K_n e_n + second order, and
-//   e_n = (u^-u).v^_n + u.(v^_n - v_n) + [what the fp16 splits of the norm terms miss + fp32 accumulation in the matrix core].
-// The bilinear part sums to (u^-u).(V^' w) + u.(dV' w) with w_n = c_n K_n, so it is bounded TWICE:
+// norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band.  u' = c x' is what the
+// feature kernel has (attribute_value_screen), u = c x the true operand: |u' - u| <= eta := 5e-6 |u'| + tiny, component-wise
+// and therefore in norm.  With e_n the error of the exp2 argument of SV n,
+//   dec^ + rho = 2^D * sum_n c_n K_n 2^e_n,
+//   e_n = (u^-u).v^_n + u.(v^_n - v_n) + [what the fp16 split of -|v_n|^2/2 misses + fp32 accumulation in the matrix core],
+//   D   = the error of the -|u|^2/2 term (computed from u', split into fp16): the SAME factor for every SV.
+// Common factor: dec^ - dec = (2^D - 1)(dec + rho) + 2^D E with E = sum_n c_n K_n (2^e_n - 1); it costs
+// (2^D - 1)(|dec^| + |rho|), next to nothing where it matters (dec near 0), instead of D * S.
+// E = ln2 * sum_n c_n K_n e_n + second order.  The bilinear part of e_n sums to (u^-u).(V^' w) + u.(dV' w), w_n = c_n K_n,
+// and is bounded TWICE:
 //   (a) per SV by Cauchy-Schwarz:   <= (|u^-u| max|v^_n| + |u| max|v^_n - v_n|) * S                          =: d_max * S
 //   (b) through the spectral norms: <= (|u^-u| sigma(V^) + |u| sigma(dV)) * |w|_2,  |w|_2^2 <= max|c_n| * S   (K_n <= 1)
 // (b) grows with sqrt(S) only and is ~7x tighter on a 4096-SV model; the kernel takes the smaller of the two.
-// Second order: |2^e - 1 - ln2 e| <= 0.6 (ln2 e)^2 for |e| <= d_max < 0.1.  The bracket is bounded per unit of S:
-// norm splits exactly (dax, das_max), matrix-core accumulation generously (11 accumulating instructions, a few ulp of the
-// largest partial sum each: 2^-18 of |u||v^| + a_x + a_s).  Output: {gA, gB, gC} of kernels.h, scaled by sp.scale.
+// |u^-u| <= |u^-u'| + eta and |u| <= |u'| + eta (norms; |u^-u'| and |u'| are accumulated exactly in fp64).
+// Second order: |2^e - 1 - ln2 e| <= 0.6 (ln2 e)^2 for |e| < 0.05.  The bracket is bounded per unit of S: norm split exactly
+// (das_max), matrix-core accumulation generously (11 accumulating instructions, a few ulp of the largest partial sum each:
+// 2^-18 of |u||v^| + a_x + a_s).  The kernel measures S^ = 2^D sum|c_n| K_n 2^e_n: the true S is at most S^ * 2^(|D| + max|e_n|),
+// folded into the outputs.  Output {gA, gB, gC, cm} (kernels.h), scaled by sp.scale:
+//   |dec^ - dec| <= [min(gA sqrt(S^), gC S^) + (guard_acc0' + gB) S^ + cm (|dec^| + |rho|)] * 1.002
 __device__ __forceinline__ void screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41, float *band)
 {
-    const double a_x = 0.5 * su2;
+    const double a_x = 0.5 * su2;                        // of u'
     _Float16 s3[3];
     const double rep = split3_f16(-a_x, s3);
     const double dax = fabs(rep + a_x);
@@ -391,19 +416,22 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, const Scre
     g40[6] = (_Float16)(1.0f / kAugScale);
     g40[7] = s3[0];
     g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
-    const double un = sqrt(su2), dn = sqrt(sd2);
+    const double un1 = sqrt(su2), dn1 = sqrt(sd2);
+    const double eta = kScreenEtaRel * un1 + kScreenEtaAbs * 18.0 * sp.c;      // |u' - u| (18 = sqrt(324) components)
+    const double un = un1 + eta, dn = dn1 + eta;                                // |u|, |u^ - u|
     const double ln2 = 0.69314718056;
     const double d_max = dn * sp.v_max + (un + dn) * sp.dv_max;
+    const double acc = 3.814697265625e-06 * (un * sp.v_max + 0.5 * un * un + sp.as_max);
+    const double D = dax + un * eta;                     // | -|u|^2/2 - (value of the three norm slots) |
+    const double e_max = d_max + sp.das_max + acc;
+    const double infl = exp2(e_max + D) * 1.000001;
     const double gA = ln2 * (dn * sp.sigma_v + (un + dn) * sp.sigma_dv) * sp.sqrt_cmax;
-    const double gB = ln2 * (dax + sp.das_max + 3.814697265625e-06 * (un * sp.v_max + a_x + sp.as_max)) +
-                      0.6 * (ln2 * d_max) * (ln2 * d_max);
-    // the kernel measures S^ = sum|c_n| K^_n; the true S is at most S^ * 2^(max |e_n|)
-    const double e_max = d_max + dax + sp.das_max + 3.814697265625e-06 * (un * sp.v_max + a_x + sp.as_max);
-    band[0] = (float)(gA * sp.scale);        // scale = 1.001: the roundings of these expressions and of the casts are far inside 0.1 %
-    band[1] = (float)(gB * sp.scale);
-    band[2] = (float)(ln2 * d_max * sp.scale);
-    band[3] = (float)(exp2(e_max) * 1.000001);
-    if (!(e_max < 0.05)) band[1] = __builtin_inff();     // outside the range the second-order bound was derived for: never trusted
+    const double gB = ln2 * (sp.das_max + acc) + 0.6 * (ln2 * e_max) * (ln2 * e_max);
+    band[0] = (float)(gA * sqrt(infl) * sp.scale);       // scale = 1.001: the roundings of these expressions and of the casts
+    band[1] = (float)(gB * infl * sp.scale);             // are far inside 0.1 %
+    band[2] = (float)(ln2 * d_max * infl * sp.scale);
+    band[3] = (float)((exp2(D) - 1.0) * sp.scale);
+    if (!(e_max + D < 0.05)) band[1] = __builtin_inff();  // outside the range the bounds were derived for: never trusted
 }
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
@@ -452,7 +480,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 double xd = 0.0;
                 if (f < d.nf && f < kAugS) {
                     const FeatDesc &F = fd[f];
-                    if (!F.skip) xd = attribute_value<true>(iir, w0, F, lower, upper, tb);
+                    if (!F.skip) xd = attribute_value_screen<true>(iir, w0, F, lower, upper, tb);
                 }
                 hi[q] = screen_operand(xd, sp.c, xx, sd2);
             }
@@ -543,7 +571,8 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
             double xd = 0.0;
             if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xd = attribute_value<true>(iir, w0, F, lower, upper, tb);
+                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? attribute_value_screen<true>(iir, w0, F, lower, upper, tb)
+                                                         : attribute_value<true>(iir, w0, F, lower, upper, tb);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {

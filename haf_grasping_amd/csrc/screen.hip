@@ -22,7 +22,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // c = sqrt(2*gamma*log2 e) and rounded to fp16 (u^ = fp16(c x), v^ = fp16(c s)); the norm terms -|u|^2/2 and -|v|^2/2
 // ride in spare K slots (kernels.h), so the 16x16 accumulator IS the exp2 argument and the epilogue is one v_exp_f32
 // and one fma per (evaluation, SV).  The result is only trusted outside a rigorous per-evaluation band
-//     |dec| > min(gA sqrt(S), gC S) + (guard_acc0 + gB) S + guard_abs,   S = sum|coef|K, {gA, gB, gC} from k_features,
+//     |dec| > min(gA sqrt(S), gC S) + (guard_acc0 + gB) S + cm (|dec| + |rho|) + guard_abs,   S = sum|coef|K,
+// {gA, gB, gC, cm} from k_features (screen_finish),
 // which is ~20x wider than the three-pass kernel's, so a few per cent of the evaluations go on to that kernel (in list
 // mode) and from there to the fp64 tiers as before: the labels stay those of libsvm, the bulk costs a third.
 //   * a wave keeps 64 evals x 336 slots in 168 VGPRs (twice the rows of the three-pass kernel: every B fragment read
@@ -273,11 +274,13 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
     if (live) {
         dec[e] = dv;
         labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-        // {gA, gB, gC}: linear term bounded through the spectral norms (~sqrt(S)) or per SV (~S), whichever is smaller
+        // {gA, gB, gC, cm} (screen_finish): linear term through the spectral norms (~sqrt(S)) or per SV (~S), whichever is
+        // smaller; S-proportional terms; the common factor of the -|u|^2/2 term on (|dec^| + |rho|)
         const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
-        const float s1 = sabs * g.w;                                // the true S is at most g.w times the measured one
-        const float lin = fminf(g.x * sqrtf(s1), g.z * s1);
-        flagged = !(fabsf(dv) > lin + (p.guard_acc0 + g.y) * s1 + p.guard_abs);   // also catches NaN
+        const float adv = fabsf(dv);
+        const float lin = fminf(g.x * sqrtf(sabs), g.z * sabs);
+        const float err = (lin + (p.guard_acc0 * 1.04f + g.y) * sabs + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
+        flagged = !(adv > err);                                     // also catches NaN
     }
     // one 64-bit word per wave (64 consecutive evaluations): k_screen_compact turns the words into the ORDERED list of
     // undecided evaluations -- neighbours in the list are neighbours on the grid, so the feature kernel that follows reads
