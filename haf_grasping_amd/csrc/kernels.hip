@@ -1196,7 +1196,9 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
                                                       int8_t *__restrict__ labels, int *__restrict__ flag2_list,
                                                       int flag2_cap, Dims d)
 {
-    __shared__ __attribute__((aligned(16))) double bt[2][kMTileDoubles];
+    // ONE SV tile in LDS (41 KiB): the next tile waits in registers while this one is consumed, and both barriers of the
+    // hand-over are needed with one buffer or two -- with one, three workgroups fit a CU instead of one
+    __shared__ __attribute__((aligned(16))) double bt[1][kMTileDoubles];
     __shared__ double xxs[kMWaves][16];
     int n_flag = counters[CNT_FLAGGED];
     if (n_flag > flag_cap) n_flag = flag_cap;
@@ -1245,7 +1247,7 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
 
         double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
         for (int t = 0; t < n_tiles; t++) {
-            const double *B = bt[t & 1];
+            const double *B = bt[0];
             if (t + 1 < n_tiles) tile_load(t + 1);
             f64x4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -1263,8 +1265,8 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
                 part[r] = fma(cf, kv, part[r]);
                 pabs[r] = fma(fabs(cf), kv, pabs[r]);
             }
-            __syncthreads();                          // everyone is done reading buffer (t+1)&1 of the previous round
-            if (t + 1 < n_tiles) tile_store((t + 1) & 1);
+            __syncthreads();                          // everyone is done reading the tile
+            if (t + 1 < n_tiles) tile_store(0);
             __syncthreads();
         }
 #pragma unroll
