@@ -526,6 +526,10 @@ int build_tables(haf_engine *e)
     if (const char *g = getenv("HAF_GUARD_REL")) guard_scale = atof(g);
     const double u = std::ldexp(1.0, -24);
     e->svm.guard_dot = (float)(guard_scale * (0.6932 * 324.0 * u + 8.0 * u));
+    // PRECISE form of the three-pass kernel (k_svm_rbf_h<true>): 31 roundings per instruction of the main pass whatever
+    // the matrix core's internal order, 11 VALU adds, one for the small-pass chain (whose own roundings are 2^-10 of
+    // that): 43 instead of 324
+    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * 44.0 * u + 8.0 * u));
     // coefficient sum: sequential over the tiles (fp32 kernel) or two-level, 8 tiles per inner sum (split-fp16 kernel);
     // +2 for the class split (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product
     const bool split_mode = !(e->cfg.flags & HAF_FLAG_FP32_MFMA);

@@ -826,6 +826,12 @@ __device__ __forceinline__ int stage_sv_tile_h(const char *__restrict__ gtile, u
     return issued;
 }
 
+// PRECISE (the list mode behind the screening pass, where speed does not matter): the dominant pass xh.sh goes ONE k-step
+// at a time into a fresh accumulator that is added to the running sum by the VALU, and the two small passes form their
+// own MFMA chain first.  Whatever order the matrix core adds the 32 products of an instruction in, the error is then at
+// most 31 u T_s per instruction (T_s = the step's sum of |products|) + one rounding per VALU add: 43 u sum|x_i s_i| in all
+// instead of one rounding per product of a 3 x 336-term chain, and the guard band shrinks with it (guard_dot_p).
+template <bool PRECISE>
 __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__restrict__ X, const float *__restrict__ ax,
                                                               const char *__restrict__ svt,
                                                               const int *__restrict__ evalcell,
@@ -930,6 +936,57 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
 #pragma unroll
             for (int n = 0; n < 2; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const char *bl = cur + lane * 16;
+        if (PRECISE) {
+            // sweep 1: xl.sh + xh.sl, magnitudes 2^-11 of the main pass: a plain MFMA chain (its roundings are negligible)
+#pragma unroll
+            for (int s = 0; s < kHFull; s++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    const half8 bhv = *reinterpret_cast<const half8 *>(bl + (s * 2 + n) * 1024);
+                    const half8 bqv = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s * 2 + n) * 1024);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], bhv, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bqv, acc[m][n], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);               // one step's fragments live at a time: no spills
+                }
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const half4 bht = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
+                const half4 bqt = *reinterpret_cast<const half4 *>(cur + kHMatBytes + kHTailOff + n * 512 + lane * 8);
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt, acc[m][n], 0, 0, 0);
+                }
+            }
+            // sweep 2: xh.sh, each k-step into a fresh accumulator, summed by the VALU
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < kHFull; s++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    const half8 bhv = *reinterpret_cast<const half8 *>(bl + (s * 2 + n) * 1024);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        const f32x4 t4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bhv, zero, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[m][n][r] = acc[m][n][r] + t4[r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const half4 bht = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const f32x4 t4 = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bht, zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[m][n][r] = acc[m][n][r] + t4[r];
+                }
+            }
+        } else {
         half8 bh[2][2], bq[2][2];                                    // [ring][column block n]
 #pragma unroll
         for (int n = 0; n < 2; n++) {
@@ -970,6 +1027,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht[n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt[n], acc[m][n], 0, 0, 0);
                 }
+        }
         }
         const float *tail = reinterpret_cast<const float *>(cur + 2 * kHMatBytes);
         float cfn[2];
@@ -1042,7 +1100,8 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     const float sabs = P - N;                       // sum |coef| K
                     dec[e] = dv;
                     labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-                    if (!(fabsf(dv) > (p.guard_acc + p.guard_dot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
+                    const float gdot = PRECISE ? p.guard_dot_p : p.guard_dot;
+                    if (!(fabsf(dv) > (p.guard_acc + gdot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
                         int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                         if (slot < flag_cap) flag_list[slot] = e;
                     }
@@ -1057,8 +1116,12 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_svm_rbf_h, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
-                       evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap);
+    if (idx_list)
+        hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
+                           evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap);
+    else
+        hipLaunchKernelGGL(k_svm_rbf_h<false>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
+                           evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap);
 }
 
 // ---------------------------------------------------------------------------------------------------
