@@ -215,7 +215,7 @@ struct haf_engine {
     DevBuf<unsigned long long> d_flag0_words;   // one bit per evaluation: undecided by the screening pass
     DevBuf<int> d_flag0_wgcount;                // popcounts per 256 words, for the ordered compaction
     DevBuf<int8_t> d_labels;
-    DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64;
+    DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64, d_part64;
     DevBuf<short> d_ev16;
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
@@ -602,6 +602,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->flag_cap);
+    ok &= hipSuccess == e->d_part64.alloc((size_t)e->flag_cap * kRecheckPartRows);
     // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->flag2_cap);
@@ -666,7 +667,7 @@ void haf_destroy(haf_engine *e)
     e->d_clouds.release(); e->d_points.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
-    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
+    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
@@ -867,7 +868,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
         // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
         // is still within 2^-40 of zero (practically nothing)
         launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, e->d_counters.p,
-                            e->d_x64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->flag2_cap, d, s);
+                            e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->flag2_cap, d, s);
         launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->flag2_cap,
                        e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
         mark(e, HAF_ST_VOTE);

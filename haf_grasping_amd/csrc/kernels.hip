@@ -1223,6 +1223,8 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
 // ---------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kMWaves = 4;
+constexpr int kMSplit = 4;                        // SV ranges a group of evaluations is split over (k_recheck_mfma tasks)
+static_assert(kRecheckPartRows == 2 * kMSplit + 1, "part64 layout");
 constexpr int kMEvals = 16 * kMWaves;
 constexpr int kMSteps = kKP / 4;                 // 81 k-steps of 4
 constexpr int kMTileDoubles = kM64Rows * 16;     // 5216 doubles = 41728 B
@@ -1255,9 +1257,7 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
 __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__ x64, const int *__restrict__ evalcell,
                                                       const double *__restrict__ sv64,
                                                       ExactParams p, const int *__restrict__ flag_list, int flag_cap,
-                                                      int *__restrict__ counters, double *__restrict__ dec_exact,
-                                                      int8_t *__restrict__ labels, int *__restrict__ flag2_list,
-                                                      int flag2_cap, Dims d)
+                                                      int *__restrict__ counters, double *__restrict__ part64, Dims d)
 {
     // ONE SV tile in LDS (41 KiB): the next tile waits in registers while this one is consumed, and both barriers of the
     // hand-over are needed with one buffer or two -- with one, three workgroups fit a CU instead of one
@@ -1270,7 +1270,13 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
     const int n_tiles = p.n_sv_pad / 16;
     typedef double double2_t __attribute__((ext_vector_type(2)));
 
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    // a task = (group of 64 evaluations, one of kMSplit ranges of SV tiles): a few thousand flagged evaluations would
+    // otherwise occupy a fraction of the CUs for the full length of the model; k_recheck_combine adds the partial sums in
+    // a fixed order
+    const int tiles_per_part = (n_tiles + kMSplit - 1) / kMSplit;
+    for (int task = blockIdx.x; task < n_groups * kMSplit; task += gridDim.x) {
+        const int g = task / kMSplit, h = task - g * kMSplit;
+        const int t_begin = h * tiles_per_part, t_end = min(n_tiles, t_begin + tiles_per_part);
         // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, from k_recheck_x's image ----
         const int grp = g * kMWaves + wave;                          // 16 flagged evaluations
         double a[kMSteps];
@@ -1304,14 +1310,13 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
                 if (idx < kMTileDoubles / 2) *reinterpret_cast<double2_t *>(&bt[buf][idx * 2]) = pre[q];
             }
         };
-        tile_load(0);
-        tile_store(0);
+        if (t_begin < t_end) { tile_load(t_begin); tile_store(0); }
         __syncthreads();
 
         double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
-        for (int t = 0; t < n_tiles; t++) {
+        for (int t = t_begin; t < t_end; t++) {
             const double *B = bt[0];
-            if (t + 1 < n_tiles) tile_load(t + 1);
+            if (t + 1 < t_end) tile_load(t + 1);
             f64x4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < kMSteps; s++) {
@@ -1329,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
                 pabs[r] = fma(fabs(cf), kv, pabs[r]);
             }
             __syncthreads();                          // everyone is done reading the tile
-            if (t + 1 < n_tiles) tile_store(0);
+            if (t + 1 < t_end) tile_store(0);
             __syncthreads();
         }
 #pragma unroll
@@ -1341,23 +1346,16 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
             v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
             part[r] = v; pabs[r] = w;
         }
-        // lane with (lane&15)==0 of 16-lane group q holds rows q + 4r; evaluation (lane&15)=e lives in every group:
-        // let the lane whose own evaluation index equals one of its rows write it
+        // lane with (lane&15)==0 of 16-lane group q holds rows q + 4r: partial sums of this SV range (+ |x|^2 once)
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = (lane >> 4) + 4 * r;
                 const int sl = g * kMEvals + wave * 16 + row;
                 if (sl < n_flag) {
-                    const double dv = part[r] - p.rho;
-                    dec_exact[sl] = dv;
-                    const int e = flag_list[sl];
-                    labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
-                    const double T = p.as_max1 + p.gamma2 * xxs[wave][row];
-                    if (!(fabs(dv) > p.guard2 * T * pabs[r])) {
-                        int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
-                        if (s2 < flag2_cap) flag2_list[s2] = e;
-                    }
+                    part64[(size_t)(2 * h) * flag_cap + sl] = part[r];
+                    part64[(size_t)(2 * h + 1) * flag_cap + sl] = pabs[r];
+                    if (h == 0) part64[(size_t)(2 * kMSplit) * flag_cap + sl] = xxs[wave][row];
                 }
             }
         }
@@ -1365,16 +1363,47 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
     }
 }
 
+// sum of the kMSplit partial decision values of every flagged evaluation (fixed order), label, and what is still too
+// close to zero for the GEMM form goes on to the strict-order kernel
+__global__ __launch_bounds__(256) void k_recheck_combine(const double *__restrict__ part64, const int *__restrict__ evalcell,
+                                                         ExactParams p, const int *__restrict__ flag_list, int flag_cap,
+                                                         int *__restrict__ counters, double *__restrict__ dec_exact,
+                                                         int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap)
+{
+    int n_flag = counters[CNT_FLAGGED];
+    if (n_flag > flag_cap) n_flag = flag_cap;
+    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
+        double P = 0.0, S = 0.0;
+#pragma unroll
+        for (int h = 0; h < kMSplit; h++) {
+            P += part64[(size_t)(2 * h) * flag_cap + sl];
+            S += part64[(size_t)(2 * h + 1) * flag_cap + sl];
+        }
+        const double dv = P - p.rho;
+        dec_exact[sl] = dv;
+        const int e = flag_list[sl];
+        labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+        const double T = p.as_max1 + p.gamma2 * part64[(size_t)(2 * kMSplit) * flag_cap + sl];
+        if (!(fabs(dv) > p.guard2 * T * S)) {
+            int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
+            if (s2 < flag2_cap) flag2_list[s2] = e;
+        }
+    }
+}
+
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
-                         const int *flag_list, int flag_cap, int *counters, double *x64, double *dec_exact, int8_t *labels,
-                         int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
+                         const int *flag_list, int flag_cap, int *counters, double *x64, double *part64, double *dec_exact,
+                         int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
 {
     int groups = (flag_cap + kMEvals - 1) / kMEvals;
     int blocks = groups < 2048 ? groups : 2048;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_recheck_x, dim3(blocks * 2), dim3(256), 0, s, ii, evalcell, fd, p, flag_list, flag_cap, counters, x64, d);
-    hipLaunchKernelGGL(k_recheck_mfma, dim3(blocks), dim3(256), 0, s, x64, evalcell, sv64, p, flag_list, flag_cap, counters,
-                       dec_exact, labels, flag2_list, flag2_cap, d);
+    const long tasks = (long)groups * kMSplit;
+    hipLaunchKernelGGL(k_recheck_mfma, dim3((unsigned)(tasks < 4096 ? tasks : 4096)), dim3(256), 0, s, x64, evalcell, sv64, p,
+                       flag_list, flag_cap, counters, part64, d);
+    hipLaunchKernelGGL(k_recheck_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, flag_cap, counters,
+                       dec_exact, labels, flag2_list, flag2_cap);
 }
 
 // ---------------------------------------------------------------------------------------------------
