@@ -2,7 +2,7 @@
 //
 // Stage -> reference function it replaces (src/calc_grasppoints_action_server.cpp unless noted):
 //   k_bin            generate_grid 406-529 (transform + max-z binning)
-//   k_integral       generate_grid 522-528 (empty cells -> 0) + calc_intimage 577-613
+//   k_integral_rows / k_integral_cols   generate_grid 522-528 (empty cells -> 0) + calc_intimage 577-613
 //   k_mask_count / k_scan / k_compact   pnt_in_box 666-749 + the row-major cell order of calc_featurevectors 637-643
 //   k_features_serial / k_features   CIntImage_to_Featurevec::calc_featurevalue (fv.cpp:141-199), the "%.4g" text
 //                    round trip (fv.cpp:133 -> svm-scale.c:270), svm-scale restore+output (svm-scale.c:333-353) and
@@ -53,33 +53,35 @@ void launch_fill_i32(int *p, int v, size_t n, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// a1: transform + binning.  One thread per point, all rolls of its cloud; max-z via atomicMax on an
+// a1: transform + binning.  One thread per (point, roll); max-z via atomicMax on an
 // order-preserving integer key (max is order independent, so the grid is deterministic).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bin(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
                                              int *__restrict__ hkeys, Dims d, float r_row, float r_col)
 {
-    const int b = blockIdx.y;
+    // grid = (points / 256, cloud * roll): workgroups are dispatched roll by roll, so the atomics in flight at any moment
+    // go to one or two height grids (1 MiB each at 512 x 512), which stay in L2; with all rolls of a point in one thread
+    // they spread over every grid of the request (37 MB for C5) and miss
+    const int br = blockIdx.y;
+    const int b = br / d.R;
     const CloudDev c = clouds[b];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= c.n) return;
     const float *p = c.xyz + (size_t)i * c.stride;
     const float x = p[0], y = p[1], z = p[2];
     const int HW = d.H * d.W;
-    for (int r = 0; r < d.R; r++) {
-        const RollGeo &g = geo[b * d.R + r];
-        // pcl::transformPointCloud (488): fp32, left to right, unfused
-        float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
-        float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
-        float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
-        if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
-            int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row)));                   // 513
-            int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col)));                   // 514
-            if (ix >= 0 && ix < d.H && iy >= 0 && iy < d.W) {
-                int *cell = hkeys + (size_t)(b * d.R + r) * HW + ix * d.W + iy;
-                int key = f2key(pz);
-                if (key > *cell) atomicMax(cell, key);   // stale read is safe: the cell only grows
-            }
+    const RollGeo &g = geo[br];
+    // pcl::transformPointCloud (488): fp32, left to right, unfused
+    float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
+    float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
+    float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
+    if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
+        int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row)));                   // 513
+        int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col)));                   // 514
+        if (ix >= 0 && ix < d.H && iy >= 0 && iy < d.W) {
+            int *cell = hkeys + (size_t)br * HW + ix * d.W + iy;
+            int key = f2key(pz);
+            if (key > *cell) atomicMax(cell, key);   // stale read is safe: the cell only grows
         }
     }
 }
@@ -88,7 +90,7 @@ void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkey
                 hipStream_t s)
 {
     if (max_n <= 0) return;
-    dim3 grid((max_n + 255) / 256, d.B);
+    dim3 grid((max_n + 255) / 256, d.B * d.R);
     hipLaunchKernelGGL(k_bin, grid, dim3(256), 0, s, clouds, geo, hkeys, d, r_row, r_col);
 }
 
@@ -96,57 +98,65 @@ void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkey
 // a1 tail + a2: finalise heights (cells < -0.99 -> 0, 522-528) and build the integral image in the
 // reference's summation ORDER: running fp64 row sum, then add the row above (cv::integral CV_64F), so the
 // fp64 partial sums and the fp32 narrowing (599-601) are bit-identical for any input, not only when the
-// sums happen to be exact.  One workgroup per (cloud, roll): thread-per-row pass, then thread-per-column pass.
+// sums happen to be exact.  Thread-per-row pass, then thread-per-column pass.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_integral(int *hk, double *__restrict__ rowsum, float *__restrict__ ii,
-                                                  Dims d)
+// Two launches: k_integral_rows (one thread per grid row: running sum along the row) and k_integral_cols (one thread per
+// column of the integral image: running sum down the column), 64 rows / columns per workgroup, so that a 36-roll request
+// occupies a few hundred workgroups instead of 36.
+__global__ __launch_bounds__(64) void k_integral_rows(int *hk, double *__restrict__ rowsum, Dims d)
 {
-    const int br = blockIdx.x;
-    const int H = d.H, W = d.W, W1 = W + 1;
+    const int br = blockIdx.y;
+    const int H = d.H, W = d.W;
     int *keys = hk + (size_t)br * H * W;
     float *hts = reinterpret_cast<float *>(keys);
     double *rs = rowsum + (size_t)br * H * W;
-    float *I = ii + (size_t)br * (H + 1) * W1;
-    for (int row = threadIdx.x; row < H; row += blockDim.x) {
-        double s = 0.0;
-        // the running sum is sequential by definition; the loads are not: fetch 8 keys ahead of the dependent chain
-        // (keys and heights share storage, so the compiler cannot hoist the loads itself)
-        for (int c0 = 0; c0 < W; c0 += 8) {
-            int kreg[8];
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= H) return;
+    double s = 0.0;
+    // the running sum is sequential by definition; the loads are not: fetch 8 keys ahead of the dependent chain
+    // (keys and heights share storage, so the compiler cannot hoist the loads itself)
+    for (int c0 = 0; c0 < W; c0 += 8) {
+        int kreg[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) kreg[q] = (c0 + q < W) ? keys[row * W + c0 + q] : 0;
+        for (int q = 0; q < 8; q++) kreg[q] = (c0 + q < W) ? keys[row * W + c0 + q] : 0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (c0 + q < W) {
-                    float h = key2f(kreg[q]);
-                    if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare)
-                    hts[row * W + c0 + q] = h;
-                    s = __dadd_rn(s, (double)h);              // 589: widened before the integral
-                    rs[row * W + c0 + q] = s;
-                }
+        for (int q = 0; q < 8; q++) {
+            if (c0 + q < W) {
+                float h = key2f(kreg[q]);
+                if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare)
+                hts[row * W + c0 + q] = h;
+                s = __dadd_rn(s, (double)h);              // 589: widened before the integral
+                rs[row * W + c0 + q] = s;
             }
         }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < W1; c += blockDim.x) {
-        I[c] = 0.0f;
-        if (c == 0) {
-            for (int r = 0; r < H; r++) I[(r + 1) * W1] = 0.0f;
-        } else {
-            double acc = 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__ rowsum, float *__restrict__ ii, Dims d)
+{
+    const int br = blockIdx.y;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    const double *rs = rowsum + (size_t)br * H * W;
+    float *I = ii + (size_t)br * (H + 1) * W1;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= W1) return;
+    I[c] = 0.0f;
+    if (c == 0) {
+        for (int r = 0; r < H; r++) I[(r + 1) * W1] = 0.0f;
+    } else {
+        double acc = 0.0;
 #pragma unroll 8
-            for (int r = 0; r < H; r++) {
-                acc = __dadd_rn(acc, rs[r * W + (c - 1)]);
-                I[(r + 1) * W1 + c] = (float)acc;     // 601
-            }
+        for (int r = 0; r < H; r++) {
+            acc = __dadd_rn(acc, rs[r * W + (c - 1)]);
+            I[(r + 1) * W1 + c] = (float)acc;     // 601
         }
     }
 }
 
 void launch_integral(int *hk, double *rowsum, float *ii, Dims d, hipStream_t s)
 {
-    int threads = d.H >= 256 ? 512 : (d.H > 64 ? 256 : 64);
-    hipLaunchKernelGGL(k_integral, dim3(d.B * d.R), dim3(threads), 0, s, hk, rowsum, ii, d);
+    hipLaunchKernelGGL(k_integral_rows, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, hk, rowsum, d);
+    hipLaunchKernelGGL(k_integral_cols, dim3((d.W + 1 + 63) / 64, d.B * d.R), dim3(64), 0, s, rowsum, ii, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
