@@ -289,8 +289,8 @@ def main():
                                              "algorithmic_bytes": b, "ms": ms, "GBps": b / ms / 1e6, "peak_GBps": 8000.0,
                                              "frac": b / ms / 1e6 / 8000.0,
                                              "note": "SURVEY 8(d): 12 B per cell per roll + 12 B per point per roll; these launches are "
-                                                     "latency-bound (36 workgroup-rows of sequential sums, 19 M scattered atomics), "
-                                                     "2 % of the step"})(
+                                                     "latency- and atomic-bound (sequential row/column sums, 19 M scattered "
+                                                     "atomics), 4 % of the step"})(
                 res["stage_ms"]["bin"] + res["stage_ms"]["integral"] + res["stage_ms"]["mask"] + res["stage_ms"]["vote"],
                 12.0 * args.rolls * (G * G + xyz.shape[0])),
             "rechecked_per_step": {"three_pass_tier": res["refined"], "fp64_mfma_tier": res["rechecked"],
