@@ -45,9 +45,11 @@ __host__ __device__ inline int h_image_offset(int r, int k)
 // u = c*x, v = c*s  =>  exp2 argument = u.v - |u|^2/2 - |v|^2/2.  The two norm terms ride in spare K slots of the
 // 336-wide operand images (attributes use slots 0..323), each as a three-term fp16 split against constants
 // (1, 2^-12, 2^-12), so the accumulator IS the exp2 argument and the epilogue is v_exp_f32 + one fma per element.
-// A wave keeps 64 evals (two 32-eval hi images) in registers; a workgroup is 8 waves = 512 evals.
+// A wave keeps 64 evals (two 32-eval hi images) in registers; a workgroup is 4 waves = 256 evals.
 constexpr int kS0WaveEvals = 64;
-constexpr int kS0BlockEvals = 512;
+constexpr int kS0Waves = 4;                           // waves per workgroup: TWO workgroups share a CU (one wave of each per SIMD)
+constexpr int kS0BlockEvals = kS0Waves * kS0WaveEvals;
+constexpr int kS0WavePieces = 6;                      // LDS-DMA pieces a wave stages per tile (4 x 6 = 24 >= 22: two go twice)
 constexpr int kS0SvTileBytes = 22528;                 // fp16 image (21504 B) + 32 coef floats, padded to 22 KiB
 constexpr int kS0Pieces = kS0SvTileBytes / 1024;      // 22 LDS-DMA wave instructions
 constexpr int kS0Buffers = 3;

@@ -27,7 +27,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // which is ~20x wider than the three-pass kernel's, so a few per cent of the evaluations go on to that kernel (in list
 // mode) and from there to the fp64 tiers as before: the labels stay those of libsvm, the bulk costs a third.
 //   * a wave keeps 64 evals x 336 slots in 168 VGPRs (twice the rows of the three-pass kernel: every B fragment read
-//     from LDS feeds 4 MFMAs), workgroup = 8 waves = 512 evals;
+//     from LDS feeds 4 MFMAs); workgroup = 4 waves = 256 evals and TWO workgroups share a CU (one wave of each per SIMD):
+//     their tile barriers, LDS-DMA bursts and prologues fall at different times, so one's stalls sit beside the other's MFMAs;
 //   * SV tiles (32 SVs, 22 KiB) stream through a 3-deep LDS ring by LDS-DMA exactly as in k_svm_rbf_h;
 //   * the exp/fma epilogue of a 16-SV column block is issued BETWEEN the MFMAs of the next block (two accumulator
 //     sets in ping-pong), so it overlaps the matrix pipe inside one wave instead of relying on the partner wave.
@@ -40,23 +41,23 @@ __device__ __forceinline__ void dma_piece(const char *gbase, unsigned lds_dst, u
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(lane16), "s"(gbase) : "memory", "m0");
 }
 
-// the three pieces of one SV tile this wave stages (22 pieces over 8 waves x 3: pieces 0 and 1 go twice)
+// the six pieces of one SV tile this wave stages (22 pieces over 4 waves x 6: pieces 0 and 1 go twice)
 struct TileDma {
-    const char *g[3];
-    unsigned l[3];
+    const char *g[kS0WavePieces];
+    unsigned l[kS0WavePieces];
 };
-__device__ __forceinline__ TileDma tile_dma(const char *gtile, unsigned lds_slot, const int (&poff)[3])
+__device__ __forceinline__ TileDma tile_dma(const char *gtile, unsigned lds_slot, const int (&poff)[kS0WavePieces])
 {
     TileDma d;
 #pragma unroll
-    for (int q = 0; q < 3; q++) { d.g[q] = gtile + poff[q]; d.l[q] = lds_slot + (unsigned)poff[q]; }
+    for (int q = 0; q < kS0WavePieces; q++) { d.g[q] = gtile + poff[q]; d.l[q] = lds_slot + (unsigned)poff[q]; }
     return d;
 }
 __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane16)
 {
     asm volatile("s_nop 4");                                         // prologue only: the bases may be fresh from v_readfirstlane
 #pragma unroll
-    for (int q = 0; q < 3; q++) dma_piece(d.g[q], d.l[q], lane16);
+    for (int q = 0; q < kS0WavePieces; q++) dma_piece(d.g[q], d.l[q], lane16);
 }
 
 // MFMAs of column block n (16 SVs) of the tile at `cur` into acc, with the epilogue of the PREVIOUS block (old, cf_old)
@@ -66,10 +67,13 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // of the v_exp_f32 -- an MFMA in between does not help -- can read the register BEFORE the transcendental unit has written
 // it (wrong sums on some waves of some launches; hipcc pads one wait state, which is not enough).  Every exp result
 // here is consumed one whole k-step (>= 4 MFMAs, >= 8 instructions) after it was issued.
-// DMA = true: the wave's three LDS-DMA pieces of the tile two ahead are issued behind the first three MFMAs of k-step 0
-// (which carries no epilogue work).  The two waves of a SIMD do this in different column blocks, so the ~60 issue cycles
-// of a piece always sit beside the partner's MFMAs instead of every wave paying them together behind the tile barrier.
-template <bool DMA>
+// The wave's three LDS-DMA pieces of the tile two ahead are issued behind the first MFMAs of k-step 0 (which carries no
+// epilogue work), inside the MFMA stream instead of all waves paying for them together behind the tile barrier.
+// No branch may sit inside this stream: with the DMA under a wave-uniform `if`, hipcc's code motion carries the epilogue of
+// the block out of the MFMA stream (into the next basic block), and with two template instantiations in the arms of an
+// if/else it hoists the epilogue they have in common in front of the branch.  So every wave issues DMA in every block:
+// pieces 0..2 of the tile two ahead in column block 0, pieces 3..5 in column block 1 (FIRST = first piece, COUNT = how many).
+template <int FIRST, int COUNT>
 __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], const half4 (&at)[4],
                                              f32x4 (&acc)[4], const f32x4 (&old)[4], float cf_old, float (&sum)[4][4],
                                              const TileDma &dma, unsigned lane16)
@@ -95,7 +99,7 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         float q0 = 0.0f, q1 = 0.0f;
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, acc[0], 0, 0, 0);
         HAF_SB();
-        if (DMA && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[0], dma.l[0], lane16); HAF_SB(); }
+        if (COUNT > 0 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST], dma.l[FIRST], lane16); HAF_SB(); }
 #if SCREEN_ABL == 1
         if (ex) { q0 = old[e0 >> 2][e0 & 3] + 1.0f; HAF_SB(); }
 #elif SCREEN_ABL == 2
@@ -105,7 +109,7 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
 #endif
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, acc[1], 0, 0, 0);
         HAF_SB();
-        if (DMA && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[1], dma.l[1], lane16); HAF_SB(); }
+        if (COUNT > 1 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 1], dma.l[FIRST + 1], lane16); HAF_SB(); }
 #if SCREEN_ABL == 1
         if (ex) { q1 = old[e1 >> 2][e1 & 3] + 1.0f; HAF_SB(); }
 #elif SCREEN_ABL == 2
@@ -115,7 +119,7 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
 #endif
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, acc[2], 0, 0, 0);
         HAF_SB();
-        if (DMA && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[2], dma.l[2], lane16); HAF_SB(); }
+        if (COUNT > 2 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 2], dma.l[FIRST + 2], lane16); HAF_SB(); }
 #if SCREEN_ABL != 2 && SCREEN_ABL != 6
         if (fm) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
 #elif SCREEN_ABL == 6
@@ -140,7 +144,7 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
 
-__global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
+__global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
                                                                const char *__restrict__ svt0,
                                                                const int *__restrict__ evalcell,
                                                                const int *__restrict__ counters, SvmParams p,
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
                                                                unsigned long long *__restrict__ flag0_words, Dims d)
 {
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
-    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 2 * 8 * kS0WaveEvals * 4];
+    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 2 * kS0Waves * kS0WaveEvals * 4];
     const int n_evals = counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
@@ -157,14 +161,14 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
     const int nt = d.n_sv_tiles;
     float *pos = reinterpret_cast<float *>(lds + kS0Buffers * kS0SvTileBytes) + wave * kS0WaveEvals;
-    float *fin = pos + 8 * kS0WaveEvals;
+    float *fin = pos + kS0Waves * kS0WaveEvals;
 
     const unsigned lane16 = (unsigned)lane * 16u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int poff[3];                                                     // byte offsets of this wave's three pieces inside a tile
+    int poff[kS0WavePieces];                                         // byte offsets of this wave's six pieces inside a tile
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        int pq = wave_u + 8 * q;
+    for (int q = 0; q < kS0WavePieces; q++) {
+        int pq = wave_u + kS0Waves * q;
         if (pq >= kS0Pieces) pq -= kS0Pieces;
         poff[q] = pq * 1024;
     }
@@ -211,27 +215,21 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_screen(const char *__res
         float cf_prev = 0.0f;                                        // the first deferred epilogue adds 0 * exp2(0)
         for (int t = ph ? d.sv_tile_neg : 0; t < t_end; t++) {
             const char *cur = lds + (t % kS0Buffers) * kS0SvTileBytes;
-            // always three DMA pieces per wave and tile, so the wait below is one constant: past the last tile the ring
+            // always six DMA pieces per wave and tile, so the wait below is one constant: past the last tile the ring
             // slot that nobody reads any more is refilled with tile (t+2) mod nt
             const int tn = (t + 2) % nt;
             const TileDma dma = tile_dma(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, poff);
             const float *cft = reinterpret_cast<const float *>(cur + kHMatBytes);
             const float cf0 = cft[lane & 15], cf1 = cft[16 + (lane & 15)];   // coef of this lane's column in either block
-            // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0; waves 0-3 stage the next
-            // tile inside block 0, their SIMD partners (waves 4-7) inside block 1
-            if (wave_u < 4) {
-                screen_block<true>(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum, dma, lane16);
-                screen_block<false>(cur, 1, lane, a, at, acc1, acc0, cf0, sum, dma, lane16);
-            } else {
-                screen_block<false>(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum, dma, lane16);
-                screen_block<true>(cur, 1, lane, a, at, acc1, acc0, cf0, sum, dma, lane16);
-            }
+            // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0
+            screen_block<0, 3>(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum, dma, lane16);
+            screen_block<3, 3>(cur, 1, lane, a, at, acc1, acc0, cf0, sum, dma, lane16);
             cf_prev = cf1;
-            // tile t+1 must have landed before anyone reads it; the three pieces just issued may stay in flight
+            // tile t+1 must have landed before anyone reads it; the six pieces just issued may stay in flight
 #if SCREEN_ABL == 3
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #endif
 #if SCREEN_ABL != 4
             __builtin_amdgcn_s_barrier();
@@ -375,7 +373,7 @@ void launch_svm_screen(const void *X0, const float *gband, const void *svt0, con
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)X0, gband, (const char *)svt0,
+    hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, (const char *)svt0,
                        evalcell, counters, p, dec, labels, flag0_words, d);
     // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
