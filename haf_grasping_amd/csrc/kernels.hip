@@ -415,6 +415,20 @@ __device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &
 // 2^-18 of |u||v^| + a_x + a_s).  The kernel measures S^ = 2^D sum|c_n| K_n 2^e_n: the true S is at most S^ * 2^(|D| + max|e_n|),
 // folded into the outputs.  Output {gA, gB, gC, cm} (kernels.h), scaled by sp.scale:
 //   |dec^ - dec| <= [min(gA sqrt(S^), gC S^) + (guard_acc0' + gB) S^ + cm (|dec^| + |rho|)] * 1.002
+// Upper bound of sqrt(x) to 1e-9 relative without a transcendental instruction (the guard band is never checked bit for
+// bit by a test, so nothing in it may hang on the v_exp/v_rsq result hazard described in screen.hip): 1/sqrt(x) by the
+// exponent-halving bit trick and four Newton steps r <- r (1.5 - 0.5 x r^2), which only multiply and add.
+__device__ __forceinline__ double sqrt_upper(double x)
+{
+    if (!(x > 0.0)) return x == 0.0 ? 0.0 : x + x;      // -0/+0 -> 0; negative or NaN -> NaN (the evaluation is then never trusted)
+    double r = __longlong_as_double(0x5FE6EB50C7B537A9LL - (__double_as_longlong(x) >> 1));
+#pragma unroll
+    for (int it = 0; it < 4; it++) r = r * fma(-0.5 * x * r, r, 1.5);
+    return x * r * (1.0 + 1e-9);
+}
+// 2^z - 1 <= ln2 z + 0.26 z^2 for 0 <= z < 0.05 (y = z ln2: e^y - 1 <= y + y^2/2 e^y)
+__device__ __forceinline__ double exp2m1_upper(double z) { return 0.69314718056 * z + 0.26 * z * z; }
+
 __device__ __forceinline__ void screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41, float *band)
 {
     const double a_x = 0.5 * su2;                        // of u'
@@ -426,7 +440,7 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, const Scre
     g40[6] = (_Float16)(1.0f / kAugScale);
     g40[7] = s3[0];
     g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
-    const double un1 = sqrt(su2), dn1 = sqrt(sd2);
+    const double un1 = sqrt_upper(su2), dn1 = sqrt_upper(sd2);
     const double eta = kScreenEtaRel * un1 + kScreenEtaAbs * 18.0 * sp.c;      // |u' - u| (18 = sqrt(324) components)
     const double un = un1 + eta, dn = dn1 + eta;                                // |u|, |u^ - u|
     const double ln2 = 0.69314718056;
@@ -434,13 +448,13 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, const Scre
     const double acc = 3.814697265625e-06 * (un * sp.v_max + 0.5 * un * un + sp.as_max);
     const double D = dax + un * eta;                     // | -|u|^2/2 - (value of the three norm slots) |
     const double e_max = d_max + sp.das_max + acc;
-    const double infl = exp2(e_max + D) * 1.000001;
+    const double infl = 1.0 + exp2m1_upper(e_max + D);   // meaningful below 0.05 only: beyond it the band is infinite anyway
     const double gA = ln2 * (dn * sp.sigma_v + (un + dn) * sp.sigma_dv) * sp.sqrt_cmax;
     const double gB = ln2 * (sp.das_max + acc) + 0.6 * (ln2 * e_max) * (ln2 * e_max);
-    band[0] = (float)(gA * sqrt(infl) * sp.scale);       // scale = 1.001: the roundings of these expressions and of the casts
-    band[1] = (float)(gB * infl * sp.scale);             // are far inside 0.1 %
+    band[0] = (float)(gA * (1.0 + 0.5 * (infl - 1.0)) * sp.scale);   // sqrt(1+z) <= 1 + z/2; scale = 1.001: the roundings of these
+    band[1] = (float)(gB * infl * sp.scale);             // expressions and of the casts are far inside 0.1 %
     band[2] = (float)(ln2 * d_max * infl * sp.scale);
-    band[3] = (float)((exp2(D) - 1.0) * sp.scale);
+    band[3] = (float)(exp2m1_upper(D) * sp.scale);
     if (!(e_max + D < 0.05)) band[1] = __builtin_inff();  // outside the range the bounds were derived for: never trusted
 }
 
