@@ -7,10 +7,14 @@
 //   k_features_serial / k_features   CIntImage_to_Featurevec::calc_featurevalue (fv.cpp:141-199), the "%.4g" text
 //                    round trip (fv.cpp:133 -> svm-scale.c:270), svm-scale restore+output (svm-scale.c:333-353) and
 //                    the "%g" round trip (svm-scale.c:350 -> svm-predict.c:108); large / small requests
-//   k_svm_rbf_h      svm_predict_values / Kernel::k_function RBF (libsvm svm.cpp:325-365, 2478-2532) as three fp16
-//                    MFMA passes on the hi/lo halves of the fp32 operands, exp epilogue, guard band (tier 1, default)
-//   k_svm_rbf        the same as one fp32 MFMA pass (tier 1, fp32 mode)
-//   k_recheck_x / k_recheck_mfma   guard-band evaluations again as an fp64 MFMA contraction (tier 2)
+//                    (the screening form, XMODE_SCREEN, skips the second round trip and writes the guard band instead)
+//   k_svm_screen     (screen.hip) svm_predict_values / Kernel::k_function RBF (libsvm svm.cpp:325-365, 2478-2532) as ONE
+//                    fp16 MFMA pass, trusted outside a rigorous band (tier 0, default mode); k_screen_count /
+//                    k_screen_compact build the ordered list of what it could not decide
+//   k_svm_rbf_h      the same as three fp16 MFMA passes on the hi/lo halves of the fp32 operands, exp epilogue, guard
+//                    band (tier 1: on the list in the default mode, on everything with HAF_FLAG_SPLIT_F16)
+//   k_svm_rbf        the same as one fp32 MFMA pass (HAF_FLAG_FP32_MFMA)
+//   k_recheck_x / k_recheck_mfma / k_recheck_combine   guard-band evaluations again as an fp64 MFMA contraction (tier 2)
 //   k_recheck        what is still within 2^-40 of zero, in libsvm's exact fp64 summation order (tier 3)
 //   k_vote_cells / k_vote_pick   show_predicted_gps 865-932 (29-tap vote, first-wins argmax, longest-run centring) and the
 //                    z window of transform_gp_in_wcs_and_publish 1342-1351
