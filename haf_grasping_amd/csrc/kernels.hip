@@ -560,16 +560,20 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
 // loads, no divergence), a small request (a few thousand evals) still fills the chip, and a single evaluation is
 // never one long serial chain of 324 attributes.
 constexpr int kFeatEvals = 64;
-template <int MODE>
-__global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
+// kFeatWaves = 8 or 16 waves per workgroup, each taking the attribute groups w, w + kFeatWaves, ...: 16 halves the serial
+// chain of a thread (a few thousand evaluations, the refinement list), 8 keeps more evaluations resident when there are
+// enough of them to fill the chip.
+template <int MODE, int kFeatWaves>
+__global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
                                                   const int *__restrict__ idx_list, int list_counter, int list_cap)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
-    __shared__ double red[8][kFeatEvals];
-    __shared__ double red2[(MODE == XMODE_SCREEN) ? 8 : 1][kFeatEvals];
+    constexpr int kFeatFinisher = (kAugS / 8) % kFeatWaves;   // the wave that holds group 40 (screening form: norm slots) sums up
+    __shared__ double red[kFeatWaves][kFeatEvals];
+    __shared__ double red2[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
     const unsigned w0 = live ? window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W) : 0u;
     double xx = 0.0, sd2 = 0.0;
     half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int g = gl; g < n_groups; g += 8) {
+    for (int g = gl; g < n_groups; g += kFeatWaves) {
         if (MODE == XMODE_SCREEN && g > kAugS / 8) break;              // group 41 holds norm slots only
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -620,19 +624,19 @@ __global__ __launch_bounds__(512) void k_features(const float *__restrict__ ii, 
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
         if (MODE == XMODE_SCREEN) {
             if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
-            else g40 = hi;                                             // wave 0 keeps group 40 until the norms are known
+            else g40 = hi;                                             // wave kFeatFinisher keeps group 40 until the norms are known
         }
     }
     red[gl][ev] = xx;
     if (MODE == XMODE_SCREEN) red2[gl][ev] = sd2;
     __syncthreads();
-    if (gl == 0) {
+    if (gl == kFeatFinisher) {
         double t = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) t += red[k][ev];                  // fixed order: deterministic
+        for (int k = 0; k < kFeatWaves; k++) t += red[k][ev];         // fixed order: deterministic
         if (MODE == XMODE_SCREEN) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) t2 += red2[k][ev];
+            for (int k = 0; k < kFeatWaves; k++) t2 += red2[k][ev];
             half8 g41;
             float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (live) screen_finish(t, t2, sp, g40, g41, band);
@@ -663,8 +667,12 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
     }
     long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
     if (idx_list && blocks > 4096) blocks = 4096;                      // grid-stride inside the kernel
-    hipLaunchKernelGGL(k_features<MODE>, dim3((unsigned)blocks), dim3(512), 0, s, ii, evalcell, counters, fd, X, ax, d, lower,
-                       upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
+    if (idx_list || max_evals <= 24576)
+        hipLaunchKernelGGL((k_features<MODE, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
+    else
+        hipLaunchKernelGGL((k_features<MODE, 8>), dim3((unsigned)blocks), dim3(8 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
 }
 
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
