@@ -23,6 +23,7 @@
 // written with explicit *_rn intrinsics as well; fma() is used only where a fused operation is intended.
 #include "kernels.h"
 #include "decq.h"
+#include <string.h>
 
 namespace haf {
 
@@ -90,10 +91,62 @@ __global__ __launch_bounds__(256) void k_bin(const CloudDev *__restrict__ clouds
     }
 }
 
+// Small grids (the reference's 56 x 56: 12.5 KB of keys): a dense cloud puts dozens of points into every cell, and one
+// global atomicMax per point and roll is all contention.  Here a workgroup bins a chunk of kBinChunk points of one
+// (cloud, roll) into a private copy of the grid in LDS (ds_max_i32) and then publishes only the cells it touched, one
+// global atomicMax each.  max is order independent: the grid is the same as k_bin's.
+constexpr int kBinChunk = 2048;
+constexpr int kBinLdsCells = 16384;              // 64 KiB of LDS: grids up to 128 x 128
+
+__global__ __launch_bounds__(256) void k_bin_lds(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
+                                                 int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty)
+{
+    extern __shared__ int cells[];
+    const int br = blockIdx.y;
+    const int b = br / d.R;
+    const CloudDev c = clouds[b];
+    const int first = blockIdx.x * kBinChunk;
+    if (first >= c.n) return;
+    const int HW = d.H * d.W;
+    for (int k = threadIdx.x; k < HW; k += 256) cells[k] = key_empty;
+    __syncthreads();
+    const RollGeo &g = geo[br];
+    const int last = min(c.n, first + kBinChunk);
+    for (int i = first + threadIdx.x; i < last; i += 256) {
+        const float *p = c.xyz + (size_t)i * c.stride;
+        const float x = p[0], y = p[1], z = p[2];
+        // pcl::transformPointCloud (488): fp32, left to right, unfused
+        float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
+        float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
+        float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
+        if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
+            int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row)));                   // 513
+            int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col)));                   // 514
+            if (ix >= 0 && ix < d.H && iy >= 0 && iy < d.W) atomicMax(&cells[ix * d.W + iy], f2key(pz));
+        }
+    }
+    __syncthreads();
+    int *out = hkeys + (size_t)br * HW;
+    for (int k = threadIdx.x; k < HW; k += 256) {
+        const int v = cells[k];
+        if (v > key_empty && v > out[k]) atomicMax(&out[k], v);    // stale read is safe: the cell only grows
+    }
+}
+
 void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkeys, Dims d, float r_row, float r_col,
                 hipStream_t s)
 {
     if (max_n <= 0) return;
+    const int HW = d.H * d.W;
+    if (HW <= kBinLdsCells && max_n >= 4 * kBinChunk) {
+        float minus_one = -1.0f;
+        int key_empty;
+        memcpy(&key_empty, &minus_one, 4);
+        key_empty ^= 0x7FFFFFFF;                                     // ordered key of -1.0f: what the grid is filled with
+        dim3 grid((max_n + kBinChunk - 1) / kBinChunk, d.B * d.R);
+        hipLaunchKernelGGL(k_bin_lds, grid, dim3(256), (size_t)HW * sizeof(int), s, clouds, geo, hkeys, d, r_row, r_col, key_empty);
+        return;
+    }
     dim3 grid((max_n + 255) / 256, d.B * d.R);
     hipLaunchKernelGGL(k_bin, grid, dim3(256), 0, s, clouds, geo, hkeys, d, r_row, r_col);
 }
