@@ -554,3 +554,30 @@ def test_screening_pass_alone_is_accurate_and_stable(data_dir, surrogate, orc, m
         else:
             assert (decs.view(np.uint64) == first.view(np.uint64)).all(), launch
     eng.close()
+
+
+@pytest.mark.parametrize("nsv,modes", [(512, (capi.FLAG_SPLIT_F16, 0, capi.FLAG_FP32_MFMA)), (4096, (capi.FLAG_SPLIT_F16, 0))])
+def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path, nsv, modes):
+    """All three contraction modes claim libsvm's labels (each tier decides only outside a rigorous error band).  At BASELINE
+    config C5 (7.9 M evaluations) the label grids of the screening mode, the three-pass mode and the fp32 mode must be
+    identical cell for cell, for a model whose decision values crowd around zero -- a hole in a band would show up here as
+    a handful of differing cells out of millions."""
+    path = str(tmp_path / ("rand%d.model" % nsv))
+    models.write_random_model(path, nsv, seed=7, balanced=True)
+    xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
+    inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
+    ref_labels, ref_rec, counts = None, None, {}
+    for mode in modes:
+        eng = make_engine(data_dir, path, mode, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+        rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
+        counts[mode] = eng.last_counts()
+        labels = np.stack([eng.debug(capi.DBG_LABELS, 0, roll) for roll in range(36)])
+        eng.close()
+        if ref_labels is None:
+            ref_labels, ref_rec = labels, rec
+            assert (labels == 1).sum() > 100000 and (labels == -1).sum() > 100000
+        else:
+            assert int((labels != ref_labels).sum()) == 0, (mode, int((labels != ref_labels).sum()))
+            assert (rec == ref_rec).all(), mode
+    assert 0 < counts[0]["n_refined"] < 0.2 * counts[0]["n_evals"]          # the screening pass was really in charge
+    STATS["c5_nsv%d_tiers" % nsv] = {str(k): v for k, v in counts.items()}
