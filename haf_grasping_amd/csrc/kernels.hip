@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void k_bin(const CloudDev *__restrict__ clouds
     const int b = br / d.R;
     const CloudDev c = clouds[b];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c.n) return;
-    const float *p = c.xyz + (size_t)i * c.stride;
+    if ((int)blockIdx.x * 256 >= c.n) return;                        // whole workgroup past the cloud
+    const bool valid = i < c.n;                                      // every lane stays for the shuffle below
+    const float *p = c.xyz + (size_t)(valid ? i : 0) * c.stride;
     const float x = p[0], y = p[1], z = p[2];
     const int HW = d.H * d.W;
     const RollGeo &g = geo[br];
@@ -80,14 +81,19 @@ __global__ __launch_bounds__(256) void k_bin(const CloudDev *__restrict__ clouds
     float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
     float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
     float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
-    if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
+    int ci = -1, key = 0;
+    if (valid && (px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
         int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row)));                   // 513
         int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col)));                   // 514
-        if (ix >= 0 && ix < d.H && iy >= 0 && iy < d.W) {
-            int *cell = hkeys + (size_t)br * HW + ix * d.W + iy;
-            int key = f2key(pz);
-            if (key > *cell) atomicMax(cell, key);   // stale read is safe: the cell only grows
-        }
+        if (ix >= 0 && ix < d.H && iy >= 0 && iy < d.W) { ci = ix * d.W + iy; key = f2key(pz); }
+    }
+    // neighbouring points of a cloud mostly share a cell: of two adjacent lanes on the same cell only the higher one (the
+    // odd lane on a tie) goes to memory
+    const int ci_o = __shfl_xor(ci, 1, 64), key_o = __shfl_xor(key, 1, 64);
+    const bool beaten = (ci_o == ci) && (key_o > key || (key_o == key && (threadIdx.x & 1) == 0));
+    if (ci >= 0 && !beaten) {
+        int *cell = hkeys + (size_t)br * HW + ci;
+        if (key > *cell) atomicMax(cell, key);   // stale read is safe: the cell only grows
     }
 }
 
