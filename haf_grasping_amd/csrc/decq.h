@@ -273,6 +273,30 @@ HAF_HD double decq4_float(float v, const Tabs &tb)
 }
 HAF_HD double decq4_float(float v) { return decq4_float(v, GlobalTabs()); }
 
+// Branch-free form for the screening pass (kernels.hip: attribute_value_screen): the same digits N as decq4_float for
+// 1e-9 <= |v| < 1e4 and for v == 0, with N * RN(10^-k) in place of the correctly rounded quotient (2^-52 relative, which the
+// screening band carries); anything else clears `ok` and the caller never trusts that evaluation.
+template <class Tabs>
+HAF_HD double decq4_float_fast(float v, const Tabs &tb, bool &ok)
+{
+    const double x = (double)v;
+    const double a = fabs(x);
+    const bool nz = !(a == 0.0);                                   // NaN counts as non-zero and fails `fin`
+    const bool fin = a < INFINITY;
+    const int b = ilogb((nz && fin) ? a : 1.0);
+    int e0 = (b * 1233) >> 12;
+    const bool inr = nz && fin && e0 >= -9 && e0 <= 3;
+    e0 = e0 < -9 ? -9 : (e0 > 3 ? 3 : e0);
+    const int e = e0 + ((a >= tb.bnd(e0 + 1)) ? 1 : 0);
+    const int k = 3 - e;                                           // -1 .. 12
+    const int kc = k < 0 ? 0 : k;
+    const double t = a * tb.p10(kc);                               // exact (float x 10^k, k <= 12)
+    const double r = rint(t) * tb.p10inv(kc);
+    ok = ok && (!nz || (inr && k >= 0 && t >= 1e3 && t < 1e4));
+    const double q = nz ? r : 0.0;
+    return x < 0.0 ? -q : q;
+}
+
 // svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed; range = fmax - fmin
 // and inv_range = RN(1/range) are per-attribute constants.  Returns the attribute value svm-predict parses
 // (0.0 when the attribute is omitted from the text).

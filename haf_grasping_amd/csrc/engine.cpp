@@ -1199,6 +1199,14 @@ double haf_test_split3(double a, float *parts)
     return rep;
 }
 
+double haf_test_decq4_fast(float v, int *ok)
+{
+    bool b = true;
+    const double r = hafq::decq4_float_fast(v, hafq::GlobalTabs(), b);
+    *ok = b ? 1 : 0;
+    return r;
+}
+
 int haf_test_decq_device(const double *in, double *out, int n, int digits)
 {
     double *di = nullptr, *dout = nullptr;

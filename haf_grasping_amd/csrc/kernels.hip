@@ -393,10 +393,10 @@ constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6);
 constexpr double kScreenEtaAbs = 1e-12;
 template <bool UNI, class Tabs>
 __device__ __forceinline__ double attribute_value_screen(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper,
-                                                         const Tabs &tb)
+                                                         const Tabs &tb, bool &ok)
 {
     const float v = feature_value<UNI>(ii, w0b, f);
-    const double q4 = hafq::decq4_float(v, tb);
+    const double q4 = hafq::decq4_float_fast(v, tb, ok);            // clears ok outside 1e-9 <= |v| < 1e4
     return lower + ((upper - lower) * (q4 - f.fmin)) * f.inv_range;
 }
 
@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
         double sd2 = 0.0;
+        bool ok = true;                                   // false: an attribute outside the fast decimal path's range
         half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0}, g41;
         for (int g = 0; g <= kAugS / 8; g++) {           // groups 0..40: attribute slots 0..327, of which 0..323 are attributes
             half8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 double xd = 0.0;
                 if (f < d.nf && f < kAugS) {
                     const FeatDesc &F = fd[f];
-                    if (!F.skip) xd = attribute_value_screen<true>(iir, w0, F, lower, upper, tb);
+                    if (!F.skip) xd = attribute_value_screen<true>(iir, w0, F, lower, upper, tb, ok);
                 }
                 hi[q] = screen_operand(xd, sp.c, xx, sd2);
             }
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             else g40 = hi;
         }
         float band[kBandFloats];
+        if (!ok) xx = __builtin_nan("");                  // NaN norms make every band NaN: the evaluation is never trusted
         screen_finish(xx, sd2, sp, g40, g41, band);
         *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
         store_group_img(xtile, r, 40, g40);
@@ -652,6 +654,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const rsrc_t iir = make_ii_rsrc(ii, d);
     const unsigned w0 = live ? window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W) : 0u;
     double xx = 0.0, sd2 = 0.0;
+    bool ok = true;
     half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         if (MODE == XMODE_SCREEN && g > kAugS / 8) break;              // group 41 holds norm slots only
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             double xd = 0.0;
             if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? attribute_value_screen<true>(iir, w0, F, lower, upper, tb)
+                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? attribute_value_screen<true>(iir, w0, F, lower, upper, tb, ok)
                                                          : attribute_value<true>(iir, w0, F, lower, upper, tb);
             }
             const float xf = (float)xd;
@@ -686,6 +689,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             else g40 = hi;                                             // wave kFeatFinisher keeps group 40 until the norms are known
         }
     }
+    if (MODE == XMODE_SCREEN && !ok) xx = __builtin_nan("");          // see k_features_serial
     red[gl][ev] = xx;
     if (MODE == XMODE_SCREEN) red2[gl][ev] = sd2;
     __syncthreads();
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
             acc[r] = __builtin_amdgcn_exp2f(fmaf(p.two_gamma2, acc[r], axr[r] + as_));   // -g2*(|x|^2 + |s|^2 - 2 x.s)
 #pragma unroll
         for (int r = 0; r < 16; r++) asm volatile("" : "+v"(acc[r]));
+        asm volatile("s_nop 7\n\ts_nop 7");                          // the last exp gets 16 wait states before any consumer
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             part[r] = fmaf(cf, acc[r], part[r]);
@@ -1145,6 +1150,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) asm volatile("" : "+v"(acc[m][n][r]));
+        asm volatile("s_nop 7\n\ts_nop 7");                          // the last exp gets 16 wait states before any consumer
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         for (int m = 0; m < 4; m++)                                  // keeps hipcc from sinking each exp next to its use
 #pragma unroll
             for (int r = 0; r < 4; r++) asm volatile("" : "+v"(acc1[m][r]));
+        asm volatile("s_nop 7\n\ts_nop 7");                          // the last exp gets 16 wait states before any consumer
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 4; m++)

@@ -321,3 +321,29 @@ def test_screening_band_host_pieces():
         assert abs(rep - a) <= 2.0 ** -25 + 2.0 ** -33 * abs(a), (a, rep)
         for v in parts:                                     # every part is an fp16 value, none of them subnormal
             assert float(np.float16(v)) == float(v) and (v == 0 or abs(v) >= 2.0 ** -14)
+
+
+def test_fast_decimal_path_of_the_screening_features():
+    """decq4_float_fast (branch-free, screening pass only): inside 1e-9 <= |v| < 1e4 and at 0 it picks the same four digits
+    as the exact "%.4g" round trip -- the result differs by the rounding of one multiplication at most -- and says so; outside
+    it clears `ok`, which makes the feature kernel distrust the whole evaluation."""
+    L = capi.lib()
+    rng = np.random.RandomState(11)
+    vals = np.concatenate([rng.standard_normal(20000) * s for s in (1e-8, 1e-5, 1e-2, 1.0, 30.0, 3e3)] +
+                          [np.array([0.0, -0.0, 999.95, 9999.5, 1e-9, 0.12345, 0.12355, 2.5e-7, 9999.4999])]).astype(np.float32)
+    ok = C.c_int()
+    n_in = 0
+    for v in vals:
+        v = float(v)
+        got = L.haf_test_decq4_fast(v, C.byref(ok))
+        want = float("%.4g" % v)
+        inside = (v == 0.0) or (1e-9 <= abs(v) < 9999.5)
+        if ok.value:
+            n_in += 1
+            assert abs(got - want) <= 2.3e-16 * abs(want), (v, got, want)
+        else:
+            assert not inside or abs(v) < 1.87e-9, (v, got, want)   # gives up outside the range (its exponent estimate starts at 2^-29)
+    assert n_in > 0.9 * len(vals)
+    for v in (1e-12, 1e5, float("inf"), float("nan"), 3e38):
+        L.haf_test_decq4_fast(v, C.byref(ok))
+        assert ok.value == 0, v
