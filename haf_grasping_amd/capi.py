@@ -97,8 +97,8 @@ def lib():
         L.haf_test_scale_host.argtypes = [C.c_double] * 5
         L.haf_test_sigma_upper.restype = C.c_double
         L.haf_test_sigma_upper.argtypes = [C.c_void_p, C.c_int, C.c_int]
-        L.haf_test_decq4_fast.restype = C.c_double
-        L.haf_test_decq4_fast.argtypes = [C.c_float, C.POINTER(C.c_int)]
+        L.haf_test_decq4_scr.restype = C.c_double
+        L.haf_test_decq4_scr.argtypes = [C.c_float]
         L.haf_test_split3.restype = C.c_double
         L.haf_test_split3.argtypes = [C.c_double, C.c_void_p]
         L.haf_test_decq_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]

@@ -273,28 +273,60 @@ HAF_HD double decq4_float(float v, const Tabs &tb)
 }
 HAF_HD double decq4_float(float v) { return decq4_float(v, GlobalTabs()); }
 
-// Branch-free form for the screening pass (kernels.hip: attribute_value_screen): the same digits N as decq4_float for
-// 1e-9 <= |v| < 1e4 and for v == 0, with N * RN(10^-k) in place of the correctly rounded quotient (2^-52 relative, which the
-// screening band carries); anything else clears `ok` and the caller never trusts that evaluation.
-template <class Tabs>
-HAF_HD double decq4_float_fast(float v, const Tabs &tb, bool &ok)
+// ---- "%.4g" of an fp32 value for the SCREENING pass (kernels.hip: screening features) ----------------------------
+// Table-driven and branch-free: the fp32 exponent byte E picks {thr, i0} from a 256-entry table, where thr is the smallest
+// float >= 10^(e0+1) (e0 = floor((E-127) log10 2); floor(log10 |v|) is e0 or e0+1, decided exactly by |v| >= thr) and i0
+// the slot of k = 3 - e0 in a table of {10^k, RN(10^-k)} pairs; the digits are N = rint(|v| 10^k), exact for k <= 12 as in
+// decq4_float, and the result N * RN(10^-k) stands in for the correctly rounded quotient (2^-52 relative, carried by the
+// screening band).  Supported: v == 0 and 1e-9 <= |v| < 1e4.  Everything else (and Inf/NaN) lands on a NaN pair and
+// returns NaN, which poisons the norms of that evaluation, so it is never trusted; fp32 subnormals return 0 (an absolute
+// error below 1.2e-38).
+#define HAFQ_THR10_LIST                                                                                            \
+    0x1.12e0c0p-30f, 0x1.5798f0p-27f, 0x1.ad7f2ap-24f, 0x1.0c6f7cp-20f, 0x1.4f8b5ap-17f, 0x1.a36e30p-14f,          \
+        0x1.0624dep-10f, 0x1.47ae16p-7f, 0x1.99999ap-4f, 0x1.0p+0f, 0x1.4p+3f, 0x1.9p+6f, 0x1.f4p+9f, 0x1.388p+13f
+static const float kThr10_host[14] = {HAFQ_THR10_LIST};      // smallest float >= 10^e, e = -9..4 (exact rationals)
+#if defined(__HIP__)
+__device__ static const float kThr10_dev[14] = {HAFQ_THR10_LIST};
+#endif
+constexpr int kScrExpEntries = 256, kScrPairs = 15;
+constexpr int kScrTabWords = kScrExpEntries + 2 * kScrPairs;   // 8-byte words: [0,256) exponent entries, then 15 pairs
+
+HAF_HD unsigned long long scr_tab_word(int i)                  // the 8-byte word the screening tables hold at index i
 {
-    const double x = (double)v;
-    const double a = fabs(x);
-    const bool nz = !(a == 0.0);                                   // NaN counts as non-zero and fails `fin`
-    const bool fin = a < INFINITY;
-    const int b = ilogb((nz && fin) ? a : 1.0);
-    int e0 = (b * 1233) >> 12;
-    const bool inr = nz && fin && e0 >= -9 && e0 <= 3;
-    e0 = e0 < -9 ? -9 : (e0 > 3 ? 3 : e0);
-    const int e = e0 + ((a >= tb.bnd(e0 + 1)) ? 1 : 0);
-    const int k = 3 - e;                                           // -1 .. 12
-    const int kc = k < 0 ? 0 : k;
-    const double t = a * tb.p10(kc);                               // exact (float x 10^k, k <= 12)
-    const double r = rint(t) * tb.p10inv(kc);
-    ok = ok && (!nz || (inr && k >= 0 && t >= 1e3 && t < 1e4));
-    const double q = nz ? r : 0.0;
-    return x < 0.0 ? -q : q;
+    const unsigned nan32 = 0x7fc00000u;
+    if (i >= kScrExpEntries) {                                 // pair slot s <-> k = s - 1; slots 0 and 14 are NaN
+        const int s = (i - kScrExpEntries) >> 1, k = s - 1;
+        double v = __builtin_nan("");
+        if (k >= 0 && k <= 12) v = ((i - kScrExpEntries) & 1) ? pow10_inv(k) : pow10_exact(k);
+        return __builtin_bit_cast(unsigned long long, v);
+    }
+    if (i == 0) return ((unsigned long long)1 << 32) | nan32;  // zero and subnormals: k = 0, never a carry
+    const int e0 = ((i - 127) * 1233) >> 12;
+    const int i0 = 4 - e0;
+    if (i0 < 1) return nan32;                                   // |v| >= 1e4 (and Inf/NaN): slot 0
+    if (i0 > 14) return ((unsigned long long)14 << 32) | nan32; // |v| < 1e-10: slot 14
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float thr = kThr10_dev[e0 + 10];
+#else
+    const float thr = kThr10_host[e0 + 10];
+#endif
+    return ((unsigned long long)i0 << 32) | __builtin_bit_cast(unsigned, thr);
+}
+
+struct ScrTabs {
+    const unsigned long long *w;                               // kScrTabWords words (LDS on the device)
+};
+HAF_HD double decq4_float_scr(float v, const ScrTabs &st)
+{
+    const unsigned bits = __builtin_bit_cast(unsigned, v);
+    const unsigned long long ent = st.w[(bits >> 23) & 0xffu];
+    const float a = __builtin_bit_cast(float, bits & 0x7fffffffu);
+    const float thr = __builtin_bit_cast(float, (unsigned)ent);
+    const int s = (int)(ent >> 32) - ((a >= thr) ? 1 : 0);
+    const double *pr = reinterpret_cast<const double *>(st.w + kScrExpEntries) + 2 * s;
+    const double q = rint((double)a * pr[0]) * pr[1];
+    const unsigned long long qb = __builtin_bit_cast(unsigned long long, q) | ((unsigned long long)(bits & 0x80000000u) << 32);
+    return __builtin_bit_cast(double, qb);
 }
 
 // svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed; range = fmax - fmin

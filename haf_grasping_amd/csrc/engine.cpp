@@ -220,6 +220,7 @@ struct haf_engine {
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
     DevBuf<FeatDesc> d_fd;
+    DevBuf<ScrDesc> d_sd;
 
     // pinned host staging
     CloudDev *h_clouds = nullptr;
@@ -426,6 +427,46 @@ int build_tables(haf_engine *e)
         // the bounds the per-evaluation guard band needs are taken over the model here (ScreenParams)
         ScreenParams &sp = e->screen;
         sp.c = std::sqrt(2.0 * m.gamma * log2e);
+        {
+            // screening attribute u' = fma(q4 - fmin, scr_mul, scr_add) (kernels.hip: screen_attribute).  Against c*x' in exact
+            // arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's range), amplified by
+            // scr_mul when q4 and fmin cancel, and by three fp64 roundings; the norm over the attributes is eta_abs.
+            std::vector<FeatDesc> fd2((size_t)e->nf);
+            HIPCHK(e, hipMemcpy(fd2.data(), e->d_fd.p, fd2.size() * sizeof(FeatDesc), hipMemcpyDeviceToHost));
+            std::vector<ScrDesc> sd((size_t)kScrGroups * 8);
+            memset(sd.data(), 0, sd.size() * sizeof(ScrDesc));
+            double ea2 = 0.0;
+            sp.fast_groups = 0;
+            for (int g = 0; g < kScrGroups; g++) {
+                bool fast = true;
+                for (int q = 0; q < 8; q++) {
+                    const int f = g * 8 + q;
+                    if (f >= e->nf || f >= kAugS) continue;
+                    FeatDesc &d = fd2[(size_t)f];
+                    ScrDesc &s = sd[(size_t)f];
+                    if (!d.skip) {
+                        d.scr_mul = sp.c * (e->range.upper - e->range.lower) * d.inv_range;
+                        d.scr_add = sp.c * e->range.lower;
+                        // x2: svm-scale's own fp64 roundings of the same expression
+                        const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin)) + 4.5e-16 * std::fabs(d.scr_add));
+                        ea2 += ef * ef;
+                    }
+                    if (d.shaf || (d.active & ~3)) fast = false;
+                    for (int k = 0; k < 2; k++) {
+                        s.w[k] = d.w[k];
+                        for (int j = 0; j < 4; j++) s.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
+                    }
+                    s.fmin = d.fmin; s.scr_mul = d.scr_mul; s.scr_add = d.scr_add;
+                }
+                if (fast) sp.fast_groups |= 1ull << g;
+            }
+            if (getenv("HAF_NO_FAST_GROUPS")) sp.fast_groups = 0;        // A/B runs and the generic-path test
+            sp.eta_abs = std::max(std::sqrt(ea2) * 1.01, 1e-12 * 18.0 * sp.c);
+            HIPCHK(e, hipMemcpy(e->d_fd.p, fd2.data(), fd2.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
+            if (hipSuccess != e->d_sd.alloc(sd.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
+            HIPCHK(e, hipMemcpy(e->d_sd.p, sd.data(), sd.size() * sizeof(ScrDesc), hipMemcpyHostToDevice));
+            sp.sd = e->d_sd.p;
+        }
         sp.v_max = sp.dv_max = sp.das_max = sp.as_max = 0.0;
         std::vector<char> img((size_t)e->n_sv_tiles * kS0SvTileBytes, 0);
         for (int n = 0; n < m.n_sv; n++) {
@@ -579,7 +620,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_ii.alloc(B * R * (H + 1) * (W + 1));
     ok &= hipSuccess == e->d_mask.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rowcount.alloc(B * R * H);
-    ok &= hipSuccess == e->d_rowoff.alloc(B * R * H + 1);
+    ok &= hipSuccess == e->d_rowoff.alloc(2 * (B * R * H + 1));      // whole-chunk and left-over starts (k_scan)
     ok &= hipSuccess == e->d_brcount.alloc(B * R);
     ok &= hipSuccess == e->d_counters.alloc(CNT_COUNT);
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
@@ -828,7 +869,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     mark(e, HAF_ST_MASK);
     launch_mask_count(e->d_ii.p, e->d_geo.p, e->d_mask.p, e->d_rowcount.p, d, s);
     launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
-    launch_compact(e->d_mask.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
+    launch_compact(e->d_mask.p, e->d_rowcount.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
     auto decide = [&](int mode) -> int {
         mark(e, HAF_ST_FEATURES);
@@ -1199,12 +1240,17 @@ double haf_test_split3(double a, float *parts)
     return rep;
 }
 
-double haf_test_decq4_fast(float v, int *ok)
+double haf_test_decq4_scr(float v)
 {
-    bool b = true;
-    const double r = hafq::decq4_float_fast(v, hafq::GlobalTabs(), b);
-    *ok = b ? 1 : 0;
-    return r;
+    static unsigned long long tab[hafq::kScrTabWords];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < hafq::kScrTabWords; i++) tab[i] = hafq::scr_tab_word(i);
+        init = true;
+    }
+    hafq::ScrTabs st;
+    st.w = tab;
+    return hafq::decq4_float_scr(v, st);
 }
 
 int haf_test_decq_device(const double *in, double *out, int n, int digits)

@@ -87,7 +87,23 @@ struct ScreenParams {
     double sigma_dv;              // the same for the matrix of the v^_n - v_n
     double sqrt_cmax;             // sqrt(max_n |coef_n|)
     double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
+    double eta_abs;               // |u' - u| beyond the relative part: fp64 roundings of the screening attribute formula (norm)
+    const struct ScrDesc *sd;     // kScrGroups * 8 compact descriptors (device) for the two-region groups
+    unsigned long long fast_groups;   // bit g: every attribute of group g is a plain HAF feature of at most two regions
 };
+// Compact descriptor of one attribute slot for the screening feature pass: 64 bytes, one s_load_dwordx16.  A slot without a
+// feature (beyond the feature file, norm slots) is all zero and evaluates to exactly 0.
+struct ScrDesc {
+    int    off[8];                // BYTE offsets of the corners of regions 0 and 1 (A-B-C+D each) from the window origin, in
+                                  // the LDS band of a wave (kBandPitch floats per row, kernels.hip: screen_quad)
+    float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
+    double fmin;                  // svm-scale's feature_min
+    double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
+    double scr_add;               // c * lower                                    (0 likewise)
+};
+static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
+constexpr int kScrGroups = 41;
+constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded    // attribute slots 0..327 in groups of 8
 // per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
 //   |dec^ - dec| <= min(gA * sqrt(S), gC * S) + (guard_acc0 + gB) * S + cm * (|dec^| + |rho|) + guard_abs,  S = sum|coef|K
 // with {gA, gB, gC, cm} per evaluation
@@ -118,6 +134,7 @@ struct FeatDesc {
     int   pad;
     double fmin, fmax;
     double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
+    double scr_mul, scr_add;      // screening pass (ScrDesc below): u' = fma(q4 - fmin, scr_mul, scr_add)
 };
 
 struct Dims {
@@ -164,7 +181,7 @@ void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkey
 void launch_integral(int *hkeys_heights, double *rowsum, float *ii, Dims d, hipStream_t s);
 void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s);
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
-void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
+void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
 // operand image the feature kernels write
 enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2 };
 // idx_list == nullptr: evaluations 0..counters[CNT_EVALS]; otherwise slot j takes evaluation idx_list[j],

@@ -265,33 +265,49 @@ void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *
     hipLaunchKernelGGL(k_mask_count, dim3(d.H, d.B * d.R), dim3(64), 0, s, ii, geo, mask, rowcount, d);
 }
 
-// exclusive scan of the per-row counts (n = B*R*H entries), single workgroup
+// Evaluation order.  The evaluations of a grid row are its masked cells from left to right, cut into chunks of 64: the
+// whole chunks of all rows come first (region A, row by row), the left-over chunks (fewer than 64 cells) of all rows follow
+// (region B).  A wave of the feature kernel takes 64 consecutive evaluations, so in region A it nearly always holds 64
+// neighbouring cells of one row -- the case its LDS window band is made for (k_features_serial) -- and only region B and rows
+// with holes fall back to per-lane addressing.  Nothing downstream depends on the order: labels, decision values and votes
+// are written per cell through evalcell.
+// Exclusive scans of the per-row counts (n = B*R*H entries), single workgroup: rowoff[k] = start of row k's whole chunks,
+// rowoff[n + 1 + k] = start of its left-over chunk.
 __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ rowcount, int *__restrict__ rowoff,
                                                int *__restrict__ brcount, int *__restrict__ counters, Dims d)
 {
-    __shared__ int part[1024];
+    __shared__ unsigned long long part[1024];            // (whole-chunk cells << 32) | left-over cells
     const int n = d.B * d.R * d.H;
     const int t = threadIdx.x;
     const int chunk = (n + 1023) / 1024;
     const int lo = t * chunk, hi = min(n, lo + chunk);
-    int s = 0;
-    for (int k = lo; k < hi; k++) s += rowcount[k];
+    unsigned long long s = 0;
+    for (int k = lo; k < hi; k++) {
+        const unsigned c = (unsigned)rowcount[k];
+        s += ((unsigned long long)(c & ~63u) << 32) | (c & 63u);
+    }
     part[t] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        int v = (t >= o) ? part[t - o] : 0;
+        unsigned long long v = (t >= o) ? part[t - o] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    int run = part[t] - s;
-    for (int k = lo; k < hi; k++) { rowoff[k] = run; run += rowcount[k]; }
-    if (t == 1023) { rowoff[n] = part[1023]; counters[CNT_EVALS] = part[1023]; }
-    __syncthreads();
+    const unsigned long long tot = part[1023];
+    const int total_a = (int)(tot >> 32), total = total_a + (int)(tot & 0xffffffffu);
+    unsigned long long run = part[t] - s;
+    for (int k = lo; k < hi; k++) {
+        const unsigned c = (unsigned)rowcount[k];
+        rowoff[k] = (int)(run >> 32);
+        rowoff[n + 1 + k] = total_a + (int)(run & 0xffffffffu);
+        run += ((unsigned long long)(c & ~63u) << 32) | (c & 63u);
+    }
+    if (t == 1023) { rowoff[n] = total_a; counters[CNT_EVALS] = total; }
     for (int br = t; br < d.B * d.R; br += 1024) {
-        int e0 = rowoff[br * d.H];
-        int e1 = (br + 1 == d.B * d.R) ? part[1023] : rowoff[(br + 1) * d.H];
-        brcount[br] = e1 - e0;
+        int c = 0;
+        for (int i = 0; i < d.H; i++) c += rowcount[br * d.H + i];
+        brcount[br] = c;
     }
 }
 
@@ -300,28 +316,30 @@ void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, 
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, rowcount, rowoff, brcount, counters, d);
 }
 
-__global__ __launch_bounds__(64) void k_compact(const uint8_t *__restrict__ mask, const int *__restrict__ rowoff,
-                                                int *__restrict__ evalcell, Dims d)
+__global__ __launch_bounds__(64) void k_compact(const uint8_t *__restrict__ mask, const int *__restrict__ rowcount,
+                                                const int *__restrict__ rowoff, int *__restrict__ evalcell, Dims d)
 {
     const int i = blockIdx.x, br = blockIdx.y, lane = threadIdx.x;
-    const int H = d.H, W = d.W;
+    const int H = d.H, W = d.W, n = d.B * d.R * H;
     const uint8_t *mrow = mask + ((size_t)br * H + i) * W;
-    int base = rowoff[br * H + i];
+    const int whole = rowcount[br * H + i] & ~63;
+    const int base_a = rowoff[br * H + i], base_b = rowoff[n + 1 + br * H + i] - whole;
+    int done = 0;
     for (int j0 = 0; j0 < W; j0 += 64) {
         int j = j0 + lane;
         bool m = (j < W) && mrow[j];
         unsigned long long bal = __ballot(m);
         if (m) {
-            int pre = __popcll(bal & ((1ull << lane) - 1ull));
-            evalcell[base + pre] = (br * H + i) * W + j;
+            const int rank = done + __popcll(bal & ((1ull << lane) - 1ull));
+            evalcell[(rank < whole ? base_a : base_b) + rank] = (br * H + i) * W + j;
         }
-        base += __popcll(bal);
+        done += __popcll(bal);
     }
 }
 
-void launch_compact(const uint8_t *mask, const int *rowoff, int *evalcell, Dims d, hipStream_t s)
+void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_compact, dim3(d.H, d.B * d.R), dim3(64), 0, s, mask, rowoff, evalcell, d);
+    hipLaunchKernelGGL(k_compact, dim3(d.H, d.B * d.R), dim3(64), 0, s, mask, rowcount, rowoff, evalcell, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -384,20 +402,70 @@ __device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper, tb);
 }
 
-// Attribute value for the SCREENING pass only: the "%.4g" round trip exactly, svm-scale's formula in plain fp64, and NO
-// "%g" round trip.  The value svm-predict would parse, x, differs from the result x' by at most 5e-6 |x'| + 1e-12 (six
-// significant decimal digits: half a unit of the sixth digit is <= 5e-6 relative; the fp64 roundings of the formula, the
-// exact-zero omission and the min/max shortcuts are inside the 1e-12).  screen_finish() carries that difference through
-// the guard band; evaluations the screening pass cannot decide get the exact attributes in the three-pass tier.
+// Attribute for the SCREENING pass only, already multiplied by c (kernels.h: ScreenParams): the "%.4g" round trip through the
+// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (one subtraction,
+// one fma), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
+// |u' - u| <= 5e-6 |u'| (six significant decimal digits: half a unit of the sixth digit is <= 5e-6 relative) plus, in norm over
+// the attributes, ScreenParams::eta_abs (engine.cpp: the fp64 roundings of both evaluations of the formula, the exact-zero
+// omission and the min/max shortcuts).  screen_finish() carries that difference through the guard band; evaluations the
+// screening pass cannot decide get the exact attributes in the three-pass tier.  An fp32 feature outside the decimal
+// path's range comes back NaN and poisons the norms: that evaluation is never trusted.
 constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6);
-constexpr double kScreenEtaAbs = 1e-12;
-template <bool UNI, class Tabs>
-__device__ __forceinline__ double attribute_value_screen(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper,
-                                                         const Tabs &tb, bool &ok)
+template <bool UNI>
+__device__ __forceinline__ double screen_attribute(rsrc_t ii, unsigned w0b, const FeatDesc &f, const hafq::ScrTabs &st)
 {
     const float v = feature_value<UNI>(ii, w0b, f);
-    const double q4 = hafq::decq4_float_fast(v, tb, ok);            // clears ok outside 1e-9 <= |v| < 1e4
-    return lower + ((upper - lower) * (q4 - f.fmin)) * f.inv_range;
+    return fma(hafq::decq4_float_scr(v, st) - f.fmin, f.scr_mul, f.scr_add);
+}
+
+// ---- the fast form of the screening feature pass ------------------------------------------------------------------
+// What bounds the per-lane form (buffer loads at window origin + corner offset) is the vector L1: the texture addresser
+// coalesces 16 lanes at a time, 64 consecutive floats at an arbitrary alignment cost ~7.5 tag accesses per load, and with
+// ~2400 loads per evaluation the TA is 97 % busy (profiles/README.md).  So a wave whose 64 evaluations are 64 neighbouring
+// cells of one row (k_scan's order makes that the rule) first copies the band of the integral image its windows cover --
+// 15 rows x 78 columns -- into LDS, and then reads every corner with ds_read_addtid_b32: LDS address = M0 + lane * 4, M0 =
+// band + corner offset from the wave-uniform descriptor, so a corner costs two scalar instructions and one conflict-free
+// LDS read, no vector address arithmetic, no L1 traffic.
+constexpr int kBandRows = 15;
+constexpr int kBandFloats4 = kBandRows * kBandPitch;  // per wave
+
+// Four attribute slots of a "fast" group (ScreenParams::fast_groups: plain HAF features of at most two regions): the 32
+// corner reads go out back to back before anything waits on them, and nothing branches.  An inactive region has weight 0
+// and its corners at the window origin: it adds 0.0f * 0.0f, which leaves the sum of fv.cpp:164 as it is.
+// hipcc does not know that the asm reads are asynchronous: the registers are handed on only through the s_waitcnt statement.
+// The descriptors are read through the constant address space: the memory clobbers around the band would otherwise make
+// hipcc fetch every wave-uniform descriptor word with a vector load.
+typedef const ScrDesc __attribute__((address_space(4))) *ScrDescK;
+__device__ __forceinline__ ScrDescK constant_ptr(const ScrDesc *p) { return (ScrDescK)(unsigned long long)p; }
+
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud)
+{
+    float c[4][8];
+    unsigned adr[4][8];                               // all descriptor words first: a volatile asm pins what follows it
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) adr[q][j] = band + (unsigned)sd[q].off[j];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned a = adr[q][j];
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_read_addtid_b32 %0" : "=v"(c[q][j]) : "s"(a) : "m0");
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[0][4]), "+v"(c[0][5]), "+v"(c[0][6]), "+v"(c[0][7]));
+#pragma unroll
+    for (int q = 1; q < 4; q++)
+        asm volatile("" : "+v"(c[q][0]), "+v"(c[q][1]), "+v"(c[q][2]), "+v"(c[q][3]), "+v"(c[q][4]), "+v"(c[q][5]), "+v"(c[q][6]),
+                          "+v"(c[q][7]));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float r0 = __fmul_rn(sd[q].w[0], __fadd_rn(__fsub_rn(__fsub_rn(c[q][0], c[q][1]), c[q][2]), c[q][3]));
+        const float r1 = __fmul_rn(sd[q].w[1], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4], c[q][5]), c[q][6]), c[q][7]));
+        const float v = __fadd_rn(r0, r1);      // 0.0f + r0 first (fv.cpp:164) only turns a -0 into +0: same decimal, same u'
+        ud[q] = fma(hafq::decq4_float_scr(v, st) - sd[q].fmin, sd[q].scr_mul, sd[q].scr_add);
+    }
 }
 
 // the decimal tables (95 doubles) in LDS: call from every thread of the workgroup before any divergent return
@@ -408,6 +476,17 @@ __device__ __forceinline__ hafq::PtrTabs load_decimal_tables(double *lds_tab)
     hafq::PtrTabs tb;
     tb.t = lds_tab;
     return tb;
+}
+
+// the screening decimal tables (decq.h: 256 exponent entries + 15 pairs, 2288 bytes) in LDS; workgroups of >= 256 threads
+__device__ __forceinline__ hafq::ScrTabs load_screen_tables(unsigned long long *lds_tab)
+{
+    if (threadIdx.x < hafq::kScrExpEntries) lds_tab[threadIdx.x] = hafq::scr_tab_word((int)threadIdx.x);
+    if (threadIdx.x < 2 * hafq::kScrPairs) lds_tab[hafq::kScrExpEntries + threadIdx.x] = hafq::scr_tab_word(hafq::kScrExpEntries + (int)threadIdx.x);
+    __syncthreads();
+    hafq::ScrTabs st;
+    st.w = lds_tab;
+    return st;
 }
 
 // BYTE offset of the 15x15 window origin II[i-7][j-7] of a cell id (br*H + i)*W + j inside the integral-image buffer
@@ -446,11 +525,10 @@ __device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 h
     store_group_img(xtile + kHMatBytes, r, g, lo);
 }
 
-// screening operand of one attribute: u' = c*x' in fp64 (x' from attribute_value_screen), u^ = fp16(u') with subnormals
+// screening operand of one attribute: u' in fp64 (screen_attribute / screen_quad), u^ = fp16(u') with subnormals
 // flushed; accumulates |u'|^2 and |u^ - u'|^2, the two norms the guard band of the screening pass is made of
-__device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &su2, double &sd2)
+__device__ __forceinline__ _Float16 screen_operand(double ud, double &su2, double &sd2)
 {
-    const double ud = xd * c;
     _Float16 h = (_Float16)(float)ud;
     if (fabsf((float)h) < kF16MinNormal) h = (_Float16)0.0f;
     const double du = (double)(float)h - ud;
@@ -460,7 +538,7 @@ __device__ __forceinline__ _Float16 screen_operand(double xd, double c, double &
 }
 
 // norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band.  u' = c x' is what the
-// feature kernel has (attribute_value_screen), u = c x the true operand: |u' - u| <= eta := 5e-6 |u'| + tiny, component-wise
+// feature kernel has (screen_attribute), u = c x the true operand: |u' - u| <= eta := 5e-6 |u'| + tiny, component-wise
 // and therefore in norm.  With e_n the error of the exp2 argument of SV n,
 //   dec^ + rho = 2^D * sum_n c_n K_n 2^e_n,
 //   e_n = (u^-u).v^_n + u.(v^_n - v_n) + [what the fp16 split of -|v_n|^2/2 misses + fp32 accumulation in the matrix core],
@@ -504,7 +582,7 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, const Scre
     g40[7] = s3[0];
     g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
     const double un1 = sqrt_upper(su2), dn1 = sqrt_upper(sd2);
-    const double eta = kScreenEtaRel * un1 + kScreenEtaAbs * 18.0 * sp.c;      // |u' - u| (18 = sqrt(324) components)
+    const double eta = kScreenEtaRel * un1 + sp.eta_abs;                        // |u' - u|
     const double un = un1 + eta, dn = dn1 + eta;                                // |u|, |u^ - u|
     const double ln2 = 0.69314718056;
     const double d_max = dn * sp.v_max + (un + dn) * sp.dv_max;
@@ -535,11 +613,41 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if ((long)blockIdx.x * 256 >= n_pad) return;
-    __shared__ double s_tab[hafq::kTabDoubles];
-    const hafq::PtrTabs tb = load_decimal_tables(s_tab);
+    __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
+    __shared__ unsigned long long s_scr[MODE == XMODE_SCREEN ? hafq::kScrTabWords : 1];
+    hafq::PtrTabs tb{};
+    hafq::ScrTabs st{};
+    if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
+    else tb = load_decimal_tables(s_tab);
     float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
     const int r = (int)(e & 31);
+    // screening form: is this wave 64 neighbouring cells of one row?  (cell ids are row-major and a masked cell is never in
+    // the first or last 7 columns, so consecutive ids are neighbours in one row)
+    __shared__ float s_band[MODE == XMODE_SCREEN ? (256 / 64) * kBandFloats4 : 1];
+    bool fastwave = false;
+    unsigned band = 0;
+    if (MODE == XMODE_SCREEN && !idx_list) {
+        const int lane = threadIdx.x & 63;
+        const int cell = (e < n_evals) ? evalcell[e] : -1;
+        const int cell0 = __builtin_amdgcn_readfirstlane(cell);
+        fastwave = __ballot(cell >= 0 && cell == cell0 + lane) == ~0ull;
+        if (fastwave) {
+            const rsrc_t iir0 = make_ii_rsrc(ii, d);
+            const unsigned w0l = window_origin(cell, d.H, d.W);            // this lane's window origin
+            float *bw = s_band + (threadIdx.x >> 6) * kBandFloats4;
+            const int ldb = (d.W + 1) * 4;
+#pragma unroll
+            for (int x = 0; x < kBandRows; x++) {
+                bw[x * kBandPitch + lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir0, (int)w0l, x * ldb, 0));
+                if (lane < 14)
+                    bw[x * kBandPitch + 64 + lane] =
+                        __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir0, (int)w0l, x * ldb + 256, 0));
+            }
+            band = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)bw);
+            asm volatile("" :: "v"(bw) : "memory");       // the band is read by asm only: keep its stores, and keep them here
+        }
+    }
     if (e >= n_evals) {                       // padding rows of the last block: zeros
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         if (MODE == XMODE_SPLIT) {
@@ -558,25 +666,30 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
         double sd2 = 0.0;
-        bool ok = true;                                   // false: an attribute outside the fast decimal path's range
         half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0}, g41;
         for (int g = 0; g <= kAugS / 8; g++) {           // groups 0..40: attribute slots 0..327, of which 0..323 are attributes
-            half8 hi = {0, 0, 0, 0, 0, 0, 0, 0};
+            double ud[8];
+            if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
+                screen_quad(band, constant_ptr(sp.sd) + g * 8, st, ud);
+                screen_quad(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int f = g * 8 + q;
-                double xd = 0.0;
-                if (f < d.nf && f < kAugS) {
-                    const FeatDesc &F = fd[f];
-                    if (!F.skip) xd = attribute_value_screen<true>(iir, w0, F, lower, upper, tb, ok);
+                for (int q = 0; q < 8; q++) {
+                    const int f = g * 8 + q;
+                    ud[q] = 0.0;
+                    if (f < d.nf && f < kAugS) {
+                        const FeatDesc &F = fd[f];
+                        if (!F.skip) ud[q] = screen_attribute<true>(iir, w0, F, st);
+                    }
                 }
-                hi[q] = screen_operand(xd, sp.c, xx, sd2);
             }
+            half8 hi;
+#pragma unroll
+            for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], xx, sd2);
             if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
             else g40 = hi;
         }
         float band[kBandFloats];
-        if (!ok) xx = __builtin_nan("");                  // NaN norms make every band NaN: the evaluation is never trusted
         screen_finish(xx, sd2, sp, g40, g41, band);
         *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
         store_group_img(xtile, r, 40, g40);
@@ -638,8 +751,12 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
-    __shared__ double s_tab[hafq::kTabDoubles];
-    const hafq::PtrTabs tb = load_decimal_tables(s_tab);
+    __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
+    __shared__ unsigned long long s_scr[MODE == XMODE_SCREEN ? hafq::kScrTabWords : 1];
+    hafq::PtrTabs tb{};
+    hafq::ScrTabs st{};
+    if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
+    else tb = load_decimal_tables(s_tab);
     const int ev = threadIdx.x & 63, gl = threadIdx.x >> 6;
     // grid-stride over blocks of 64 evaluations: a list launch is sized for a few thousand workgroups, not for the list's
     // capacity (tens of thousands of workgroups that would only find out that there is nothing for them)
@@ -654,7 +771,6 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const rsrc_t iir = make_ii_rsrc(ii, d);
     const unsigned w0 = live ? window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W) : 0u;
     double xx = 0.0, sd2 = 0.0;
-    bool ok = true;
     half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         if (MODE == XMODE_SCREEN && g > kAugS / 8) break;              // group 41 holds norm slots only
@@ -665,12 +781,12 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             double xd = 0.0;
             if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? attribute_value_screen<true>(iir, w0, F, lower, upper, tb, ok)
+                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? screen_attribute<true>(iir, w0, F, st)     // u' = c x', not x'
                                                          : attribute_value<true>(iir, w0, F, lower, upper, tb);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
-                hi[q] = screen_operand(xd, sp.c, xx, sd2);
+                hi[q] = screen_operand(xd, xx, sd2);
             } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -689,7 +805,6 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             else g40 = hi;                                             // wave kFeatFinisher keeps group 40 until the norms are known
         }
     }
-    if (MODE == XMODE_SCREEN && !ok) xx = __builtin_nan("");          // see k_features_serial
     red[gl][ev] = xx;
     if (MODE == XMODE_SCREEN) red2[gl][ev] = sd2;
     __syncthreads();

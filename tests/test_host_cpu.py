@@ -324,26 +324,33 @@ def test_screening_band_host_pieces():
 
 
 def test_fast_decimal_path_of_the_screening_features():
-    """decq4_float_fast (branch-free, screening pass only): inside 1e-9 <= |v| < 1e4 and at 0 it picks the same four digits
-    as the exact "%.4g" round trip -- the result differs by the rounding of one multiplication at most -- and says so; outside
-    it clears `ok`, which makes the feature kernel distrust the whole evaluation."""
+    """decq4_float_scr (table-driven, branch-free, screening pass only): for v == 0 and 1e-9 <= |v| < 1e4 it picks the same four
+    digits as the exact "%.4g" round trip -- the result differs by the rounding of one multiplication at most; everything else
+    comes back NaN (which makes the feature kernel distrust the whole evaluation), fp32 subnormals come back 0."""
     L = capi.lib()
     rng = np.random.RandomState(11)
+    edge = []
+    for e in range(-10, 6):                                   # both sides of every power of ten and of every rounding carry
+        for m in (1.0, 9.9995, 9.99949, 9.99951, 1.0005, 1.00049, 5.0):
+            x = np.float32(m * 10.0 ** e)
+            edge += [x, np.nextafter(x, np.float32(0)), np.nextafter(x, np.float32(np.inf))]
     vals = np.concatenate([rng.standard_normal(20000) * s for s in (1e-8, 1e-5, 1e-2, 1.0, 30.0, 3e3)] +
-                          [np.array([0.0, -0.0, 999.95, 9999.5, 1e-9, 0.12345, 0.12355, 2.5e-7, 9999.4999])]).astype(np.float32)
-    ok = C.c_int()
+                          [np.array([0.0, -0.0, 999.95, 9999.5, 1e-9, 0.12345, 0.12355, 2.5e-7, 9999.4999]), np.array(edge)]
+                          ).astype(np.float32)
+    vals = np.concatenate([vals, -vals])
     n_in = 0
     for v in vals:
         v = float(v)
-        got = L.haf_test_decq4_fast(v, C.byref(ok))
+        got = L.haf_test_decq4_scr(v)
         want = float("%.4g" % v)
-        inside = (v == 0.0) or (1e-9 <= abs(v) < 9999.5)
-        if ok.value:
+        inside = (v == 0.0) or (1e-9 <= abs(v) < 1e4)
+        if inside:
             n_in += 1
             assert abs(got - want) <= 2.3e-16 * abs(want), (v, got, want)
+            assert np.signbit(got) == np.signbit(want), (v, got, want)
         else:
-            assert not inside or abs(v) < 1.87e-9, (v, got, want)   # gives up outside the range (its exponent estimate starts at 2^-29)
+            assert np.isnan(got) or (abs(v) < 1.2e-38 and got == 0.0), (v, got, want)
     assert n_in > 0.9 * len(vals)
-    for v in (1e-12, 1e5, float("inf"), float("nan"), 3e38):
-        L.haf_test_decq4_fast(v, C.byref(ok))
-        assert ok.value == 0, v
+    for v in (1e-12, 1e5, float("inf"), float("-inf"), float("nan"), 3e38, 1e4, 10000.001):
+        assert np.isnan(L.haf_test_decq4_scr(v)), v
+    assert L.haf_test_decq4_scr(1e-40) == 0.0
