@@ -324,9 +324,7 @@ HAF_HD double decq4_float_scr(float v, const ScrTabs &st)
     const float thr = __builtin_bit_cast(float, (unsigned)ent);
     const int s = (int)(ent >> 32) - ((a >= thr) ? 1 : 0);
     const double *pr = reinterpret_cast<const double *>(st.w + kScrExpEntries) + 2 * s;
-    const double q = rint((double)a * pr[0]) * pr[1];
-    const unsigned long long qb = __builtin_bit_cast(unsigned long long, q) | ((unsigned long long)(bits & 0x80000000u) << 32);
-    return __builtin_bit_cast(double, qb);
+    return rint((double)v * pr[0]) * pr[1];          // round-half-even is symmetric: the sign (of a zero too) rides along
 }
 
 // svm-scale output() (svm-scale.c:333-353) + "%g" round trip.  q4 is the value svm-scale parsed; range = fmax - fmin

@@ -221,6 +221,7 @@ struct haf_engine {
     DevBuf<unsigned long long> d_topkey;
     DevBuf<FeatDesc> d_fd;
     DevBuf<ScrDesc> d_sd;
+    DevBuf<ScrDesc3> d_sd3;
 
     // pinned host staging
     CloudDev *h_clouds = nullptr;
@@ -428,13 +429,16 @@ int build_tables(haf_engine *e)
         ScreenParams &sp = e->screen;
         sp.c = std::sqrt(2.0 * m.gamma * log2e);
         {
-            // screening attribute u' = fma(q4 - fmin, scr_mul, scr_add) (kernels.hip: screen_attribute).  Against c*x' in exact
-            // arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's range), amplified by
-            // scr_mul when q4 and fmin cancel, and by three fp64 roundings; the norm over the attributes is eta_abs.
+            // screening attribute u' = fma(q4, scr_mul, scr_add), scr_add = c*lower - fmin*scr_mul (kernels.hip: screen_attribute).
+            // Against c*x' in exact arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's
+            // range) and the rounding of scr_add, both amplified by scr_mul when q4 and fmin cancel, and by the roundings of
+            // scr_mul and of the fma; the norm over the attributes is eta_abs.
             std::vector<FeatDesc> fd2((size_t)e->nf);
             HIPCHK(e, hipMemcpy(fd2.data(), e->d_fd.p, fd2.size() * sizeof(FeatDesc), hipMemcpyDeviceToHost));
             std::vector<ScrDesc> sd((size_t)kScrGroups * 8);
             memset(sd.data(), 0, sd.size() * sizeof(ScrDesc));
+            std::vector<ScrDesc3> sd3((size_t)kScrGroups * 8);
+            memset(sd3.data(), 0, sd3.size() * sizeof(ScrDesc3));
             double ea2 = 0.0;
             sp.fast_groups = 0;
             for (int g = 0; g < kScrGroups; g++) {
@@ -446,9 +450,9 @@ int build_tables(haf_engine *e)
                     ScrDesc &s = sd[(size_t)f];
                     if (!d.skip) {
                         d.scr_mul = sp.c * (e->range.upper - e->range.lower) * d.inv_range;
-                        d.scr_add = sp.c * e->range.lower;
+                        d.scr_add = std::fma(-d.fmin, d.scr_mul, sp.c * e->range.lower);
                         // x2: svm-scale's own fp64 roundings of the same expression
-                        const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin)) + 4.5e-16 * std::fabs(d.scr_add));
+                        const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin)) + 4.5e-16 * std::fabs(sp.c * e->range.lower));
                         ea2 += ef * ef;
                     }
                     if (d.shaf || (d.active & ~3)) fast = false;
@@ -456,7 +460,14 @@ int build_tables(haf_engine *e)
                         s.w[k] = d.w[k];
                         for (int j = 0; j < 4; j++) s.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
-                    s.fmin = d.fmin; s.scr_mul = d.scr_mul; s.scr_add = d.scr_add;
+                    s.scr_mul = d.scr_mul; s.scr_add = d.scr_add;
+                    ScrDesc3 &s3 = sd3[(size_t)f];
+                    for (int k = 0; k < 3; k++) {
+                        s3.w[k] = d.w[k];
+                        for (int j = 0; j < 4; j++) s3.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
+                    }
+                    s3.shaf = d.shaf;
+                    s3.scr_mul = d.scr_mul; s3.scr_add = d.scr_add;
                 }
                 if (fast) sp.fast_groups |= 1ull << g;
             }
@@ -466,6 +477,9 @@ int build_tables(haf_engine *e)
             if (hipSuccess != e->d_sd.alloc(sd.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
             HIPCHK(e, hipMemcpy(e->d_sd.p, sd.data(), sd.size() * sizeof(ScrDesc), hipMemcpyHostToDevice));
             sp.sd = e->d_sd.p;
+            if (hipSuccess != e->d_sd3.alloc(sd3.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
+            HIPCHK(e, hipMemcpy(e->d_sd3.p, sd3.data(), sd3.size() * sizeof(ScrDesc3), hipMemcpyHostToDevice));
+            sp.sd3 = e->d_sd3.p;
         }
         sp.v_max = sp.dv_max = sp.das_max = sp.as_max = 0.0;
         std::vector<char> img((size_t)e->n_sv_tiles * kS0SvTileBytes, 0);

@@ -89,6 +89,7 @@ struct ScreenParams {
     double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
     double eta_abs;               // |u' - u| beyond the relative part: fp64 roundings of the screening attribute formula (norm)
     const struct ScrDesc *sd;     // kScrGroups * 8 compact descriptors (device) for the two-region groups
+    const struct ScrDesc3 *sd3;   // kScrGroups * 8 general descriptors (device)
     unsigned long long fast_groups;   // bit g: every attribute of group g is a plain HAF feature of at most two regions
 };
 // Compact descriptor of one attribute slot for the screening feature pass: 64 bytes, one s_load_dwordx16.  A slot without a
@@ -97,11 +98,20 @@ struct ScrDesc {
     int    off[8];                // BYTE offsets of the corners of regions 0 and 1 (A-B-C+D each) from the window origin, in
                                   // the LDS band of a wave (kBandPitch floats per row, kernels.hip: screen_quad)
     float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
-    double fmin;                  // svm-scale's feature_min
     double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
-    double scr_add;               // c * lower                                    (0 likewise)
+    double scr_add;               // c * lower - fmin * scr_mul                   (0 likewise):  u' = fma(q4, scr_mul, scr_add)
+    double pad;
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
+// The same for any feature (three regions, HAF or SHAF rule): the groups that are not in ScreenParams::fast_groups
+struct ScrDesc3 {
+    int    off[12];               // band BYTE offsets of the corners of regions 0..2
+    float  w[3];
+    int    shaf;                  // fv.cpp:187-191 instead of the weighted sum
+    double scr_mul, scr_add;
+    double pad[2];
+};
+static_assert(sizeof(ScrDesc3) == 96, "ScrDesc3 layout");
 constexpr int kScrGroups = 41;
 constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded    // attribute slots 0..327 in groups of 8
 // per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
@@ -134,7 +144,7 @@ struct FeatDesc {
     int   pad;
     double fmin, fmax;
     double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
-    double scr_mul, scr_add;      // screening pass (ScrDesc below): u' = fma(q4 - fmin, scr_mul, scr_add)
+    double scr_mul, scr_add;      // screening pass (ScrDesc below): u' = fma(q4, scr_mul, scr_add)
 };
 
 struct Dims {

@@ -403,8 +403,7 @@ __device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const
 }
 
 // Attribute for the SCREENING pass only, already multiplied by c (kernels.h: ScreenParams): the "%.4g" round trip through the
-// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (one subtraction,
-// one fma), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
+// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (one fma), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
 // |u' - u| <= 5e-6 |u'| (six significant decimal digits: half a unit of the sixth digit is <= 5e-6 relative) plus, in norm over
 // the attributes, ScreenParams::eta_abs (engine.cpp: the fp64 roundings of both evaluations of the formula, the exact-zero
 // omission and the min/max shortcuts).  screen_finish() carries that difference through the guard band; evaluations the
@@ -415,7 +414,7 @@ template <bool UNI>
 __device__ __forceinline__ double screen_attribute(rsrc_t ii, unsigned w0b, const FeatDesc &f, const hafq::ScrTabs &st)
 {
     const float v = feature_value<UNI>(ii, w0b, f);
-    return fma(hafq::decq4_float_scr(v, st) - f.fmin, f.scr_mul, f.scr_add);
+    return fma(hafq::decq4_float_scr(v, st), f.scr_mul, f.scr_add);
 }
 
 // ---- the fast form of the screening feature pass ------------------------------------------------------------------
@@ -464,7 +463,53 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         const float r0 = __fmul_rn(sd[q].w[0], __fadd_rn(__fsub_rn(__fsub_rn(c[q][0], c[q][1]), c[q][2]), c[q][3]));
         const float r1 = __fmul_rn(sd[q].w[1], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4], c[q][5]), c[q][6]), c[q][7]));
         const float v = __fadd_rn(r0, r1);      // 0.0f + r0 first (fv.cpp:164) only turns a -0 into +0: same decimal, same u'
-        ud[q] = fma(hafq::decq4_float_scr(v, st) - sd[q].fmin, sd[q].scr_mul, sd[q].scr_add);
+        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
+    }
+}
+
+// Two attribute slots of any other group, from the band: three regions each, the HAF sum or the SHAF rule (feature_value).
+// A slot of a dropped or absent attribute has scr_mul = scr_add = 0: its u' is 0 (NaN if its feature value left the decimal
+// path's range, which only costs that evaluation the screening pass).
+typedef const ScrDesc3 __attribute__((address_space(4))) *ScrDesc3K;
+__device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (ScrDesc3K)(unsigned long long)p; }
+
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud)
+{
+    float c[2][12];
+    unsigned adr[2][12];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int j = 0; j < 12; j++) adr[q][j] = band + (unsigned)sd[q].off[j];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const unsigned a = adr[q][j];
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_read_addtid_b32 %0" : "=v"(c[q][j]) : "s"(a) : "m0");
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[0][4]), "+v"(c[0][5]), "+v"(c[0][6]), "+v"(c[0][7]),
+                   "+v"(c[0][8]), "+v"(c[0][9]), "+v"(c[0][10]), "+v"(c[0][11]));
+    asm volatile("" : "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]), "+v"(c[1][4]), "+v"(c[1][5]), "+v"(c[1][6]), "+v"(c[1][7]),
+                      "+v"(c[1][8]), "+v"(c[1][9]), "+v"(c[1][10]), "+v"(c[1][11]));
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            r[k] = __fmul_rn(sd[q].w[k], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4 * k], c[q][4 * k + 1]), c[q][4 * k + 2]), c[q][4 * k + 3]));
+        float v;
+        if (sd[q].shaf) {                                              // wave-uniform
+            v = -1.0f;
+            if (r[1] > r[0] && r[1] > r[2]) {                          // fv.cpp:187-191
+                const float a = __fsub_rn(r[1], r[0]), b = __fsub_rn(r[1], r[2]);
+                v = (b < a) ? b : a;
+            }
+        } else {
+            v = __fadd_rn(__fadd_rn(r[0], r[1]), r[2]);
+        }
+        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
     }
 }
 
@@ -672,6 +717,9 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
                 screen_quad(band, constant_ptr(sp.sd) + g * 8, st, ud);
                 screen_quad(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4);
+            } else if (fastwave) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) screen_pair3(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q);
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {

@@ -261,6 +261,22 @@ def test_generalised_grid_and_rolls(data_dir, surrogate, orc, mode):
     eng.close()
 
 
+def test_screening_feature_paths_agree_with_the_oracle(data_dir, surrogate, orc, monkeypatch):
+    """The screening feature kernel has three routes to an attribute: waves of 64 neighbouring cells read an LDS band of the
+    integral image, two-region HAF groups through screen_quad and every other group through screen_pair3; all other waves
+    address per lane.  A 96-wide area gives rows of 82 cells (one whole 64-chunk + a left-over each, so both wave kinds
+    occur); HAF_NO_FAST_GROUPS sends every group through screen_pair3.  Stage by stage against the oracle both times."""
+    xyz = models.synthetic_cloud(grid=96, k=2, seed=11)
+    for env in (None, "1"):
+        if env: monkeypatch.setenv("HAF_NO_FAST_GROUPS", env)
+        eng = make_engine(data_dir, surrogate, 0, grid_h=96, grid_w=96, n_rolls=4, roll_step_deg=45)
+        compare_full(eng, orc, xyz, dict(n_rolls=4, roll_step_deg=45, grid_h=96, grid_w=96),
+                     dict(grasp_area_length_x=96, grasp_area_length_y=96))
+        c = eng.last_counts()
+        assert c["n_evals"] > 4 * 40 * 40
+        eng.close()
+
+
 def test_edge_inputs(data_dir, surrogate, orc):
     eng = make_engine(data_dir, surrogate)
     inp = dict(grasp_area_length_x=32, grasp_area_length_y=32)
