@@ -340,6 +340,7 @@ int build_tables(haf_engine *e)
             d.off[k][1] = x1 * ld + (y2 + 1);
             d.off[k][2] = (x2 + 1) * ld + y1;
             d.off[k][3] = x1 * ld + y1;
+            for (int j = 0; j < 4; j++) d.offw[k][j] = (d.off[k][j] / ld) * 15 + d.off[k][j] % ld;
         }
         const int idx = f + 1;
         if (idx <= e->range.max_index && e->range.present[(size_t)idx]) {

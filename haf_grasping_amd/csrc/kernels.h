@@ -137,6 +137,7 @@ struct RollGeo {
 // one HAF/SHAF feature (fv.cpp:141-199) with its svm-scale range (svm-scale.c:333-353)
 struct FeatDesc {
     int   off[3][4];              // II offsets of the 4 corners of region k relative to the window origin: A-B-C+D
+    int   offw[3][4];             // the same inside a 15x15 copy of the window (row pitch 15)
     float w[3];                   // region weights; the 4th region's weight is always 0 in the reference (CHaarFeature.cpp:56-60)
     int   active;                 // bit k: region k survives the skip rule (fv.cpp:155-159)
     int   shaf;                   // feature index >= nr_features_without_shaf

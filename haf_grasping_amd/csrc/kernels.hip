@@ -303,11 +303,11 @@ __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ rowcount,
         rowoff[n + 1 + k] = total_a + (int)(run & 0xffffffffu);
         run += ((unsigned long long)(c & ~63u) << 32) | (c & 63u);
     }
-    if (t == 1023) { rowoff[n] = total_a; counters[CNT_EVALS] = total; }
-    for (int br = t; br < d.B * d.R; br += 1024) {
-        int c = 0;
-        for (int i = 0; i < d.H; i++) c += rowcount[br * d.H + i];
-        brcount[br] = c;
+    if (t == 1023) { rowoff[n] = total_a; rowoff[2 * n + 1] = total; counters[CNT_EVALS] = total; }
+    __syncthreads();
+    for (int br = t; br < d.B * d.R; br += 1024) {       // cells of (cloud, roll) br: difference of the two prefixes, summed
+        const int k0 = br * d.H, k1 = k0 + d.H;
+        brcount[br] = (rowoff[k1] - rowoff[k0]) + (rowoff[n + 1 + k1] - rowoff[n + 1 + k0]);
     }
 }
 
@@ -363,28 +363,42 @@ __device__ __forceinline__ float ii_load(rsrc_t r, unsigned w0b, int off)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(w0b + (unsigned)off * 4u), 0, 0));
 }
 
+// Where the corners of a feature's regions come from: the integral image through the buffer descriptor (corner offset in
+// an SGPR when the feature is wave-uniform, UNI, else folded into the VGPR), or a copy of the evaluation's 15x15 window in
+// LDS (k_features).  Same values, same arithmetic.
 template <bool UNI>
-__device__ __forceinline__ float region_sum(rsrc_t ii, unsigned w0b, const int *off)
+struct SrcBuf {
+    rsrc_t r;
+    unsigned w0b;
+    __device__ __forceinline__ float corner(const FeatDesc &f, int k, int j) const { return ii_load<UNI>(r, w0b, f.off[k][j]); }
+};
+struct SrcWin {
+    const float *win;             // this lane's window, row pitch 15
+    __device__ __forceinline__ float corner(const FeatDesc &f, int k, int j) const { return win[f.offw[k][j]]; }
+};
+
+template <class Src>
+__device__ __forceinline__ float region_sum(const Src &src, const FeatDesc &f, int k)
 {
-    float s = __fsub_rn(ii_load<UNI>(ii, w0b, off[0]), ii_load<UNI>(ii, w0b, off[1]));
-    s = __fsub_rn(s, ii_load<UNI>(ii, w0b, off[2]));
-    return __fadd_rn(s, ii_load<UNI>(ii, w0b, off[3]));                  // fv.cpp:161-162 / 183-184
+    float s = __fsub_rn(src.corner(f, k, 0), src.corner(f, k, 1));
+    s = __fsub_rn(s, src.corner(f, k, 2));
+    return __fadd_rn(s, src.corner(f, k, 3));                            // fv.cpp:161-162 / 183-184
 }
 
-template <bool UNI>
-__device__ __forceinline__ float feature_value(rsrc_t ii, unsigned w0b, const FeatDesc &f)
+template <class Src>
+__device__ __forceinline__ float feature_value(const Src &src, const FeatDesc &f)
 {
     if (!f.shaf) {
         float rv = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            if (f.active & (1 << k)) rv = __fadd_rn(rv, __fmul_rn(f.w[k], region_sum<UNI>(ii, w0b, f.off[k])));
+            if (f.active & (1 << k)) rv = __fadd_rn(rv, __fmul_rn(f.w[k], region_sum(src, f, k)));
         return rv;
     }
     float r[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        if (f.active & (1 << k)) r[k] = __fmul_rn(f.w[k], region_sum<UNI>(ii, w0b, f.off[k]));
+        if (f.active & (1 << k)) r[k] = __fmul_rn(f.w[k], region_sum(src, f, k));
     if (r[1] > r[0] && r[1] > r[2]) {                                    // fv.cpp:187-191
         float a = __fsub_rn(r[1], r[0]), b = __fsub_rn(r[1], r[2]);
         return (b < a) ? b : a;
@@ -393,11 +407,10 @@ __device__ __forceinline__ float feature_value(rsrc_t ii, unsigned w0b, const Fe
 }
 
 // fp32 feature -> attribute value svm-predict would parse (both decimal text round trips emulated exactly)
-template <bool UNI, class Tabs>
-__device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const FeatDesc &f, double lower, double upper,
-                                                  const Tabs &tb)
+template <class Src, class Tabs>
+__device__ __forceinline__ double attribute_value(const Src &src, const FeatDesc &f, double lower, double upper, const Tabs &tb)
 {
-    float v = feature_value<UNI>(ii, w0b, f);
+    float v = feature_value(src, f);
     double q4 = hafq::decq4_float(v, tb);
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper, tb);
 }
@@ -410,10 +423,10 @@ __device__ __forceinline__ double attribute_value(rsrc_t ii, unsigned w0b, const
 // screening pass cannot decide get the exact attributes in the three-pass tier.  An fp32 feature outside the decimal
 // path's range comes back NaN and poisons the norms: that evaluation is never trusted.
 constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6);
-template <bool UNI>
-__device__ __forceinline__ double screen_attribute(rsrc_t ii, unsigned w0b, const FeatDesc &f, const hafq::ScrTabs &st)
+template <class Src>
+__device__ __forceinline__ double screen_attribute(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st)
 {
-    const float v = feature_value<UNI>(ii, w0b, f);
+    const float v = feature_value(src, f);
     return fma(hafq::decq4_float_scr(v, st), f.scr_mul, f.scr_add);
 }
 
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                     ud[q] = 0.0;
                     if (f < d.nf && f < kAugS) {
                         const FeatDesc &F = fd[f];
-                        if (!F.skip) ud[q] = screen_attribute<true>(iir, w0, F, st);
+                        if (!F.skip) ud[q] = screen_attribute(SrcBuf<true>{iir, w0}, F, st);
                     }
                 }
             }
@@ -753,7 +766,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 float xf = 0.0f;
                 if (f < d.nf) {
                     const FeatDesc &F = fd[f];
-                    if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper, tb);
+                    if (!F.skip) xf = (float)attribute_value(SrcBuf<true>{iir, w0}, F, lower, upper, tb);
                 }
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -768,7 +781,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         for (int f = 0; f < d.nf; f++) {
             const FeatDesc &F = fd[f];
             float xf = 0.0f;
-            if (!F.skip) xf = (float)attribute_value<true>(iir, w0, F, lower, upper, tb);
+            if (!F.skip) xf = (float)attribute_value(SrcBuf<true>{iir, w0}, F, lower, upper, tb);
             xcol[f * kTile] = xf;
             xx = fma((double)xf, (double)xf, xx);
         }
@@ -782,6 +795,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
 // loads, no divergence), a small request (a few thousand evals) still fills the chip, and a single evaluation is
 // never one long serial chain of 324 attributes.
 constexpr int kFeatEvals = 64;
+constexpr int kWinPitch = 225;        // floats per staged window (15 x 15); odd, so the 64 lanes of a read hit 32 banks twice over
 // kFeatWaves = 8 or 16 waves per workgroup, each taking the attribute groups w, w + kFeatWaves, ...: 16 halves the serial
 // chain of a thread (a few thousand evaluations, the refinement list), 8 keeps more evaluations resident when there are
 // enough of them to fill the chip.
@@ -795,6 +809,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     constexpr int kFeatFinisher = (kAugS / 8) % kFeatWaves;   // the wave that holds group 40 (screening form: norm slots) sums up
     __shared__ double red[kFeatWaves][kFeatEvals];
+    __shared__ float s_win[kFeatEvals * kWinPitch];
+    __shared__ unsigned s_w0[kFeatEvals];
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
@@ -818,6 +834,20 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
     const unsigned w0 = live ? window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W) : 0u;
+    // The 15x15 windows of the block's 64 evaluations go to LDS first (every wave works on the same 64): the evaluations of
+    // a list are scattered cells, so a corner load of 64 lanes is 64 separate L1 accesses, ~2700 times per evaluation and
+    // wave group -- the vector L1 was what bounded this kernel.  Staged, a window row is one or two accesses, once.
+    if (gl == 0) s_w0[ev] = live ? w0 : 0xffffffffu;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kFeatEvals * 15 * 16; idx += kFeatWaves * 64) {
+        const int col = idx & 15, seg = idx >> 4, wev = seg & (kFeatEvals - 1), x = seg >> 6;      // 16 lanes = one window row
+        const unsigned o = s_w0[wev];
+        if (col < 15)
+            s_win[wev * kWinPitch + x * 15 + col] =
+                (o != 0xffffffffu) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, (int)(o + (unsigned)(x * (d.W + 1) + col) * 4u), 0, 0)) : 0.0f;
+    }
+    __syncthreads();
+    const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0, sd2 = 0.0;
     half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = gl; g < n_groups; g += kFeatWaves) {
@@ -829,8 +859,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             double xd = 0.0;
             if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? screen_attribute<true>(iir, w0, F, st)     // u' = c x', not x'
-                                                         : attribute_value<true>(iir, w0, F, lower, upper, tb);
+                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? screen_attribute(src, F, st)               // u' = c x', not x'
+                                                         : attribute_value(src, F, lower, upper, tb);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
@@ -1421,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
             const int slot = g * kRB + ev;
             double x = 0.0;
             if (slot < n_flag && f < d.nf && !fd[f].skip)
-                x = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[f], p.lower, p.upper, hafq::GlobalTabs());
+                x = attribute_value(SrcBuf<false>{iir, window_origin(evalcell[flag_list[slot]], H, W)}, fd[f], p.lower, p.upper, hafq::GlobalTabs());
             xs[ev][f] = x;
         }
         if (tid < kRB) run_sum[tid] = 0.0;
@@ -1512,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
             const int slot = grp * 16 + ev;
             double v = 0.0;
             if (slot < n_flag && k < d.nf && !fd[k].skip)
-                v = attribute_value<false>(iir, window_origin(evalcell[flag_list[slot]], H, W), fd[k], p.lower, p.upper, hafq::GlobalTabs());
+                v = attribute_value(SrcBuf<false>{iir, window_origin(evalcell[flag_list[slot]], H, W)}, fd[k], p.lower, p.upper, hafq::GlobalTabs());
             x64[(size_t)grp * kKP * 16 + it] = v;
         }
     }
