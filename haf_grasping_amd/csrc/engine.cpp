@@ -221,6 +221,8 @@ struct haf_engine {
     DevBuf<unsigned long long> d_topkey;
     DevBuf<FeatDesc> d_fd;
     DevBuf<ScrDesc> d_sd;
+    DevBuf<float> d_part1;
+    long part1_stride = 0;
     DevBuf<ScrDesc3> d_sd3;
 
     // pinned host staging
@@ -589,7 +591,8 @@ int build_tables(haf_engine *e)
     // coefficient sum: sequential over the tiles (fp32 kernel) or two-level, 8 tiles per inner sum (split-fp16 kernel);
     // +2 for the class split (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product
     const bool split_mode = !(e->cfg.flags & HAF_FLAG_FP32_MFMA);
-    const double acc_adds = split_mode ? (8.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0) : (e->n_sv_tiles + 5.0);
+    // (+ kHListParts: the list mode sums the class sums of that many tile ranges, k_svm_h_combine)
+    const double acc_adds = split_mode ? (8.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0 + kHListParts) : (e->n_sv_tiles + 5.0);
     e->svm.guard_acc = (float)(guard_scale * ((acc_adds + 6.0) * u));
     // screening pass: one sequential fp32 sum per lane over two column blocks per tile, the 4-step lane reduction, the
     // class split, v_exp_f32 and the coefficient product; the band is ~3e-4, so nothing is gained by a two-level sum.
@@ -647,6 +650,8 @@ int alloc_buffers(haf_engine *e)
         const size_t slots = ((size_t)e->flag0_cap + kSvmBlockEvals - 1) / kSvmBlockEvals * kSvmBlockEvals;
         ok &= hipSuccess == e->d_X1.alloc(slots / kTile * (size_t)(kHXTileBytes / 4));
         ok &= hipSuccess == e->d_ax1.alloc(slots);
+        e->part1_stride = (long)slots;
+        ok &= hipSuccess == e->d_part1.alloc(slots * 2 * kHListParts);      // class sums per SV tile range (k_svm_h_combine)
         ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad * kBandFloats);
         ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
         ok &= hipSuccess == e->d_flag0_words.alloc((size_t)e->max_evals_pad / 64);
@@ -726,6 +731,7 @@ void haf_destroy(haf_engine *e)
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
+    e->d_sd.release(); e->d_sd3.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
     if (e->h_rec) (void)hipHostFree(e->h_rec);
@@ -904,13 +910,14 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
                             e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
                             e->flag0_cap, false, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap, s);
+                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
+                         e->d_part1.p, e->part1_stride, s);
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, s);
             mark(e, HAF_ST_SVM);
             launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, s);
+                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s);
             mark(e, HAF_ST_REFINE);
         } else {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,

@@ -15,6 +15,7 @@ constexpr int kTile = 32;           // evals per A tile / SVs per B tile
 constexpr int kTileFloats = kDP * kTile;          // 10496 floats = 41 KiB: 41 LDS-DMA wave instructions of 1 KiB
 constexpr int kSvmBlockEvals = 256; // 8 waves x 32 evals
 constexpr int kSvmThreads = 512;
+constexpr int kHListParts = 4;      // list mode of the three-pass kernel: SV tile ranges per evaluation block (k_svm_h_combine)
 
 // ---- split-fp16 variant of the contraction (three fp16 MFMA passes: hi*hi + lo*hi + hi*lo) ----
 // MFMA shape 16x16x32 (+ one 16x16x16 step for the K tail): on MI355X the chip sustains ~15 % more FLOP/s on this
@@ -208,7 +209,8 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
                 long max_evals, hipStream_t s);
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
-                  long max_evals, const int *idx_list, int list_counter, int list_cap, hipStream_t s);
+                  long max_evals, const int *idx_list, int list_counter, int list_cap, float *part_out, long part_stride,
+                  hipStream_t s);
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);

@@ -1132,7 +1132,8 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                                                               float *__restrict__ dec, int8_t *__restrict__ labels,
                                                               int *__restrict__ flag_list, int flag_cap,
                                                               int *__restrict__ counters_rw, Dims d,
-                                                              const int *__restrict__ idx_list, int list_counter, int list_cap)
+                                                              const int *__restrict__ idx_list, int list_counter, int list_cap,
+                                                              float *__restrict__ part_out, long part_stride)
 {
     // the ONLY LDS object: 3 SV tile images + per wave one row of a_x and one row of positive-group sums
     __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 2 * 8 * kTile * 4];
@@ -1143,12 +1144,16 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long tile32 = (base >> 5) + wave;
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
-    const int nt = d.n_sv_tiles;
+    // part_out (list mode): the SV tiles are cut into gridDim.y ranges and workgroup (x, y) sums range y only; its two class
+    // sums go to part_out and k_svm_h_combine finishes the evaluation.  A list of 150 k evaluations is 589 workgroups for
+    // 512 slots: whole sweeps would run as two rounds with the second one 15 % full, quarter sweeps pack the slots.
+    const int t0 = part_out ? (int)((long)d.n_sv_tiles * blockIdx.y / gridDim.y) : 0;
+    const int nt = part_out ? (int)((long)d.n_sv_tiles * (blockIdx.y + 1) / gridDim.y) : d.n_sv_tiles;
     float *axs = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + wave * kTile;
     float *pos = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + 8 * kTile + wave * kTile;
 
-    stage_sv_tile_h(svt, lds0, wave, lane);                                              // tile 0
-    if (nt > 1) stage_sv_tile_h(svt + (size_t)kHSvTileBytes, lds0 + kHSvTileBytes, wave, lane);   // tile 1
+    if (t0 < nt) stage_sv_tile_h(svt + (size_t)t0 * kHSvTileBytes, lds0, wave, lane);                          // first tile
+    if (t0 + 1 < nt) stage_sv_tile_h(svt + (size_t)(t0 + 1) * kHSvTileBytes, lds0 + kHSvTileBytes, wave, lane);   // second
 
     // A fragments: [k-step][row block m][hi|lo]; lane holds A[row 16m + (lane&15)][k = 32s + 8(lane>>4) + j]
     half8 ah[kHFull][2], al[kHFull][2];
@@ -1198,11 +1203,11 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++) axr[m][r] = axs[16 * m + 4 * (lane >> 4) + r];
-    for (int t = 0; t < nt; t++) {
-        const char *cur = lds + (t % kHBuffers) * kHSvTileBytes;
+    for (int t = t0; t < nt; t++) {
+        const char *cur = lds + ((t - t0) % kHBuffers) * kHSvTileBytes;
         const bool more = t + 2 < nt;
         if (more)
-            stage_sv_tile_h(svt + (size_t)(t + 2) * kHSvTileBytes, lds0 + ((t + 2) % kHBuffers) * kHSvTileBytes, wave, lane);
+            stage_sv_tile_h(svt + (size_t)(t + 2) * kHSvTileBytes, lds0 + ((t - t0 + 2) % kHBuffers) * kHSvTileBytes, wave, lane);
         if (t == d.sv_tile_neg) {
             // The tile images hold the non-negative coefficients first: what has been summed so far is
             // P = sum_{coef>0} coef*K, what follows is N = sum_{coef<0} coef*K.  dec = P + N - rho and the guard scale
@@ -1379,7 +1384,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             part[m][r] = v;
         }
     if ((lane & 15) == 0) {
-        const bool has_neg = d.sv_tile_neg < nt;
+        const bool has_neg = d.sv_tile_neg < nt;      // (a range that starts behind the class boundary found pos[] = 0)
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -1390,6 +1395,11 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     const int e = idx_list ? idx_list[es] : (int)es;
                     const float P = has_neg ? pos[row] : part[m][r];
                     const float N = has_neg ? part[m][r] : 0.0f;
+                    if (part_out) {
+                        part_out[(2 * blockIdx.y) * part_stride + es] = P;
+                        part_out[(2 * blockIdx.y + 1) * part_stride + es] = N;
+                        continue;
+                    }
                     const float dv = (P + N) - p.rho;
                     const float sabs = P - N;                       // sum |coef| K
                     dec[e] = dv;
@@ -1404,18 +1414,54 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     }
 }
 
+// list mode: sums the class sums of the kHListParts tile ranges in a fixed order and finishes the evaluation exactly as the
+// kernel's own epilogue does
+__global__ __launch_bounds__(256) void k_svm_h_combine(const float *__restrict__ part_out, long part_stride, int parts,
+                                                       const float *__restrict__ ax, const int *__restrict__ evalcell,
+                                                       const int *__restrict__ counters, SvmParams p, float *__restrict__ dec,
+                                                       int8_t *__restrict__ labels, int *__restrict__ flag_list, int flag_cap,
+                                                       int *__restrict__ counters_rw, const int *__restrict__ idx_list,
+                                                       int list_counter, int list_cap)
+{
+    const int n_evals = min(counters[list_counter], list_cap);
+    for (long es = (long)blockIdx.x * 256 + threadIdx.x; es < n_evals; es += (long)gridDim.x * 256) {
+        float P = 0.0f, N = 0.0f;
+        for (int y = 0; y < parts; y++) {
+            P += part_out[(2 * y) * part_stride + es];
+            N += part_out[(2 * y + 1) * part_stride + es];
+        }
+        const int e = idx_list[es];
+        const float dv = (P + N) - p.rho;
+        const float sabs = P - N;                       // sum |coef| K
+        dec[e] = dv;
+        labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
+        if (!(fabsf(dv) > (p.guard_acc + p.guard_dot_p * (p.as_max + fabsf(ax[es]))) * sabs + p.guard_abs)) {
+            int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
+            if (slot < flag_cap) flag_list[slot] = e;
+        }
+    }
+}
+
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters, SvmParams p,
                   float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
-                  const int *idx_list, int list_counter, int list_cap, hipStream_t s)
+                  const int *idx_list, int list_counter, int list_cap, float *part_out, long part_stride, hipStream_t s)
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
-    if (idx_list)
-        hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
-                           evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap);
-    else
+    if (idx_list) {
+        const int parts = (part_out && d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;
+        float *po = parts > 1 ? part_out : nullptr;
+        hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
+                           (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
+                           list_counter, list_cap, po, part_stride);
+        if (po)
+            hipLaunchKernelGGL(k_svm_h_combine, dim3(1024), dim3(256), 0, s, po, part_stride, parts, ax, evalcell, counters, p, dec,
+                               labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap);
+    } else {
         hipLaunchKernelGGL(k_svm_rbf_h<false>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
-                           evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap);
+                           evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap,
+                           (float *)nullptr, 0L);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
