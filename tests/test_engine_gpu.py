@@ -275,6 +275,26 @@ def test_screening_feature_paths_agree_with_the_oracle(data_dir, surrogate, orc,
         c = eng.last_counts()
         assert c["n_evals"] > 4 * 40 * 40
         eng.close()
+    monkeypatch.delenv("HAF_NO_FAST_GROUPS")
+    # rows with holes: 13x13-cell patches without points leave 5x5 cells outside the mask in the middle of long rows, so some
+    # 64-chunks of region A are not 64 neighbouring cells and take the per-lane route next to band waves of the same workgroup
+    grid = 160
+    xyz = models.synthetic_cloud(grid=grid, k=2, seed=12)
+    cx = np.floor((xyz[:, 0] + grid * 0.005) / 0.01).astype(int)
+    cy = np.floor((xyz[:, 1] + grid * 0.005) / 0.01).astype(int)
+    keep = np.ones(len(xyz), bool)
+    rng = np.random.RandomState(5)
+    for _ in range(7):
+        a, b = rng.randint(20, grid - 33, size=2)
+        keep &= ~((cx >= a) & (cx < a + 13) & (cy >= b) & (cy < b + 13))
+    xyz = np.ascontiguousarray(xyz[keep])
+    eng = make_engine(data_dir, surrogate, 0, grid_h=grid, grid_w=grid, n_rolls=2, roll_step_deg=90)
+    compare_full(eng, orc, xyz, dict(n_rolls=2, roll_step_deg=90, grid_h=grid, grid_w=grid),
+                 dict(grasp_area_length_x=grid, grasp_area_length_y=grid))
+    m0 = eng.debug(capi.DBG_MASK, 0, 0)
+    inner = m0[7:grid - 7, 7:grid - 7]
+    assert inner.sum() < inner.size and (inner.sum(axis=1) >= 64).all()      # holes, and every row still has a whole chunk
+    eng.close()
 
 
 def test_edge_inputs(data_dir, surrogate, orc):

@@ -12,6 +12,10 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $B1 > $O/write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_ANY --output-format csv -d $O/sq -- python3 $B1 > $O/sq.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/lds -- python3 $B1 > $O/lds.log 2>&1
+# vector-L1 side of the feature kernels (two counters per pass: more do not fit the TA / TCP blocks)
+timeout 200 rocprofv3 --pmc TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum --output-format csv -d $O/ta -- python3 $B1 > $O/ta.log 2>&1
+timeout 200 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/tcp -- python3 $B1 > $O/tcp.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $O/sqf -- python3 $B1 > $O/sqf.log 2>&1
 # the other two contraction modes: kernel trace + traffic
 for M in f16x3 f32; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$M -- python3 $B --precision $M > $O/kt_$M.log 2>&1
