@@ -432,10 +432,10 @@ int build_tables(haf_engine *e)
         ScreenParams &sp = e->screen;
         sp.c = std::sqrt(2.0 * m.gamma * log2e);
         {
-            // screening attribute u' = fma(q4, scr_mul, scr_add), scr_add = c*lower - fmin*scr_mul (kernels.hip: screen_attribute).
+            // screening attribute u' = (q4 - scr_sub) * scr_mul, scr_sub = fmin - c*lower/scr_mul (kernels.hip: screen_attribute).
             // Against c*x' in exact arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's
-            // range) and the rounding of scr_add, both amplified by scr_mul when q4 and fmin cancel, and by the roundings of
-            // scr_mul and of the fma; the norm over the attributes is eta_abs.
+            // range) and the rounding of scr_sub, both amplified by scr_mul when q4 and scr_sub cancel, and by the roundings of
+            // scr_mul, the subtraction and the product; the norm over the attributes is eta_abs.
             std::vector<FeatDesc> fd2((size_t)e->nf);
             HIPCHK(e, hipMemcpy(fd2.data(), e->d_fd.p, fd2.size() * sizeof(FeatDesc), hipMemcpyDeviceToHost));
             std::vector<ScrDesc> sd((size_t)kScrGroups * 8);
@@ -453,9 +453,10 @@ int build_tables(haf_engine *e)
                     ScrDesc &s = sd[(size_t)f];
                     if (!d.skip) {
                         d.scr_mul = sp.c * (e->range.upper - e->range.lower) * d.inv_range;
-                        d.scr_add = std::fma(-d.fmin, d.scr_mul, sp.c * e->range.lower);
+                        d.scr_sub = d.scr_mul != 0.0 ? d.fmin - sp.c * e->range.lower / d.scr_mul : 0.0;
                         // x2: svm-scale's own fp64 roundings of the same expression
-                        const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin)) + 4.5e-16 * std::fabs(sp.c * e->range.lower));
+                        const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin) + std::fabs(d.scr_sub)) +
+                                                 4.5e-16 * std::fabs(sp.c * e->range.lower));
                         ea2 += ef * ef;
                     }
                     if (d.shaf || (d.active & ~3)) fast = false;
@@ -463,18 +464,20 @@ int build_tables(haf_engine *e)
                         s.w[k] = d.w[k];
                         for (int j = 0; j < 4; j++) s.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
-                    s.scr_mul = d.scr_mul; s.scr_add = d.scr_add;
+                    s.scr_mul = d.scr_mul; s.scr_sub = d.scr_sub;
                     ScrDesc3 &s3 = sd3[(size_t)f];
                     for (int k = 0; k < 3; k++) {
                         s3.w[k] = d.w[k];
                         for (int j = 0; j < 4; j++) s3.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
                     s3.shaf = d.shaf;
-                    s3.scr_mul = d.scr_mul; s3.scr_add = d.scr_add;
+                    s3.scr_mul = d.scr_mul; s3.scr_sub = d.scr_sub;
                 }
                 if (fast) sp.fast_groups |= 1ull << g;
             }
             if (getenv("HAF_NO_FAST_GROUPS")) sp.fast_groups = 0;        // A/B runs and the generic-path test
+            // a degenerate target range or bounds beyond the decimal path's error budget: serve the model without screening
+            if (!(e->range.upper > e->range.lower) || std::fabs(e->range.lower) > 1e3 || std::fabs(e->range.upper) > 1e3) e->screen_active = false;
             sp.eta_abs = std::max(std::sqrt(ea2) * 1.01, 1e-12 * 18.0 * sp.c);
             HIPCHK(e, hipMemcpy(e->d_fd.p, fd2.data(), fd2.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
             if (hipSuccess != e->d_sd.alloc(sd.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");

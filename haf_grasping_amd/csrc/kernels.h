@@ -100,7 +100,7 @@ struct ScrDesc {
                                   // the LDS band of a wave (kBandPitch floats per row, kernels.hip: screen_quad)
     float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
     double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
-    double scr_add;               // c * lower - fmin * scr_mul                   (0 likewise):  u' = fma(q4, scr_mul, scr_add)
+    double scr_sub;               // fmin - c * lower / scr_mul                   (0 likewise):  u' = (q4 - scr_sub) * scr_mul
     double pad;
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
@@ -109,7 +109,7 @@ struct ScrDesc3 {
     int    off[12];               // band BYTE offsets of the corners of regions 0..2
     float  w[3];
     int    shaf;                  // fv.cpp:187-191 instead of the weighted sum
-    double scr_mul, scr_add;
+    double scr_mul, scr_sub;
     double pad[2];
 };
 static_assert(sizeof(ScrDesc3) == 96, "ScrDesc3 layout");
@@ -146,7 +146,7 @@ struct FeatDesc {
     int   pad;
     double fmin, fmax;
     double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
-    double scr_mul, scr_add;      // screening pass (ScrDesc below): u' = fma(q4, scr_mul, scr_add)
+    double scr_mul, scr_sub;      // screening pass (ScrDesc below): u' = (q4 - scr_sub) * scr_mul
 };
 
 struct Dims {

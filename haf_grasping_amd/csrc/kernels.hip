@@ -416,7 +416,8 @@ __device__ __forceinline__ double attribute_value(const Src &src, const FeatDesc
 }
 
 // Attribute for the SCREENING pass only, already multiplied by c (kernels.h: ScreenParams): the "%.4g" round trip through the
-// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (one fma), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
+// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (u' = (q4 - scr_sub) *
+// scr_mul: a subtraction and a product, each with one scalar operand), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
 // |u' - u| <= 5e-6 |u'| (six significant decimal digits: half a unit of the sixth digit is <= 5e-6 relative) plus, in norm over
 // the attributes, ScreenParams::eta_abs (engine.cpp: the fp64 roundings of both evaluations of the formula, the exact-zero
 // omission and the min/max shortcuts).  screen_finish() carries that difference through the guard band; evaluations the
@@ -427,7 +428,7 @@ template <class Src>
 __device__ __forceinline__ double screen_attribute(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st)
 {
     const float v = feature_value(src, f);
-    return fma(hafq::decq4_float_scr(v, st), f.scr_mul, f.scr_add);
+    return (hafq::decq4_float_scr(v, st) - f.scr_sub) * f.scr_mul;
 }
 
 // ---- the fast form of the screening feature pass ------------------------------------------------------------------
@@ -476,12 +477,12 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         const float r0 = __fmul_rn(sd[q].w[0], __fadd_rn(__fsub_rn(__fsub_rn(c[q][0], c[q][1]), c[q][2]), c[q][3]));
         const float r1 = __fmul_rn(sd[q].w[1], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4], c[q][5]), c[q][6]), c[q][7]));
         const float v = __fadd_rn(r0, r1);      // 0.0f + r0 first (fv.cpp:164) only turns a -0 into +0: same decimal, same u'
-        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
+        ud[q] = (hafq::decq4_float_scr(v, st) - sd[q].scr_sub) * sd[q].scr_mul;
     }
 }
 
 // Two attribute slots of any other group, from the band: three regions each, the HAF sum or the SHAF rule (feature_value).
-// A slot of a dropped or absent attribute has scr_mul = scr_add = 0: its u' is 0 (NaN if its feature value left the decimal
+// A slot of a dropped or absent attribute has scr_mul = scr_sub = 0: its u' is 0 (NaN if its feature value left the decimal
 // path's range, which only costs that evaluation the screening pass).
 typedef const ScrDesc3 __attribute__((address_space(4))) *ScrDesc3K;
 __device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (ScrDesc3K)(unsigned long long)p; }
@@ -522,7 +523,7 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
         } else {
             v = __fadd_rn(__fadd_rn(r[0], r[1]), r[2]);
         }
-        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
+        ud[q] = (hafq::decq4_float_scr(v, st) - sd[q].scr_sub) * sd[q].scr_mul;
     }
 }
 
@@ -583,15 +584,16 @@ __device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 h
     store_group_img(xtile + kHMatBytes, r, g, lo);
 }
 
-// screening operand of one attribute: u' in fp64 (screen_attribute / screen_quad), u^ = fp16(u') with subnormals
-// flushed; accumulates |u'|^2 and |u^ - u'|^2, the two norms the guard band of the screening pass is made of
-__device__ __forceinline__ _Float16 screen_operand(double ud, double &su2, double &sd2)
+// screening operand of one attribute: u' in fp64 (screen_attribute / screen_quad), u^ = fp16(fl32(u')) with subnormals
+// flushed; accumulates |fl32(u')|^2 and |u^ - fl32(u')|^2 in fp32, the two norms the guard band of the screening pass is made of
+__device__ __forceinline__ _Float16 screen_operand(double ud, float &su2, float &sd2)
 {
-    _Float16 h = (_Float16)(float)ud;
+    const float f = (float)ud;                       // fl32(u'): |f - u'| <= 2^-24 |u'|
+    _Float16 h = (_Float16)f;
     if (fabsf((float)h) < kF16MinNormal) h = (_Float16)0.0f;
-    const double du = (double)(float)h - ud;
-    su2 = fma(ud, ud, su2);
-    sd2 = fma(du, du, sd2);
+    const float du = (float)h - f;                   // exact in fp32 (h is f rounded to fewer bits, or 0)
+    su2 = fmaf(f, f, su2);                           // both sums in fp32: screen_finish() carries the 326 roundings
+    sd2 = fmaf(du, du, sd2);
     return h;
 }
 
@@ -630,16 +632,21 @@ __device__ __forceinline__ double exp2m1_upper(double z) { return 0.69314718056 
 
 __device__ __forceinline__ void screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41, float *band)
 {
-    const double a_x = 0.5 * su2;                        // of u'
+    // su2, sd2: fp32 sums (screen_operand) of 324 squares of fp32-rounded terms: off by at most 326 * 2^-24 relative.  For the
+    // norms that is an inflation; for a_x (which goes into the operand) it is one more part of D, the error of the -|u|^2/2
+    // term that all SVs share, and costs (2^D - 1)(|dec^| + |rho|) like the rest of D.
+    constexpr double kF32Acc = 326.0 * 5.9604644775390625e-08 * 1.01;
+    const double a_x = 0.5 * su2;                        // what the norm slots carry
     _Float16 s3[3];
     const double rep = split3_f16(-a_x, s3);
-    const double dax = fabs(rep + a_x);
+    const double dax = fabs(rep + a_x) + kF32Acc * a_x;
     g40[4] = (_Float16)1.0f;
     g40[5] = (_Float16)(1.0f / kAugScale);
     g40[6] = (_Float16)(1.0f / kAugScale);
     g40[7] = s3[0];
     g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
-    const double un1 = sqrt_upper(su2), dn1 = sqrt_upper(sd2);
+    const double un1 = sqrt_upper(su2 * (1.0 + kF32Acc));                         // |u'|
+    const double dn1 = sqrt_upper(sd2 * (1.0 + kF32Acc)) + 5.97e-8 * un1 + 1e-17;  // |u^ - u'| <= |u^ - fl32(u')| + 2^-24 |u'|
     const double eta = kScreenEtaRel * un1 + sp.eta_abs;                        // |u' - u|
     const double un = un1 + eta, dn = dn1 + eta;                                // |u|, |u^ - u|
     const double ln2 = 0.69314718056;
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     const unsigned w0 = window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W);
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
-        double sd2 = 0.0;
+        float su2 = 0.0f, sd2 = 0.0f;
         half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0}, g41;
         for (int g = 0; g <= kAugS / 8; g++) {           // groups 0..40: attribute slots 0..327, of which 0..323 are attributes
             double ud[8];
@@ -746,12 +753,12 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             }
             half8 hi;
 #pragma unroll
-            for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], xx, sd2);
+            for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], su2, sd2);
             if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
             else g40 = hi;
         }
         float band[kBandFloats];
-        screen_finish(xx, sd2, sp, g40, g41, band);
+        screen_finish((double)su2, (double)sd2, sp, g40, g41, band);
         *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
         store_group_img(xtile, r, 40, g40);
         store_group_img(xtile, r, 41, g41);
@@ -848,7 +855,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     }
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
-    double xx = 0.0, sd2 = 0.0;
+    double xx = 0.0;
+    float su2 = 0.0f, sd2 = 0.0f;                                      // screening form: fp32 partial norms of this wave's groups
     half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         if (MODE == XMODE_SCREEN && g > kAugS / 8) break;              // group 41 holds norm slots only
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
-                hi[q] = screen_operand(xd, xx, sd2);
+                hi[q] = screen_operand(xd, su2, sd2);
             } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -883,8 +891,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             else g40 = hi;                                             // wave kFeatFinisher keeps group 40 until the norms are known
         }
     }
-    red[gl][ev] = xx;
-    if (MODE == XMODE_SCREEN) red2[gl][ev] = sd2;
+    red[gl][ev] = (MODE == XMODE_SCREEN) ? (double)su2 : xx;
+    if (MODE == XMODE_SCREEN) red2[gl][ev] = (double)sd2;
     __syncthreads();
     if (gl == kFeatFinisher) {
         double t = 0.0, t2 = 0.0;
