@@ -776,6 +776,15 @@ int haf_create(const haf_config *cfg, haf_engine **out)
     e->own_stream = true;
     for (auto &ev : e->ev) if (hipEventCreate(&ev) != hipSuccess) { e->error = "hipEventCreate failed"; return bail(HAF_E_DEVICE); }
 
+#ifndef HAF_FLUSH_F16_SUBNORMALS
+    if (contraction_mode(e->cfg) == MODE_SCREEN) {
+        // the screening operands keep fp16 subnormals (kernels.hip: screen_operand): make sure the matrix core does too
+        static int keeps = -2;                        // per process
+        if (keeps == -2) keeps = probe_f16_subnormal_mfma(e->stream);
+        if (keeps < 0) { e->error = "fp16 subnormal probe failed to run"; return bail(HAF_E_DEVICE); }
+        if (keeps == 0) { e->error = "this device flushes fp16 subnormal MFMA operands: rebuild with -DHAF_FLUSH_F16_SUBNORMALS"; return bail(HAF_E_DEVICE); }
+    }
+#endif
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
     rc = alloc_buffers(e);

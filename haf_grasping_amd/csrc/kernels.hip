@@ -584,13 +584,14 @@ __device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 h
     store_group_img(xtile + kHMatBytes, r, g, lo);
 }
 
-// screening operand of one attribute: u' in fp64 (screen_attribute / screen_quad), u^ = fp16(fl32(u')) with subnormals
-// flushed; accumulates |fl32(u')|^2 and |u^ - fl32(u')|^2 in fp32, the two norms the guard band of the screening pass is made of
+// screening operand of one attribute: u' in fp64 (screen_attribute / screen_quad), u^ = fp16(fl32(u')); accumulates |fl32(u')|^2 and |u^ - fl32(u')|^2 in fp32, the two norms the guard band of the screening pass is made of
 __device__ __forceinline__ _Float16 screen_operand(double ud, float &su2, float &sd2)
 {
     const float f = (float)ud;                       // fl32(u'): |f - u'| <= 2^-24 |u'|
-    _Float16 h = (_Float16)f;
+    _Float16 h = (_Float16)f;                        // subnormal results stay: the matrix core multiplies them as they are
+#ifdef HAF_FLUSH_F16_SUBNORMALS                      // (checked at haf_create: probe_f16_subnormal_mfma, screen.hip)
     if (fabsf((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+#endif
     const float du = (float)h - f;                   // exact in fp32 (h is f rounded to fewer bits, or 0)
     su2 = fmaf(f, f, su2);                           // both sums in fp32: screen_finish() carries the 326 roundings
     sd2 = fmaf(du, du, sd2);

@@ -368,6 +368,42 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned
     }
 }
 
+// Does the matrix core take fp16 subnormal A operands at their value?  The screening feature kernel stores u^ = fp16(u') without
+// flushing small magnitudes (two vector instructions per attribute saved) and counts |u^ - u'| from the stored value; that is
+// only right if the MFMA multiplies what is stored.  haf_create runs this once per process and refuses a device that flushes
+// (build with -DHAF_FLUSH_F16_SUBNORMALS there).  All A elements 2^-20 (subnormal), all B elements 2^4: every output element is
+// K * 2^-16, exactly.
+__global__ __launch_bounds__(64) void k_probe_f16_subnormal(float *out)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const _Float16 tiny = (_Float16)9.5367431640625e-07f, big = (_Float16)16.0f;
+    h8 a, b;
+    h4 at, bt;
+    for (int i = 0; i < 8; i++) { a[i] = tiny; b[i] = big; }
+    for (int i = 0; i < 4; i++) { at[i] = tiny; bt[i] = big; }
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(at), "+v"(bt));          // no constant folding
+    f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f4 c32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, z, 0, 0, 0);
+    const f4 c16 = __builtin_amdgcn_mfma_f32_16x16x16f16(at, bt, z, 0, 0, 0);
+    bool ok = true;
+    for (int r = 0; r < 4; r++) ok = ok && c32[r] == 32.0f * 1.52587890625e-05f && c16[r] == 16.0f * 1.52587890625e-05f;
+    const unsigned long long all = __ballot(ok);
+    if (threadIdx.x == 0) out[0] = (all == ~0ull) ? 1.0f : 0.0f;
+}
+
+int probe_f16_subnormal_mfma(hipStream_t s)
+{
+    float *d = nullptr, h = -1.0f;
+    if (hipMalloc((void **)&d, sizeof(float)) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_probe_f16_subnormal, dim3(1), dim3(64), 0, s, d);
+    const bool fine = hipMemcpyAsync(&h, d, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d);
+    if (!fine) return -1;
+    return h == 1.0f ? 1 : 0;
+}
+
 void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s)
