@@ -1591,15 +1591,17 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
     const int n_grp = (n_flag + 63) / 64 * 4;          // whole k_recheck_mfma workgroups (64 evaluations): unused slots get zeros
     const int H = d.H, W = d.W;
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    for (int grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
-        for (int it = threadIdx.x; it < 16 * kKP; it += 256) {
-            const int k = it >> 4, ev = it & 15;
-            const int slot = grp * 16 + ev;
-            double v = 0.0;
-            if (slot < n_flag && k < d.nf && !fd[k].skip)
-                v = attribute_value(SrcBuf<false>{iir, window_origin(evalcell[flag_list[slot]], H, W)}, fd[k], p.lower, p.upper, hafq::GlobalTabs());
-            x64[(size_t)grp * kKP * 16 + it] = v;
-        }
+    // grid-stride over the (group, attribute, evaluation) items: a handful of flagged evaluations (a small request) still
+    // spreads over the whole launch instead of keeping one workgroup busy for twenty rounds
+    const long n_items = (long)n_grp * 16 * kKP;
+    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < n_items; item += (long)gridDim.x * 256) {
+        const int grp = (int)(item / (16 * kKP)), it = (int)(item - (long)grp * (16 * kKP));
+        const int k = it >> 4, ev = it & 15;
+        const int slot = grp * 16 + ev;
+        double v = 0.0;
+        if (slot < n_flag && k < d.nf && !fd[k].skip)
+            v = attribute_value(SrcBuf<false>{iir, window_origin(evalcell[flag_list[slot]], H, W)}, fd[k], p.lower, p.upper, hafq::GlobalTabs());
+        x64[(size_t)grp * kKP * 16 + it] = v;
     }
 }
 

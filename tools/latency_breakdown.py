@@ -36,6 +36,8 @@ def bench(name, clouds, inputs, **cfg):
 if __name__ == "__main__":
     pcd2 = capi.load_pcd(os.path.join(DATA, "pcd2.pcd"))
     bench("C2 pcd2 32x32 12 rolls", [pcd2], [capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32)])
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "C2":
+        sys.exit(0)
     t1 = capi.load_pcd(os.path.join(DATA, "table1_mult_obj_rcs_1428580506606673.pcd"))
     bench("C3 table1 56x56 20 rolls", [t1], [capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56,
                                                                  grasp_area_center=(0.13, 0.25, 0.0))], n_rolls=20, roll_step_deg=9)

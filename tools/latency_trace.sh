@@ -1,0 +1,24 @@
+# kernel-by-kernel timeline of one small request (C2) on the GPU box: bash tools/latency_trace.sh
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/lat
+rm -rf $O; mkdir -p $O
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/latency_breakdown.py --only C2 > $O/kt.log 2>&1
+python3 - <<'PY'
+import csv,glob
+f=glob.glob("/root/repo/gpurun_out/lat/kt/**/*kernel_trace.csv", recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+# last request = last occurrence of k_bin / k_bin_lds / k_fill to the end
+names=[r["Kernel_Name"].split("(")[0].replace("void ","").replace("haf::","") for r in rows]
+last=max(i for i,n in enumerate(names) if n.startswith("k_fill") ) 
+# find start of last request: walk back to the first k_fill of the trailing group
+i=last
+while i>0 and names[i-1].startswith("k_fill"): i-=1
+t0=int(rows[i]["Start_Timestamp"]); prev=t0
+for r,n in zip(rows[i:],names[i:]):
+    s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
+    print("%-26s start %8.1f us  dur %7.1f us  gap %6.1f us  grid %s" % (n[:26], (s-t0)/1e3, (e-s)/1e3, (s-prev)/1e3, r.get("Grid_Size_X", r.get("Grid_Size",""))))
+    prev=e
+print("total %.1f us" % ((prev-t0)/1e3))
+PY
