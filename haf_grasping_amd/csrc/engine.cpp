@@ -223,6 +223,9 @@ struct haf_engine {
     DevBuf<ScrDesc> d_sd;
     DevBuf<float> d_part1;
     long part1_stride = 0;
+    // requests with at least this many evaluation slots take the thread-per-evaluation feature kernel: its floor is one thread's
+    // chain of 324 attributes (~0.2 ms), the cooperative kernel costs ~1.3 us per 1000 evaluations (crossover measured at ~3e5)
+    long large_evals = 1L << 18;
     DevBuf<ScrDesc3> d_sd3;
 
     // pinned host staging
@@ -785,6 +788,7 @@ int haf_create(const haf_config *cfg, haf_engine **out)
         if (keeps == 0) { e->error = "this device flushes fp16 subnormal MFMA operands: rebuild with -DHAF_FLUSH_F16_SUBNORMALS"; return bail(HAF_E_DEVICE); }
     }
 #endif
+    if (const char *v = getenv("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
     rc = alloc_buffers(e);
@@ -906,7 +910,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
     auto decide = [&](int mode) -> int {
         mark(e, HAF_ST_FEATURES);
-        const bool large = evals_cap >= (1L << 20);          // enough evaluations to fill the chip with one thread each
+        const bool large = evals_cap >= e->large_evals;      // enough evaluations to fill the chip with one thread each
         if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,

@@ -262,10 +262,12 @@ def test_generalised_grid_and_rolls(data_dir, surrogate, orc, mode):
 
 
 def test_screening_feature_paths_agree_with_the_oracle(data_dir, surrogate, orc, monkeypatch):
-    """The screening feature kernel has three routes to an attribute: waves of 64 neighbouring cells read an LDS band of the
+    """The thread-per-evaluation screening feature kernel (large requests; forced here through HAF_LARGE_EVALS) has three routes
+    to an attribute: waves of 64 neighbouring cells read an LDS band of the
     integral image, two-region HAF groups through screen_quad and every other group through screen_pair3; all other waves
     address per lane.  A 96-wide area gives rows of 82 cells (one whole 64-chunk + a left-over each, so both wave kinds
     occur); HAF_NO_FAST_GROUPS sends every group through screen_pair3.  Stage by stage against the oracle both times."""
+    monkeypatch.setenv("HAF_LARGE_EVALS", "1")        # the thread-per-evaluation kernel whatever the request size
     xyz = models.synthetic_cloud(grid=96, k=2, seed=11)
     for env in (None, "1"):
         if env: monkeypatch.setenv("HAF_NO_FAST_GROUPS", env)
