@@ -74,6 +74,8 @@ def load_pcd(path):
     if mode == "ascii":
         rows = raw[pos:].decode("ascii").split("\n")
         out = np.empty((npts, 3), np.float32)
+        col = np.cumsum([0] + counts)                 # token position of a field (COUNT > 1 fields take several tokens)
+        ix = [int(col[i]) for i in ix]
         k = 0
         for r in rows:
             if k == npts:

@@ -198,6 +198,38 @@ def test_pcd_reader_matches_test_reader(data_dir):
             assert a.shape == b.shape and (a.view(np.uint32) == b.view(np.uint32)).all(), name
 
 
+def test_pcd_reader_organised_clouds_nan_and_extra_fields(tmp_path):
+    """organised clouds (HEIGHT > 1) with NaN holes, as a depth camera delivers them, extra fields around
+    x/y/z (rgb, a 3-float normal), in the ascii and binary forms; the points come back in file order with the NaNs in place
+    (the binning kernel drops them, like the comparisons of generate_grid do)."""
+    rng = np.random.RandomState(3)
+    W, H = 7, 5
+    xyz = rng.uniform(-0.3, 0.3, size=(W * H, 3)).astype(np.float32)
+    xyz[[3, 4, 17]] = np.nan
+    xyz[20, 2] = np.nan
+    rgb = rng.randint(0, 1 << 24, size=W * H).astype(np.uint32)
+    nrm = rng.standard_normal((W * H, 3)).astype(np.float32)
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS rgb x y normal z\nSIZE 4 4 4 4 4\nTYPE U F F F F\n"
+            "COUNT 1 1 1 3 1\nWIDTH %d\nHEIGHT %d\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\n" % (W, H, W * H))
+    rows = []
+    for i in range(W * H):
+        f = lambda v: "nan" if np.isnan(v) else repr(float(v))
+        rows.append("%d %s %s %s %s %s %s" % (rgb[i], f(xyz[i, 0]), f(xyz[i, 1]), f(nrm[i, 0]), f(nrm[i, 1]), f(nrm[i, 2]), f(xyz[i, 2])))
+    pa = tmp_path / "org_ascii.pcd"
+    pa.write_text(head + "DATA ascii\n" + "\n".join(rows) + "\n")
+    rec = np.zeros(W * H, dtype=[("rgb", "<u4"), ("x", "<f4"), ("y", "<f4"), ("n", "<f4", 3), ("z", "<f4")])
+    rec["rgb"], rec["x"], rec["y"], rec["n"], rec["z"] = rgb, xyz[:, 0], xyz[:, 1], nrm, xyz[:, 2]
+    pb = tmp_path / "org_binary.pcd"
+    pb.write_bytes((head + "DATA binary\n").encode() + rec.tobytes())
+    for path in (pa, pb):
+        got = capi.load_pcd(str(path))
+        assert got.shape == (W * H, 3)
+        assert (np.isnan(got) == np.isnan(xyz)).all()
+        assert (got[~np.isnan(xyz)].view(np.uint32) == xyz[~np.isnan(xyz)].view(np.uint32)).all(), path
+        ref = pcdio.load_pcd(str(path))
+        assert (np.isnan(ref) == np.isnan(xyz)).all()
+
+
 INPUTS = [dict(), dict(grasp_area_center=(0.13, 0.25, 0.02), grasp_area_length_x=56, grasp_area_length_y=56),
           dict(approach_vector=(0.2, -0.1, 1.0)), dict(approach_vector=(0.0, 0.0, -2.0), gripper_opening_width=2),
           dict(approach_vector=(1.0, 1.0, 0.3), grasp_area_center=(-0.05, 0.01, 0.1), grasp_area_length_x=47.9)]
