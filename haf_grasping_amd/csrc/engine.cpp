@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -782,8 +783,12 @@ int haf_create(const haf_config *cfg, haf_engine **out)
 #ifndef HAF_FLUSH_F16_SUBNORMALS
     if (contraction_mode(e->cfg) == MODE_SCREEN) {
         // the screening operands keep fp16 subnormals (kernels.hip: screen_operand): make sure the matrix core does too
-        static int keeps = -2;                        // per process
-        if (keeps == -2) keeps = probe_f16_subnormal_mfma(e->stream);
+        static std::mutex probe_mutex;                // one probe per process, whichever thread creates the first engine
+        static int keeps = -2;
+        {
+            std::lock_guard<std::mutex> lock(probe_mutex);
+            if (keeps == -2) keeps = probe_f16_subnormal_mfma(e->stream);
+        }
         if (keeps < 0) { e->error = "fp16 subnormal probe failed to run"; return bail(HAF_E_DEVICE); }
         if (keeps == 0) { e->error = "this device flushes fp16 subnormal MFMA operands: rebuild with -DHAF_FLUSH_F16_SUBNORMALS"; return bail(HAF_E_DEVICE); }
     }
