@@ -899,6 +899,14 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     d.H = H; d.W = W; d.R = R; d.B = B; d.nf = e->nf; d.n_sv = e->model.n_sv; d.n_sv_tiles = e->n_sv_tiles; d.sv_tile_neg = e->sv_tile_neg;
     const float r_row = (float)((0.5 * (float)H) / 100.0), r_col = (float)((0.5 * (float)W) / 100.0);   // server.cpp:410-411
     const long evals_cap = (long)B * R * (H - 14) * (W - 14);
+    // For choosing between the feature kernels only: the masked cells of a roll lie inside the rotated search rectangle of
+    // half sizes sx/2 - 7, sy/2 - 7 (pnt_in_box 687-688), at most (a + 2)(b + 2) lattice points for sides a, b -- usually far
+    // fewer than the grid could hold (the client's default 32 x 44 area on the 56 x 56 grid: a third).
+    long evals_sel = 0;
+    for (int b = 0; b < B; b++) {
+        const long a2 = std::max(0, 2 * ((int)in[b].grasp_area_length_x / 2 - 7)) + 2, b2 = std::max(0, 2 * ((int)in[b].grasp_area_length_y / 2 - 7)) + 2;
+        evals_sel += (long)R * std::min<long>((long)(H - 14) * (W - 14), a2 * b2);
+    }
 
     float minus_one = -1.0f;
     int key_m1;
@@ -915,11 +923,11 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
     auto decide = [&](int mode) -> int {
         mark(e, HAF_ST_FEATURES);
-        const bool large = evals_cap >= e->large_evals;      // enough evaluations to fill the chip with one thread each
+        const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
         if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, s);
             mark(e, HAF_ST_SVM);
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
@@ -929,20 +937,20 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
             // workgroups beyond the list's end exit at once)
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
-                            e->flag0_cap, false, s);
+                            e->flag0_cap, false, list_cap, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
                          e->d_part1.p, e->part1_stride, s);
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, s);
             mark(e, HAF_ST_SVM);
             launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s);
             mark(e, HAF_ST_REFINE);
         } else {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, evals_sel, s);
             mark(e, HAF_ST_SVM);
             launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                        e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);

@@ -200,7 +200,7 @@ enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2 };
 // j < min(counters[list_counter], list_cap) (the screened evaluations that go on to the three-pass kernel)
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
-                     const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s);
+                     const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, hipStream_t s);
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,

@@ -920,10 +920,118 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     }
 }
 
+// Small requests (a few thousand evaluations: the reference's own 56 x 56 grid): k_features would occupy one CU per 64
+// evaluations and leave most of the chip idle while each thread walks three groups of attributes.  Here a workgroup takes 16
+// evaluations and a quarter wave one group of 8 attributes of them: 44 quarter waves cover the 41 / 42 groups at once, four
+// times as many workgroups, a third of the chain per thread.  The attribute index differs between the quarters of a wave, so
+// the descriptors come by vector loads (four addresses per wave) and the HAF / SHAF branch may diverge in the one group
+// where both occur.  Same arithmetic, same operand images.
+constexpr int kSmEvals = 16;
+constexpr int kSmWaves = 11;
+constexpr int kSmSlots = kSmWaves * 4;                 // quarter waves: >= 42 attribute groups
+constexpr long kSmallEvals = 12288;                    // requests of up to this many evaluations (host estimate) take k_features_small
+
+template <int MODE>
+__global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                  const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
+                                                  float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
+                                                  double upper, float neg_gamma2, ScreenParams sp)
+{
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
+    constexpr int kFinisher = kAugS / 8;              // slot 40: holds group 40 (screening form: norm slots) and sums up
+    static_assert(kSmSlots >= 2 * kHSteps && kFinisher < kSmSlots, "slots cover the groups");
+    __shared__ double red[kSmSlots][kSmEvals];
+    __shared__ double red2[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
+    __shared__ float s_win[kSmEvals * kWinPitch];
+    __shared__ unsigned s_w0[kSmEvals];
+    const int n_evals = counters[CNT_EVALS];
+    const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
+    if ((long)blockIdx.x * kSmEvals >= n_pad) return;
+    __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
+    __shared__ unsigned long long s_scr[MODE == XMODE_SCREEN ? hafq::kScrTabWords : 1];
+    hafq::PtrTabs tb{};
+    hafq::ScrTabs st{};
+    if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
+    else tb = load_decimal_tables(s_tab);
+    const int ev = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const long e = (long)blockIdx.x * kSmEvals + ev;
+    const long tile = e >> 5;
+    const int r = (int)(e & 31);
+    float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
+    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : 2 * kHSteps;          // 41 / 42
+    const bool live = e < n_evals;
+    const rsrc_t iir = make_ii_rsrc(ii, d);
+    if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e], d.H, d.W) : 0xffffffffu;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kSmEvals * 15 * 16; idx += kSmWaves * 64) {
+        const int col = idx & 15, seg = idx >> 4, wev = seg & (kSmEvals - 1), x = seg >> 4;       // 16 lanes = one window row
+        const unsigned o = s_w0[wev];
+        if (col < 15)
+            s_win[wev * kWinPitch + x * 15 + col] =
+                (o != 0xffffffffu) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, (int)(o + (unsigned)(x * (d.W + 1) + col) * 4u), 0, 0)) : 0.0f;
+    }
+    __syncthreads();
+    const SrcWin src{s_win + ev * kWinPitch};
+    double xx = 0.0;
+    float su2 = 0.0f, sd2 = 0.0f;
+    half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int g = slot;
+    const bool has_group = g < n_groups && !(MODE == XMODE_SCREEN && g > kAugS / 8);     // group 41 of the screening form: norm slots only
+    if (has_group) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int f = g * 8 + q;
+            double xd = 0.0;
+            if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
+                const FeatDesc &F = fd[f];
+                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? screen_attribute(src, F, st) : attribute_value(src, F, lower, upper, tb);
+            }
+            const float xf = (float)xd;
+            if (MODE == XMODE_SCREEN) {
+                hi[q] = screen_operand(xd, su2, sd2);
+            } else if (MODE == XMODE_SPLIT) {
+                const _Float16 h = (_Float16)xf;                       // RN
+                const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
+                hi[q] = h;
+                lo[q] = l;
+                const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
+                xx = fma((double)xe, (double)xe, xx);
+            } else {
+                if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
+                xx = fma((double)xf, (double)xf, xx);
+            }
+        }
+        if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
+        if (MODE == XMODE_SCREEN && g < kAugS / 8) store_group_img(xtile, r, g, hi);
+    }
+    red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)su2 : xx;
+    if (MODE == XMODE_SCREEN) red2[slot][ev] = (double)sd2;
+    __syncthreads();
+    if (slot == kFinisher) {
+        double t = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSmSlots; k++) t += red[k][ev];            // fixed order: deterministic
+        if (MODE == XMODE_SCREEN) {
+#pragma unroll
+            for (int k = 0; k < kSmSlots; k++) t2 += red2[k][ev];
+            half8 g40 = hi, g41;
+            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (live) screen_finish(t, t2, sp, g40, g41, band);
+            else g41 = g40;                                            // padding rows: all zero
+            *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
+            store_group_img(xtile, r, 40, g40);
+            store_group_img(xtile, r, 41, g41);
+        } else {
+            ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+        }
+    }
+}
+
 template <int MODE>
 static void launch_features_mode(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                                  Dims d, double lower, double upper, float neg_gamma2, long max_evals, ScreenParams sp,
-                                 const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s)
+                                 const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, hipStream_t s)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     if (large) {
@@ -933,9 +1041,15 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
                            lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
         return;
     }
+    if (!idx_list && sel_evals <= kSmallEvals) {
+        const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
+        hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                           lower, upper, neg_gamma2, sp);
+        return;
+    }
     long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
     if (idx_list && blocks > 4096) blocks = 4096;                      // grid-stride inside the kernel
-    if (idx_list || max_evals <= 24576)
+    if (idx_list || sel_evals <= 24576)
         hipLaunchKernelGGL((k_features<MODE, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
                            lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
     else
@@ -945,18 +1059,18 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
 
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
-                     const int *idx_list, int list_counter, int list_cap, bool large, hipStream_t s)
+                     const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, hipStream_t s)
 {
     if (max_evals <= 0) return;
     if (xmode == XMODE_SCREEN)
         launch_features_mode<XMODE_SCREEN>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                           list_counter, list_cap, large, s);
+                                           list_counter, list_cap, large, sel_evals, s);
     else if (xmode == XMODE_SPLIT)
         launch_features_mode<XMODE_SPLIT>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                          list_counter, list_cap, large, s);
+                                          list_counter, list_cap, large, sel_evals, s);
     else
         launch_features_mode<XMODE_F32>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                        list_counter, list_cap, large, s);
+                                        list_counter, list_cap, large, sel_evals, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
