@@ -595,12 +595,18 @@ int build_tables(haf_engine *e)
     // the matrix core's internal order, 11 VALU adds, one for the small-pass chain (whose own roundings are 2^-10 of
     // that): 43 instead of 324
     e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * 44.0 * u + 8.0 * u));
-    // coefficient sum: sequential over the tiles (fp32 kernel) or two-level, 8 tiles per inner sum (split-fp16 kernel);
-    // +2 for the class split (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product
+    // coefficient sum: sequential over the tiles (fp32 kernel: one fma per tile and sum register) or two-level (split-fp16
+    // kernel: an inner sum takes the 2 column blocks of 8 tiles, 16 fmas, then one add per 8 tiles); +2 for the class split
+    // (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product.  All terms of a class sum have
+    // one sign, so n roundings cost at most n u of it.
     const bool split_mode = !(e->cfg.flags & HAF_FLAG_FP32_MFMA);
-    // (+ kHListParts: the list mode sums the class sums of that many tile ranges, k_svm_h_combine)
-    const double acc_adds = split_mode ? (8.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0 + kHListParts) : (e->n_sv_tiles + 5.0);
+    const double acc_adds = split_mode ? (16.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0) : (e->n_sv_tiles + 5.0);
     e->svm.guard_acc = (float)(guard_scale * ((acc_adds + 6.0) * u));
+    // list mode of the three-pass kernel with the SV tiles cut into kHListParts ranges (launch_svm_h): the outer sum of a range
+    // is that much shorter, and k_svm_h_combine adds the ranges in fp64 (one rounding back to fp32)
+    const bool parts_on = e->n_sv_tiles >= 4 * kHListParts;
+    const double acc_adds_l = 16.0 + std::ceil((double)e->n_sv_tiles / kHListParts) / 8.0 + 2.0 + 4.0 + 1.0;
+    e->svm.guard_acc_l = parts_on ? (float)(guard_scale * ((acc_adds_l + 6.0) * u)) : e->svm.guard_acc;
     // screening pass: one sequential fp32 sum per lane over two column blocks per tile, the 4-step lane reduction, the
     // class split, v_exp_f32 and the coefficient product; the band is ~3e-4, so nothing is gained by a two-level sum.
     // HAF_GUARD0_REL scales the whole screening band (this term and the per-evaluation one) for experiments.

@@ -1551,17 +1551,17 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const float *__restrict__
 {
     const int n_evals = min(counters[list_counter], list_cap);
     for (long es = (long)blockIdx.x * 256 + threadIdx.x; es < n_evals; es += (long)gridDim.x * 256) {
-        float P = 0.0f, N = 0.0f;
+        double P = 0.0, N = 0.0;                        // the ranges are added in fp64: no rounding of their own
         for (int y = 0; y < parts; y++) {
-            P += part_out[(2 * y) * part_stride + es];
-            N += part_out[(2 * y + 1) * part_stride + es];
+            P += (double)part_out[(2 * y) * part_stride + es];
+            N += (double)part_out[(2 * y + 1) * part_stride + es];
         }
         const int e = idx_list[es];
-        const float dv = (P + N) - p.rho;
-        const float sabs = P - N;                       // sum |coef| K
+        const float dv = (float)((P + N) - (double)p.rho);
+        const float sabs = (float)(P - N);              // sum |coef| K
         dec[e] = dv;
         labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-        if (!(fabsf(dv) > (p.guard_acc + p.guard_dot_p * (p.as_max + fabsf(ax[es]))) * sabs + p.guard_abs)) {
+        if (!(fabsf(dv) > (p.guard_acc_l + p.guard_dot_p * (p.as_max + fabsf(ax[es]))) * sabs + p.guard_abs)) {
             int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
             if (slot < flag_cap) flag_list[slot] = e;
         }
@@ -1575,7 +1575,7 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
     if (idx_list) {
-        const int parts = (part_out && d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;
+        const int parts = (part_out && d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;     // engine.cpp: guard_acc_l follows this rule
         float *po = parts > 1 ? part_out : nullptr;
         hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
                            (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
