@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Ad-hoc confidence run (not a test): default (screened) mode vs three-pass mode, every label of C5-size requests, over several
+"""Ad-hoc confidence run (not a test): default (screened) mode and fp32 mode vs three-pass mode, every label of C5-size requests, over several
 seeded models and clouds, including unbalanced coefficients and other gammas."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ for nsv, mseed, cseed, bal in ((1024, 11, 1, True), (2048, 12, 2, False), (777, 
     models.write_random_model(path, nsv, seed=mseed, balanced=bal)
     xyz = models.synthetic_cloud(grid=G, k=2, seed=cseed)
     ref = None
-    for flags in (capi.FLAG_SPLIT_F16, 0):
+    for flags in (capi.FLAG_SPLIT_F16, 0, capi.FLAG_FP32_MFMA):
         eng = capi.Engine(feat, rng_file, path, grid_h=G, grid_w=G, n_rolls=R, roll_step_deg=5, max_clouds=1, max_points=1 << 20, flags=flags | capi.FLAG_KEEP_DEBUG)
         rec = eng.score_rolls([xyz], [inp], 0, R)[0]
         c = eng.last_counts()
