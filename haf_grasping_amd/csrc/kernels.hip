@@ -1385,31 +1385,48 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt, acc[m][n], 0, 0, 0);
                 }
             }
-            // sweep 2: xh.sh, each k-step into a fresh accumulator, summed by the VALU
+            // sweep 2: xh.sh, each k-step into a fresh accumulator, summed by the VALU -- one step behind: the adds of a step
+            // are issued after the MFMAs of the next one, so the matrix pipe does not idle under the result latency
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 tp[2] = {zero, zero};
 #pragma unroll
             for (int s = 0; s < kHFull; s++)
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
                     const half8 bhv = *reinterpret_cast<const half8 *>(bl + (s * 2 + n) * 1024);
+                    f32x4 t4[2];
 #pragma unroll
-                    for (int m = 0; m < 2; m++) {
-                        const f32x4 t4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bhv, zero, 0, 0, 0);
+                    for (int m = 0; m < 2; m++) t4[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bhv, zero, 0, 0, 0);
+                    if (s + n > 0) {
+                        const int pn = n ^ 1;                          // the previous (s, n) pair had the other column block
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[m][n][r] = acc[m][n][r] + t4[r];
+                        for (int m = 0; m < 2; m++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) acc[m][pn][r] = acc[m][pn][r] + tp[m][r];
                     }
+                    tp[0] = t4[0];
+                    tp[1] = t4[1];
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
             for (int n = 0; n < 2; n++) {
                 const half4 bht = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
+                f32x4 t4[2];
 #pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    const f32x4 t4 = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bht, zero, 0, 0, 0);
+                for (int m = 0; m < 2; m++) t4[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bht, zero, 0, 0, 0);
+                const int pn = n ^ 1;                                  // (kHFull - 1, 1) before tail 0, tail 0 before tail 1
 #pragma unroll
-                    for (int r = 0; r < 4; r++) acc[m][n][r] = acc[m][n][r] + t4[r];
-                }
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[m][pn][r] = acc[m][pn][r] + tp[m][r];
+                tp[0] = t4[0];
+                tp[1] = t4[1];
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[m][1][r] = acc[m][1][r] + tp[m][r];      // tail 1
         } else {
         half8 bh[2][2], bq[2][2];                                    // [ring][column block n]
 #pragma unroll
