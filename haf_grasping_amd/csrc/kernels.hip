@@ -1368,11 +1368,11 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                 for (int n = 0; n < 2; n++) {
                     const half8 bhv = *reinterpret_cast<const half8 *>(bl + (s * 2 + n) * 1024);
                     const half8 bqv = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s * 2 + n) * 1024);
+                    // (the two row blocks alternate, so an accumulator is not needed again by the very next MFMA)
 #pragma unroll
-                    for (int m = 0; m < 2; m++) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], bhv, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bqv, acc[m][n], 0, 0, 0);
-                    }
+                    for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], bhv, acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bqv, acc[m][n], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);               // one step's fragments live at a time: no spills
                 }
 #pragma unroll
