@@ -1389,11 +1389,13 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             // are issued after the MFMAs of the next one, so the matrix pipe does not idle under the result latency
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             f32x4 tp[2] = {zero, zero};
+            half8 bnx = *reinterpret_cast<const half8 *>(bl);         // B fragments are read one step ahead as well
 #pragma unroll
             for (int s = 0; s < kHFull; s++)
 #pragma unroll
                 for (int n = 0; n < 2; n++) {
-                    const half8 bhv = *reinterpret_cast<const half8 *>(bl + (s * 2 + n) * 1024);
+                    const half8 bhv = bnx;
+                    if (s * 2 + n + 1 < kHFull * 2) bnx = *reinterpret_cast<const half8 *>(bl + (s * 2 + n + 1) * 1024);
                     f32x4 t4[2];
 #pragma unroll
                     for (int m = 0; m < 2; m++) t4[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bhv, zero, 0, 0, 0);
