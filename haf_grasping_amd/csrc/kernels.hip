@@ -1361,29 +1361,41 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int n = 0; n < 2; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const char *bl = cur + lane * 16;
         if (PRECISE) {
-            // sweep 1: xl.sh + xh.sl, magnitudes 2^-11 of the main pass: a plain MFMA chain (its roundings are negligible)
+            // sweep 1: xl.sh, then xh.sl, magnitudes 2^-11 of the main pass: a plain MFMA chain (its roundings are negligible).
+            // One B fragment live and one in flight (read a step ahead); consecutive steps alternate the column block, so an
+            // accumulator is needed again only four MFMAs later.
+            {
+                half8 bnx = *reinterpret_cast<const half8 *>(bl);
 #pragma unroll
-            for (int s = 0; s < kHFull; s++)
+                for (int s = 0; s < kHFull; s++)
 #pragma unroll
-                for (int n = 0; n < 2; n++) {
-                    const half8 bhv = *reinterpret_cast<const half8 *>(bl + (s * 2 + n) * 1024);
-                    const half8 bqv = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s * 2 + n) * 1024);
-                    // (the two row blocks alternate, so an accumulator is not needed again by the very next MFMA)
+                    for (int n = 0; n < 2; n++) {
+                        const half8 b = bnx;
+                        if (s * 2 + n + 1 < kHFull * 2) bnx = *reinterpret_cast<const half8 *>(bl + (s * 2 + n + 1) * 1024);
+                        else bnx = *reinterpret_cast<const half8 *>(bl + kHMatBytes);                 // first fragment of the lo image
 #pragma unroll
-                    for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], bhv, acc[m][n], 0, 0, 0);
+                        for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], b, acc[m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);           // one step's fragments live at a time: no spills
+                    }
 #pragma unroll
-                    for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bqv, acc[m][n], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);               // one step's fragments live at a time: no spills
-                }
+                for (int s = 0; s < kHFull; s++)
+#pragma unroll
+                    for (int n = 0; n < 2; n++) {
+                        const half8 b = bnx;
+                        if (s * 2 + n + 1 < kHFull * 2) bnx = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s * 2 + n + 1) * 1024);
+#pragma unroll
+                        for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], b, acc[m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
 #pragma unroll
             for (int n = 0; n < 2; n++) {
                 const half4 bht = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
                 const half4 bqt = *reinterpret_cast<const half4 *>(cur + kHMatBytes + kHTailOff + n * 512 + lane * 8);
 #pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt, acc[m][n], 0, 0, 0);
-                }
+                for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht, acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt, acc[m][n], 0, 0, 0);
             }
             // sweep 2: xh.sh, each k-step into a fresh accumulator, summed by the VALU -- one step behind: the adds of a step
             // are issued after the MFMAs of the next one, so the matrix pipe does not idle under the result latency
