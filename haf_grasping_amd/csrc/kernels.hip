@@ -1720,7 +1720,7 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
 // ---------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kMWaves = 4;
-constexpr int kMSplit = 4;                        // SV ranges a group of evaluations is split over (k_recheck_mfma tasks)
+constexpr int kMSplit = 8;                        // SV ranges a group of evaluations is split over (k_recheck_mfma tasks)
 static_assert(kRecheckPartRows == 2 * kMSplit + 1, "part64 layout");
 constexpr int kMEvals = 16 * kMWaves;
 constexpr int kMSteps = kKP / 4;                 // 81 k-steps of 4
