@@ -51,7 +51,93 @@ def parse():
     ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-f32-side", action="store_true", help="skip the side measurements of the other contraction modes")
+    ap.add_argument("--no-cabi-side", action="store_true",
+                    help="skip the side measurement of the C++-host multi-GPU path (haf_create_multi / haf_score_sharded: one "
+                         "process, N GPUs, RCCL all-gather behind the C-ABI)")
+    ap.add_argument("--cabi-child", action="store_true", help=argparse.SUPPRESS)   # internal: run that side measurement, print JSON
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one rank process per GPU ourselves (what torch.distributed.run
+    would do), BEFORE anything in this process touches a GPU -- this parent never imports torch -- and wait for them.
+    Rank 0's JSON line goes straight to our stdout.  Any rank failing fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for r, p in enumerate(procs):
+        code = p.wait()
+        if code != 0 and rc == 0:
+            rc = code or 1
+            sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+    return rc
+
+
+def cabi_child(args):
+    """The C++-host multi-GPU path, measured from ONE process: haf_create_multi over devices 0..N-1, the rolls of one C5
+    request sharded 5,5,5,5,4,4,4,4-style, the cloud resident on device 0 and broadcast by RCCL, one ncclAllGather of
+    the roll records per request, haf_finalize.  Strong scaling of a single request.  Prints one JSON object."""
+    import torch
+    import models
+    from haf_grasping_amd import capi
+    n = args.gpus
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    feat, rng_file = os.path.join(data, "Features.txt"), os.path.join(data, "range21062012_allfeatures")
+    tmp = tempfile.mkdtemp(prefix="hafbench_cabi_")
+    model_path = os.path.join(tmp, "rand%d.model" % args.nsv)
+    models.write_random_model(model_path, args.nsv, D=D_ATTR, seed=1234, balanced=True)
+    G = args.grid
+    xyz = models.synthetic_cloud(grid=G, k=2, seed=0)
+    torch.cuda.set_device(0)
+    d_xyz = torch.from_numpy(xyz).cuda()
+    cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
+    inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
+    me = capi.MultiEngine(feat, rng_file, model_path, list(range(n)), capi.SHARD_ROLLS, grid_h=G, grid_w=G, n_rolls=args.rolls,
+                          roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2, flags=capi.FLAG_PROFILE)
+    info = me.info()
+    for _ in range(max(1, args.warmup)):
+        out = me.score_sharded(cloud, inp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = me.score_sharded(cloud, inp)
+    dt = time.perf_counter() - t0
+    stage = [me.shard_stage_ms(s) for s in range(n)]
+    me.close()
+    print(json.dumps({"value": out["n_evals"] * args.steps / dt, "unit": "evals/s", "ms_per_request": 1e3 * dt / args.steps,
+                      "n_devices": n, "rccl_ranks": info["n_ranks"], "rccl_version": info["rccl_version"], "scaling": "strong",
+                      "evals_per_request": out["n_evals"], "shard_svm_ms": [st["svm"] if st else None for st in stage],
+                      "best": {"eval": out["eval"], "row": out["best_row"], "col": out["best_col"], "roll": out["best_roll"]},
+                      "workload": "ONE C5 request (cloud on device 0 -> ncclBroadcast), rolls sharded over %d GPUs in one process, "
+                                  "one ncclAllGather of the 16-byte roll records, haf_finalize" % n}), flush=True)
+
+
+def run_cabi_side(args, world):
+    """Rank 0, after the ranks have let go of the GPUs: the measurement above in a fresh child process (a crash there cannot
+    take the bench line with it)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cabi-child", "--gpus", str(world), "--steps", str(max(3, min(args.steps, 10))),
+           "--warmup", "1", "--nsv", str(args.nsv), "--grid", str(args.grid), "--rolls", str(args.rolls), "--roll-step", str(args.roll_step)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                           "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
+        if p.returncode != 0:
+            return {"error": "child exited with %d: %s" % (p.returncode, p.stderr.strip()[-400:])}
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as ex:          # noqa: BLE001 -- a side measurement must never cost the main line
+        return {"error": repr(ex)}
 
 
 def pmc_traffic(args, kernel):
@@ -152,12 +238,14 @@ def latency_c2(feat, rng_file, device, flags):
 
 def main():
     args = parse()
+    if args.cabi_child:
+        return cabi_child(args)
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))          # one rank per GPU, started here; this process stays off the GPUs
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one rank per GPU: launch with torch.distributed.run" % args.gpus)
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
 
     import torch
@@ -316,10 +404,26 @@ def main():
         if world == 1 and not args.no_latency:
             line["grasp_latency"] = latency_c2(feat, rng_file, local_rank,
                                                {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision])
-        print(json.dumps(line), flush=True)
+        line["ranks"] = {"world_size": world, "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                         ("bench.py (self-spawned ranks)" if world > 1 else "single process"),
+                         "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if use_dist else None}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cabi_side:
+            # every rank has let go of its engine; give the other rank processes a moment to exit, then measure the C++-host
+            # path (one process driving all the GPUs through the C-ABI) in a child of its own
+            del d_xyz
+            torch.cuda.empty_cache()
+            if world > 1:
+                time.sleep(3.0)
+            side = run_cabi_side(args, world)
+            if "best" in side:
+                side["same_best_as_rank0"] = bool(side["best"] == line["best"])
+            line["c_abi_sharded"] = side
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,52 +1,175 @@
-"""Builds haf_grasping_amd/libhafgrasp.so (gfx950 only) with hipcc.  In-tree, so the .so travels to the GPU box."""
+"""Builds the gfx950 libraries with hipcc, in-tree, so the .so files travel to the GPU box.
+
+  libhafgrasp.so           the product: C-ABI of include/hafgrasp.h, nothing else exported for tests or experiments
+  libhafgrasp_testing.so   the same objects + engine.cpp compiled with -DHAF_TESTING: haf_test_* hooks and the
+                           environment switches that scale the guard bands (tests/ only)
+  haf_grasp_cli            ROS-free command line front end (C++ over the C-ABI)
+
+After compiling, check_exp_hazard() disassembles the contraction kernels and fails the build when a v_exp_f32 result is
+read too soon (a measured gfx950 hazard that a compiler update could silently re-open).
+"""
 import os
+import re
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhafgrasp.so")
-SOURCES = ["kernels.hip", "screen.hip", "engine.cpp", "parsers.cpp"]
+LIB_TESTING = os.path.join(HERE, "libhafgrasp_testing.so")
+SOURCES = ["kernels.hip", "screen.hip", "engine.cpp", "parsers.cpp", "multi.cpp"]
 # per-file extra flags (screen.hip: see its header)
 EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["kernels.h", "parsers.h", "decq.h", os.path.join("..", "..", "include", "hafgrasp.h"),
-           os.path.join("..", "cli", "haf_grasp_cli.cpp")]
+HEADERS = ["kernels.h", "parsers.h", "decq.h", "engine_internal.h", os.path.join("..", "..", "include", "hafgrasp.h"),
+           os.path.join("..", "cli", "haf_grasp_cli.cpp"), os.path.join("..", "..", "ros_shim", "shim_core.h")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-Wno-inline-asm"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+OBJDUMP = os.path.join(ROCM, "lib", "llvm", "bin", "llvm-objdump")
+# kernels whose epilogue consumes v_exp_f32 results next to MFMAs, and the distance (instructions between the exp and the
+# first reader of its destination register) the build insists on.  Measured: 3 fails on hardware, >= 8 never did.
+EXP_HAZARD_KERNELS = ["k_svm_screen", "k_svm_rbf_h", "k_svm_rbf"]
+EXP_MIN_DISTANCE = 8
 
 
 def up_to_date():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(LIB_TESTING)):
         return False
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_TESTING))
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return all(os.path.getmtime(d) <= t for d in deps)
+    return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
+def _regs(tok):
+    """Registers named by one operand token: v12 -> {12}; v[12:15] -> {12..15}; anything else -> {}."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def exp_hazard_report(lib=None, kernels=None):
+    """Per kernel: the smallest number of instructions between a v_exp_f32 and the first later instruction that reads
+    its destination VGPR (straight-line distance inside the kernel's disassembly; a write to the register ends the
+    search; s_nop N counts as N + 1 instructions because it is that many wait states).  {kernel: (min_distance, n_exps)}"""
+    lib = lib or LIB
+    kernels = kernels or EXP_HAZARD_KERNELS
+    # the gfx950 code objects are bundled inside the host .so: llvm-objdump --offloading writes them out, one per
+    # translation unit, into the working directory
+    import glob
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="haf_isa_")
+    try:
+        shutil.copy(lib, os.path.join(tmp, "lib.so"))          # the bundles are written next to the input file
+        subprocess.check_call([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, stdout=subprocess.DEVNULL)
+        text = ""
+        for co in sorted(glob.glob(os.path.join(tmp, "*gfx950*"))):
+            text += subprocess.check_output([OBJDUMP, "-d", co]).decode(errors="replace")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    report = {}
+    cur, body = None, {}
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            body[cur] = []
+            continue
+        if cur is None:
+            continue
+        ins = line.split("//")[0].strip()
+        if ins and not ins.endswith(":"):
+            body[cur].append(ins)
+    for want in kernels:
+        names = [k for k in body if want in k and not k.endswith(".kd")]
+        worst, count = None, 0
+        for name in names:
+            code = body[name]
+            for i, ins in enumerate(code):
+                if not ins.startswith("v_exp_f32"):
+                    continue
+                ops = [t.strip() for t in ins.split(None, 1)[1].split(",")]
+                dst = _regs(ops[0])
+                if not dst:
+                    continue
+                count += 1
+                dist = 0
+                for later in code[i + 1:]:
+                    parts = later.split(None, 1)
+                    op = parts[0]
+                    toks = [t.strip() for t in parts[1].split(",")] if len(parts) > 1 else []
+                    if op.startswith("s_branch") or op.startswith("s_cbranch") or op.startswith("s_endpgm") or op.startswith("s_setpc"):
+                        break                      # leaves the straight line: the loop back edge is >= a whole tile away
+                    srcs = set()
+                    for t in toks[1:]:
+                        srcs |= _regs(t)
+                    # stores and MFMA C operands read their "first" operand too
+                    reads_first = op.startswith(("global_store", "buffer_store", "ds_write", "ds_store", "flat_store", "scratch_store"))
+                    if reads_first and toks:
+                        srcs |= _regs(toks[0])
+                    if srcs & dst:
+                        worst = dist if worst is None else min(worst, dist)
+                        break
+                    if toks and (_regs(toks[0]) & dst) and not reads_first:
+                        break                      # overwritten before anybody read it
+                    m2 = re.fullmatch(r"s_nop\s+(\d+)", later)
+                    dist += (int(m2.group(1)) + 1) if m2 else 1
+        report[want] = (worst, count)
+    return report
+
+
+def check_exp_hazard(lib=None, verbose=False):
+    rep = exp_hazard_report(lib)
+    bad = []
+    for k, (dist, n) in rep.items():
+        if verbose:
+            print("  v_exp_f32 hazard check: %-14s %3d exps, nearest reader %s instructions behind" % (k, n, dist))
+        if n == 0:
+            bad.append("%s: no v_exp_f32 found in the disassembly (kernel renamed? check EXP_HAZARD_KERNELS)" % k)
+        elif dist is not None and dist < EXP_MIN_DISTANCE:
+            bad.append("%s: a v_exp_f32 result is read %d instructions after the exp (< %d): the gfx950 transcendental "
+                       "hazard of DESIGN.md §2 is open again" % (k, dist, EXP_MIN_DISTANCE))
+    if bad:
+        raise RuntimeError("build check failed:\n  " + "\n  ".join(bad))
+    return rep
 
 
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    hipcc = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
+
+    def compile_one(src, suffix="", defs=()):
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + list(defs) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        return obj
+
+    objs = {src: compile_one(src) for src in SOURCES}
+    engine_testing = compile_one("engine.cpp", "_testing", ["-DHAF_TESTING"])
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"]
+    libs = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    for out, eng in ((LIB, objs["engine.cpp"]), (LIB_TESTING, engine_testing)):
+        cmd = link + [eng if s == "engine.cpp" else objs[s] for s in SOURCES] + libs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     # ROS-free command line front end (C++ host code over the C-ABI)
     cli = os.path.join(HERE, "haf_grasp_cli")
-    cmd = [hipcc, "-O2", "-std=c++17", os.path.join(HERE, "cli", "haf_grasp_cli.cpp"), "-o", cli, "-L" + HERE, "-lhafgrasp",
-           "-Wl,-rpath,$ORIGIN"]
+    cmd = [hipcc, "-O2", "-std=c++17", "-I" + os.path.join(HERE, "..", "ros_shim"), "-I" + os.path.join(HERE, "..", "include"),
+           os.path.join(HERE, "cli", "haf_grasp_cli.cpp"),
+           "-o", cli, "-L" + HERE, "-lhafgrasp", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    check_exp_hazard(LIB, verbose=verbose)
     return LIB
 
 

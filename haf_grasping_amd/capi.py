@@ -7,10 +7,14 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAF_LIB", os.path.join(HERE, "libhafgrasp.so"))   # HAF_LIB: A/B another build of the same ABI
+# the TESTING build (-DHAF_TESTING): same kernels, plus the haf_test_* hooks and the environment switches that scale the
+# guard bands.  Only tests/ load it (testlib(), Engine(..., testing=True)); the product library has neither.
+TESTLIB_PATH = os.path.join(HERE, "libhafgrasp_testing.so")
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16 = 1, 2, 4, 8
 DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM = range(6)
+SHARD_ROLLS, SHARD_CLOUDS = 0, 1
 STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "refine", "recheck", "vote", "download"]
 
 
@@ -19,7 +23,8 @@ class Config(C.Structure):
                 ("nr_features_without_shaf", C.c_int32), ("grid_h", C.c_int32), ("grid_w", C.c_int32),
                 ("n_rolls", C.c_int32), ("roll_step_deg", C.c_int32), ("z_shift", C.c_float),
                 ("graspval_top", C.c_int32), ("device", C.c_int32), ("max_clouds", C.c_int32),
-                ("max_points", C.c_int64), ("flags", C.c_uint32)]
+                ("max_points", C.c_int64), ("flags", C.c_uint32), ("graspval_th", C.c_int32),
+                ("max_rolls_per_call", C.c_int32)]
 
 
 class GraspInput(C.Structure):
@@ -45,11 +50,15 @@ class Cloud(C.Structure):
     _fields_ = [("xyz", C.c_void_p), ("n_points", C.c_size_t), ("stride_floats", C.c_size_t), ("on_device", C.c_int32)]
 
 
+ATTR_RECORD_DTYPE = np.dtype([("feature", np.float32), ("pad", np.float32), ("q4", np.float64), ("scaled", np.float64)])
+assert ATTR_RECORD_DTYPE.itemsize == 24
+
 ROLL_RECORD_DTYPE = np.dtype([("vote", np.int32), ("row", np.int16), ("col", np.int16), ("h_locmax", np.float32),
                               ("n_evals", np.int32)])
 assert ROLL_RECORD_DTYPE.itemsize == C.sizeof(RollRecord) == 16
 
 _lib = None
+_testlib = None
 
 
 class HafError(RuntimeError):
@@ -58,39 +67,53 @@ class HafError(RuntimeError):
         self.code = code
 
 
-def lib():
-    """Loads libhafgrasp.so.  Raises if it has not been built: the product path never falls back to anything else."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
-                               "there is no CPU fallback" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        E = C.c_void_p
-        L.haf_abi_version.restype = C.c_int
-        L.haf_config_default.argtypes = [C.POINTER(Config)]
-        L.haf_grasp_input_default.argtypes = [C.POINTER(GraspInput)]
-        L.haf_create.argtypes = [C.POINTER(Config), C.POINTER(E)]
-        L.haf_destroy.argtypes = [E]
-        L.haf_last_error.restype = C.c_char_p
-        L.haf_last_error.argtypes = [E]
-        L.haf_score.argtypes = [E, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
-        L.haf_score_batch.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
-        L.haf_score_rolls.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.c_int32, C.c_int32,
-                                      C.c_void_p]
-        L.haf_finalize.argtypes = [E, C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
-        L.haf_get_roll_grid.argtypes = [E, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
-        L.haf_debug_fetch.argtypes = [E, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
-        L.haf_set_stream.argtypes = [E, C.c_void_p]
-        L.haf_get_stream.restype = C.c_void_p
-        L.haf_get_stream.argtypes = [E]
-        L.haf_get_stage_ms.argtypes = [E, C.POINTER(C.c_float)]
-        L.haf_model_info.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        L.haf_last_tiers.argtypes = [E] + [C.POINTER(C.c_int64)] * 4
-        L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
-                                   C.c_size_t]
-        L.haf_free.argtypes = [C.c_void_p]
+def _bind(path, testing):
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950); "
+                           "there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    E = C.c_void_p
+    L.haf_abi_version.restype = C.c_int
+    L.haf_config_default.argtypes = [C.POINTER(Config)]
+    L.haf_grasp_input_default.argtypes = [C.POINTER(GraspInput)]
+    L.haf_create.argtypes = [C.POINTER(Config), C.POINTER(E)]
+    L.haf_destroy.argtypes = [E]
+    L.haf_last_error.restype = C.c_char_p
+    L.haf_last_error.argtypes = [E]
+    L.haf_score.argtypes = [E, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
+    L.haf_score_batch.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
+    L.haf_score_rolls.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.c_int32, C.c_int32,
+                                  C.c_void_p]
+    L.haf_finalize.argtypes = [E, C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
+    L.haf_roll_pose.argtypes = [E, C.POINTER(GraspInput), C.c_void_p, C.c_int32, C.POINTER(GraspOutput),
+                                C.POINTER(C.c_int32)]
+    L.haf_get_roll_grid.argtypes = [E, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.haf_debug_fetch.argtypes = [E, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
+    L.haf_debug_fetch_attr.argtypes = [E, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_int32)]
+    L.haf_set_stream.argtypes = [E, C.c_void_p]
+    L.haf_get_stream.restype = C.c_void_p
+    L.haf_get_stream.argtypes = [E]
+    L.haf_get_stage_ms.argtypes = [E, C.POINTER(C.c_float)]
+    L.haf_model_info.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.haf_last_tiers.argtypes = [E] + [C.POINTER(C.c_int64)] * 4
+    L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
+                               C.c_size_t]
+    L.haf_free.argtypes = [C.c_void_p]
+    # several GPUs in one process (csrc/multi.cpp)
+    L.haf_create_multi.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(E)]
+    L.haf_destroy_multi.argtypes = [E]
+    L.haf_multi_last_error.restype = C.c_char_p
+    L.haf_multi_last_error.argtypes = [E]
+    L.haf_score_sharded.argtypes = [E, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput)]
+    L.haf_score_batch_sharded.argtypes = [E, C.c_int32, C.POINTER(Cloud), C.POINTER(GraspInput), C.POINTER(GraspOutput),
+                                          C.POINTER(C.c_int32)]
+    L.haf_multi_info.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.haf_multi_engine.restype = C.c_void_p
+    L.haf_multi_engine.argtypes = [E, C.c_int32]
+    L.haf_multi_last_records.argtypes = [E, C.c_int32, C.c_void_p]
+    if testing:
         L.haf_test_decq_host.restype = C.c_double
         L.haf_test_decq_host.argtypes = [C.c_double, C.c_int]
         L.haf_test_scale_host.restype = C.c_double
@@ -112,8 +135,25 @@ def lib():
         L.haf_test_roll_geo.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
         L.haf_test_finalize.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
-        _lib = L
+        L.haf_test_roll_pose.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.c_int,
+                                         C.POINTER(GraspOutput), C.POINTER(C.c_int32)]
+    return L
+
+
+def lib():
+    """Loads libhafgrasp.so (the product).  Raises if it has not been built: nothing here falls back to anything else."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(LIB_PATH, testing=False)
     return _lib
+
+
+def testlib():
+    """Loads libhafgrasp_testing.so: the same kernels with the haf_test_* hooks and the guard-band environment switches."""
+    global _testlib
+    if _testlib is None:
+        _testlib = _bind(TESTLIB_PATH, testing=True)
+    return _testlib
 
 
 def default_config(**kw):
@@ -160,8 +200,8 @@ def load_pcd(path):
 class Engine:
     """Owns one haf_engine handle (one GPU)."""
 
-    def __init__(self, feature_file, range_file, model_file, **cfg):
-        self._L = lib()
+    def __init__(self, feature_file, range_file, model_file, testing=False, **cfg):
+        self._L = testlib() if testing else lib()
         self.cfg = default_config(feature_file=feature_file, range_file=range_file, model_file=model_file, **cfg)
         self._h = C.c_void_p()
         rc = self._L.haf_create(C.byref(self.cfg), C.byref(self._h))
@@ -237,6 +277,26 @@ class Engine:
         self._check(self._L.haf_finalize(self._h, C.byref(grasp_input), rec.ctypes.data, C.byref(out)))
         return output_to_dict(out)
 
+    def roll_pose(self, grasp_input, records, roll):
+        """One roll's own hypothesis (server.cpp:962-969): (output dict, published flag)."""
+        rec = np.ascontiguousarray(records, dtype=ROLL_RECORD_DTYPE)
+        assert rec.shape == (self.cfg.n_rolls,)
+        out, pub = GraspOutput(), C.c_int32()
+        self._check(self._L.haf_roll_pose(self._h, C.byref(grasp_input), rec.ctypes.data, roll, C.byref(out), C.byref(pub)))
+        return output_to_dict(out), bool(pub.value)
+
+    def debug_attr(self, cloud, roll):
+        """Attribute records of the masked cells of (cloud, roll): cells [n, 2], records [n, 324], computed [n]."""
+        n = C.c_int32()
+        self._check(self._L.haf_debug_fetch_attr(self._h, cloud, roll, 0, None, None, None, C.byref(n)))
+        cells = np.zeros((n.value, 2), np.int32)
+        attr = np.zeros((n.value, 324), ATTR_RECORD_DTYPE)
+        comp = np.zeros(n.value, np.uint8)
+        if n.value:
+            self._check(self._L.haf_debug_fetch_attr(self._h, cloud, roll, n.value, cells.ctypes.data, attr.ctypes.data,
+                                                     comp.ctypes.data, C.byref(n)))
+        return cells, attr, comp.astype(bool)
+
     def roll_grid(self, cloud, roll):
         H, W = self.cfg.grid_h, self.cfg.grid_w
         ev = np.zeros((H, W), np.float32)
@@ -259,4 +319,69 @@ class Engine:
     def stage_ms(self):
         ms = (C.c_float * len(STAGES))()
         self._check(self._L.haf_get_stage_ms(self._h, ms))
+        return dict(zip(STAGES, list(ms)))
+
+
+class MultiEngine:
+    """Owns one haf_multi handle: several GPUs of one node in this process, RCCL collectives behind the C-ABI."""
+
+    def __init__(self, feature_file, range_file, model_file, devices, shard_mode=SHARD_ROLLS, **cfg):
+        self._L = lib()
+        self.cfg = default_config(feature_file=feature_file, range_file=range_file, model_file=model_file, **cfg)
+        self.devices = list(devices)
+        dev = (C.c_int32 * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        rc = self._L.haf_create_multi(C.byref(self.cfg), dev, len(self.devices), shard_mode, C.byref(self._h))
+        if rc != HAF_OK:
+            raise HafError(rc, (self._L.haf_multi_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.haf_destroy_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != HAF_OK:
+            raise HafError(rc, (self._L.haf_multi_last_error(self._h) or b"").decode())
+
+    def info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.haf_multi_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_shards=a.value, n_ranks=b.value, rccl_version=c.value)
+
+    def score_sharded(self, xyz, grasp_input):
+        cl, keep = Engine._cloud(xyz)
+        out = GraspOutput()
+        self._check(self._L.haf_score_sharded(self._h, C.byref(cl), C.byref(grasp_input), C.byref(out)))
+        return output_to_dict(out)
+
+    def score_batch_sharded(self, clouds, inputs):
+        n = len(clouds)
+        keep = []
+        arr = (Cloud * n)()
+        for i, c in enumerate(clouds):
+            arr[i], k = Engine._cloud(c)
+            keep.append(k)
+        gi = (GraspInput * n)(*inputs)
+        out = (GraspOutput * n)()
+        best = C.c_int32(-1)
+        self._check(self._L.haf_score_batch_sharded(self._h, n, arr, gi, out, C.byref(best)))
+        return [output_to_dict(o) for o in out], best.value
+
+    def last_records(self, rank):
+        rec = np.zeros(self.cfg.n_rolls, dtype=ROLL_RECORD_DTYPE)
+        self._check(self._L.haf_multi_last_records(self._h, rank, rec.ctypes.data))
+        return rec
+
+    def shard_stage_ms(self, shard):
+        e = self._L.haf_multi_engine(self._h, shard)
+        ms = (C.c_float * len(STAGES))()
+        if self._L.haf_get_stage_ms(C.c_void_p(e), ms) != HAF_OK:
+            return None
         return dict(zip(STAGES, list(ms)))

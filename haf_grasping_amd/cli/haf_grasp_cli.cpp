@@ -9,20 +9,78 @@
 //   --max-time s              max_calculation_time           (default 50)
 //   --show-only-best          show_only_best_grasp
 //   --gripper-width w         gripper_width                  (default 1)
-// plus the engine's generalisations: --grid N, --rolls N, --roll-step deg.
+// plus the engine's generalisations: --grid N, --rolls N, --roll-step deg, and
+//   --gpus N [--shard rolls|clouds]   N GPUs of this node in ONE process through haf_create_multi: the rolls of every request
+//                                     sharded with one RCCL all-gather of the roll records (default), or the clouds given on
+//                                     the command line sharded with one RCCL all-reduce(max) electing the best grasp
+//   --hypotheses                      also print the per-roll hypotheses the server publishes when show_only_best is off
+//                                     (server.cpp:962-969), in its string format
 #include "../../include/hafgrasp.h"
+
+#include "shim_core.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
+
+static void usage();
+
+// --gpus N: the same requests through the multi-device front end of the C-ABI
+static int run_multi(haf_config cfg, const haf_grasp_input &in, int gpus, const std::string &shard, int argc, char **argv, int first_cloud)
+{
+    std::vector<int32_t> devices((size_t)gpus);
+    for (int g = 0; g < gpus; g++) devices[(size_t)g] = g;
+    const bool by_cloud = shard == "clouds";
+    const int n_clouds = argc - first_cloud;
+    if (by_cloud) cfg.max_clouds = n_clouds;
+    haf_multi *m = nullptr;
+    if (haf_create_multi(&cfg, devices.data(), gpus, by_cloud ? HAF_SHARD_CLOUDS : HAF_SHARD_ROLLS, &m) != HAF_OK) {
+        fprintf(stderr, "haf_create_multi: %s\n", haf_multi_last_error(nullptr));
+        return 1;
+    }
+    int32_t n_shards = 0, n_ranks = 0, ver = 0;
+    haf_multi_info(m, &n_shards, &n_ranks, &ver);
+    fprintf(stderr, "%d shards on %d RCCL ranks (RCCL %d), sharding %s\n", n_shards, n_ranks, ver, by_cloud ? "clouds" : "rolls");
+    int rc = 0;
+    std::vector<float *> xyz((size_t)n_clouds, nullptr);
+    std::vector<haf_cloud> clouds((size_t)n_clouds);
+    for (int i = 0; i < n_clouds; i++) {
+        size_t n = 0;
+        char err[256];
+        if (haf_pcd_load(argv[first_cloud + i], &xyz[(size_t)i], &n, err, sizeof err) != HAF_OK) { fprintf(stderr, "%s: %s\n", argv[first_cloud + i], err); return 1; }
+        clouds[(size_t)i] = haf_cloud{xyz[(size_t)i], n, 3, 0};
+    }
+    std::vector<haf_grasp_output> out((size_t)n_clouds);
+    if (by_cloud) {
+        std::vector<haf_grasp_input> ins((size_t)n_clouds, in);
+        int32_t best = -1;
+        if (haf_score_batch_sharded(m, n_clouds, clouds.data(), ins.data(), out.data(), &best) != HAF_OK) { fprintf(stderr, "%s\n", haf_multi_last_error(m)); rc = 1; }
+        else {
+            for (int i = 0; i < n_clouds; i++) printf("%s\n", hafshim::hypothesis_string(out[(size_t)i], cfg.roll_step_deg).c_str());
+            fprintf(stderr, "best grasp of the batch: cloud %d (%s), vote %d\n", best, argv[first_cloud + best], out[(size_t)best].best_vote);
+        }
+    } else {
+        for (int i = 0; i < n_clouds; i++) {
+            if (haf_score_sharded(m, &clouds[(size_t)i], &in, &out[(size_t)i]) != HAF_OK) { fprintf(stderr, "%s: %s\n", argv[first_cloud + i], haf_multi_last_error(m)); rc = 1; continue; }
+            printf("%s\n", hafshim::hypothesis_string(out[(size_t)i], cfg.roll_step_deg).c_str());
+            fprintf(stderr, "%s: %lld evaluations, best vote %d at row %d col %d roll %d\n", argv[first_cloud + i], (long long)out[(size_t)i].n_evals,
+                    out[(size_t)i].best_vote, out[(size_t)i].best_row, out[(size_t)i].best_col, out[(size_t)i].best_roll);
+        }
+    }
+    for (float *p : xyz) haf_free(p);
+    haf_destroy_multi(m);
+    return rc;
+}
 
 static void usage()
 {
     fprintf(stderr,
             "usage: haf_grasp_cli --features F --range R --model M [options] cloud.pcd [cloud2.pcd ...]\n"
             "  --center x y z  --search-size x y  --approach x y z  --max-time s  --show-only-best  --gripper-width w\n"
-            "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll\n");
+            "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll  --hypotheses\n"
+            "  --gpus N [--shard rolls|clouds]\n");
 }
 
 int main(int argc, char **argv)
@@ -32,7 +90,9 @@ int main(int argc, char **argv)
     haf_grasp_input in;
     haf_grasp_input_default(&in);
     double sx = 18, sy = 30;                       // launch defaults (launch/haf_grasping_all.launch:25-65)
-    bool per_roll = false;
+    bool per_roll = false, hypotheses = false;
+    int gpus = 0;
+    std::string shard = "rolls";
     std::string features, range, model;
     int first_cloud = argc;
     for (int i = 1; i < argc; i++) {
@@ -52,6 +112,9 @@ int main(int argc, char **argv)
         else if (a == "--roll-step") { need(1); cfg.roll_step_deg = atoi(argv[++i]); }
         else if (a == "--device") { need(1); cfg.device = atoi(argv[++i]); }
         else if (a == "--per-roll") per_roll = true;
+        else if (a == "--hypotheses") hypotheses = true;
+        else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
+        else if (a == "--shard") { need(1); shard = argv[++i]; }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { first_cloud = i; break; }
     }
@@ -63,6 +126,8 @@ int main(int argc, char **argv)
     cfg.model_file = model.c_str();
     cfg.max_points = 1 << 22;
 
+    if (gpus > 0) return run_multi(cfg, in, gpus, shard, argc, argv, first_cloud);
+
     haf_engine *eng = nullptr;
     if (haf_create(&cfg, &eng) != HAF_OK) { fprintf(stderr, "haf_create: %s\n", haf_last_error(nullptr)); return 1; }
     int rc = 0;
@@ -72,13 +137,29 @@ int main(int argc, char **argv)
         char err[256];
         if (haf_pcd_load(argv[i], &xyz, &n, err, sizeof err) != HAF_OK) { fprintf(stderr, "%s: %s\n", argv[i], err); rc = 1; continue; }
         haf_cloud cloud = {xyz, n, 3, 0};
+        // the goal goes the way the ROS adapter sends it: GoalFields -> hafshim::run_goal (ros_shim/shim_core.h).  stdout gets
+        // what the server publishes on /haf_grasping/grasp_hypothesis_with_eval: with --hypotheses every roll's own
+        // hypothesis first (server.cpp:962-969), always the overall best last (390 -> 1384, 1419)
+        hafshim::GoalFields goal;
+        for (int k = 0; k < 3; k++) { goal.center[k] = in.grasp_area_center[k]; goal.approach_vector[k] = in.approach_vector[k]; }
+        goal.length_x = in.grasp_area_length_x; goal.length_y = in.grasp_area_length_y;
+        goal.max_calculation_time = in.max_calculation_time;
+        goal.show_only_best_grasp = in.show_only_best_grasp != 0;
+        goal.gripper_opening_width = in.gripper_opening_width;
+        std::vector<std::string> lines;
+        hafshim::ResultFields res;
         haf_grasp_output out;
-        if (haf_score(eng, &cloud, &in, &out) != HAF_OK) { fprintf(stderr, "%s: %s\n", argv[i], haf_last_error(eng)); rc = 1; haf_free(xyz); continue; }
-        // the string the server publishes on /haf_grasping/grasp_hypothesis_with_eval (server.cpp:1384)
-        printf("%d %g %g %g %g %g %g %g %g %g %g %g %g %d\n", out.eval, out.grasp_point1[0], out.grasp_point1[1], out.grasp_point1[2],
-               out.grasp_point2[0], out.grasp_point2[1], out.grasp_point2[2], out.approach_vector[0], out.approach_vector[1],
-               out.approach_vector[2], out.averaged_grasp_point[0], out.averaged_grasp_point[1], out.averaged_grasp_point[2],
-               out.best_roll * cfg.roll_step_deg);
+        std::string serr;
+        if (hafshim::run_goal(eng, cfg, goal, cloud, [&](const std::string &l) { lines.push_back(l); }, &res, &out, &serr) != HAF_OK) {
+            fprintf(stderr, "%s: %s\n", argv[i], serr.c_str());
+            rc = 1;
+            haf_free(xyz);
+            continue;
+        }
+        for (size_t l = 0; l + 1 < lines.size(); l++)
+            if (hypotheses) printf("hypothesis %s\n", lines[l].c_str());
+        printf("%s\n", lines.back().c_str());
+        (void)res;
         fprintf(stderr, "%s: %zu points, %lld evaluations (%lld re-evaluated in fp64), best vote %d at row %d col %d roll %d\n", argv[i], n,
                 (long long)out.n_evals, (long long)out.n_rechecked, out.best_vote, out.best_row, out.best_col, out.best_roll);
         if (per_roll) {

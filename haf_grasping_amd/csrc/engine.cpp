@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "parsers.h"
 #include "decq.h"
+#include "engine_internal.h"
 
 #include <algorithm>
 #include <chrono>
@@ -16,12 +17,22 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
 using namespace haf;
 
 namespace {
+
+// Environment switches for experiments and for the tests that force the recheck tiers exist in the TESTING build only
+// (libhafgrasp_testing.so, -DHAF_TESTING): the guard bands are what makes the fast tiers give libsvm's labels, and a stray
+// variable must not be able to scale them in the library a server links.
+#ifdef HAF_TESTING
+const char *test_env(const char *name) { return getenv(name); }
+#else
+const char *test_env(const char *) { return nullptr; }
+#endif
 
 constexpr double kPi = 3.141592653;   // server.cpp:94 -- the reference's truncated constant, NOT M_PI
 
@@ -193,7 +204,12 @@ struct haf_engine {
     float stage_ms[HAF_ST_COUNT] = {};
 
     long max_evals = 0, max_evals_pad = 0;
-    int flag_cap = 0, flag2_cap = 0;
+    int max_rolls = 0;      // rolls per haf_score_rolls call the buffers are sized for (cfg.max_rolls_per_call, default n_rolls)
+    // Tier lists hold one entry per evaluation of the largest request (list_cap), so no request can overflow them.  flag_cap
+    // is the WINDOW of the fp64 MFMA tier: what its operand image (2.6 KB per evaluation) is sized for.  A request that flags
+    // more walks the list window by window (decide(), below): slower, never an error.
+    int list_cap = 0;
+    int flag_cap = 0;
     int flag0_cap = 0;      // screening pass: evaluations that go on to the three-pass kernel
     bool screen_active = true;   // default mode only: cleared (for good) once more than 60 % of a call's evaluations fell inside
                                  // the screening band -- for such a model the single pass is wasted work
@@ -218,6 +234,7 @@ struct haf_engine {
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64, d_part64;
     DevBuf<short> d_ev16;
+    DevBuf<AttrRecord> d_attr;      // HAF_FLAG_KEEP_DEBUG: [max_evals][kKP] attribute records of the exact-form feature kernels
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
     DevBuf<FeatDesc> d_fd;
@@ -268,6 +285,23 @@ int fail(haf_engine *e, int code, const std::string &msg)
     e->error = msg;
     return code;
 }
+
+// ---- no C++ exception may cross the C-ABI: a corrupt input file or an exhausted host must come back as a status the ROS
+// shim can turn into setAborted(), not as std::terminate() of the action server ----
+template <class F> int guarded(std::string *err, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        if (err) *err = "out of host memory";
+    } catch (const std::exception &ex) {
+        if (err) *err = std::string("internal error: ") + ex.what();
+    } catch (...) {
+        if (err) *err = "internal error (unknown exception)";
+    }
+    return HAF_E_INTERNAL;
+}
+
 
 int label_grid_value(int label)
 {
@@ -479,7 +513,7 @@ int build_tables(haf_engine *e)
                 }
                 if (fast) sp.fast_groups |= 1ull << g;
             }
-            if (getenv("HAF_NO_FAST_GROUPS")) sp.fast_groups = 0;        // A/B runs and the generic-path test
+            if (test_env("HAF_NO_FAST_GROUPS")) sp.fast_groups = 0;        // A/B runs and the generic-path test
             // a degenerate target range or bounds beyond the decimal path's error budget: serve the model without screening
             if (!(e->range.upper > e->range.lower) || std::fabs(e->range.lower) > 1e3 || std::fabs(e->range.upper) > 1e3) e->screen_active = false;
             sp.eta_abs = std::max(std::sqrt(ea2) * 1.01, 1e-12 * 18.0 * sp.c);
@@ -570,7 +604,7 @@ int build_tables(haf_engine *e)
     e->exact.as_max1 = 1.0 + m.gamma * log2e * ss_max;
     // fp64 GEMM-form tier: worst-case error ~ 324 * 2^-53 per unit of (a_x + a_s) * sum|coef|K, i.e. < 2^-44; 2^-40 leaves 16x
     e->exact.guard2 = std::ldexp(1.0, -40);
-    if (const char *g = getenv("HAF_GUARD2_REL")) e->exact.guard2 = atof(g);
+    if (const char *g = test_env("HAF_GUARD2_REL")) e->exact.guard2 = atof(g);
 
     e->gv0 = label_grid_value(m.label[0]);
     e->gv1 = label_grid_value(m.label[1]);
@@ -588,7 +622,7 @@ int build_tables(haf_engine *e)
     //              v_exp_f32 and the coefficient product (3 * 2^-23).
     // tests/diag_guard.py measures the actual error with the band disabled: 20-30x smaller.  HAF_GUARD_REL scales the band.
     double guard_scale = 1.0;
-    if (const char *g = getenv("HAF_GUARD_REL")) guard_scale = atof(g);
+    if (const char *g = test_env("HAF_GUARD_REL")) guard_scale = atof(g);
     const double u = std::ldexp(1.0, -24);
     e->svm.guard_dot = (float)(guard_scale * (0.6932 * 324.0 * u + 8.0 * u));
     // PRECISE form of the three-pass kernel (k_svm_rbf_h<true>): 31 roundings per instruction of the main pass whatever
@@ -611,7 +645,7 @@ int build_tables(haf_engine *e)
     // class split, v_exp_f32 and the coefficient product; the band is ~3e-4, so nothing is gained by a two-level sum.
     // HAF_GUARD0_REL scales the whole screening band (this term and the per-evaluation one) for experiments.
     double guard0_scale = 1.0;
-    if (const char *g = getenv("HAF_GUARD0_REL")) guard0_scale = atof(g);
+    if (const char *g = test_env("HAF_GUARD0_REL")) guard0_scale = atof(g);
     e->svm.guard_acc0 = (float)(guard0_scale * ((2.0 * e->n_sv_tiles + 4.0 + 2.0 + 6.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
@@ -632,16 +666,18 @@ int build_tables(haf_engine *e)
 int alloc_buffers(haf_engine *e)
 {
     const haf_config &c = e->cfg;
-    const size_t B = (size_t)c.max_clouds, R = (size_t)c.n_rolls, H = (size_t)c.grid_h, W = (size_t)c.grid_w;
+    e->max_rolls = (c.max_rolls_per_call > 0) ? std::min(c.max_rolls_per_call, c.n_rolls) : c.n_rolls;
+    const size_t B = (size_t)c.max_clouds, R = (size_t)e->max_rolls, H = (size_t)c.grid_h, W = (size_t)c.grid_w;
     e->cells_cap = B * R * H * W;
     e->max_evals = (long)(B * R * (H - 14) * (W - 14));
     e->max_evals_pad = (e->max_evals + kS0BlockEvals - 1) / kS0BlockEvals * kS0BlockEvals;
+    e->list_cap = (int)e->max_evals_pad;             // (< 2^31: cells are 32-bit ids, checked in haf_create)
     e->flag_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 4), 1L << 22);
+    if (const char *v = test_env("HAF_FLAG_WINDOW")) e->flag_cap = std::max(64, atoi(v));     // tests: many small windows
     const int mode = contraction_mode(c);
-    // screening pass: up to half of the evaluations may go on to the three-pass kernel before the call fails loudly
+    // screening pass: up to half of the evaluations may go on to the three-pass kernel; a model that sends more is served by
+    // the three-pass kernel alone from then on (haf_score_rolls)
     e->flag0_cap = mode == MODE_SCREEN ? (int)std::min<long>(std::max<long>(4096, (e->max_evals / 2 + 255) / 256 * 256), 1L << 23) : 0;
-    if (mode == MODE_SCREEN) e->flag_cap = std::min(e->flag_cap, e->flag0_cap);
-    e->flag2_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 64), 1L << 20);
     bool ok = true;
     ok &= hipSuccess == e->d_clouds.alloc(B);
     ok &= hipSuccess == e->d_points.alloc((size_t)c.max_points * 3);
@@ -655,7 +691,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_brcount.alloc(B * R);
     ok &= hipSuccess == e->d_counters.alloc(CNT_COUNT);
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
-    ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->flag_cap);
+    ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->list_cap);
     if (mode == MODE_SCREEN) {
         // sized for the three-pass form as well: a model whose decisions crowd inside the screening band is served by
         // the three-pass kernel alone (screen_active)
@@ -675,12 +711,18 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_ax.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_dec.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
-    ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->flag_cap);
+    ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->list_cap);
     ok &= hipSuccess == e->d_part64.alloc((size_t)e->flag_cap * kRecheckPartRows);
     // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
-    ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->flag2_cap);
-    ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->flag2_cap);
+    ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->list_cap);
+    ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->list_cap);
+    if (c.flags & HAF_FLAG_KEEP_DEBUG) {
+        // attribute records of the exact-form feature kernels (haf_debug_fetch_attr): 7.6 KB per evaluation, so only for
+        // engines of reference size (up to 2 GiB); a larger debug engine runs without them and the fetch says so
+        const size_t bytes = (size_t)e->max_evals * kKP * sizeof(AttrRecord);
+        if (bytes <= (2ull << 30)) ok &= hipSuccess == e->d_attr.alloc((size_t)e->max_evals * kKP);
+    }
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rec.alloc(B * R);
     ok &= hipSuccess == e->d_topkey.alloc(B * R);
@@ -700,6 +742,16 @@ void mark(haf_engine *e, int idx)
 
 }  // namespace
 
+// ---- engine_internal.h ----
+namespace haf {
+static_assert(sizeof(RollRecordDev) == sizeof(haf_roll_record) && sizeof(haf_roll_record) == 16, "roll records travel as 16 bytes");
+static_assert(sizeof(AttrRecord) == sizeof(haf_attr_record) && sizeof(haf_attr_record) == 24, "attribute debug record layout");
+const void *engine_records_dev(const haf_engine *e) { return e->d_rec.p; }
+hipStream_t engine_stream(const haf_engine *e) { return e->stream; }
+const haf_config *engine_config(const haf_engine *e) { return &e->cfg; }
+void engine_set_error(haf_engine *e, const char *msg) { e->error = msg; }
+}  // namespace haf
+
 // ---------------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------------
@@ -716,6 +768,8 @@ void haf_config_default(haf_config *c)
     c->roll_step_deg = 15;
     c->z_shift = 0.15f;
     c->graspval_top = 119;
+    c->graspval_th = 70;
+    c->max_rolls_per_call = 0;
     c->device = 0;
     c->max_clouds = 1;
     c->max_points = 1 << 20;
@@ -743,7 +797,7 @@ void haf_destroy(haf_engine *e)
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
-    e->d_coef64.release(); e->d_ev16.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
+    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
     e->d_sd.release(); e->d_sd3.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -755,12 +809,13 @@ void haf_destroy(haf_engine *e)
     delete e;
 }
 
-int haf_create(const haf_config *cfg, haf_engine **out)
+static int create_impl(const haf_config *cfg, haf_engine **out)
 {
     if (out) *out = nullptr;
     if (!cfg || !out) { g_create_error = "haf_create: null argument"; return HAF_E_ARG; }
     haf_engine *e = new haf_engine();
-    auto bail = [&](int code) { g_create_error = e->error; haf_destroy(e); return code; };
+    struct Guard { haf_engine *e; ~Guard() { if (e) haf_destroy(e); } } guard{e};      // an exception below must not leak the engine
+    auto bail = [&](int code) { g_create_error = e->error; return code; };
     e->cfg = *cfg;
     if (!cfg->feature_file || !cfg->range_file || !cfg->model_file) { e->error = "feature_file, range_file and model_file are required"; return bail(HAF_E_ARG); }
     e->feature_file = cfg->feature_file; e->range_file = cfg->range_file; e->model_file = cfg->model_file;
@@ -769,7 +824,11 @@ int haf_create(const haf_config *cfg, haf_engine **out)
     if (cfg->grid_h < 15 || cfg->grid_h > 4096) { e->error = "grid size must be in [15, 4096]"; return bail(HAF_E_ARG); }
     if (cfg->n_rolls < 1 || cfg->n_rolls > 4096 || cfg->max_clouds < 1 || cfg->max_points < 1) { e->error = "n_rolls, max_clouds and max_points must be positive"; return bail(HAF_E_ARG); }
     // integral images are read through a buffer descriptor (32-bit byte offsets): all of them must fit 4 GiB
-    if ((double)cfg->max_clouds * cfg->n_rolls * (cfg->grid_h + 1) * (cfg->grid_w + 1) * 4.0 >= 4294967296.0) { e->error = "max_clouds*n_rolls*grid cells exceeds 2^30"; return bail(HAF_E_CAPACITY); }
+    if (cfg->max_rolls_per_call < 0) { e->error = "max_rolls_per_call must be >= 0"; return bail(HAF_E_ARG); }
+    {
+        const int rolls_cap = (cfg->max_rolls_per_call > 0) ? std::min(cfg->max_rolls_per_call, cfg->n_rolls) : cfg->n_rolls;
+        if ((double)cfg->max_clouds * rolls_cap * (cfg->grid_h + 1) * (cfg->grid_w + 1) * 4.0 >= 4294967296.0) { e->error = "max_clouds*rolls per call*grid cells exceeds 2^30"; return bail(HAF_E_CAPACITY); }
+    }
 
     if (!load_features(e->feature_file, e->features, e->error)) return bail(HAF_E_IO);
     if (!load_range(e->range_file, e->range, e->error)) return bail(HAF_E_IO);
@@ -789,21 +848,29 @@ int haf_create(const haf_config *cfg, haf_engine **out)
 #ifndef HAF_FLUSH_F16_SUBNORMALS
     if (contraction_mode(e->cfg) == MODE_SCREEN) {
         // the screening operands keep fp16 subnormals (kernels.hip: screen_operand): make sure the matrix core does too
-        static std::mutex probe_mutex;                // one probe per process, whichever thread creates the first engine
-        static int keeps = -2;
+        static std::mutex probe_mutex;                // one probe per DEVICE and process, whichever thread gets there first
+        static int probed[64];                        // 0: not yet; else result + 2
+        int keeps;
         {
             std::lock_guard<std::mutex> lock(probe_mutex);
-            if (keeps == -2) keeps = probe_f16_subnormal_mfma(e->stream);
+            const int slot = cfg->device & 63;
+            if (cfg->device >= 64 || probed[slot] == 0) {
+                keeps = probe_f16_subnormal_mfma(e->stream);
+                if (cfg->device < 64 && keeps >= 0) probed[slot] = keeps + 2;
+            } else {
+                keeps = probed[slot] - 2;
+            }
         }
         if (keeps < 0) { e->error = "fp16 subnormal probe failed to run"; return bail(HAF_E_DEVICE); }
         if (keeps == 0) { e->error = "this device flushes fp16 subnormal MFMA operands: rebuild with -DHAF_FLUSH_F16_SUBNORMALS"; return bail(HAF_E_DEVICE); }
     }
 #endif
-    if (const char *v = getenv("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
+    if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
     rc = alloc_buffers(e);
     if (rc != HAF_OK) return bail(rc);
+    guard.e = nullptr;
     *out = e;
     return HAF_OK;
 }
@@ -847,14 +914,15 @@ int haf_set_stream(haf_engine *e, void *s)
 
 void *haf_get_stream(haf_engine *e) { return e ? (void *)e->stream : nullptr; }
 
-int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
-                    int32_t roll_count, haf_roll_record *records)
+static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
+                            int32_t roll_count, haf_roll_record *records)
 {
     if (!e) return HAF_E_ARG;
     if (!clouds || !in || !records || n_clouds < 1) return fail(e, HAF_E_ARG, "haf_score_rolls: null or empty argument");
     const haf_config &c = e->cfg;
     if (n_clouds > c.max_clouds) return fail(e, HAF_E_CAPACITY, "more clouds than max_clouds");
     if (roll_first < 0 || roll_count < 1 || roll_first + roll_count > c.n_rolls) return fail(e, HAF_E_ARG, "roll range outside [0, n_rolls)");
+    if (roll_count > e->max_rolls) return fail(e, HAF_E_CAPACITY, "more rolls in one call than max_rolls_per_call");
     HIPCHK(e, hipSetDevice(c.device));
     const int B = n_clouds, R = roll_count, H = c.grid_h, W = c.grid_w;
 
@@ -899,6 +967,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s));
     const size_t cells = (size_t)B * R * H * W;
     HIPCHK(e, hipMemsetAsync(e->d_labels.p, 0xFF, cells, s));            // -1: no feature vector for this cell (server.cpp:828-829)
+    if (e->d_attr.p) HIPCHK(e, hipMemsetAsync(e->d_attr.p, 0xFF, e->d_attr.n * sizeof(AttrRecord), s));   // debug: "not computed"
     mark(e, HAF_ST_BIN);
 
     Dims d;
@@ -933,7 +1002,7 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
         if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, nullptr, s);
             mark(e, HAF_ST_SVM);
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
@@ -943,40 +1012,61 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
             // workgroups beyond the list's end exit at once)
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
-                            e->flag0_cap, false, list_cap, s);
+                            e->flag0_cap, false, list_cap, e->d_attr.p, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
+                         e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
                          e->d_part1.p, e->part1_stride, s);
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, s);
             mark(e, HAF_ST_SVM);
             launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                         e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s);
+                         e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s);
             mark(e, HAF_ST_REFINE);
         } else {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, evals_sel, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, s);
             mark(e, HAF_ST_SVM);
             launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                       e->d_flag_list.p, e->flag_cap, e->d_counters.p, d, evals_cap, s);
+                       e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, s);
             mark(e, HAF_ST_REFINE);
         }
         mark(e, HAF_ST_RECHECK);
         // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
-        // is still within 2^-40 of zero (practically nothing)
-        launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, e->d_counters.p,
-                            e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->flag2_cap, d, s);
-        launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->flag2_cap,
+        // is still within 2^-40 of zero (practically nothing).  Window 0 of the tier-2 list goes with every request.
+        launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, 0, e->d_counters.p,
+                            e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s);
+        launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
                        e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
-        mark(e, HAF_ST_VOTE);
-        launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rec.p, d, s);
-        mark(e, HAF_ST_DOWNLOAD);
-        HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
-        HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
-        mark(e, HAF_ST_COUNT);
-        HIPCHK(e, hipStreamSynchronize(s));
-        HIPCHK(e, hipGetLastError());
+        // the counters come back with the roll records: a second window costs nothing unless it is needed
+        auto vote = [&]() -> int {
+            mark(e, HAF_ST_VOTE);
+            launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rec.p, d, s);
+            mark(e, HAF_ST_DOWNLOAD);
+            HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
+            HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+            mark(e, HAF_ST_COUNT);
+            HIPCHK(e, hipStreamSynchronize(s));
+            HIPCHK(e, hipGetLastError());
+            return HAF_OK;
+        };
+        int rc = vote();
+        if (rc != HAF_OK) return rc;
+        const int flagged = e->h_counters[CNT_FLAGGED];
+        if (flagged > e->flag_cap && !(mode == MODE_SCREEN && e->h_counters[CNT_FLAGGED0] > e->flag0_cap)) {
+            // More evaluations inside the guard band of the fast contraction than one window of the fp64 tier holds (an
+            // ill-conditioned model): the reference never fails a goal on this path (server.cpp:778-796), so neither does
+            // the engine -- the remaining windows of the list go through the same kernels one after the other, then the
+            // strict tier once more over its whole list (it is idempotent), then the vote again.  Slower, same labels.
+            for (int off = e->flag_cap; off < flagged; off += e->flag_cap)
+                launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, off,
+                                    e->d_counters.p, e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p,
+                                    e->list_cap, d, s);
+            launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
+                           e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+            rc = vote();
+            if (rc != HAF_OK) return rc;
+        }
         return HAF_OK;
     };
     int mode = contraction_mode(c);
@@ -1006,13 +1096,8 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
     e->last_inputs.assign(in, in + B);
-    if (e->last_flagged > e->flag_cap) {
-        char msg[200];
-        snprintf(msg, sizeof msg, "%d of %d evaluations fell inside the guard band, more than the recheck capacity %d", e->last_flagged,
-                 e->last_evals, e->flag_cap);
-        return fail(e, HAF_E_CAPACITY, msg);
-    }
-    if (e->last_flagged2 > e->flag2_cap) return fail(e, HAF_E_CAPACITY, "strict-order recheck list overflow");
+    // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
+    if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
     for (int i = 0; i < B * R; i++) {
         records[i].vote = e->h_rec[i].vote;
         records[i].row = e->h_rec[i].row;
@@ -1020,6 +1105,43 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
         records[i].h_locmax = e->h_rec[i].h_locmax;
         records[i].n_evals = e->h_rec[i].n_evals;
     }
+    return HAF_OK;
+}
+
+// grasp pose of (row, col) found at `roll` (transform_gp_in_wcs_and_publish, server.cpp:1274-1401) into out; `av_roll` is the
+// roll whose matrix the reference's av_trans_mat holds at that moment (the last one generate_grid ran, 484)
+static int pose_impl(const haf_config &c, const haf_grasp_input *in, const haf_roll_record &rec, int roll, int av_roll,
+                     haf_grasp_output *out, std::string &error)
+{
+    NormalisedInput n = normalise(*in);
+    Mat4 m = roll_transform(c, *in, n, roll, false), inv;
+    float x_gp_roll = -((float)(c.grid_h / 2 - rec.row)) / 100;                // 1339
+    float y_gp_roll = -((float)(c.grid_w / 2 - rec.col)) / 100;                // 1340
+    float h_locmax = rec.h_locmax;                                             // 1342-1351 (device, k_vote)
+    h_locmax = (float)(h_locmax - 0.01);                                       // 1354
+    const float x_gp_dis = 0.03f;                                              // 1360
+    const float gp[2][4] = {{x_gp_roll - x_gp_dis, y_gp_roll, h_locmax, 1.0f}, {x_gp_roll + x_gp_dis, y_gp_roll, h_locmax, 1.0f}};
+    if (!invert(m, inv)) { error = "transform is singular (gripper_opening_width 0?)"; return HAF_E_ARG; }
+    float w[2][3];
+    for (int p = 0; p < 2; p++)
+        for (int i = 0; i < 3; i++) {                                          // 1367-1368
+            float s = inv.a[i][0] * gp[p][0];
+            s = s + inv.a[i][1] * gp[p][1];
+            s = s + inv.a[i][2] * gp[p][2];
+            s = s + inv.a[i][3] * gp[p][3];
+            w[p][i] = s;
+        }
+    for (int i = 0; i < 3; i++) {
+        out->grasp_point1[i] = w[0][i];
+        out->grasp_point2[i] = w[1][i];
+        out->averaged_grasp_point[i] = (w[0][i] + w[1][i]) / 2.0;             // 1395-1397
+    }
+    // av_trans_mat is the matrix of the LAST roll generate_grid ran (484); its third row does not depend on the roll
+    Mat4 last = roll_transform(c, *in, n, av_roll, true);
+    out->approach_vector[0] = last.a[2][0];                                    // 1370-1374
+    out->approach_vector[1] = last.a[2][1];
+    out->approach_vector[2] = last.a[2][2];
+    out->roll = (float)((roll * c.roll_step_deg * kPi) / 180);                 // 1401
     return HAF_OK;
 }
 
@@ -1042,37 +1164,24 @@ static int finalize_impl(const haf_config &c, const haf_grasp_input *in, const h
     out->n_evals = evals;
     out->eval = o_top - 20;                                                   // 390
     if (o_roll < 0) return HAF_OK;
+    return pose_impl(c, in, rec[o_roll], o_roll, std::max(0, done - 1), out, error);
+}
 
-    NormalisedInput n = normalise(*in);
-    Mat4 m = roll_transform(c, *in, n, o_roll, false), inv;
-    float x_gp_roll = -((float)(c.grid_h / 2 - o_row)) / 100;                 // 1339
-    float y_gp_roll = -((float)(c.grid_w / 2 - o_col)) / 100;                 // 1340
-    float h_locmax = rec[o_roll].h_locmax;                                    // 1342-1351 (device, k_vote)
-    h_locmax = (float)(h_locmax - 0.01);                                      // 1354
-    const float x_gp_dis = 0.03f;                                             // 1360
-    const float gp[2][4] = {{x_gp_roll - x_gp_dis, y_gp_roll, h_locmax, 1.0f}, {x_gp_roll + x_gp_dis, y_gp_roll, h_locmax, 1.0f}};
-    if (!invert(m, inv)) { error = "transform is singular (gripper_opening_width 0?)"; return HAF_E_ARG; }
-    float w[2][3];
-    for (int p = 0; p < 2; p++)
-        for (int i = 0; i < 3; i++) {                                         // 1367-1368
-            float s = inv.a[i][0] * gp[p][0];
-            s = s + inv.a[i][1] * gp[p][1];
-            s = s + inv.a[i][2] * gp[p][2];
-            s = s + inv.a[i][3] * gp[p][3];
-            w[p][i] = s;
-        }
-    for (int i = 0; i < 3; i++) {
-        out->grasp_point1[i] = w[0][i];
-        out->grasp_point2[i] = w[1][i];
-        out->averaged_grasp_point[i] = (w[0][i] + w[1][i]) / 2.0;            // 1395-1397
-    }
-    // av_trans_mat is the matrix of the LAST roll generate_grid ran (484); its third row does not depend on the roll
-    Mat4 last = roll_transform(c, *in, n, std::max(0, done - 1), true);
-    out->approach_vector[0] = last.a[2][0];                                   // 1370-1374
-    out->approach_vector[1] = last.a[2][1];
-    out->approach_vector[2] = last.a[2][2];
-    out->roll = (float)((o_roll * c.roll_step_deg * kPi) / 180);              // 1401
-    return HAF_OK;
+// one roll's own hypothesis (show_predicted_gps, server.cpp:962-969)
+static int roll_pose_impl(const haf_config &c, const haf_grasp_input *in, const haf_roll_record *rec, int roll, haf_grasp_output *out,
+                          int32_t *published, std::string &error)
+{
+    memset(out, 0, sizeof *out);
+    if (roll < 0 || roll >= c.n_rolls) { error = "haf_roll_pose: roll outside [0, n_rolls)"; return HAF_E_ARG; }
+    const haf_roll_record &r = rec[roll];
+    int scaled = r.vote - 20;                                                  // 965
+    if (scaled < 10) scaled = 10;                                              // 966
+    out->eval = scaled;
+    out->best_row = r.row; out->best_col = r.col; out->best_roll = roll; out->best_vote = r.vote;
+    out->rolls_done = roll + 1;
+    out->n_evals = r.n_evals;
+    if (published) *published = (!in->show_only_best_grasp && r.vote > c.graspval_th) ? 1 : 0;   // 960-962
+    return pose_impl(c, in, r, roll, roll, out, error);
 }
 
 int haf_finalize(haf_engine *e, const haf_grasp_input *in, const haf_roll_record *rec, haf_grasp_output *out)
@@ -1082,7 +1191,7 @@ int haf_finalize(haf_engine *e, const haf_grasp_input *in, const haf_roll_record
     return finalize_impl(e->cfg, in, rec, out, e->error);
 }
 
-int haf_score_batch(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, haf_grasp_output *out)
+static int score_batch_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, haf_grasp_output *out)
 {
     if (!e) return HAF_E_ARG;
     if (!out) return fail(e, HAF_E_ARG, "haf_score_batch: null output");
@@ -1098,12 +1207,8 @@ int haf_score_batch(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
     return HAF_OK;
 }
 
-int haf_score(haf_engine *e, const haf_cloud *cloud, const haf_grasp_input *in, haf_grasp_output *out)
-{
-    return haf_score_batch(e, 1, cloud, in, out);
-}
 
-int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask)
+static int get_roll_grid_impl(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask)
 {
     if (!e) return HAF_E_ARG;
     const int rl = roll - e->last_roll_first;
@@ -1118,7 +1223,7 @@ int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_gr
     return HAF_OK;
 }
 
-int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes)
+static int debug_fetch_impl(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes)
 {
     if (!e) return HAF_E_ARG;
     if (!dst) return fail(e, HAF_E_ARG, "haf_debug_fetch: null dst");
@@ -1162,7 +1267,7 @@ int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, vo
             std::vector<float> dec(ne);
             HIPCHK(e, hipMemcpy(cell.data(), e->d_evalcell.p, ne * 4, hipMemcpyDeviceToHost));
             HIPCHK(e, hipMemcpy(dec.data(), e->d_dec.p, ne * 4, hipMemcpyDeviceToHost));
-            const size_t nfl = (size_t)std::min(e->last_flagged, e->flag_cap);
+            const size_t nfl = (size_t)std::min(e->last_flagged, e->list_cap);
             std::vector<int> fl(nfl);
             std::vector<double> ex(nfl);
             if (nfl) {
@@ -1171,7 +1276,7 @@ int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, vo
             }
             std::vector<double> d64(dec.begin(), dec.end());
             for (size_t k = 0; k < nfl; k++) d64[(size_t)fl[k]] = ex[k];
-            const size_t nf2 = (size_t)std::min(e->last_flagged2, e->flag2_cap);
+            const size_t nf2 = (size_t)std::min(e->last_flagged2, e->list_cap);
             if (nf2) {
                 std::vector<int> fl2(nf2);
                 std::vector<double> ex2(nf2);
@@ -1191,6 +1296,49 @@ int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, vo
     return fail(e, HAF_E_ARG, "haf_debug_fetch: dst too small");
 }
 
+static int debug_fetch_attr_impl(haf_engine *e, int32_t cloud, int32_t roll, int32_t max_cells, int32_t *cells, haf_attr_record *attr,
+                                 uint8_t *computed, int32_t *n_cells)
+{
+    if (!e) return HAF_E_ARG;
+    if (!n_cells || max_cells < 0) return fail(e, HAF_E_ARG, "haf_debug_fetch_attr: bad argument");
+    if (!(e->cfg.flags & HAF_FLAG_KEEP_DEBUG)) return fail(e, HAF_E_ARG, "haf_debug_fetch_attr: engine was created without HAF_FLAG_KEEP_DEBUG");
+    if (!e->d_attr.p) return fail(e, HAF_E_CAPACITY, "haf_debug_fetch_attr: attribute records are kept for engines of up to 2 GiB of them only");
+    const int rl = roll - e->last_roll_first;
+    if (cloud < 0 || cloud >= e->last_B || rl < 0 || rl >= e->last_R) return fail(e, HAF_E_ARG, "haf_debug_fetch_attr: (cloud, roll) not in the last scored batch");
+    const size_t H = (size_t)e->cfg.grid_h, W = (size_t)e->cfg.grid_w, HW = H * W;
+    const size_t br = (size_t)cloud * e->last_R + rl;
+    const size_t ne = (size_t)e->last_evals;
+    std::vector<int> cell(ne);
+    if (ne) HIPCHK(e, hipMemcpy(cell.data(), e->d_evalcell.p, ne * 4, hipMemcpyDeviceToHost));
+    std::vector<int> eval_of(HW, -1);
+    for (size_t k = 0; k < ne; k++)
+        if ((size_t)cell[k] / HW == br) eval_of[(size_t)cell[k] - br * HW] = (int)k;
+    int n = 0;
+    std::vector<haf_attr_record> row((size_t)kKP);
+    for (size_t idx = 0; idx < HW; idx++) {                     // row-major = the reference's line order
+        if (eval_of[idx] < 0) continue;
+        if (n < max_cells) {
+            if (cells) { cells[2 * n] = (int)(idx / W); cells[2 * n + 1] = (int)(idx % W); }
+            if (attr || computed) {
+                HIPCHK(e, hipMemcpy(row.data(), e->d_attr.p + (size_t)eval_of[idx] * kKP, (size_t)kKP * sizeof(AttrRecord), hipMemcpyDeviceToHost));
+                uint32_t bits;
+                memcpy(&bits, &row[0].feature, 4);
+                if (computed) computed[n] = bits != 0xFFFFFFFFu;
+                if (attr) memcpy(attr + (size_t)n * kKP, row.data(), (size_t)kKP * sizeof(haf_attr_record));
+            }
+        }
+        n++;
+    }
+    *n_cells = n;
+    return HAF_OK;
+}
+
+int haf_debug_fetch_attr(haf_engine *e, int32_t cloud, int32_t roll, int32_t max_cells, int32_t *cells, haf_attr_record *attr,
+                         uint8_t *computed, int32_t *n_cells)
+{
+    return guarded(e ? &e->error : nullptr, [&] { return debug_fetch_attr_impl(e, cloud, roll, max_cells, cells, attr, computed, n_cells); });
+}
+
 int haf_get_stage_ms(haf_engine *e, float *ms)
 {
     if (!e || !ms) return HAF_E_ARG;
@@ -1199,7 +1347,7 @@ int haf_get_stage_ms(haf_engine *e, float *ms)
     return HAF_OK;
 }
 
-int haf_pcd_load(const char *path, float **xyz, size_t *n_points, char *err, size_t err_cap)
+static int pcd_load_impl(const char *path, float **xyz, size_t *n_points, char *err, size_t err_cap)
 {
     if (!path || !xyz || !n_points) return HAF_E_ARG;
     std::vector<float> v;
@@ -1217,7 +1365,56 @@ int haf_pcd_load(const char *path, float **xyz, size_t *n_points, char *err, siz
 
 void haf_free(void *p) { free(p); }
 
+int haf_create(const haf_config *cfg, haf_engine **out)
+{
+    return guarded(&g_create_error, [&] { return create_impl(cfg, out); });
+}
 
+int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
+                    int32_t roll_count, haf_roll_record *records)
+{
+    return guarded(e ? &e->error : nullptr, [&] { return score_rolls_impl(e, n_clouds, clouds, in, roll_first, roll_count, records); });
+}
+
+int haf_roll_pose(haf_engine *e, const haf_grasp_input *in, const haf_roll_record *rec, int32_t roll, haf_grasp_output *out,
+                  int32_t *published)
+{
+    if (!e) return HAF_E_ARG;
+    if (!in || !rec || !out) return fail(e, HAF_E_ARG, "haf_roll_pose: null argument");
+    return roll_pose_impl(e->cfg, in, rec, roll, out, published, e->error);
+}
+
+int haf_score_batch(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, haf_grasp_output *out)
+{
+    return guarded(e ? &e->error : nullptr, [&] { return score_batch_impl(e, n_clouds, clouds, in, out); });
+}
+
+int haf_score(haf_engine *e, const haf_cloud *cloud, const haf_grasp_input *in, haf_grasp_output *out)
+{
+    return haf_score_batch(e, 1, cloud, in, out);
+}
+
+int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask)
+{
+    return guarded(e ? &e->error : nullptr, [&] { return get_roll_grid_impl(e, cloud, roll, eval_grid, mask); });
+}
+
+int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes)
+{
+    return guarded(e ? &e->error : nullptr, [&] { return debug_fetch_impl(e, what, cloud, roll, dst, dst_bytes); });
+}
+
+int haf_pcd_load(const char *path, float **xyz, size_t *n_points, char *err, size_t err_cap)
+{
+    std::string msg;
+    const int rc = guarded(&msg, [&] { return pcd_load_impl(path, xyz, n_points, err, err_cap); });
+    if (rc == HAF_E_INTERNAL && !msg.empty() && err && err_cap) snprintf(err, err_cap, "%s", msg.c_str());
+    return rc;
+}
+
+
+#ifdef HAF_TESTING
+// ---- the hooks below exist in libhafgrasp_testing.so only (-DHAF_TESTING); the product library does not export them ----
 // host-only hooks: parsers, per-roll geometry and the cross-roll rule/pose, none of which touches a device
 int haf_test_feature_table(const char *path, int *n, int *reg /* cap*16 */, float *w /* cap*4 */, int cap)
 {
@@ -1279,6 +1476,13 @@ int haf_test_finalize(const haf_config *cfg, const haf_grasp_input *in, const ha
     return finalize_impl(*cfg, in, rec, out, err);
 }
 
+int haf_test_roll_pose(const haf_config *cfg, const haf_grasp_input *in, const haf_roll_record *rec, int roll, haf_grasp_output *out,
+                       int32_t *published)
+{
+    std::string err;
+    return roll_pose_impl(*cfg, in, rec, roll, out, published, err);
+}
+
 // ---- test hooks (host and device builds of the decimal round-trip arithmetic; see tests/) ----
 double haf_test_decq_host(double x, int digits) { return digits == 40 ? hafq::decq4_float((float)x) : hafq::decq(x, digits); }
 double haf_test_scale_host(double q4, double fmin, double fmax, double lower, double upper)
@@ -1333,5 +1537,6 @@ int haf_test_scale_device(const double *q4, const double *fmin, const double *fm
     for (auto &p : d) (void)hipFree(p);
     return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
 }
+#endif  // HAF_TESTING
 
 }  // extern "C"

@@ -149,6 +149,9 @@ struct FeatDesc {
     double scr_mul, scr_sub;      // screening pass (ScrDesc below): u' = (q4 - scr_sub) * scr_mul
 };
 
+// haf_attr_record of include/hafgrasp.h: the three stages of one attribute of one evaluation (HAF_FLAG_KEEP_DEBUG)
+struct AttrRecord { float feature, pad; double q4, scaled; };
+
 struct Dims {
     int H, W, R, B;               // grid, rolls in this launch, clouds
     int nf;                       // feature rows (324)
@@ -201,7 +204,8 @@ enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2 };
 // j < min(counters[list_counter], list_cap) (the screened evaluations that go on to the three-pass kernel)
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
-                     const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, hipStream_t s);
+                     const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
+                     hipStream_t s);
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
@@ -217,8 +221,8 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
-                         const int *flag_list, int flag_cap, int *counters, double *x64, double *part64, double *dec_exact,
-                         int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s);
+                         const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
+                         double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s);
 constexpr int kRecheckPartRows = 2 * 8 + 1;       // part64: [2 * kMSplit + 1][flag_cap] doubles (partial sums + |x|^2)
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
                  RollRecordDev *rec, Dims d, hipStream_t s);

@@ -415,6 +415,21 @@ __device__ __forceinline__ double attribute_value(const Src &src, const FeatDesc
     return hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper, tb);
 }
 
+// The same, leaving the three stages of the attribute behind for haf_debug_fetch_attr (HAF_FLAG_KEEP_DEBUG): rec == nullptr in
+// every production call.  An attribute svm-scale drops (f.skip) is 0 for the contraction; its feature and "%.4g" value are
+// still what fv.cpp writes into the text file, so the record keeps them.
+template <class Src, class Tabs>
+__device__ __forceinline__ double attribute_value_rec(const Src &src, const FeatDesc &f, double lower, double upper, const Tabs &tb,
+                                                      AttrRecord *rec)
+{
+    if (f.skip && !rec) return 0.0;
+    const float v = feature_value(src, f);
+    const double q4 = hafq::decq4_float(v, tb);
+    const double x = f.skip ? 0.0 : hafq::scale_q6(q4, f.fmin, f.fmax, f.range, f.inv_range, lower, upper, tb);
+    if (rec) { rec->feature = v; rec->pad = 0.0f; rec->q4 = q4; rec->scaled = x; }
+    return x;
+}
+
 // Attribute for the SCREENING pass only, already multiplied by c (kernels.h: ScreenParams): the "%.4g" round trip through the
 // table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (u' = (q4 - scr_sub) *
 // scr_mul: a subtraction and a product, each with one scalar operand), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
@@ -675,7 +690,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
-                                                  const int *__restrict__ idx_list, int list_counter, int list_cap)
+                                                  const int *__restrict__ idx_list, int list_counter, int list_cap,
+                                                  AttrRecord *__restrict__ dbg)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
@@ -731,7 +747,9 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         return;
     }
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    const unsigned w0 = window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W);
+    const int e_src = idx_list ? idx_list[e] : (int)e;                 // the evaluation this slot holds
+    const unsigned w0 = window_origin(evalcell[e_src], d.H, d.W);
+    AttrRecord *rec = (MODE != XMODE_SCREEN && dbg) ? dbg + (size_t)e_src * kKP : nullptr;   // KEEP_DEBUG only
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
         float su2 = 0.0f, sd2 = 0.0f;
@@ -775,10 +793,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             for (int q = 0; q < 8; q++) {
                 const int f = g * 8 + q;
                 float xf = 0.0f;
-                if (f < d.nf) {
-                    const FeatDesc &F = fd[f];
-                    if (!F.skip) xf = (float)attribute_value(SrcBuf<true>{iir, w0}, F, lower, upper, tb);
-                }
+                if (f < d.nf) xf = (float)attribute_value_rec(SrcBuf<true>{iir, w0}, fd[f], lower, upper, tb, rec ? rec + f : nullptr);
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
                 hi[q] = h;
@@ -790,9 +805,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         }
     } else {
         for (int f = 0; f < d.nf; f++) {
-            const FeatDesc &F = fd[f];
-            float xf = 0.0f;
-            if (!F.skip) xf = (float)attribute_value(SrcBuf<true>{iir, w0}, F, lower, upper, tb);
+            const float xf = (float)attribute_value_rec(SrcBuf<true>{iir, w0}, fd[f], lower, upper, tb, rec ? rec + f : nullptr);
             xcol[f * kTile] = xf;
             xx = fma((double)xf, (double)xf, xx);
         }
@@ -815,7 +828,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
-                                                  const int *__restrict__ idx_list, int list_counter, int list_cap)
+                                                  const int *__restrict__ idx_list, int list_counter, int list_cap,
+                                                  AttrRecord *__restrict__ dbg)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     constexpr int kFeatFinisher = (kAugS / 8) % kFeatWaves;   // the wave that holds group 40 (screening form: norm slots) sums up
@@ -844,7 +858,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : 2 * kHSteps;          // 41 / 42
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    const unsigned w0 = live ? window_origin(evalcell[idx_list ? idx_list[e] : (int)e], d.H, d.W) : 0u;
+    const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;  // the evaluation this slot holds
+    const unsigned w0 = live ? window_origin(evalcell[e_src], d.H, d.W) : 0u;
+    AttrRecord *rec = (MODE != XMODE_SCREEN && dbg && live) ? dbg + (size_t)e_src * kKP : nullptr;   // KEEP_DEBUG only
     // The 15x15 windows of the block's 64 evaluations go to LDS first (every wave works on the same 64): the evaluations of
     // a list are scattered cells, so a corner load of 64 lanes is 64 separate L1 accesses, ~2700 times per evaluation and
     // wave group -- the vector L1 was what bounded this kernel.  Staged, a window row is one or two accesses, once.
@@ -871,8 +887,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             double xd = 0.0;
             if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? screen_attribute(src, F, st)               // u' = c x', not x'
-                                                         : attribute_value(src, F, lower, upper, tb);
+                if (MODE == XMODE_SCREEN) { if (!F.skip) xd = screen_attribute(src, F, st); }     // u' = c x', not x'
+                else xd = attribute_value_rec(src, F, lower, upper, tb, rec ? rec + f : nullptr);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
@@ -935,7 +951,8 @@ template <int MODE>
 __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
-                                                  double upper, float neg_gamma2, ScreenParams sp)
+                                                  double upper, float neg_gamma2, ScreenParams sp,
+                                                  AttrRecord *__restrict__ dbg)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     constexpr int kFinisher = kAugS / 8;              // slot 40: holds group 40 (screening form: norm slots) and sums up
@@ -985,7 +1002,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             double xd = 0.0;
             if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
                 const FeatDesc &F = fd[f];
-                if (!F.skip) xd = (MODE == XMODE_SCREEN) ? screen_attribute(src, F, st) : attribute_value(src, F, lower, upper, tb);
+                if (MODE == XMODE_SCREEN) { if (!F.skip) xd = screen_attribute(src, F, st); }
+                else xd = attribute_value_rec(src, F, lower, upper, tb, (dbg) ? dbg + (size_t)e * kKP + f : nullptr);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
@@ -1031,46 +1049,48 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
 template <int MODE>
 static void launch_features_mode(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                                  Dims d, double lower, double upper, float neg_gamma2, long max_evals, ScreenParams sp,
-                                 const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, hipStream_t s)
+                                 const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals,
+                                 AttrRecord *dbg, hipStream_t s)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     if (large) {
         // enough evaluations to fill the chip with one thread each
         long blocks = (max_evals + kBlock - 1) / kBlock * (kBlock / 256);
         hipLaunchKernelGGL(k_features_serial<MODE>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg);
         return;
     }
     if (!idx_list && sel_evals <= kSmallEvals) {
         const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
         hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp);
+                           lower, upper, neg_gamma2, sp, dbg);
         return;
     }
     long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
     if (idx_list && blocks > 4096) blocks = 4096;                      // grid-stride inside the kernel
     if (idx_list || sel_evals <= 24576)
         hipLaunchKernelGGL((k_features<MODE, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg);
     else
         hipLaunchKernelGGL((k_features<MODE, 8>), dim3((unsigned)blocks), dim3(8 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg);
 }
 
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
-                     const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, hipStream_t s)
+                     const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
+                     hipStream_t s)
 {
     if (max_evals <= 0) return;
     if (xmode == XMODE_SCREEN)
         launch_features_mode<XMODE_SCREEN>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                           list_counter, list_cap, large, sel_evals, s);
+                                           list_counter, list_cap, large, sel_evals, dbg, s);
     else if (xmode == XMODE_SPLIT)
         launch_features_mode<XMODE_SPLIT>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                          list_counter, list_cap, large, sel_evals, s);
+                                          list_counter, list_cap, large, sel_evals, dbg, s);
     else
         launch_features_mode<XMODE_F32>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                        list_counter, list_cap, large, sel_evals, s);
+                                        list_counter, list_cap, large, sel_evals, dbg, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1160,9 +1180,10 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; r++)
             acc[r] = __builtin_amdgcn_exp2f(fmaf(p.two_gamma2, acc[r], axr[r] + as_));   // -g2*(|x|^2 + |s|^2 - 2 x.s)
-#pragma unroll
-        for (int r = 0; r < 16; r++) asm volatile("" : "+v"(acc[r]));
-        asm volatile("s_nop 7\n\ts_nop 7");                          // the last exp gets 16 wait states before any consumer
+        // the wait states hang on the data: the asm reads and "writes" all sixteen results, so every exp is in front of it
+        // and every consumer behind it whatever the scheduler does (a free-standing s_nop asm was moved to the end of the
+        // tile by hipcc in one build; haf_grasping_amd/build.py now checks the distance in the ISA)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));             // the last exp gets 16 wait states before any consumer
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             part[r] = fmaf(cf, acc[r], part[r]);
@@ -1499,13 +1520,8 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                 for (int r = 0; r < 4; r++)                          // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
                     acc[m][n][r] = __builtin_amdgcn_exp2f(fmaf(p.two_gamma2, acc[m][n][r], axr[m][r] + as_));
         }
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) asm volatile("" : "+v"(acc[m][n][r]));
-        asm volatile("s_nop 7\n\ts_nop 7");                          // the last exp gets 16 wait states before any consumer
+        // the wait states hang on the data (see k_svm_rbf): all sixteen results go through the asm
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
@@ -1719,6 +1735,8 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
 // (326 x 16: attributes, |s|^2, coef) is shared through LDS, double buffered with a register-staged prefetch.
 // ---------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+// entries of a list of `total` that fall into the window [off, off + cap)
+__device__ __forceinline__ int window_count(int total, int off, int cap) { return max(0, min(total - off, cap)); }
 constexpr int kMWaves = 4;
 constexpr int kMSplit = 8;                        // SV ranges a group of evaluations is split over (k_recheck_mfma tasks)
 static_assert(kRecheckPartRows == 2 * kMSplit + 1, "part64 layout");
@@ -1731,11 +1749,11 @@ constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per 
 // the register image of the fp64 MFMA A operand (64 consecutive doubles per k-step).
 __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                    const FeatDesc *__restrict__ fd, ExactParams p,
-                                                   const int *__restrict__ flag_list, int flag_cap,
+                                                   const int *__restrict__ flag_list, int flag_cap, int list_off,
                                                    const int *__restrict__ counters, double *__restrict__ x64, Dims d)
 {
-    int n_flag = counters[CNT_FLAGGED];
-    if (n_flag > flag_cap) n_flag = flag_cap;
+    // flag_list points at entry list_off of the tier's list; this launch takes the window [list_off, list_off + flag_cap)
+    const int n_flag = window_count(counters[CNT_FLAGGED], list_off, flag_cap);
     const int n_grp = (n_flag + 63) / 64 * 4;          // whole k_recheck_mfma workgroups (64 evaluations): unused slots get zeros
     const int H = d.H, W = d.W;
     const rsrc_t iir = make_ii_rsrc(ii, d);
@@ -1756,14 +1774,13 @@ __global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii,
 __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__ x64, const int *__restrict__ evalcell,
                                                       const double *__restrict__ sv64,
                                                       ExactParams p, const int *__restrict__ flag_list, int flag_cap,
-                                                      int *__restrict__ counters, double *__restrict__ part64, Dims d)
+                                                      int list_off, int *__restrict__ counters, double *__restrict__ part64, Dims d)
 {
     // ONE SV tile in LDS (41 KiB): the next tile waits in registers while this one is consumed, and both barriers of the
     // hand-over are needed with one buffer or two -- with one, three workgroups fit a CU instead of one
     __shared__ __attribute__((aligned(16))) double bt[1][kMTileDoubles];
     __shared__ double xxs[kMWaves][16];
-    int n_flag = counters[CNT_FLAGGED];
-    if (n_flag > flag_cap) n_flag = flag_cap;
+    const int n_flag = window_count(counters[CNT_FLAGGED], list_off, flag_cap);
     const int n_groups = (n_flag + kMEvals - 1) / kMEvals;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_tiles = p.n_sv_pad / 16;
@@ -1866,11 +1883,10 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
 // close to zero for the GEMM form goes on to the strict-order kernel
 __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restrict__ part64, const int *__restrict__ evalcell,
                                                          ExactParams p, const int *__restrict__ flag_list, int flag_cap,
-                                                         int *__restrict__ counters, double *__restrict__ dec_exact,
+                                                         int list_off, int *__restrict__ counters, double *__restrict__ dec_exact,
                                                          int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap)
 {
-    int n_flag = counters[CNT_FLAGGED];
-    if (n_flag > flag_cap) n_flag = flag_cap;
+    const int n_flag = window_count(counters[CNT_FLAGGED], list_off, flag_cap);
     for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
         double P = 0.0, S = 0.0;
 #pragma unroll
@@ -1890,18 +1906,23 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
     }
 }
 
+// flag_list and dec_exact are the WHOLE lists (one entry per flagged evaluation, sized for every evaluation of a request);
+// the launch works on the window [list_off, list_off + window_cap) of them, which is what x64 / part64 are sized for.  The
+// host runs window 0 with every request and further windows only when more evaluations were flagged than one window holds.
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
-                         const int *flag_list, int flag_cap, int *counters, double *x64, double *part64, double *dec_exact,
-                         int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
+                         const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
+                         double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
 {
-    int groups = (flag_cap + kMEvals - 1) / kMEvals;
+    int groups = (window_cap + kMEvals - 1) / kMEvals;
     int blocks = groups < 2048 ? groups : 2048;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_recheck_x, dim3(blocks * 2), dim3(256), 0, s, ii, evalcell, fd, p, flag_list, flag_cap, counters, x64, d);
+    flag_list += list_off;
+    dec_exact += list_off;
+    hipLaunchKernelGGL(k_recheck_x, dim3(blocks * 2), dim3(256), 0, s, ii, evalcell, fd, p, flag_list, window_cap, list_off, counters, x64, d);
     const long tasks = (long)groups * kMSplit;
     hipLaunchKernelGGL(k_recheck_mfma, dim3((unsigned)(tasks < 4096 ? tasks : 4096)), dim3(256), 0, s, x64, evalcell, sv64, p,
-                       flag_list, flag_cap, counters, part64, d);
-    hipLaunchKernelGGL(k_recheck_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, flag_cap, counters,
+                       flag_list, window_cap, list_off, counters, part64, d);
+    hipLaunchKernelGGL(k_recheck_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, window_cap, list_off, counters,
                        dec_exact, labels, flag2_list, flag2_cap);
 }
 

@@ -1,6 +1,7 @@
 // parsers.cpp -- see parsers.h.  Host-only, no device code.
 #include "parsers.h"
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
@@ -87,6 +88,12 @@ bool load_range(const std::string &path, RangeTable &rt, std::string &err)
     int idx; double lo, hi;
     while (fscanf(fp, "%d %lf %lf\n", &idx, &lo, &hi) == 3) {
         if (idx < 0) continue;
+        // the table is indexed by attribute: bound it BEFORE it sizes an allocation (a corrupt line must not ask for 16 GiB)
+        if (idx > kMaxAttributeIndex) {
+            fclose(fp);
+            err = "range file " + path + ": attribute index " + std::to_string(idx) + " exceeds " + std::to_string(kMaxAttributeIndex);
+            return false;
+        }
         if (idx >= (int)rt.fmin.size()) {
             rt.fmin.resize((size_t)idx + 1, 0.0);
             rt.fmax.resize((size_t)idx + 1, 0.0);
@@ -135,7 +142,7 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
         else if (key == "degree") { int d; if (!integer(d)) { err = "model: bad degree"; return false; } }
         else if (key == "coef0") { double d; if (!number(d)) { err = "model: bad coef0"; return false; } }
         else if (key == "nr_class") { if (!integer(nr_class) || nr_class != 2) { err = "model: nr_class must be 2"; return false; } }
-        else if (key == "total_sv") { if (!integer(m.n_sv) || m.n_sv <= 0) { err = "model: bad total_sv"; return false; } }
+        else if (key == "total_sv") { if (!integer(m.n_sv) || m.n_sv <= 0 || m.n_sv > kMaxSupportVectors) { err = "model: bad total_sv (must be in [1, " + std::to_string(kMaxSupportVectors) + "])"; return false; } }
         else if (key == "rho") { if (nr_class != 2 || !number(m.rho)) { err = "model: bad rho"; return false; } }
         else if (key == "label") { if (nr_class != 2 || !integer(m.label[0]) || !integer(m.label[1])) { err = "model: bad label"; return false; } }
         else if (key == "probA" || key == "probB") { double d; if (!number(d)) { err = "model: bad prob"; return false; } }
@@ -153,6 +160,7 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
     // body: one line per SV: coef idx:val idx:val ...   (svm.cpp:2890-2916)
     struct Entry { int sv, idx; double val; };
     std::vector<Entry> entries;
+    if ((size_t)m.n_sv > (text.size() - std::min(pos, text.size())) / 2 + 1) { err = "model: fewer SV lines than total_sv"; return false; }
     m.coef.assign((size_t)m.n_sv, 0.0);
     int maxidx = 0;
     for (int i = 0; i < m.n_sv; i++) {
@@ -174,6 +182,7 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
             if (q == p) { err = "model: bad attribute value"; return false; }
             p = q;
             if (idx < 1) { err = "model: attribute index < 1 (precomputed kernels are not supported)"; return false; }
+            if (idx > kMaxAttributeIndex) { err = "model: attribute index " + std::to_string(idx) + " exceeds " + std::to_string(kMaxAttributeIndex); return false; }
             entries.push_back({i, (int)idx, v});
             if (idx > maxidx) maxidx = (int)idx;
         }
@@ -181,6 +190,7 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
     }
     if (maxidx <= 0) { err = "model: support vectors carry no attributes"; return false; }
     m.dim = maxidx;
+    if ((size_t)m.n_sv * (size_t)m.dim > ((size_t)1 << 28)) { err = "model: total_sv x attribute dimension exceeds 2^28 values"; return false; }
     m.sv.assign((size_t)m.n_sv * (size_t)m.dim, 0.0);
     for (const Entry &e : entries) m.sv[(size_t)e.sv * m.dim + (e.idx - 1)] = e.val;
     return true;
@@ -251,6 +261,9 @@ bool load_pcd(const std::string &path, std::vector<float> &xyz, std::string &err
         err = "malformed PCD header in " + path; return false;
     }
     if (counts.empty()) counts.assign(fields.size(), 1);
+    if (counts.size() != fields.size()) { err = "malformed PCD header in " + path + " (COUNT)"; return false; }
+    for (size_t i = 0; i < fields.size(); i++)
+        if (sizes[i] <= 0 || sizes[i] > 8 || counts[i] <= 0 || counts[i] > (1 << 20)) { err = "PCD header: SIZE/COUNT out of range in " + path; return false; }
     if (points < 0) points = (width > 0 && height > 0) ? width * height : -1;   // POINTS wins over the row count, like PCL
     if (points < 0) { err = "PCD header without POINTS/WIDTH/HEIGHT"; return false; }
     int fx = -1, fy = -1, fz = -1;
@@ -265,6 +278,11 @@ bool load_pcd(const std::string &path, std::vector<float> &xyz, std::string &err
     for (int f : {fx, fy, fz})
         if (sizes[(size_t)f] != 4 || types[(size_t)f] != "F" || counts[(size_t)f] != 1) { err = "x/y/z must be 4-byte floats"; return false; }
     const size_t rec = offs.back();
+    // POINTS sizes the output: it must be backed by data.  ascii needs >= 2 bytes per row, binary `rec` bytes per point; a
+    // compressed stream expands by at most 264/3 (LZF: a 3-byte back reference yields up to 264 bytes)
+    const size_t remain = raw.size() - std::min(pos, raw.size());
+    const size_t max_points = (mode == "ascii") ? remain / 2 + 1 : (mode == "binary") ? remain / rec : remain / rec * 100 + 1024;
+    if ((unsigned long)points > max_points) { err = "PCD: POINTS " + std::to_string(points) + " exceeds what the file can hold"; return false; }
     xyz.assign((size_t)points * 3, 0.0f);
     if (mode == "ascii") {
         // column position of x/y/z among the whitespace separated tokens of a row
@@ -295,7 +313,7 @@ bool load_pcd(const std::string &path, std::vector<float> &xyz, std::string &err
         return true;
     }
     if (mode == "binary") {
-        if (pos + (size_t)points * rec > raw.size()) { err = "PCD binary: truncated"; return false; }
+        if ((size_t)points * rec > remain) { err = "PCD binary: truncated"; return false; }   // (points <= remain / rec: no wrap)
         const char *base = raw.data() + pos;
         for (long k = 0; k < points; k++) {
             memcpy(&xyz[(size_t)k * 3 + 0], base + (size_t)k * rec + offs[(size_t)fx], 4);
@@ -309,7 +327,7 @@ bool load_pcd(const std::string &path, std::vector<float> &xyz, std::string &err
         uint32_t csize, usize;
         memcpy(&csize, raw.data() + pos, 4);
         memcpy(&usize, raw.data() + pos + 4, 4);
-        if (pos + 8 + csize > raw.size() || (size_t)usize < (size_t)points * rec) { err = "PCD compressed: bad sizes"; return false; }
+        if ((size_t)csize > remain - 8 || (size_t)usize < (size_t)points * rec || (size_t)usize > (size_t)csize * 100 + 1024) { err = "PCD compressed: bad sizes"; return false; }
         std::vector<unsigned char> buf(usize);
         if (!lzf_decompress((const unsigned char *)raw.data() + pos + 8, csize, buf.data(), usize)) { err = "PCD compressed: LZF stream corrupt"; return false; }
         // structure of arrays: all values of field 0, then field 1, ...

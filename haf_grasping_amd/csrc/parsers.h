@@ -7,6 +7,11 @@
 
 namespace haf {
 
+// Bounds applied to numbers read out of the files BEFORE they size an allocation: the engine itself takes at most 324
+// attributes (kernels.h: kKP); these only keep a corrupt or hostile file from asking for gigabytes.
+constexpr int kMaxAttributeIndex = 65536;
+constexpr int kMaxSupportVectors = 1 << 22;
+
 // data/Features.txt as CIntImage_to_Featurevec::read_features (fv.cpp:47-84) sees it
 struct FeatureRow {
     int   reg[16];   // 4 regions x (x1, x2, y1, y2), inclusive cell coordinates in the 14x14 window

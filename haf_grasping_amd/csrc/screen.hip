@@ -246,11 +246,9 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc1[m][r] = __builtin_amdgcn_exp2f(acc1[m][r]);
-#pragma unroll
-        for (int m = 0; m < 4; m++)                                  // keeps hipcc from sinking each exp next to its use
-#pragma unroll
-            for (int r = 0; r < 4; r++) asm volatile("" : "+v"(acc1[m][r]));
-        asm volatile("s_nop 7\n\ts_nop 7");                          // the last exp gets 16 wait states before any consumer
+        // the wait states hang on the data: all sixteen results go through the asm, so no exp can sink behind it and no
+        // consumer can rise above it
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 4; m++)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HAF_ABI_VERSION 1
+#define HAF_ABI_VERSION 2
 
 enum {
     HAF_OK = 0,
@@ -53,6 +53,11 @@ typedef struct haf_config {
     int32_t max_clouds;              /* capacity: clouds per batch call                                   */
     int64_t max_points;              /* capacity: total points per batch call                             */
     uint32_t flags;                  /* HAF_FLAG_*                                                        */
+    int32_t graspval_th;             /* 70 (202): a roll whose best vote exceeds it is published as its own hypothesis
+                                        when show_only_best_grasp is off (962-969; haf_roll_pose)                          */
+    int32_t max_rolls_per_call;      /* capacity: rolls per haf_score_rolls call; 0 = n_rolls.  A roll-sharded engine (one
+                                        of N GPUs) only ever scores ceil(n_rolls / N) rolls at a time: its working buffers
+                                        are sized for that, the roll geometry still uses the global roll index           */
 } haf_config;
 
 #define HAF_FLAG_KEEP_DEBUG 1u       /* keep per-roll intermediates for haf_debug_fetch()                 */
@@ -71,7 +76,11 @@ typedef struct haf_grasp_input {
     float   grasp_area_length_x;         /* "in m" in the .msg, used as integer cm incl. the +14 border    */
     float   grasp_area_length_y;         /*   (server.cpp:266-267 truncates to int; client.cpp:183-184)    */
     double  approach_vector[3];          /* normalised by the engine as server.cpp:270-273                 */
-    double  max_calculation_time;        /* seconds (277); checked between roll batches, 1 s granularity   */
+    double  max_calculation_time;        /* seconds (277), truncated to int like server.cpp:337.  The reference tests it
+                                            at the START of every roll with time()'s 1 s resolution (367-374); this engine
+                                            starts all rolls of a request together, so every roll sees 0 s elapsed and
+                                            the budget only stops a request whose truncated value is negative
+                                            (HAF_E_BUDGET) -- it never cuts the roll set of a request that has begun      */
     int32_t show_only_best_grasp;        /* changes the result: early exit at >= graspval_top (362-365)    */
     int32_t threshold_grasp_evaluation;  /* carried for API parity; the reference server never reads it    */
     int32_t gripper_opening_width;       /* x-scale factor (281, 433)                                      */
@@ -133,6 +142,41 @@ int haf_score_rolls(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, co
  * show_only_best_grasp; server.cpp:362-365, 953-960) and the grasp pose (1274-1401) from n_rolls records. */
 int haf_finalize(haf_engine *e, const haf_grasp_input *in, const haf_roll_record *records, haf_grasp_output *out);
 
+/* One roll's own hypothesis: what show_predicted_gps() hands to transform_gp_in_wcs_and_publish() for that roll when
+ * show_only_best_grasp is off and the roll's best vote exceeds graspval_th (server.cpp:962-969): pose from the roll's
+ * record, eval = max(vote - 20, 10).  *published = 1 when the reference would publish it, 0 otherwise (out is filled
+ * either way, with the clamped eval).  records = the n_rolls records of one cloud (haf_score_rolls / an all-gather). */
+int haf_roll_pose(haf_engine *e, const haf_grasp_input *in, const haf_roll_record *records, int32_t roll,
+                  haf_grasp_output *out, int32_t *published);
+
+/* ---- several GPUs of one node in ONE process (csrc/multi.cpp) ---------------------------------------------------------
+ * For a C++ host such as the action server: one engine, one host thread and one HIP stream per entry of devices[], one RCCL
+ * communicator over the distinct devices (ncclCommInitAll), collectives over xGMI.  What is sharded is what the reference
+ * leaves independent: the rolls of one request (the body of the roll loop, server.cpp:343-386) or the clouds of a batch.
+ * A device may appear more than once in devices[] (several shards on one GPU share its rank); every device must then appear
+ * the same number of times.  cfg->device is ignored; cfg->max_clouds / n_rolls are the capacity of the WHOLE handle. */
+enum { HAF_SHARD_ROLLS = 0,    /* haf_score_sharded: rolls of one request split 5,5,5,5,4,4,4,4-style over the shards   */
+       HAF_SHARD_CLOUDS = 1 }; /* haf_score_batch_sharded: cloud b of a batch goes to shard b % n                       */
+typedef struct haf_multi haf_multi;
+int  haf_create_multi(const haf_config *cfg, const int32_t *devices, int32_t n_devices, int32_t shard_mode, haf_multi **out);
+void haf_destroy_multi(haf_multi *m);
+const char *haf_multi_last_error(const haf_multi *m);   /* m == NULL: error of the last failed haf_create_multi in this thread */
+
+/* GraspInput -> GraspOutput for one cloud with the rolls sharded: every shard scores its rolls (haf_score_rolls), ONE
+ * ncclAllGather exchanges the 16-byte roll records so that every rank holds all n_rolls of them, then the sequential
+ * cross-roll rule and the pose (haf_finalize; server.cpp:362-365, 953-960, 1274-1401).  Same result as haf_score.
+ * A host cloud is copied to every GPU over that GPU's own PCIe link; a device-resident one (on_device = 1) must live on
+ * devices[0] and reaches the other GPUs by one ncclBroadcast. */
+int haf_score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *in, haf_grasp_output *out);
+/* Batch of host clouds, cloud b on shard b % n, no data-path exchange; ONE ncclAllReduce(max) of a packed 64-bit
+ * (vote, cloud) key elects the best grasp of the batch: *best_cloud = its index (highest vote, then lowest index). */
+int haf_score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in,
+                            haf_grasp_output *out, int32_t *best_cloud);
+int haf_multi_info(const haf_multi *m, int32_t *n_shards, int32_t *n_ranks, int32_t *rccl_version);
+haf_engine *haf_multi_engine(haf_multi *m, int32_t shard);      /* the shard's engine (stage timings, counters, roll grids) */
+/* rank `rank`'s copy of the n_rolls gathered records of the last haf_score_sharded call (all ranks hold the same) */
+int haf_multi_last_records(const haf_multi *m, int32_t rank, haf_roll_record *records);
+
 /* Per-roll vote grid and mask of the LAST scored batch, for the marker grid the ROS shim publishes
  * (publish_grasp_grid, server.cpp:901-902, 979-1016).  eval_grid: H*W floats, mask: H*W bytes; either may be NULL. */
 int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask);
@@ -143,6 +187,20 @@ int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_gr
 enum { HAF_DBG_HEIGHTS = 0, HAF_DBG_INTEGRAL = 1, HAF_DBG_MASK = 2, HAF_DBG_LABELS = 3, HAF_DBG_DECISION = 4,
        HAF_DBG_TRANSFORM = 5 };
 int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes);
+
+/* The attribute pipeline of the masked cells of one (cloud, roll) of the last scored batch, as the exact-form feature
+ * kernels left it (HAF_FLAG_KEEP_DEBUG; engines of up to 2 GiB of records): per masked cell, in the row-major order of the
+ * reference's feature file (server.cpp:637-643), 324 records of
+ *   feature  the fp32 HAF/SHAF value (fv.cpp:141-199),
+ *   q4       the double svm-scale reads back from its "%.4g" text (fv.cpp:133 -> svm-scale.c:270),
+ *   scaled   the double svm-predict reads back from svm-scale's "%g" text (svm-scale.c:344-350 -> svm-predict.c:108);
+ *            0 where svm-scale omits the attribute.
+ * cells: row, col per masked cell; computed[i] = 1 when an exact-form feature kernel evaluated cell i in the last call
+ * (every cell with HAF_FLAG_SPLIT_F16 / HAF_FLAG_FP32_MFMA; in the default mode only the cells the screening pass
+ * handed on).  Returns the number of masked cells in *n_cells; fills at most max_cells entries. */
+typedef struct haf_attr_record { float feature; float pad; double q4; double scaled; } haf_attr_record;
+int haf_debug_fetch_attr(haf_engine *e, int32_t cloud, int32_t roll, int32_t max_cells, int32_t *cells /* [max_cells][2] */,
+                         haf_attr_record *attr /* [max_cells][324] */, uint8_t *computed /* [max_cells] */, int32_t *n_cells);
 
 /* Launch everything on this hipStream_t (default: a stream the engine creates).  The caller keeps ownership. */
 int haf_set_stream(haf_engine *e, void *hip_stream);

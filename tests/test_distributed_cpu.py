@@ -45,7 +45,7 @@ def worker(rank, world, port, q):
             out = capi.GraspOutput()
             cfg = capi.default_config(n_rolls=n_rolls, roll_step_deg=step)
             gi = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44, show_only_best_grasp=show_best)
-            assert capi.lib().haf_test_finalize(C.byref(cfg), C.byref(gi), full[0].ctypes.data, C.byref(out)) == 0
+            assert capi.testlib().haf_test_finalize(C.byref(cfg), C.byref(gi), full[0].ctypes.data, C.byref(out)) == 0
             assert (out.eval, out.best_row, out.best_col, out.best_roll, out.rolls_done) == \
                    (want["eval"], want["row"], want["col"], want["roll_idx"], want["rolls_done"])
             np.testing.assert_allclose(tuple(out.grasp_point1), want["gp1"], atol=1e-6)

@@ -48,10 +48,17 @@ MODES = [pytest.param(capi.FLAG_FP32_MFMA, id="f32mfma"), pytest.param(capi.FLAG
 DEC_REL_SCREEN = 2.0 ** -8
 
 
+# environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
+TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW")
+
+
 def make_engine(data_dir, model, mode=0, **cfg):
+    """The product library, unless a test has set one of the guard-band / kernel-choice switches: those exist in the
+    testing build only (same kernels, same objects; engine.cpp compiled with -DHAF_TESTING)."""
     f, r = _files(data_dir)
     cfg.setdefault("flags", capi.FLAG_KEEP_DEBUG | capi.FLAG_PROFILE)
     cfg["flags"] |= mode
+    cfg.setdefault("testing", any(k in os.environ for k in TEST_KNOBS))
     return capi.Engine(f, r, model, **cfg)
 
 
@@ -103,7 +110,7 @@ def compare_full(eng, orc, xyz, cfg_kw, in_kw, check_dec=True):
 
 def test_device_decimal_roundtrip_matches_host():
     """csrc/decq.h compiled for gfx950 gives the same bits as its host build (which test_host_cpu pins to glibc)."""
-    L = capi.lib()
+    L = capi.testlib()
     rng = np.random.RandomState(11)
     for digits in (4, 6):
         parts = [rng.standard_normal(20000) * s for s in (1e-9, 1e-4, 1.0, 50.0, 1e4, 1e9, 1e-18, 1e24, 1e-30, 1e35)]
@@ -125,7 +132,7 @@ def test_device_decimal_roundtrip_matches_host():
 
 
 def test_device_scale_matches_host(data_dir):
-    L = capi.lib()
+    L = capi.testlib()
     f, r = _files(data_dir)
     o = O.Oracle(f, r, None)
     lo, up, fmin, fmax, _ = o.range_table()
@@ -447,14 +454,27 @@ def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
             monkeypatch.delenv("HAF_GUARD2_REL")
 
 
-def test_guard_list_overflow_is_loud(data_dir, surrogate, monkeypatch):
-    """More guard-band evaluations than the fp64 tier's capacity must fail the call, never silently keep fast-tier labels."""
-    monkeypatch.setenv("HAF_GUARD_REL", "1e30")            # every evaluation lands in the band
-    xyz = models.synthetic_cloud(grid=56, k=3, seed=1)     # dense: all 42x42 cells x 12 rolls masked (>= 4x the capacity)
-    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16)
-    with pytest.raises(capi.HafError) as ei:
-        eng.score(xyz, capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56))
-    assert ei.value.code == capi.HAF_E_CAPACITY and "guard band" in str(ei.value)
+@pytest.mark.parametrize("mode", [pytest.param(capi.FLAG_SPLIT_F16, id="splitf16"), pytest.param(0, id="screen")])
+def test_guard_list_overflow_degrades_to_windows(data_dir, surrogate, orc, monkeypatch, mode):
+    """More guard-band evaluations than one window of the fp64 tier holds must NOT fail the goal (the reference never fails
+    one on this path, server.cpp:778-796): the list is walked window by window.  HAF_GUARD_REL = 1e30 puts every
+    evaluation of a dense 56 x 56 cloud (all 42 x 42 cells x 12 rolls) into the band, HAF_FLAG_WINDOW makes the windows
+    small (5 of them and a ragged last one); labels, votes and the grasp are the oracle's."""
+    monkeypatch.setenv("HAF_GUARD_REL", "1e30")            # every evaluation lands in the band of the three-pass kernel
+    monkeypatch.setenv("HAF_FLAG_WINDOW", "4000")
+    if mode == 0:
+        monkeypatch.setenv("HAF_GUARD0_REL", "1e30")       # default mode: the screening pass hands everything on first
+        xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))      # (a request the refinement list can hold)
+        inp = dict(grasp_area_length_x=56, grasp_area_length_y=56)
+    else:
+        xyz = models.synthetic_cloud(grid=56, k=3, seed=1)
+        inp = dict(grasp_area_length_x=56, grasp_area_length_y=56)
+    eng = make_engine(data_dir, surrogate, mode)
+    compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
+    cnt = eng.last_counts()
+    assert cnt["n_rechecked"] == cnt["n_evals"] > 4000
+    if mode:
+        assert cnt["n_evals"] == 12 * 42 * 42
     eng.close()
 
 
@@ -619,3 +639,210 @@ def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path,
             assert (rec == ref_rec).all(), mode
     assert 0 < counts[0]["n_refined"] < 0.2 * counts[0]["n_evals"]          # the screening pass was really in charge
     STATS["c5_nsv%d_tiers" % nsv] = {str(k): v for k, v in counts.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: the attribute pipeline itself (not only labels): feature -> "%.4g" -> svm-scale -> "%g", bit for bit
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_attr_rows(orc, ii, cells):
+    """(features fp32 [n, 324], q4 [n, 324], scaled [n, 323]) of the oracle for the given cells of one integral image."""
+    skip = np.zeros(325, np.uint8)
+    skip[324] = 1               # phantom attribute: constant -1 in every row -> dropped by svm-scale.c:336-337
+    F, Q, S = [], [], []
+    for i, j in cells:
+        f = orc.feature_values(ii[i - 7:i + 8, j - 7:j + 8])
+        q = np.array([O.q4(v) for v in f])
+        F.append(f)
+        Q.append(q)
+        S.append(orc.scale_row(q, 323, skip))
+    return np.array(F), np.array(Q), np.array(S)
+
+
+def _bits32(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _bits64(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+ATTR_CASES = [("pcd2", "C2"), ("pcd3", "C4"), ("pcd12", "default"), ("plastic_mug2", "default"), ("pcd2", "tilt"),
+              ("table1_mult_obj_rcs_1428580506606673", "C3c")]
+
+
+@pytest.mark.parametrize("mode", [pytest.param(capi.FLAG_SPLIT_F16, id="splitf16"), pytest.param(capi.FLAG_FP32_MFMA, id="f32mfma")])
+@pytest.mark.parametrize("name,cname", ATTR_CASES)
+def test_attribute_pipeline_bit_exact_against_oracle(data_dir, surrogate, orc, mode, name, cname):
+    """HAF_DBG_ATTR: what the exact-form feature kernels computed for EVERY masked cell -- the fp32 feature
+    (fv.cpp:141-199), its "%.4g" round trip (fv.cpp:133 -> svm-scale.c:270) and the scaled value after the "%g" round trip
+    (svm-scale.c:333-353 -> svm-predict.c:108) -- against hafo_feature_values / hafo_q4 / hafo_scale_row, bit for bit.
+    Small requests take k_features_small, larger ones k_features; the thread-per-evaluation kernel has its own test."""
+    import make_fixtures as MF
+    spec = MF.CONFIGS[cname]
+    xyz = pcdio.load_pcd(os.path.join(data_dir, name + ".pcd"))
+    cfg_kw = dict(spec["cfg"])
+    in_kw = dict(grasp_area_length_x=spec["inp"]["length_x"], grasp_area_length_y=spec["inp"]["length_y"])
+    if "center" in spec["inp"]: in_kw["grasp_area_center"] = spec["inp"]["center"]
+    if "approach" in spec["inp"]: in_kw["approach_vector"] = spec["inp"]["approach"]
+    eng = make_engine(data_dir, surrogate, mode, **cfg_kw)
+    eng.score(xyz, capi.default_input(**in_kw))
+    want = orc.run(xyz, O.make_cfg(**cfg_kw), oracle_input(in_kw))
+    total = 0
+    for roll in range(cfg_kw["n_rolls"]):
+        cells, attr, comp = eng.debug_attr(0, roll)
+        mask_cells = np.stack(np.nonzero(want["mask"][roll]), 1)
+        assert (cells == mask_cells).all() and comp.all()
+        if roll % 3 and len(cells) > 64:          # every roll's cell list, every third roll's values (the oracle side is slow)
+            continue
+        F, Q, S = _oracle_attr_rows(orc, want["integral"][roll], cells)
+        assert (_bits32(attr["feature"]) == _bits32(F)).all(), (roll, "feature")
+        assert (_bits64(attr["q4"]) == _bits64(Q)).all(), (roll, "q4")
+        got_s = attr["scaled"][:, :323]
+        assert (_bits64(got_s + 0.0) == _bits64(S + 0.0)).all(), (roll, "scaled")      # (+0.0: -0 and +0 are the same text)
+        assert (attr["scaled"][:, 323] == 0).all()             # attribute 324: dropped by svm-scale
+        total += len(cells)
+    assert total > 0 or want["n_evals"] == 0
+    eng.close()
+
+
+def test_attribute_pipeline_thread_per_evaluation_kernel_and_list_mode(data_dir, surrogate, orc, monkeypatch):
+    """The same check for the other two exact-form routes: k_features_serial (HAF_LARGE_EVALS forces it) and the list mode
+    behind the screening pass (default mode: only the cells the screening pass handed on are computed, and exactly those)."""
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    in_kw = dict(grasp_area_length_x=32, grasp_area_length_y=44)
+    want = orc.run(xyz, O.make_cfg(), oracle_input(in_kw))
+    monkeypatch.setenv("HAF_LARGE_EVALS", "1")
+    for mode in (capi.FLAG_SPLIT_F16, capi.FLAG_FP32_MFMA):
+        eng = make_engine(data_dir, surrogate, mode)
+        eng.score(xyz, capi.default_input(**in_kw))
+        for roll in (0, 5, 11):
+            cells, attr, comp = eng.debug_attr(0, roll)
+            assert comp.all()
+            F, Q, S = _oracle_attr_rows(orc, want["integral"][roll], cells)
+            assert (_bits32(attr["feature"]) == _bits32(F)).all() and (_bits64(attr["q4"]) == _bits64(Q)).all()
+            assert (_bits64(attr["scaled"][:, :323] + 0.0) == _bits64(S + 0.0)).all()
+        eng.close()
+    monkeypatch.delenv("HAF_LARGE_EVALS")
+    eng = make_engine(data_dir, surrogate, 0)                   # default mode, product library
+    eng.score(xyz, capi.default_input(**in_kw))
+    n_comp = 0
+    for roll in range(12):
+        cells, attr, comp = eng.debug_attr(0, roll)
+        n_comp += int(comp.sum())
+        if comp.any() and roll in (0, 5, 11):
+            F, Q, S = _oracle_attr_rows(orc, want["integral"][roll], cells[comp])
+            assert (_bits32(attr["feature"][comp]) == _bits32(F)).all() and (_bits64(attr["q4"][comp]) == _bits64(Q)).all()
+            assert (_bits64(attr["scaled"][comp][:, :323] + 0.0) == _bits64(S + 0.0)).all()
+    assert n_comp == eng.last_counts()["n_refined"] > 0
+    eng.close()
+
+
+@pytest.mark.parametrize("name,roll", [("pcd2", 0), ("pcd2", 5), ("pcd3", 2), ("plastic_mug2", 7)])
+def test_attribute_pipeline_against_reference_tool_fixtures(data_dir, golden_dir, surrogate, name, roll):
+    """The same records against tests/golden/g23_*.npz: the q4 column is what the REAL svm-scale read from the feature
+    text, `scaled` what the REAL svm-predict read from svm-scale's output (tests/golden/make_fixtures.py ran the reference's
+    own binaries).  No oracle in between."""
+    g = np.load(os.path.join(golden_dir, "g23_%s_r%d.npz" % (name, roll)))
+    xyz = pcdio.load_pcd(os.path.join(data_dir, name + ".pcd"))
+    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16)
+    eng.score(xyz, capi.default_input())                         # make_fixtures.py: default cfg, O.make_input() = 32 x 32
+    cells, attr, comp = eng.debug_attr(0, roll)
+    eng.close()
+    index = {(int(i), int(j)): k for k, (i, j) in enumerate(cells)}
+    rows = [index[(int(i), int(j))] for i, j in g["cells"]]
+    assert len(rows) == len(g["cells"]) > 0
+    a = attr[rows]
+    assert (_bits32(a["feature"]) == _bits32(g["features"])).all()
+    assert (_bits64(a["q4"]) == _bits64(g["q4"])).all()
+    D = g["scaled"].shape[1]
+    assert (_bits64(a["scaled"][:, :D] + 0.0) == _bits64(g["scaled"] + 0.0)).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: several GPUs in ONE process behind the C-ABI (csrc/multi.cpp), RCCL collectives
+# ---------------------------------------------------------------------------------------------------------------------
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _multi_devices():
+    """[(id, devices)]: two shards sharing the one GPU of the test box (one RCCL rank), and -- on a node with more GPUs --
+    one shard per GPU."""
+    out = [("1rank_1shard", [0]), ("1rank_2shards", [0, 0]), ("1rank_3shards", [0, 0, 0])]
+    n = _n_gpus()
+    if n >= 2:
+        out.append(("%dranks" % min(n, 4), list(range(min(n, 4)))))
+        out.append(("2ranks_2shards_each", [0, 1, 0, 1]))
+    return out
+
+
+@pytest.mark.parametrize("label,devices", _multi_devices() if os.environ.get("HAF_COLLECT_MULTI", "1") == "1" else [])
+def test_roll_sharded_request_through_the_c_abi(data_dir, golden_dir, surrogate, label, devices):
+    """haf_score_sharded: rolls of one request split over the shards, one ncclAllGather of the 16-byte roll records, the
+    sequential cross-roll rule on the gathered set.  Same GraspOutput as the committed oracle goldens (incl. the
+    show_only_best early exit, which is why the exchange is an all-gather), and every rank holds identical records."""
+    import make_fixtures as MF
+    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+        gold = json.load(f)
+    f_, r_ = _files(data_dir)
+    for name, cname in [("pcd2", "C2"), ("pcd2", "C2best"), ("plastic_mug2", "C2best"), ("pcd3", "C4"), ("pcd7", "C4")]:
+        spec = MF.CONFIGS[cname]
+        xyz = pcdio.load_pcd(os.path.join(data_dir, name + ".pcd"))
+        me = capi.MultiEngine(f_, r_, surrogate, devices, capi.SHARD_ROLLS, **spec["cfg"])
+        info = me.info()
+        assert info["n_shards"] == len(devices) and info["n_ranks"] == len(set(devices)) and info["rccl_version"] > 0
+        inp = capi.default_input(grasp_area_length_x=spec["inp"]["length_x"], grasp_area_length_y=spec["inp"]["length_y"],
+                                 show_only_best_grasp=spec["inp"].get("show_only_best", 0))
+        if len(devices) > spec["cfg"]["n_rolls"]:
+            continue
+        got = me.score_sharded(xyz, inp)
+        w = gold["%s/%s" % (name, cname)]
+        assert (got["eval"], got["best_row"], got["best_col"], got["best_roll"], got["rolls_done"]) == \
+               (w["eval"], w["row"], w["col"], w["roll_idx"], w["rolls_done"]), (name, cname, label)
+        assert np.allclose(got["grasp_point1"], w["gp1"], atol=1e-4) and np.allclose(got["grasp_point2"], w["gp2"], atol=1e-4)
+        rec0 = me.last_records(0)
+        for roll in range(w["rolls_done"]):                      # (rolls behind an early exit: the oracle never ran them)
+            assert [int(rec0["row"][roll]), int(rec0["col"][roll]), int(rec0["vote"][roll])] == w["roll_best"][roll], (name, cname, roll)
+            assert int(rec0["n_evals"][roll]) == w["masked"][roll]
+        for rk in range(1, info["n_ranks"]):
+            assert me.last_records(rk).tobytes() == rec0.tobytes()
+        # device-resident cloud: lives on devices[0], reaches the other ranks by ncclBroadcast
+        import torch
+        with torch.cuda.device(devices[0]):
+            d_xyz = torch.from_numpy(xyz).cuda(devices[0])
+            got2 = me.score_sharded((d_xyz.data_ptr(), xyz.shape[0], 3), inp)
+        assert got2 == got
+        me.close()
+
+
+@pytest.mark.parametrize("label,devices", _multi_devices() if os.environ.get("HAF_COLLECT_MULTI", "1") == "1" else [])
+def test_cloud_sharded_batch_through_the_c_abi(data_dir, golden_dir, surrogate, label, devices):
+    """haf_score_batch_sharded (BASELINE config C4): pcd1..8, 20 rolls of 9 degrees, cloud b on shard b % n, ONE
+    ncclAllReduce(max) of the packed best-grasp key.  Outputs = the committed goldens; the elected cloud = argmax by hand."""
+    import make_fixtures as MF
+    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+        gold = json.load(f)
+    f_, r_ = _files(data_dir)
+    spec = MF.CONFIGS["C4"]
+    names = ["pcd%d" % k for k in range(1, 9)]
+    clouds = [pcdio.load_pcd(os.path.join(data_dir, n + ".pcd")) for n in names]
+    me = capi.MultiEngine(f_, r_, surrogate, devices, capi.SHARD_CLOUDS, max_clouds=8, **spec["cfg"])
+    inp = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44)
+    outs, best = me.score_batch_sharded(clouds, [inp] * 8)
+    for n, o in zip(names, outs):
+        w = gold[n + "/C4"]
+        assert (o["eval"], o["best_row"], o["best_col"], o["best_roll"], o["n_evals"]) == (w["eval"], w["row"], w["col"], w["roll_idx"], w["n_evals"]), n
+    votes = [o["best_vote"] for o in outs]
+    assert best == int(np.argmax(votes))                       # argmax = first maximum = lowest cloud index on ties
+    me.close()
+
+
+def test_multi_rejects_bad_requests(data_dir, surrogate):
+    f_, r_ = _files(data_dir)
+    with pytest.raises(capi.HafError):
+        capi.MultiEngine(f_, r_, surrogate, [0, 0, 1] if _n_gpus() >= 2 else [0] * 13, capi.SHARD_ROLLS)   # uneven shards / more shards than rolls
+    me = capi.MultiEngine(f_, r_, surrogate, [0], capi.SHARD_CLOUDS, max_clouds=2)
+    with pytest.raises(capi.HafError):
+        me.score_sharded(np.zeros((4, 3), np.float32), capi.default_input())      # wrong mode
+    me.close()

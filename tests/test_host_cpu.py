@@ -2,6 +2,7 @@
 the decimal round-trip arithmetic (host build of csrc/decq.h) equals glibc printf+strtod, and the parsers, per-roll
 geometry, cross-roll rule and pose agree with the oracle.  No kernel is launched here."""
 import ctypes as C
+import json
 import os
 import re
 import struct
@@ -23,14 +24,21 @@ def test_library_exports_every_declared_symbol():
     names = set(re.findall(r"\b(haf_[a-z_0-9]+)\s*\(", text))
     assert {"haf_create", "haf_score", "haf_score_batch", "haf_score_rolls", "haf_finalize", "haf_destroy",
             "haf_last_error", "haf_get_roll_grid", "haf_pcd_load"} <= names
+    assert {"haf_create_multi", "haf_score_sharded", "haf_score_batch_sharded", "haf_roll_pose", "haf_debug_fetch_attr"} <= names
     for n in sorted(names):
         assert hasattr(L, n), n
-    assert L.haf_abi_version() == 1
+    assert L.haf_abi_version() == 2
+    # the product library carries no test hooks; the testing build has the ABI and the hooks
+    assert not hasattr(L, "haf_test_finalize") and not hasattr(L, "haf_test_decq_device")
+    T = capi.testlib()
+    for n in sorted(names) + ["haf_test_finalize", "haf_test_roll_pose", "haf_test_decq_device"]:
+        assert hasattr(T, n), n
 
 
 def test_struct_layouts_match_header_sizes():
     assert C.sizeof(capi.RollRecord) == 16
     assert C.sizeof(capi.Cloud) == 32
+    assert C.sizeof(capi.Config) == 88 and C.sizeof(capi.GraspInput) == 80 and C.sizeof(capi.GraspOutput) == 144
     cfg = capi.default_config()
     assert (cfg.grid_h, cfg.grid_w, cfg.n_rolls, cfg.roll_step_deg, cfg.graspval_top) == (56, 56, 12, 15, 119)
     assert cfg.nr_features_without_shaf == 302 and abs(cfg.z_shift - 0.15) < 1e-7
@@ -59,7 +67,7 @@ def _bits(x):
 
 @pytest.mark.parametrize("digits", [4, 6])
 def test_decq_host_matches_printf_strtod(digits):
-    L = capi.lib()
+    L = capi.testlib()
     rng = np.random.RandomState(digits)
     vals = []
     # feature-like magnitudes, float32 inputs for %.4g, doubles for %g
@@ -92,7 +100,7 @@ def test_decq_host_matches_printf_strtod(digits):
 
 def test_decq4_float_entry_matches_printf_strtod():
     """The fp32 "%.4g" entry the kernels use (digits code 40): exact-product shortcut for k <= 12, general path beyond."""
-    L = capi.lib()
+    L = capi.testlib()
     rng = np.random.RandomState(40)
     parts = [(rng.standard_normal(30000) * s).astype(np.float32) for s in (1e-12, 1e-9, 1e-7, 1e-4, 1e-2, 1.0, 30.0, 1e3, 1e5, 1e9)]
     base = rng.randint(1000, 10000, size=4000).astype(np.float64)
@@ -111,7 +119,7 @@ def test_decq4_float_entry_matches_printf_strtod():
 
 def test_decq_wide_window_against_glibc():
     """Outside 1e-19..1e26 the double-double path is used; it is expected (not proven) to agree with glibc."""
-    L = capi.lib()
+    L = capi.testlib()
     rng = np.random.RandomState(7)
     for digits in (4, 6):
         for e in list(range(-300, -20, 7)) + list(range(27, 300, 7)):
@@ -124,7 +132,7 @@ def test_decq_wide_window_against_glibc():
 
 
 def test_scale_host_matches_oracle(data_dir):
-    L = capi.lib()
+    L = capi.testlib()
     orc = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"), None)
     lo, up, fmin, fmax, present = orc.range_table()
     rng = np.random.RandomState(3)
@@ -142,7 +150,7 @@ def test_scale_host_matches_oracle(data_dir):
 
 
 def test_parsers_match_oracle(data_dir, golden_dir):
-    L = capi.lib()
+    L = capi.testlib()
     orc = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"),
                    os.path.join(golden_dir, "surrogate.model"))
     n = C.c_int()
@@ -175,7 +183,7 @@ def test_parsers_match_oracle(data_dir, golden_dir):
 
 def test_feature_file_trailing_line_quirks(tmp_path):
     """fv.cpp:60-82: a final EMPTY line adds a phantom all-zero feature; a last line WITHOUT newline is dropped."""
-    L = capi.lib()
+    L = capi.testlib()
     row = "\t".join(["1", "2", "3", "4"] * 4 + ["1", "-1", "2", "5"])
     reg = np.zeros((8, 16), np.int32)
     w = np.zeros((8, 4), np.float32)
@@ -244,7 +252,7 @@ def _oracle_input(kw):
 @pytest.mark.parametrize("kw", INPUTS)
 @pytest.mark.parametrize("step,rolls", [(15, 12), (9, 20), (5, 36)])
 def test_roll_geometry_matches_oracle(kw, step, rolls):
-    L = capi.lib()
+    L = capi.testlib()
     cfg = capi.default_config(n_rolls=rolls, roll_step_deg=step)
     gi = capi.default_input(**kw)
     ocfg = O.make_cfg(n_rolls=rolls, roll_step_deg=step)
@@ -264,7 +272,7 @@ def test_roll_geometry_matches_oracle(kw, step, rolls):
 
 def test_finalize_matches_oracle_pose(data_dir, golden_dir):
     """Cross-roll rule + pose (host code) from the ORACLE's per-roll winners and height grids."""
-    L = capi.lib()
+    L = capi.testlib()
     orc = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"),
                    os.path.join(golden_dir, "surrogate.model"))
     cases = [("pcd2", dict(grasp_area_length_x=32, grasp_area_length_y=32)),
@@ -333,7 +341,7 @@ def test_screening_band_host_pieces():
     """Host arithmetic behind the screening pass's guard band: the spectral-norm bound is an UPPER bound of
     numpy's largest singular value and at most d^(1/128) above it; the three-term fp16 split reports exactly what its three
     products add up to and misses at most 2^-25 + 2^-33 |a|."""
-    L = capi.lib()
+    L = capi.testlib()
     rng = np.random.RandomState(5)
     for n, d, kind in ((300, 40, "uniform"), (64, 324, "uniform"), (500, 324, "lowrank"), (10, 7, "zero")):
         if kind == "uniform":
@@ -359,7 +367,7 @@ def test_fast_decimal_path_of_the_screening_features():
     """decq4_float_scr (table-driven, branch-free, screening pass only): for v == 0 and 1e-9 <= |v| < 1e4 it picks the same four
     digits as the exact "%.4g" round trip -- the result differs by the rounding of one multiplication at most; everything else
     comes back NaN (which makes the feature kernel distrust the whole evaluation), fp32 subnormals come back 0."""
-    L = capi.lib()
+    L = capi.testlib()
     rng = np.random.RandomState(11)
     edge = []
     for e in range(-10, 6):                                   # both sides of every power of ten and of every rounding carry
@@ -386,3 +394,78 @@ def test_fast_decimal_path_of_the_screening_features():
     for v in (1e-12, 1e5, float("inf"), float("-inf"), float("nan"), 3e38, 1e4, 10000.001):
         assert np.isnan(L.haf_test_decq4_scr(v)), v
     assert L.haf_test_decq4_scr(1e-40) == 0.0
+
+
+def test_roll_pose_rule_and_pose(data_dir, golden_dir):
+    """haf_roll_pose = what show_predicted_gps hands to transform_gp_in_wcs_and_publish for ONE roll (server.cpp:962-969):
+    published iff !show_only_best and vote > 70, eval = max(vote - 20, 10); the pose of the overall winner's roll equals
+    haf_finalize's pose (same record, same transform)."""
+    L = capi.testlib()
+    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+        gold = json.load(f)
+    g = gold["pcd2/C2"]
+    rec = np.zeros(12, capi.ROLL_RECORD_DTYPE)
+    for r, (row, col, vote) in enumerate(g["roll_best"]):
+        rec[r] = (vote, row, col, 0.25 + 0.01 * r, g["masked"][r])
+    cfg = capi.default_config()
+    for show_best in (0, 1):
+        gi = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32, show_only_best_grasp=show_best)
+        fin = capi.GraspOutput()
+        assert L.haf_test_finalize(C.byref(cfg), C.byref(gi), rec.ctypes.data, C.byref(fin)) == 0
+        for r in range(12):
+            out, pub = capi.GraspOutput(), C.c_int32(-1)
+            assert L.haf_test_roll_pose(C.byref(cfg), C.byref(gi), rec.ctypes.data, r, C.byref(out), C.byref(pub)) == 0
+            vote = int(rec["vote"][r])
+            assert pub.value == (1 if (not show_best and vote > 70) else 0)
+            assert out.eval == max(vote - 20, 10) and (out.best_row, out.best_col, out.best_roll) == (int(rec["row"][r]), int(rec["col"][r]), r)
+            assert abs(out.roll - r * 15 * 3.141592653 / 180) < 1e-6
+            if r == fin.best_roll:
+                assert tuple(out.grasp_point1) == tuple(fin.grasp_point1) and tuple(out.grasp_point2) == tuple(fin.grasp_point2)
+                assert tuple(out.approach_vector) == tuple(fin.approach_vector)
+    out, pub = capi.GraspOutput(), C.c_int32()
+    assert L.haf_test_roll_pose(C.byref(cfg), C.byref(gi), rec.ctypes.data, 12, C.byref(out), C.byref(pub)) == capi.HAF_E_ARG
+
+
+def test_hostile_files_return_errors_not_exceptions(data_dir, golden_dir, tmp_path):
+    """Numbers read out of the input files are bounded before they size an allocation, and no C++ exception crosses the
+    C-ABI (a corrupt model must come back as HAF_E_IO / HAF_E_INTERNAL, not as std::terminate of the action server)."""
+    L = capi.testlib()
+    feat = os.path.join(data_dir, "Features.txt")
+    rng = os.path.join(data_dir, "range21062012_allfeatures")
+    model = os.path.join(golden_dir, "surrogate.model")
+    text = open(model).read()
+    head, body = text.split("SV\n", 1)
+
+    def create(f=feat, r=rng, m=model):
+        with pytest.raises(capi.HafError) as ei:
+            capi.Engine(str(f), str(r), str(m))
+        return ei.value
+
+    # model: absurd total_sv, absurd attribute index, more SVs promised than lines present
+    p = tmp_path / "m1.model"
+    p.write_text(head.replace("total_sv 172", "total_sv 2000000000") + "SV\n" + body)
+    assert create(m=p).code == capi.HAF_E_IO
+    p = tmp_path / "m2.model"
+    p.write_text(head + "SV\n" + body.replace(" 1:", " 2000000000:", 1))
+    assert create(m=p).code == capi.HAF_E_IO
+    p = tmp_path / "m3.model"
+    p.write_text(head.replace("total_sv 172", "total_sv 4000000").replace("nr_sv 84 88", "nr_sv 2000000 2000000") + "SV\n" + body)
+    e = create(m=p)
+    assert e.code == capi.HAF_E_IO and "fewer SV lines" in str(e)
+    # range file: index far beyond anything the engine takes
+    p = tmp_path / "r1"
+    p.write_text(open(rng).read() + "2000000000 0 1\n")
+    e = create(r=p)
+    assert e.code == capi.HAF_E_IO and "exceeds" in str(e)
+    # PCD: POINTS that the file cannot back, negative SIZE, compressed sizes that wrap
+    err = C.create_string_buffer(256)
+    ptr, n = C.POINTER(C.c_float)(), C.c_size_t()
+    hdr = "# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE %s\nTYPE F F F\nCOUNT 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n"
+    cases = [("4 4 4", 4000000000, "ascii", b"0 0 0\n"), ("4 4 4", 3000000000, "binary", b"\0" * 24),
+             ("-4 4 4", 2, "binary", b"\0" * 24), ("4 4 4", 2, "binary_compressed", struct.pack("<II", 0xFFFFFFF0, 24) + b"\0" * 8),
+             ("4 4 4", 2, "binary_compressed", struct.pack("<II", 4, 0xFFFFFFFF) + b"\0\0\0\0")]
+    for k, (sz, pts, mode, payload) in enumerate(cases):
+        p = tmp_path / ("bad%d.pcd" % k)
+        p.write_bytes((hdr % (sz, pts, pts, mode)).encode() + payload)
+        rc = L.haf_pcd_load(str(p).encode(), C.byref(ptr), C.byref(n), err, 256)
+        assert rc in (capi.HAF_E_IO, capi.HAF_E_INTERNAL) and err.value, (k, rc)
