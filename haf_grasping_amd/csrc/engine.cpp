@@ -237,7 +237,7 @@ struct haf_engine {
     DevBuf<AttrRecord> d_attr;      // HAF_FLAG_KEEP_DEBUG: [max_evals][kKP] attribute records of the exact-form feature kernels
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
-    DevBuf<FeatDesc> d_fd;
+    DevBuf<FeatDesc> d_fd, d_fd_slot;
     DevBuf<ScrDesc> d_sd;
     DevBuf<float> d_part1;
     long part1_stride = 0;
@@ -465,51 +465,88 @@ int build_tables(haf_engine *e)
     }
 
     if (contraction_mode(e->cfg) == MODE_SCREEN) {
-        // screening images: v^ = fp16(c*s) with c = sqrt(2*gamma*log2 e), the norm slots (kernels.h) and 32 coefficients;
-        // the bounds the per-evaluation guard band needs are taken over the model here (ScreenParams)
+        // ---- screening pass: K slots, operand images, and the model-wide bounds of the per-evaluation guard band ----
         ScreenParams &sp = e->screen;
         sp.c = std::sqrt(2.0 * m.gamma * log2e);
+        std::vector<FeatDesc> fd2((size_t)e->nf);
+        HIPCHK(e, hipMemcpy(fd2.data(), e->d_fd.p, fd2.size() * sizeof(FeatDesc), hipMemcpyDeviceToHost));
+        // Slots (kernels.h): attributes that are the same function of the window (same active regions, weights and rule) with
+        // the same svm-scale range take the same value in every evaluation -- before and after both text round trips -- so
+        // u_a v_a + u_b v_b = u_a (v_a + v_b): they share one K slot whose SV-side operand is the sum of their SV components.
+        // Every attribute svm-scale keeps gets a slot, whether or not the model has it (it counts in |u|^2 either way); the
+        // ones it drops get none.
+        const int n_attr = std::min(e->nf, kKP);
+        std::vector<int> slot_of_attr((size_t)kKP, -1), rep;          // rep[s] = first attribute of slot s
+        std::vector<int> extra;                                         // attributes in slot s beyond the first
+        auto same_feature = [&](const FeatDesc &a, const FeatDesc &b) {
+            if (a.active != b.active || a.shaf != b.shaf || a.fmin != b.fmin || a.fmax != b.fmax) return false;
+            for (int k = 0; k < 3; k++) {
+                if (!(a.active & (1 << k))) continue;
+                if (a.w[k] != b.w[k]) return false;
+                for (int j = 0; j < 4; j++) if (a.off[k][j] != b.off[k][j]) return false;
+            }
+            return true;
+        };
+        for (int f = 0; f < n_attr; f++) {
+            if (fd2[(size_t)f].skip) continue;
+            int s = -1;
+            for (size_t r = 0; r < rep.size() && s < 0; r++) if (same_feature(fd2[(size_t)rep[r]], fd2[(size_t)f])) s = (int)r;
+            if (s < 0) { rep.push_back(f); extra.push_back(0); s = (int)rep.size() - 1; }
+            else extra[(size_t)s]++;
+            slot_of_attr[(size_t)f] = s;
+        }
+        const int n_slots = (int)rep.size();
+        if (n_slots > kS0K) e->screen_active = false;   // more distinct attributes than the ten k-steps hold: three-pass kernel for everything
         {
             // screening attribute u' = (q4 - scr_sub) * scr_mul, scr_sub = fmin - c*lower/scr_mul (kernels.hip: screen_attribute).
             // Against c*x' in exact arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's
             // range) and the rounding of scr_sub, both amplified by scr_mul when q4 and scr_sub cancel, and by the roundings of
             // scr_mul, the subtraction and the product; the norm over the attributes is eta_abs.
-            std::vector<FeatDesc> fd2((size_t)e->nf);
-            HIPCHK(e, hipMemcpy(fd2.data(), e->d_fd.p, fd2.size() * sizeof(FeatDesc), hipMemcpyDeviceToHost));
-            std::vector<ScrDesc> sd((size_t)kScrGroups * 8);
+            std::vector<ScrDesc> sd((size_t)kS0K);
             memset(sd.data(), 0, sd.size() * sizeof(ScrDesc));
-            std::vector<ScrDesc3> sd3((size_t)kScrGroups * 8);
+            std::vector<ScrDesc3> sd3((size_t)kS0K);
             memset(sd3.data(), 0, sd3.size() * sizeof(ScrDesc3));
+            std::vector<FeatDesc> fds((size_t)kS0K);
+            memset(fds.data(), 0, fds.size() * sizeof(FeatDesc));
+            for (auto &x : fds) x.skip = 1;                          // unused slots evaluate to exactly 0
             double ea2 = 0.0;
             sp.fast_groups = 0;
-            for (int g = 0; g < kScrGroups; g++) {
+            sp.extra_groups = 0;
+            for (int f = 0; f < n_attr; f++) {
+                FeatDesc &d = fd2[(size_t)f];
+                if (d.skip) continue;
+                d.scr_mul = sp.c * (e->range.upper - e->range.lower) * d.inv_range;
+                d.scr_sub = d.scr_mul != 0.0 ? d.fmin - sp.c * e->range.lower / d.scr_mul : 0.0;
+                // x2: svm-scale's own fp64 roundings of the same expression
+                const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin) + std::fabs(d.scr_sub)) +
+                                         4.5e-16 * std::fabs(sp.c * e->range.lower));
+                ea2 += ef * ef;
+            }
+            for (int g = 0; g < kS0Groups; g++) {
                 bool fast = true;
                 for (int q = 0; q < 8; q++) {
-                    const int f = g * 8 + q;
-                    if (f >= e->nf || f >= kAugS) continue;
-                    FeatDesc &d = fd2[(size_t)f];
-                    ScrDesc &s = sd[(size_t)f];
-                    if (!d.skip) {
-                        d.scr_mul = sp.c * (e->range.upper - e->range.lower) * d.inv_range;
-                        d.scr_sub = d.scr_mul != 0.0 ? d.fmin - sp.c * e->range.lower / d.scr_mul : 0.0;
-                        // x2: svm-scale's own fp64 roundings of the same expression
-                        const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin) + std::fabs(d.scr_sub)) +
-                                                 4.5e-16 * std::fabs(sp.c * e->range.lower));
-                        ea2 += ef * ef;
-                    }
+                    const int sl = g * 8 + q;
+                    if (sl >= n_slots || sl >= kS0K) continue;
+                    FeatDesc &d = fd2[(size_t)rep[(size_t)sl]];
+                    ScrDesc &sdesc = sd[(size_t)sl];
                     if (d.shaf || (d.active & ~3)) fast = false;
                     for (int k = 0; k < 2; k++) {
-                        s.w[k] = d.w[k];
-                        for (int j = 0; j < 4; j++) s.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
+                        sdesc.w[k] = d.w[k];
+                        for (int j = 0; j < 4; j++) sdesc.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
-                    s.scr_mul = d.scr_mul; s.scr_sub = d.scr_sub;
-                    ScrDesc3 &s3 = sd3[(size_t)f];
+                    sdesc.scr_mul = d.scr_mul; sdesc.scr_sub = d.scr_sub;
+                    sdesc.extra = (float)extra[(size_t)sl];
+                    ScrDesc3 &s3 = sd3[(size_t)sl];
                     for (int k = 0; k < 3; k++) {
                         s3.w[k] = d.w[k];
                         for (int j = 0; j < 4; j++) s3.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
                     s3.shaf = d.shaf;
                     s3.scr_mul = d.scr_mul; s3.scr_sub = d.scr_sub;
+                    s3.extra = (float)extra[(size_t)sl];
+                    fds[(size_t)sl] = d;
+                    fds[(size_t)sl].scr_extra = (float)extra[(size_t)sl];
+                    if (extra[(size_t)sl]) sp.extra_groups |= 1ull << g;
                 }
                 if (fast) sp.fast_groups |= 1ull << g;
             }
@@ -524,58 +561,61 @@ int build_tables(haf_engine *e)
             if (hipSuccess != e->d_sd3.alloc(sd3.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
             HIPCHK(e, hipMemcpy(e->d_sd3.p, sd3.data(), sd3.size() * sizeof(ScrDesc3), hipMemcpyHostToDevice));
             sp.sd3 = e->d_sd3.p;
+            if (hipSuccess != e->d_fd_slot.alloc(fds.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
+            HIPCHK(e, hipMemcpy(e->d_fd_slot.p, fds.data(), fds.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
+            sp.fd_slot = e->d_fd_slot.p;
         }
+        // SV side in slot space: w_n[s] = c * sum of s_n[k] over the attributes k of slot s (a model attribute svm-scale drops
+        // never reaches svm-predict's x: it multiplies 0 in libsvm too, but its square still counts in |s_n|^2)
+        const int S = std::min(n_slots, kS0K);
+        std::vector<double> W((size_t)m.n_sv * kS0K, 0.0);              // exact (fp64) slot-space operands
+        for (int n = 0; n < m.n_sv; n++)
+            for (int k = 0; k < m.dim && k < kKP; k++) {
+                const int sl = slot_of_attr[(size_t)k];
+                if (sl >= 0 && sl < S) W[(size_t)n * kS0K + sl] += m.sv[(size_t)n * m.dim + k] * sp.c;
+            }
         sp.v_max = sp.dv_max = sp.das_max = sp.as_max = 0.0;
         std::vector<char> img((size_t)e->n_sv_tiles * kS0SvTileBytes, 0);
+        std::vector<double> Wh((size_t)m.n_sv * kS0K, 0.0), Wd((size_t)m.n_sv * kS0K, 0.0);
         for (int n = 0; n < m.n_sv; n++) {
             const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
             char *tile = img.data() + (size_t)t * kS0SvTileBytes;
-            double vv = 0, hh = 0, dd = 0;
-            for (int k = 0; k < m.dim; k++) {
-                const double v = m.sv[(size_t)n * m.dim + k] * sp.c;
+            double hh = 0, dd = 0;
+            for (int sl = 0; sl < kS0K; sl++) {
+                const double v = W[(size_t)n * kS0K + sl];
                 _Float16 h = (_Float16)(float)v;
                 if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
-                memcpy(tile + h_image_offset(j, k), &h, 2);
+                memcpy(tile + h_image_offset(j, sl), &h, 2);
                 const double hd = (double)(float)h;
-                vv += v * v; hh += hd * hd; dd += (hd - v) * (hd - v);
+                Wh[(size_t)n * kS0K + sl] = hd;
+                Wd[(size_t)n * kS0K + sl] = hd - v;
+                hh += hd * hd; dd += (hd - v) * (hd - v);
             }
-            const double a_s = 0.5 * vv;
-            _Float16 s3[3];
-            const double rep = split3_f16(-a_s, s3);
-            for (int q = 0; q < 3; q++) memcpy(tile + h_image_offset(j, kAugS + q), &s3[q], 2);
-            const _Float16 one = (_Float16)1.0f, tiny = (_Float16)(1.0f / kAugScale);
-            memcpy(tile + h_image_offset(j, kAugX), &one, 2);
-            memcpy(tile + h_image_offset(j, kAugX + 1), &tiny, 2);
-            memcpy(tile + h_image_offset(j, kAugX + 2), &tiny, 2);
-            reinterpret_cast<float *>(tile + kHMatBytes)[j] = (float)m.coef[(size_t)n];
+            // |v_n|^2 over ALL attributes of the model (libsvm's x has 0 where svm-scale dropped an attribute, so those
+            // products vanish, the SV's own square does not)
+            double vv = 0;
+            for (int k = 0; k < m.dim; k++) { const double v = m.sv[(size_t)n * m.dim + k] * sp.c; vv += v * v; }
+            const double tn = -0.5 * vv;
+            const float tf = (float)tn;
+            reinterpret_cast<float *>(tile + kS0MatBytes)[j] = tf;                          // padding columns: t = 0, coef = 0
+            reinterpret_cast<float *>(tile + kS0MatBytes)[kTile + j] = (float)m.coef[(size_t)n];
             sp.v_max = std::max(sp.v_max, std::sqrt(hh));
             sp.dv_max = std::max(sp.dv_max, std::sqrt(dd));
-            sp.das_max = std::max(sp.das_max, std::fabs(rep + a_s));
-            sp.as_max = std::max(sp.as_max, a_s);
+            sp.das_max = std::max(sp.das_max, std::fabs((double)tf - tn));
+            sp.as_max = std::max(sp.as_max, std::fabs(tn));
         }
-        // spectral norms of V^ and dV = V^ - V (n_sv x dim) for the sqrt(S) form of the band: sigma^2 = lambda_max(M'M),
-        // bounded from ABOVE by (trace (M'M)^(2^j))^(1/2^j), j = 7 (at most dim^(1/128) = 4.6 % above the true value)
+        // spectral norms of W^ and dW = W^ - W (n_sv x 320) for the sqrt(S) form of the band: sigma^2 = lambda_max(M'M),
+        // bounded from ABOVE by (trace (M'M)^(2^j))^(1/2^j), j = 7 (at most 320^(1/128) = 4.6 % above the true value)
+        sp.sigma_v = sigma_upper_bound(Wh.data(), m.n_sv, kS0K);
+        sp.sigma_dv = sigma_upper_bound(Wd.data(), m.n_sv, kS0K);
         {
-            const int D = m.dim;
-            auto sigma_upper = [&](bool delta) {
-                std::vector<double> M((size_t)m.n_sv * D);
-                for (int n = 0; n < m.n_sv; n++)
-                    for (int k = 0; k < D; k++) {
-                        const double v = m.sv[(size_t)n * D + k] * sp.c;
-                        _Float16 h = (_Float16)(float)v;
-                        if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
-                        M[(size_t)n * D + k] = delta ? (double)(float)h - v : (double)(float)h;
-                    }
-                return sigma_upper_bound(M.data(), m.n_sv, D);
-            };
-            sp.sigma_v = sigma_upper(false);
-            sp.sigma_dv = sigma_upper(true);
             double cmax = 0.0;
             for (int n = 0; n < m.n_sv; n++) cmax = std::max(cmax, std::fabs(m.coef[(size_t)n]));
             sp.sqrt_cmax = std::sqrt(cmax) * (1.0 + 1e-12);
         }
         // the bounds feed a rigorous band: round them up past their own fp64 rounding
         sp.v_max *= 1.0 + 1e-12; sp.dv_max *= 1.0 + 1e-12; sp.das_max = sp.das_max * (1.0 + 1e-12) + 1e-300;
+        sp.as_max *= 1.0 + 1e-12;
         if (!(sp.v_max < 60000.0)) return fail(e, HAF_E_ARG, "support vectors too large for the fp16 screening pass; use HAF_FLAG_SPLIT_F16");
         if (hipSuccess != e->d_svt0.alloc(img.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening sv tiles)");
         HIPCHK(e, hipMemcpy(e->d_svt0.p, img.data(), img.size(), hipMemcpyHostToDevice));
@@ -798,7 +838,7 @@ void haf_destroy(haf_engine *e)
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
-    e->d_sd.release(); e->d_sd3.release(); e->d_part1.release();
+    e->d_sd.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
     if (e->h_rec) (void)hipHostFree(e->h_rec);
@@ -1002,9 +1042,9 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, nullptr, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
             mark(e, HAF_ST_SVM);
-            launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+            launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
             mark(e, HAF_ST_REFINE);
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
@@ -1012,20 +1052,20 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             // workgroups beyond the list's end exit at once)
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
-                            e->flag0_cap, false, list_cap, e->d_attr.p, s);
+                            e->flag0_cap, false, list_cap, e->d_attr.p, nullptr, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
                          e->d_part1.p, e->part1_stride, s);
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, nullptr, s);
             mark(e, HAF_ST_SVM);
             launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s);
             mark(e, HAF_ST_REFINE);
         } else {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, s);
+                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, nullptr, s);
             mark(e, HAF_ST_SVM);
             launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                        e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, s);

@@ -43,20 +43,27 @@ __host__ __device__ inline int h_image_offset(int r, int k)
 }
 
 // ---- screening pass (tier 0): ONE fp16 MFMA pass on operands pre-scaled by c = sqrt(2*gamma*log2 e) ----
-// u = c*x, v = c*s  =>  exp2 argument = u.v - |u|^2/2 - |v|^2/2.  The two norm terms ride in spare K slots of the
-// 336-wide operand images (attributes use slots 0..323), each as a three-term fp16 split against constants
-// (1, 2^-12, 2^-12), so the accumulator IS the exp2 argument and the epilogue is v_exp_f32 + one fma per element.
-// A wave keeps 64 evals (two 32-eval hi images) in registers; a workgroup is 4 waves = 256 evals.
+// u = c*x, v = c*s  =>  exp2 argument = u.v - |u|^2/2 - |v|^2/2.  Only u.v goes through the matrix core:
+//   * -|v_n|^2/2 is a constant of SV n: it is the INITIAL VALUE of the accumulator column (t_n, one fp32 per SV in the
+//     tile image), so the accumulator comes out as log2(K_n) + |u|^2/2 and the epilogue is v_exp_f32 + one fma with the
+//     coefficient per (evaluation, SV);
+//   * 2^(-|u|^2/2) is common to all SVs of an evaluation: applied once to the two class sums after the sweep.
+// K holds SLOTS, not attributes: attributes that are the same function of the window with the same svm-scale range (the
+// reference's Features.txt has three such pairs: rows 4/5, 19/20 and -- once the 4th weight is dropped -- 297/302) share a
+// slot whose SV-side operand is the SUM of their SV components: u_a v_a + u_b v_b = u_a (v_a + v_b) exactly.  323
+// attributes -> 320 slots = 10 k-steps of 32: no K padding and no half-filled tail step.  A feature file with more than
+// 320 distinct attributes is served without the screening pass (engine.cpp).
+// A wave keeps 64 evals x 320 slots in 160 VGPRs; a workgroup is 4 waves = 256 evals.
 constexpr int kS0WaveEvals = 64;
 constexpr int kS0Waves = 4;                           // waves per workgroup: TWO workgroups share a CU (one wave of each per SIMD)
 constexpr int kS0BlockEvals = kS0Waves * kS0WaveEvals;
-constexpr int kS0WavePieces = 6;                      // LDS-DMA pieces a wave stages per tile (4 x 6 = 24 >= 22: two go twice)
-constexpr int kS0SvTileBytes = 22528;                 // fp16 image (21504 B) + 32 coef floats, padded to 22 KiB
-constexpr int kS0Pieces = kS0SvTileBytes / 1024;      // 22 LDS-DMA wave instructions
+constexpr int kS0K = 320;                             // slots
+constexpr int kS0Groups = kS0K / 8;                   // 40 groups of 8 slots (feature kernels)
+constexpr int kS0MatBytes = kHFull * 2048;            // one 32 x 320 fp16 operand image = 20 KiB (h_image_offset, k < 320)
+constexpr int kS0WavePieces = 6;                      // LDS-DMA pieces a wave stages per tile (4 x 6 = 24 >= 21: three go twice)
+constexpr int kS0SvTileBytes = 21504;                 // fp16 image (20480 B) + 32 floats t_n = -|v_n|^2/2 + 32 coefficients, padded to 21 KiB
+constexpr int kS0Pieces = kS0SvTileBytes / 1024;      // 21 LDS-DMA wave instructions
 constexpr int kS0Buffers = 3;
-constexpr int kAugS = 324;                            // slots 324..326: x = (1, 2^-12, 2^-12), s = split3(-|v|^2/2)
-constexpr int kAugX = 327;                            // slots 327..329: x = split3(-|u|^2/2), s = (1, 2^-12, 2^-12)
-constexpr float kAugScale = 4096.0f;                  // 2^12
 constexpr float kF16MinNormal = 6.103515625e-05f;     // 2^-14: smaller fp16 magnitudes are flushed in software
 
 // a = h + (m + l) * 2^-12 with fp16 h, m, l (subnormal halves flushed to 0, so the value is the same whether or not the
@@ -80,18 +87,21 @@ __host__ __device__ inline double split3_f16(double a, _Float16 out[3])
 // constants of the screening pass that the feature kernel needs to write the per-evaluation guard band
 struct ScreenParams {
     double c;                     // sqrt(2*gamma*log2 e)
-    double v_max;                 // max_n |v^_n|  (stored fp16 operand)
-    double dv_max;                // max_n |v^_n - v_n|
-    double das_max;               // max_n |split3(-a_s) - (-a_s)|
-    double as_max;                // max_n |v_n|^2/2
-    double sigma_v;               // upper bound of the largest singular value of the N x D matrix of the v^_n
-    double sigma_dv;              // the same for the matrix of the v^_n - v_n
+    // the SV side in SLOT space: w_n[s] = sum of c*s_n[k] over the attributes k of slot s, w^_n = fp16(w_n)
+    double v_max;                 // max_n |w^_n|  (stored fp16 operand)
+    double dv_max;                // max_n |w^_n - w_n|
+    double das_max;               // max_n |fl32(t_n) - t_n|: the accumulator's initial value -|v_n|^2/2 held in fp32
+    double as_max;                // max_n |t_n| (what the fp32 accumulation inside the matrix core starts from)
+    double sigma_v;               // upper bound of the largest singular value of the N x 320 matrix of the w^_n
+    double sigma_dv;              // the same for the matrix of the w^_n - w_n
     double sqrt_cmax;             // sqrt(max_n |coef_n|)
     double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
     double eta_abs;               // |u' - u| beyond the relative part: fp64 roundings of the screening attribute formula (norm)
-    const struct ScrDesc *sd;     // kScrGroups * 8 compact descriptors (device) for the two-region groups
-    const struct ScrDesc3 *sd3;   // kScrGroups * 8 general descriptors (device)
-    unsigned long long fast_groups;   // bit g: every attribute of group g is a plain HAF feature of at most two regions
+    const struct ScrDesc *sd;     // kS0K compact descriptors (device), one per SLOT, for the two-region groups
+    const struct ScrDesc3 *sd3;   // kS0K general descriptors (device), one per slot
+    const struct FeatDesc *fd_slot;   // kS0K feature descriptors (device): the representative attribute of every slot
+    unsigned long long fast_groups;   // bit g: every slot of group g is a plain HAF feature of at most two regions
+    unsigned long long extra_groups;  // bit g: some slot of group g is shared by more than one attribute (ScrDesc::extra != 0)
 };
 // Compact descriptor of one attribute slot for the screening feature pass: 64 bytes, one s_load_dwordx16.  A slot without a
 // feature (beyond the feature file, norm slots) is all zero and evaluates to exactly 0.
@@ -101,7 +111,8 @@ struct ScrDesc {
     float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
     double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
     double scr_sub;               // fmin - c * lower / scr_mul                   (0 likewise):  u' = (q4 - scr_sub) * scr_mul
-    double pad;
+    float  extra;                 // attributes sharing this slot beyond the first (0 almost everywhere): |u|^2 counts u'^2 that often more
+    float  pad;
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
 // The same for any feature (three regions, HAF or SHAF rule): the groups that are not in ScreenParams::fast_groups
@@ -110,11 +121,11 @@ struct ScrDesc3 {
     float  w[3];
     int    shaf;                  // fv.cpp:187-191 instead of the weighted sum
     double scr_mul, scr_sub;
-    double pad[2];
+    float  extra;                 // as in ScrDesc
+    float  pad[3];
 };
 static_assert(sizeof(ScrDesc3) == 96, "ScrDesc3 layout");
-constexpr int kScrGroups = 41;
-constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded    // attribute slots 0..327 in groups of 8
+constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded
 // per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
 //   |dec^ - dec| <= min(gA * sqrt(S), gC * S) + (guard_acc0 + gB) * S + cm * (|dec^| + |rho|) + guard_abs,  S = sum|coef|K
 // with {gA, gB, gC, cm} per evaluation
@@ -147,6 +158,8 @@ struct FeatDesc {
     double fmin, fmax;
     double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
     double scr_mul, scr_sub;      // screening pass (ScrDesc below): u' = (q4 - scr_sub) * scr_mul
+    float  scr_extra;             // fd_slot entries only: attributes sharing the slot beyond the first
+    float  pad2;
 };
 
 // haf_attr_record of include/hafgrasp.h: the three stages of one attribute of one evaluation (HAF_FLAG_KEEP_DEBUG)
@@ -205,9 +218,9 @@ enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2 };
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
                      const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
-                     hipStream_t s);
+                     float *ax2, hipStream_t s);   // ax2: screening form only, -|u|^2/2 per evaluation
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
-void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
+void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s);
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,

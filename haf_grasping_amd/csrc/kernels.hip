@@ -616,12 +616,27 @@ __device__ __forceinline__ _Float16 screen_operand(double ud, float &su2, float 
     return h;
 }
 
-// norm slots of an evaluation (groups 40 and 41 of its operand image) and its guard band.  u' = c x' is what the
+// attributes that share a slot beyond the first count once more in |u|^2 (the common factor), not in the operand: sx gets
+// extra * u'^2 for the slots of group g that have any (wave-uniform; three slots of the reference's feature file)
+__device__ __forceinline__ void screen_extra_norm(const ScreenParams &sp, int g, const double *ud, float &sx)
+{
+    if (!((sp.extra_groups >> g) & 1)) return;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float ex = constant_ptr(sp.sd)[g * 8 + q].extra;
+        if (ex != 0.0f) {
+            const float f = (float)ud[q];
+            sx = fmaf(ex * f, f, sx);
+        }
+    }
+}
+
+// guard band of an evaluation (and -|u|^2/2 for the common factor).  u' = c x' is what the
 // feature kernel has (screen_attribute), u = c x the true operand: |u' - u| <= eta := 5e-6 |u'| + tiny, component-wise
 // and therefore in norm.  With e_n the error of the exp2 argument of SV n,
 //   dec^ + rho = 2^D * sum_n c_n K_n 2^e_n,
-//   e_n = (u^-u).v^_n + u.(v^_n - v_n) + [what the fp16 split of -|v_n|^2/2 misses + fp32 accumulation in the matrix core],
-//   D   = the error of the -|u|^2/2 term (computed from u', split into fp16): the SAME factor for every SV.
+//   e_n = (u^-u).w^_n + u.(w^_n - w_n) + [fl32(t_n) - t_n + fp32 accumulation in the matrix core]   (slot space, kernels.h),
+//   D   = the error of the common factor 2^(-|u|^2/2) (computed from u' in fp32): the SAME factor for every SV.
 // Common factor: dec^ - dec = (2^D - 1)(dec + rho) + 2^D E with E = sum_n c_n K_n (2^e_n - 1); it costs
 // (2^D - 1)(|dec^| + |rho|), next to nothing where it matters (dec near 0), instead of D * S.
 // E = ln2 * sum_n c_n K_n e_n + second order.  The bilinear part of e_n sums to (u^-u).(V^' w) + u.(dV' w), w_n = c_n K_n,
@@ -649,29 +664,31 @@ __device__ __forceinline__ double sqrt_upper(double x)
 // 2^z - 1 <= ln2 z + 0.26 z^2 for 0 <= z < 0.05 (y = z ln2: e^y - 1 <= y + y^2/2 e^y)
 __device__ __forceinline__ double exp2m1_upper(double z) { return 0.69314718056 * z + 0.26 * z * z; }
 
-__device__ __forceinline__ void screen_finish(double su2, double sd2, const ScreenParams &sp, half8 &g40, half8 &g41, float *band)
+__device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2, const ScreenParams &sp, float *band, float &nax)
 {
-    // su2, sd2: fp32 sums (screen_operand) of 324 squares of fp32-rounded terms: off by at most 326 * 2^-24 relative.  For the
-    // norms that is an inflation; for a_x (which goes into the operand) it is one more part of D, the error of the -|u|^2/2
-    // term that all SVs share, and costs (2^D - 1)(|dec^| + |rho|) like the rest of D.
+    // su2 = sum over the SLOTS of fl32(u')^2 and sd2 = sum over the slots of (u^ - fl32(u'))^2: the two norms of the operand the
+    // contraction sees (kernels.h: attributes that share a slot are one operand).  sx2 = su2 + the squares of the attributes
+    // beyond the first of every slot = |u'|^2 over ALL attributes, which is what the common factor 2^(-|u|^2/2) needs.
+    // All three are fp32 sums (screen_operand) of at most 324 squares of fp32-rounded terms: off by at most 326 * 2^-24
+    // relative.  For the norms that is an inflation; for a_x it is one more part of D, the error of the common factor, and costs
+    // (2^D - 1)(|dec^| + |rho|) like the rest of D.
     constexpr double kF32Acc = 326.0 * 5.9604644775390625e-08 * 1.01;
-    const double a_x = 0.5 * su2;                        // what the norm slots carry
-    _Float16 s3[3];
-    const double rep = split3_f16(-a_x, s3);
-    const double dax = fabs(rep + a_x) + kF32Acc * a_x;
-    g40[4] = (_Float16)1.0f;
-    g40[5] = (_Float16)(1.0f / kAugScale);
-    g40[6] = (_Float16)(1.0f / kAugScale);
-    g40[7] = s3[0];
-    g41 = half8{s3[1], s3[2], 0, 0, 0, 0, 0, 0};
-    const double un1 = sqrt_upper(su2 * (1.0 + kF32Acc));                         // |u'|
+    const double a_x = 0.5 * sx2;
+    nax = (float)(-a_x);                                 // k_svm_screen multiplies both class sums by exp2(nax)
+    const double un_t = sqrt_upper(sx2 * (1.0 + kF32Acc));                        // |u'| over all attributes
+    const double eta_t = kScreenEtaRel * un_t + sp.eta_abs;                      // |u' - u| over all attributes
+    const double un1 = sqrt_upper(su2 * (1.0 + kF32Acc));                         // |u'| in slot space
     const double dn1 = sqrt_upper(sd2 * (1.0 + kF32Acc)) + 5.97e-8 * un1 + 1e-17;  // |u^ - u'| <= |u^ - fl32(u')| + 2^-24 |u'|
-    const double eta = kScreenEtaRel * un1 + sp.eta_abs;                        // |u' - u|
+    const double eta = kScreenEtaRel * un1 + sp.eta_abs;                        // |u' - u| in slot space
     const double un = un1 + eta, dn = dn1 + eta;                                // |u|, |u^ - u|
     const double ln2 = 0.69314718056;
     const double d_max = dn * sp.v_max + (un + dn) * sp.dv_max;
-    const double acc = 3.814697265625e-06 * (un * sp.v_max + 0.5 * un * un + sp.as_max);
-    const double D = dax + un * eta;                     // | -|u|^2/2 - (value of the three norm slots) |
+    // fp32 accumulation inside the matrix core: ten accumulating instructions per element, a few ulp of the largest partial sum
+    // each, bounded generously by 2^-18 of |t_n| + |u||w^_n| (the chain starts at t_n)
+    const double acc = 3.814697265625e-06 * (un * sp.v_max + sp.as_max);
+    // D = | log2 of (the factor the kernel applies / 2^(-|u|^2/2)) |: a_x from the fp32 sums and u' instead of u, its cast to
+    // fp32, v_exp_f32 and the two products (3 * 2^-23 relative = 5.2e-7 in the exponent)
+    const double D = (kF32Acc + 6.0e-8) * a_x + un_t * eta_t + 0.5 * eta_t * eta_t + 6.0e-7;
     const double e_max = d_max + sp.das_max + acc;
     const double infl = 1.0 + exp2m1_upper(e_max + D);   // meaningful below 0.05 only: beyond it the band is infinite anyway
     const double gA = ln2 * (dn * sp.sigma_v + (un + dn) * sp.sigma_dv) * sp.sqrt_cmax;
@@ -680,7 +697,8 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, const Scre
     band[1] = (float)(gB * infl * sp.scale);             // expressions and of the casts are far inside 0.1 %
     band[2] = (float)(ln2 * d_max * infl * sp.scale);
     band[3] = (float)(exp2m1_upper(D) * sp.scale);
-    if (!(e_max + D < 0.05)) band[1] = __builtin_inff();  // outside the range the bounds were derived for: never trusted
+    // outside the range the bounds were derived for, or a common factor 2^(a_x) that fp32 sums could overflow on: never trusted
+    if (!(e_max + D < 0.05) || !(a_x < 64.0)) band[1] = __builtin_inff();
 }
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
@@ -691,7 +709,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
                                                   const int *__restrict__ idx_list, int list_counter, int list_cap,
-                                                  AttrRecord *__restrict__ dbg)
+                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
@@ -705,7 +723,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
     else tb = load_decimal_tables(s_tab);
     float *xcol = X + (size_t)(e >> 5) * kTileFloats + (e & 31);
-    char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)(e >> 5) * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
     const int r = (int)(e & 31);
     // screening form: is this wave 64 neighbouring cells of one row?  (cell ids are row-major and a masked cell is never in
     // the first or last 7 columns, so consecutive ids are neighbours in one row)
@@ -738,11 +756,11 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         if (MODE == XMODE_SPLIT) {
             for (int g = 0; g < 2 * kHSteps; g++) store_group_h(xtile, r, g, z, z);
         } else if (MODE == XMODE_SCREEN) {
-            for (int g = 0; g < 2 * kHSteps; g++) store_group_img(xtile, r, g, z);
+            for (int g = 0; g < kS0Groups; g++) store_group_img(xtile, r, g, z);
         } else {
             for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
         }
-        if (MODE == XMODE_SCREEN) *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (MODE == XMODE_SCREEN) { *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{0.0f, 0.0f, 0.0f, 0.0f}; ax2[e] = 0.0f; }
         else ax[e] = 0.0f;
         return;
     }
@@ -752,9 +770,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     AttrRecord *rec = (MODE != XMODE_SCREEN && dbg) ? dbg + (size_t)e_src * kKP : nullptr;   // KEEP_DEBUG only
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
-        float su2 = 0.0f, sd2 = 0.0f;
-        half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0}, g41;
-        for (int g = 0; g <= kAugS / 8; g++) {           // groups 0..40: attribute slots 0..327, of which 0..323 are attributes
+        float su2 = 0.0f, sd2 = 0.0f, sx = 0.0f;
+        for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
             double ud[8];
             if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
                 screen_quad(band, constant_ptr(sp.sd) + g * 8, st, ud);
@@ -765,25 +782,20 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const int f = g * 8 + q;
-                    ud[q] = 0.0;
-                    if (f < d.nf && f < kAugS) {
-                        const FeatDesc &F = fd[f];
-                        if (!F.skip) ud[q] = screen_attribute(SrcBuf<true>{iir, w0}, F, st);
-                    }
+                    const FeatDesc &F = fd[g * 8 + q];               // screening form: fd = one descriptor per SLOT (an unused slot has skip = 1)
+                    ud[q] = F.skip ? 0.0 : screen_attribute(SrcBuf<true>{iir, w0}, F, st);
                 }
             }
             half8 hi;
 #pragma unroll
             for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], su2, sd2);
-            if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
-            else g40 = hi;
+            screen_extra_norm(sp, g, ud, sx);
+            store_group_img(xtile, r, g, hi);
         }
-        float band[kBandFloats];
-        screen_finish((double)su2, (double)sd2, sp, g40, g41, band);
+        float band[kBandFloats], nax;
+        screen_finish((double)su2, (double)sd2, (double)su2 + (double)sx, sp, band, nax);
         *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
-        store_group_img(xtile, r, 40, g40);
-        store_group_img(xtile, r, 41, g41);
+        ax2[e] = nax;
         return;
     }
     if (MODE == XMODE_SPLIT) {
@@ -829,14 +841,15 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
                                                   const int *__restrict__ idx_list, int list_counter, int list_cap,
-                                                  AttrRecord *__restrict__ dbg)
+                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
-    constexpr int kFeatFinisher = (kAugS / 8) % kFeatWaves;   // the wave that holds group 40 (screening form: norm slots) sums up
+    constexpr int kFeatFinisher = 0;                          // the wave that sums up the partial norms
     __shared__ double red[kFeatWaves][kFeatEvals];
     __shared__ float s_win[kFeatEvals * kWinPitch];
     __shared__ unsigned s_w0[kFeatEvals];
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
+    __shared__ double red3[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
@@ -854,8 +867,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const long tile = e >> 5;
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
-    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : 2 * kHSteps;          // 41 / 42
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
+    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
     const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;  // the evaluation this slot holds
@@ -876,20 +889,21 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0;
-    float su2 = 0.0f, sd2 = 0.0f;                                      // screening form: fp32 partial norms of this wave's groups
-    half8 g40 = {0, 0, 0, 0, 0, 0, 0, 0};
+    float su2 = 0.0f, sd2 = 0.0f, sx = 0.0f;                           // screening form: fp32 partial norms of this wave's groups
     for (int g = gl; g < n_groups; g += kFeatWaves) {
-        if (MODE == XMODE_SCREEN && g > kAugS / 8) break;              // group 41 holds norm slots only
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+        double udv[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int f = g * 8 + q;
             double xd = 0.0;
-            if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
-                const FeatDesc &F = fd[f];
-                if (MODE == XMODE_SCREEN) { if (!F.skip) xd = screen_attribute(src, F, st); }     // u' = c x', not x'
-                else xd = attribute_value_rec(src, F, lower, upper, tb, rec ? rec + f : nullptr);
+            if (MODE == XMODE_SCREEN) {
+                const FeatDesc &F = fd[f];                               // screening form: fd = one descriptor per SLOT (an unused slot has skip = 1)
+                if (live && !F.skip) xd = screen_attribute(src, F, st);  // u' = c x', not x'
+            } else if (live && f < d.nf) {
+                xd = attribute_value_rec(src, fd[f], lower, upper, tb, rec ? rec + f : nullptr);
             }
+            udv[q] = xd;
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
                 hi[q] = screen_operand(xd, su2, sd2);
@@ -907,27 +921,24 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
         }
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
         if (MODE == XMODE_SCREEN) {
-            if (g < kAugS / 8) store_group_img(xtile, r, g, hi);
-            else g40 = hi;                                             // wave kFeatFinisher keeps group 40 until the norms are known
+            screen_extra_norm(sp, g, udv, sx);
+            store_group_img(xtile, r, g, hi);
         }
     }
     red[gl][ev] = (MODE == XMODE_SCREEN) ? (double)su2 : xx;
-    if (MODE == XMODE_SCREEN) red2[gl][ev] = (double)sd2;
+    if (MODE == XMODE_SCREEN) { red2[gl][ev] = (double)sd2; red3[gl][ev] = (double)sx; }
     __syncthreads();
     if (gl == kFeatFinisher) {
-        double t = 0.0, t2 = 0.0;
+        double t = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
         for (int k = 0; k < kFeatWaves; k++) t += red[k][ev];         // fixed order: deterministic
         if (MODE == XMODE_SCREEN) {
 #pragma unroll
-            for (int k = 0; k < kFeatWaves; k++) t2 += red2[k][ev];
-            half8 g41;
-            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (live) screen_finish(t, t2, sp, g40, g41, band);
-            else g41 = g40;                                            // padding rows: all zero
+            for (int k = 0; k < kFeatWaves; k++) { t2 += red2[k][ev]; t3 += red3[k][ev]; }
+            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f}, nax = 0.0f;
+            if (live) screen_finish(t, t2, t + t3, sp, band, nax);
             *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
-            store_group_img(xtile, r, 40, g40);
-            store_group_img(xtile, r, 41, g41);
+            ax2[e] = nax;
         } else {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
@@ -952,13 +963,14 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
-                                                  AttrRecord *__restrict__ dbg)
+                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
-    constexpr int kFinisher = kAugS / 8;              // slot 40: holds group 40 (screening form: norm slots) and sums up
+    constexpr int kFinisher = 40;                     // the quarter wave that sums up the partial norms (one without a group of its own in the screening form)
     static_assert(kSmSlots >= 2 * kHSteps && kFinisher < kSmSlots, "slots cover the groups");
     __shared__ double red[kSmSlots][kSmEvals];
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
+    __shared__ double red3[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
     __shared__ float s_win[kSmEvals * kWinPitch];
     __shared__ unsigned s_w0[kSmEvals];
     const int n_evals = counters[CNT_EVALS];
@@ -975,8 +987,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     const long tile = e >> 5;
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
-    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kHMatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : 2 * kHSteps;          // 41 / 42
+    char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
+    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
     if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e], d.H, d.W) : 0xffffffffu;
@@ -991,19 +1003,22 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0;
-    float su2 = 0.0f, sd2 = 0.0f;
+    float su2 = 0.0f, sd2 = 0.0f, sx = 0.0f;
     half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
     const int g = slot;
-    const bool has_group = g < n_groups && !(MODE == XMODE_SCREEN && g > kAugS / 8);     // group 41 of the screening form: norm slots only
+    const bool has_group = g < n_groups;
     if (has_group) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int f = g * 8 + q;
             double xd = 0.0;
-            if (live && f < d.nf && (MODE != XMODE_SCREEN || f < kAugS)) {
-                const FeatDesc &F = fd[f];
-                if (MODE == XMODE_SCREEN) { if (!F.skip) xd = screen_attribute(src, F, st); }
-                else xd = attribute_value_rec(src, F, lower, upper, tb, (dbg) ? dbg + (size_t)e * kKP + f : nullptr);
+            if (MODE == XMODE_SCREEN) {
+                const FeatDesc &F = fd[f];                               // screening form: fd = one descriptor per SLOT (an unused slot has skip = 1)
+                if (live && !F.skip) xd = screen_attribute(src, F, st);
+                const float ex = F.scr_extra;                            // (per quarter wave here: the group differs between them)
+                if (ex != 0.0f) { const float ff = (float)xd; sx = fmaf(ex * ff, ff, sx); }
+            } else if (live && f < d.nf) {
+                xd = attribute_value_rec(src, fd[f], lower, upper, tb, (dbg) ? dbg + (size_t)e * kKP + f : nullptr);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
@@ -1021,25 +1036,22 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             }
         }
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
-        if (MODE == XMODE_SCREEN && g < kAugS / 8) store_group_img(xtile, r, g, hi);
+        if (MODE == XMODE_SCREEN) store_group_img(xtile, r, g, hi);
     }
     red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)su2 : xx;
-    if (MODE == XMODE_SCREEN) red2[slot][ev] = (double)sd2;
+    if (MODE == XMODE_SCREEN) { red2[slot][ev] = (double)sd2; red3[slot][ev] = (double)sx; }
     __syncthreads();
     if (slot == kFinisher) {
-        double t = 0.0, t2 = 0.0;
+        double t = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
         for (int k = 0; k < kSmSlots; k++) t += red[k][ev];            // fixed order: deterministic
         if (MODE == XMODE_SCREEN) {
 #pragma unroll
-            for (int k = 0; k < kSmSlots; k++) t2 += red2[k][ev];
-            half8 g40 = hi, g41;
-            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (live) screen_finish(t, t2, sp, g40, g41, band);
-            else g41 = g40;                                            // padding rows: all zero
+            for (int k = 0; k < kSmSlots; k++) { t2 += red2[k][ev]; t3 += red3[k][ev]; }
+            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f}, nax = 0.0f;
+            if (live) screen_finish(t, t2, t + t3, sp, band, nax);
             *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
-            store_group_img(xtile, r, 40, g40);
-            store_group_img(xtile, r, 41, g41);
+            ax2[e] = nax;
         } else {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
@@ -1050,47 +1062,49 @@ template <int MODE>
 static void launch_features_mode(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                                  Dims d, double lower, double upper, float neg_gamma2, long max_evals, ScreenParams sp,
                                  const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals,
-                                 AttrRecord *dbg, hipStream_t s)
+                                 AttrRecord *dbg, float *ax2, hipStream_t s)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
     if (large) {
         // enough evaluations to fill the chip with one thread each
         long blocks = (max_evals + kBlock - 1) / kBlock * (kBlock / 256);
         hipLaunchKernelGGL(k_features_serial<MODE>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
         return;
     }
     if (!idx_list && sel_evals <= kSmallEvals) {
         const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
         hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, dbg);
+                           lower, upper, neg_gamma2, sp, dbg, ax2);
         return;
     }
     long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
     if (idx_list && blocks > 4096) blocks = 4096;                      // grid-stride inside the kernel
     if (idx_list || sel_evals <= 24576)
         hipLaunchKernelGGL((k_features<MODE, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
     else
         hipLaunchKernelGGL((k_features<MODE, 8>), dim3((unsigned)blocks), dim3(8 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
 }
 
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
                      const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
-                     hipStream_t s)
+                     float *ax2, hipStream_t s)
 {
     if (max_evals <= 0) return;
+    // (screening form: the kernels index their descriptor argument by SLOT; through the __restrict__ kernel argument the
+    // wave-uniform descriptor words arrive by scalar loads -- through the pointer inside ScreenParams they would not)
     if (xmode == XMODE_SCREEN)
-        launch_features_mode<XMODE_SCREEN>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                           list_counter, list_cap, large, sel_evals, dbg, s);
+        launch_features_mode<XMODE_SCREEN>(ii, evalcell, counters, sp.fd_slot, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
+                                           list_counter, list_cap, large, sel_evals, dbg, ax2, s);
     else if (xmode == XMODE_SPLIT)
         launch_features_mode<XMODE_SPLIT>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                          list_counter, list_cap, large, sel_evals, dbg, s);
+                                          list_counter, list_cap, large, sel_evals, dbg, ax2, s);
     else
         launch_features_mode<XMODE_F32>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
-                                        list_counter, list_cap, large, sel_evals, dbg, s);
+                                        list_counter, list_cap, large, sel_evals, dbg, ax2, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

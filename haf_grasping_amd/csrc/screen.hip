@@ -8,8 +8,8 @@ namespace haf {
 #ifndef SCREEN_VARIANT
 #define SCREEN_VARIANT 0
 #endif
-// SCREEN_ABL: timing experiments only (results are wrong): 1 = no v_exp_f32, 2 = no epilogue VALU at all,
-// 3 = no LDS-DMA inside the loop, 4 = no tile barrier, 5 = no B-fragment LDS reads inside the k loop, 6 = exps but no fmas
+// SCREEN_ABL: timing experiments only (results are wrong; never defined in a product or testing build): 2 = no epilogue VALU
+// at all, 3 = no LDS-DMA inside the loop, 4 = no tile barrier, 5 = no B-fragment LDS reads inside the k loop
 #ifndef SCREEN_ABL
 #define SCREEN_ABL 0
 #endif
@@ -19,18 +19,25 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------
 // a8, screening pass (tier 0): the same decision function as ONE fp16 MFMA pass.  Operands are pre-scaled by
-// c = sqrt(2*gamma*log2 e) and rounded to fp16 (u^ = fp16(c x), v^ = fp16(c s)); the norm terms -|u|^2/2 and -|v|^2/2
-// ride in spare K slots (kernels.h), so the 16x16 accumulator IS the exp2 argument and the epilogue is one v_exp_f32
-// and one fma per (evaluation, SV).  The result is only trusted outside a rigorous per-evaluation band
+// c = sqrt(2*gamma*log2 e) and rounded to fp16 (u^ = fp16(c x), w^ = fp16(c s), attributes that are the same function of the
+// window sharing one of 320 K slots: kernels.h).  Only u.w goes through the matrix core:
+//     exp2 argument of (evaluation e, SV n) = u_e.w_n + t_n - |u_e|^2/2,    t_n = -|v_n|^2/2.
+// t_n is the INITIAL VALUE of the accumulator column (the C operand of the first MFMA of each chain, one fp32 per SV from the
+// tile image), -|u|^2/2 is common to all SVs of an evaluation and multiplies the two class sums once after the sweep.  So
+// the epilogue is one v_exp_f32 and one fma per (evaluation, SV), and K is exactly ten 16x16x32 steps.
+// (The coefficient stays a multiplier: as log2|coef_n| inside t_n it would save nothing -- hipcc splits a packed add next to
+// MFMAs into two adds anyway -- and a tiny coefficient would put |t_n| ~ 12 into the accumulator, which the worst-case bound
+// of the matrix core's fp32 accumulation pays for with a 2x wider band: measured 2.9 % instead of 1.9 % refined.)
+// The result is only trusted outside a rigorous per-evaluation band
 //     |dec| > min(gA sqrt(S), gC S) + (guard_acc0 + gB) S + cm (|dec| + |rho|) + guard_abs,   S = sum|coef|K,
 // {gA, gB, gC, cm} from k_features (screen_finish),
 // which is ~20x wider than the three-pass kernel's, so a few per cent of the evaluations go on to that kernel (in list
 // mode) and from there to the fp64 tiers as before: the labels stay those of libsvm, the bulk costs a third.
-//   * a wave keeps 64 evals x 336 slots in 168 VGPRs (twice the rows of the three-pass kernel: every B fragment read
+//   * a wave keeps 64 evals x 320 slots in 160 VGPRs (twice the rows of the three-pass kernel: every B fragment read
 //     from LDS feeds 4 MFMAs); workgroup = 4 waves = 256 evals and TWO workgroups share a CU (one wave of each per SIMD):
 //     their tile barriers, LDS-DMA bursts and prologues fall at different times, so one's stalls sit beside the other's MFMAs;
-//   * SV tiles (32 SVs, 22 KiB) stream through a 3-deep LDS ring by LDS-DMA exactly as in k_svm_rbf_h;
-//   * the exp/fma epilogue of a 16-SV column block is issued BETWEEN the MFMAs of the next block (two accumulator
+//   * SV tiles (32 SVs, 21 KiB) stream through a 3-deep LDS ring by LDS-DMA exactly as in k_svm_rbf_h;
+//   * the exp/add epilogue of a 16-SV column block is issued BETWEEN the MFMAs of the next block (two accumulator
 //     sets in ping-pong), so it overlaps the matrix pipe inside one wave instead of relying on the partner wave.
 // ---------------------------------------------------------------------------------------------------
 // One LDS-DMA piece (1 KiB): wave-uniform global base + lane*16, LDS destination M0 + lane*16.  Base and M0 must come out
@@ -41,7 +48,7 @@ __device__ __forceinline__ void dma_piece(const char *gbase, unsigned lds_dst, u
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(lane16), "s"(gbase) : "memory", "m0");
 }
 
-// the six pieces of one SV tile this wave stages (22 pieces over 4 waves x 6: pieces 0 and 1 go twice)
+// the six pieces of one SV tile this wave stages (21 pieces over 4 waves x 6: pieces 0..2 go twice)
 struct TileDma {
     const char *g[kS0WavePieces];
     unsigned l[kS0WavePieces];
@@ -60,13 +67,14 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
     for (int q = 0; q < kS0WavePieces; q++) dma_piece(d.g[q], d.l[q], lane16);
 }
 
-// MFMAs of column block n (16 SVs) of the tile at `cur` into acc, with the epilogue of the PREVIOUS block (old, cf_old)
-// spread over the k-steps: behind the four MFMAs of step s come the two v_exp_f32 of element pair s-1 and the two fmas of
-// pair s-2.
+// MFMAs of column block n (16 SVs) of the tile at `cur` into acc, with the epilogue of the PREVIOUS block (old) spread over the
+// k-steps: behind the four MFMAs of step s come the two v_exp_f32 of element pair s-1 and the two fmas of pair s-2.
+// The chains start from t (this lane's column of the block: -|v|^2/2) as the C operand of their first MFMA.
 // HAZARD (measured on gfx950, two waves per SIMD): a VALU instruction that reads a v_exp_f32 result within ~4 instructions
 // of the v_exp_f32 -- an MFMA in between does not help -- can read the register BEFORE the transcendental unit has written
 // it (wrong sums on some waves of some launches; hipcc pads one wait state, which is not enough).  Every exp result
-// here is consumed one whole k-step (>= 4 MFMAs, >= 8 instructions) after it was issued.
+// here is consumed one whole k-step (>= 4 MFMAs, >= 8 instructions) after it was issued; haf_grasping_amd/build.py checks
+// that distance in the ISA of every build.
 // The wave's three LDS-DMA pieces of the tile two ahead are issued behind the first MFMAs of k-step 0 (which carries no
 // epilogue work), inside the MFMA stream instead of all waves paying for them together behind the tile barrier.
 // No branch may sit inside this stream: with the DMA under a wave-uniform `if`, hipcc's code motion carries the epilogue of
@@ -74,14 +82,13 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // if/else it hoists the epilogue they have in common in front of the branch.  So every wave issues DMA in every block:
 // pieces 0..2 of the tile two ahead in column block 0, pieces 3..5 in column block 1 (FIRST = first piece, COUNT = how many).
 template <int FIRST, int COUNT>
-__device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], const half4 (&at)[4],
-                                             f32x4 (&acc)[4], const f32x4 (&old)[4], float cf_old, float (&sum)[4][4],
-                                             const TileDma &dma, unsigned lane16)
+__device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], f32x4 (&acc)[4],
+                                             const f32x4 (&old)[4], float t, float cf_old, float (&sum)[4][4], const TileDma &dma,
+                                             unsigned lane16)
 {
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
-#pragma unroll
-    for (int m = 0; m < 4; m++) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 t4 = {t, t, t, t};                                   // rows differ, the column (this lane's SV) is the same
     half8 b = *reinterpret_cast<const half8 *>(bl);                  // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
     half8 b1 = *reinterpret_cast<const half8 *>(bl + 2048);          // fragments are read two k-steps ahead of their MFMAs
     float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
@@ -97,40 +104,32 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         const bool ex = s >= 1 && s < 9, fm = s >= 2;
         const int e0 = 2 * (s - 1), e1 = e0 + 1, f0 = 2 * (s - 2), f1 = f0 + 1;
         float q0 = 0.0f, q1 = 0.0f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, s == 0 ? t4 : acc[0], 0, 0, 0);
         HAF_SB();
         if (COUNT > 0 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST], dma.l[FIRST], lane16); HAF_SB(); }
-#if SCREEN_ABL == 1
-        if (ex) { q0 = old[e0 >> 2][e0 & 3] + 1.0f; HAF_SB(); }
-#elif SCREEN_ABL == 2
+#if SCREEN_ABL == 2
         if (ex) { asm volatile("" ::"v"(old[e0 >> 2][e0 & 3])); HAF_SB(); }
 #else
         if (ex) { q0 = __builtin_amdgcn_exp2f(old[e0 >> 2][e0 & 3]); HAF_SB(); }
 #endif
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, s == 0 ? t4 : acc[1], 0, 0, 0);
         HAF_SB();
         if (COUNT > 1 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 1], dma.l[FIRST + 1], lane16); HAF_SB(); }
-#if SCREEN_ABL == 1
-        if (ex) { q1 = old[e1 >> 2][e1 & 3] + 1.0f; HAF_SB(); }
-#elif SCREEN_ABL == 2
+#if SCREEN_ABL == 2
         if (ex) { asm volatile("" ::"v"(old[e1 >> 2][e1 & 3])); HAF_SB(); }
 #else
         if (ex) { q1 = __builtin_amdgcn_exp2f(old[e1 >> 2][e1 & 3]); HAF_SB(); }
 #endif
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, acc[2], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, s == 0 ? t4 : acc[2], 0, 0, 0);
         HAF_SB();
         if (COUNT > 2 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 2], dma.l[FIRST + 2], lane16); HAF_SB(); }
-#if SCREEN_ABL != 2 && SCREEN_ABL != 6
+#if SCREEN_ABL != 2
         if (fm) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
-#elif SCREEN_ABL == 6
-        if (fm) { asm volatile("" ::"v"(k0)); HAF_SB(); }
 #endif
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, acc[3], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, s == 0 ? t4 : acc[3], 0, 0, 0);
         HAF_SB();
-#if SCREEN_ABL != 2 && SCREEN_ABL != 6
+#if SCREEN_ABL != 2
         if (fm) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
-#elif SCREEN_ABL == 6
-        if (fm) { asm volatile("" ::"v"(k1)); HAF_SB(); }
 #endif
         k0 = q0;
         k1 = q1;
@@ -138,13 +137,11 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         b1 = b2;
     }
 #undef HAF_SB
-    const half4 bt = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
-#pragma unroll
-    for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(at[m], bt, acc[m], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
 
 __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
+                                                               const float *__restrict__ nax,
                                                                const char *__restrict__ svt0,
                                                                const int *__restrict__ evalcell,
                                                                const int *__restrict__ counters, SvmParams p,
@@ -176,29 +173,22 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     if (nt > 1) stage_sv_tile_s0(tile_dma(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, poff), lane16);   // tile 1
 
     // A fragments: row block m = 0..3 (rows 16m..16m+15 of the wave's 64); lane holds A[16m + (lane&15)][32s + 8(lane>>4) + j]
-    // read once, with the nt hint: 5.3 GB of operands stream past the 2.9 MB of SV tiles that every workgroup re-reads from L2
-    // (A/B on one box: 15.38 -> 15.2 ms)
+    // read once, with the nt hint: 5 GB of operands stream past the 2.8 MB of SV tiles that every workgroup re-reads from L2
 #define SCREEN_A_LOAD(p) __builtin_nontemporal_load(p)
     half8 a[kHFull][4];
-    half4 at[4];                                                     // K tail: A[row][320 + 4(lane>>4) + j]
     {
-        const char *xt = X0 + (size_t)tile32 * kHMatBytes;
+        const char *xt = X0 + (size_t)tile32 * kS0MatBytes;
 #pragma unroll
         for (int s = 0; s < kHFull; s++)
 #pragma unroll
             for (int m = 0; m < 4; m++)
-                a[s][m] = SCREEN_A_LOAD(reinterpret_cast<const half8 *>(xt + (m >> 1) * kHMatBytes + (s * 2 + (m & 1)) * 1024 + lane * 16));
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-            at[m] = SCREEN_A_LOAD(reinterpret_cast<const half4 *>(xt + (m >> 1) * kHMatBytes + kHTailOff + (m & 1) * 512 + lane * 8));
+                a[s][m] = SCREEN_A_LOAD(reinterpret_cast<const half8 *>(xt + (m >> 1) * kS0MatBytes + (s * 2 + (m & 1)) * 1024 + lane * 16));
     }
     // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
 #pragma unroll
     for (int s = 0; s < kHFull; s++)
 #pragma unroll
         for (int m = 0; m < 4; m++) asm volatile("" : "+v"(a[s][m]));
-#pragma unroll
-    for (int m = 0; m < 4; m++) asm volatile("" : "+v"(at[m]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tiles 0 and 1 (this wave's pieces) have landed
     __syncthreads();
 
@@ -222,11 +212,12 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
             // slot that nobody reads any more is refilled with tile (t+2) mod nt
             const int tn = (t + 2) % nt;
             const TileDma dma = tile_dma(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, poff);
-            const float *cft = reinterpret_cast<const float *>(cur + kHMatBytes);
-            const float cf0 = cft[lane & 15], cf1 = cft[16 + (lane & 15)];   // coef of this lane's column in either block
+            const float *tt = reinterpret_cast<const float *>(cur + kS0MatBytes);
+            const float t0 = tt[lane & 15], t1 = tt[16 + (lane & 15)];   // t_n of this lane's column in either block
+            const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];   // and its coefficient (0 for padding SVs)
             // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0
-            screen_block<0, 3>(cur, 0, lane, a, at, acc0, acc1, cf_prev, sum, dma, lane16);
-            screen_block<3, 3>(cur, 1, lane, a, at, acc1, acc0, cf0, sum, dma, lane16);
+            screen_block<0, 3>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, dma, lane16);
+            screen_block<3, 3>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, dma, lane16);
             cf_prev = cf1;
             // tile t+1 must have landed before anyone reads it; the six pieces just issued may stay in flight
 #if SCREEN_ABL == 3
@@ -241,13 +232,11 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         }
         // epilogue of the sweep's last block, then the sum over the 16 column lanes
         float *dst = ph ? fin : pos;
-        // (all sixteen v_exp_f32 first, their consumers behind a scheduling barrier: see the hazard note at screen_block)
+        // (all sixteen v_exp_f32 first, their consumers behind wait states that hang on the data: see the hazard note)
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc1[m][r] = __builtin_amdgcn_exp2f(acc1[m][r]);
-        // the wait states hang on the data: all sixteen results go through the asm, so no exp can sink behind it and no
-        // consumer can rise above it
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -264,19 +253,24 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the refills past the last tile
     __syncthreads();
-    // one evaluation per lane from here: coalesced stores, one list reservation per wave
+    // one evaluation per lane from here: coalesced stores, one flag word per wave
     const long e = base + wave * kS0WaveEvals + lane;
     const bool live = e < n_evals;
-    const float P = pos[lane], N = fin[lane];
-    const float dv = (P + N) - p.rho;
-    const float sabs = P - N;                                       // sum |coef| K
     bool flagged = false;
     if (live) {
+        // the common factor 2^(-|u|^2/2) of every term of both sums (its v_exp_f32 is consumed many instructions later:
+        // the LDS reads and their wait sit in between)
+        float sc = __builtin_amdgcn_exp2f(nax[e]);
+        const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
+        const float Ps = pos[lane], Ns = fin[lane];
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
+        const float P = Ps * sc, N = Ns * sc;
+        const float dv = (P + N) - p.rho;
+        const float sabs = P - N;                                   // sum |coef| K
         dec[e] = dv;
         labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
         // {gA, gB, gC, cm} (screen_finish): linear term through the spectral norms (~sqrt(S)) or per SV (~S), whichever is
-        // smaller; S-proportional terms; the common factor of the -|u|^2/2 term on (|dec^| + |rho|)
-        const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
+        // smaller; S-proportional terms; the common factor on (|dec^| + |rho|)
         const float adv = fabsf(dv);
         const float lin = fminf(g.x * sqrtf(sabs), g.z * sabs);
         const float err = (lin + (p.guard_acc0 * 1.04f + g.y) * sabs + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
@@ -405,13 +399,13 @@ int probe_f16_subnormal_mfma(hipStream_t s)
     return h == 1.0f ? 1 : 0;
 }
 
-void launch_svm_screen(const void *X0, const float *gband, const void *svt0, const int *evalcell, const int *counters,
+void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, (const char *)svt0,
+    hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax, (const char *)svt0,
                        evalcell, counters, p, dec, labels, flag0_words, d);
     // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
