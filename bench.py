@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-crop", type=int, default=70, help="grid size of the single-core CPU-baseline sample (one roll)")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-f32-side", action="store_true", help="skip the side measurements of the other contraction modes")
+    ap.add_argument("--no-hard-side", action="store_true",
+                    help="skip the side measurement on the ill-conditioned model (the committed libsvm-trained surrogate, C = 512, "
+                         "replicated to bench size)")
     ap.add_argument("--no-cabi-side", action="store_true",
                     help="skip the side measurement of the C++-host multi-GPU path (haf_create_multi / haf_score_sharded: one "
                          "process, N GPUs, RCCL all-gather behind the C-ABI)")
@@ -271,8 +274,8 @@ def main():
     cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
     inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
 
-    def make_engine(precision):
-        return capi.Engine(feat, rng_file, model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
+    def make_engine(precision, model_file=None):
+        return capi.Engine(feat, rng_file, model_file or model_path, device=local_rank, grid_h=G, grid_w=G, n_rolls=args.rolls,
                            roll_step_deg=args.roll_step, max_clouds=1, max_points=G * G * 2,
                            flags=capi.FLAG_PROFILE | {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[precision])
 
@@ -327,9 +330,10 @@ def main():
     elapsed = float(t.item())
     total_evals = int(ev.item())
 
-    def roofline(r, precision):
+    def roofline(r, precision, nsv=None):
+        nsv = nsv or args.nsv
         evals_per_launch = r["evals"] / r["steps"]
-        flop = evals_per_launch * 2.0 * D_ATTR * args.nsv           # algorithmic: 646*nSV per eval, ONE pass
+        flop = evals_per_launch * 2.0 * D_ATTR * nsv                # algorithmic: 646*nSV per eval, ONE pass
         achieved = flop / r["svm_s"] / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
         kernel = {"f16s": "k_svm_screen", "f16x3": "k_svm_rbf_h", "f32": "k_svm_rbf"}[precision]
@@ -345,11 +349,12 @@ def main():
                       "note": "fp32 operands split into fp16 hi+lo; x.s = xh.sh + xl.sh + xh.sl (3 MFMA passes, fp32 "
                               "accumulate); algorithmic flop counted once, per SURVEY.md 8(d)"})
         if precision == "f16s":
-            executed = flop * 336.0 / D_ATTR
+            executed = flop * 320.0 / D_ATTR
             o.update({"passes": 1, "executed_tflops": executed / r["svm_s"] / 1e12,
-                      "note": "single fp16 MFMA pass over every evaluation (K padded 323 -> 336, the padding carries the norm "
-                              "terms); evaluations inside its rigorous guard band are re-done by the three-pass kernel "
-                              "(stage 'refine') and the fp64 tiers, so the labels are libsvm's",
+                      "note": "single fp16 MFMA pass over every evaluation; K = 320 slots for the 323 attributes (three pairs of "
+                              "Features.txt rows are the same feature with the same range and share a slot; the norm terms are the "
+                              "accumulator's initial value and a common factor, not K slots); evaluations inside its rigorous guard "
+                              "band are re-done by the three-pass kernel (stage 'refine') and the fp64 tiers, so the labels are libsvm's",
                       "refined_per_launch": r["refined"], "refined_share": r["refined"] / max(1.0, evals_per_launch),
                       "refine_ms": r["stage_ms"].get("refine")})
         return o
@@ -397,6 +402,28 @@ def main():
                                                            r2["out"]["best_row"] == res["out"]["best_row"] and
                                                            r2["out"]["best_col"] == res["out"]["best_col"] and
                                                            r2["out"]["best_roll"] == res["out"]["best_roll"])}
+        if world == 1 and not args.no_hard_side and args.precision == "f16s":
+            # The headline model is benign (seeded random coefficients: decisions spread wide against sum|coef|K).  The only
+            # genuinely libsvm-trained model in the repo (tests/golden/surrogate.model, svm-train -c 512: most coefficients at
+            # the bound, decisions crowding around zero) is the hard case: replicated to bench size it shows what an
+            # ill-conditioned model costs.  The engine finds out by itself (first call) and switches the screening kernel to
+            # the variant that measures |w|_2 = sqrt(sum (coef K)^2).
+            hard_path = os.path.join(tmp, "hard.model")
+            models.write_replicated_model(hard_path, os.path.join(ROOT, "tests", "golden", "surrogate.model"), copies=24, jitter=0.01, seed=5)
+            eh = make_engine("f16s", hard_path)
+            nsv_h = eh.model_info()["n_sv"]
+            rh = run(eh, 3, 2, False)
+            eh.close()
+            e3 = make_engine("f16x3", hard_path)
+            r3 = run(e3, 1, 1, False)
+            e3.close()
+            line["hard_model"] = {"model": "tests/golden/surrogate.model (libsvm-3.12 svm-train -c 512 -g 0.0031 on real feature rows) x 24 "
+                                           "jittered copies: nSV=%d" % nsv_h,
+                                  "value": rh["evals"] / rh["elapsed"], "unit": "evals/s", "ms_per_step": 1e3 * rh["elapsed"] / 3,
+                                  "roofline": roofline(rh, "f16s", nsv_h), "stage_ms_per_step": rh["stage_ms"],
+                                  "refined_share": rh["refined"] / max(1.0, rh["evals"] / 3),
+                                  "f16x3_ms_per_step": 1e3 * r3["elapsed"],
+                                  "same_best_as_f16x3": bool(all(r3["out"][k] == rh["out"][k] for k in ("eval", "best_row", "best_col", "best_roll")))}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(feat, rng_file, model_path, xyz, args)
         else:

@@ -212,7 +212,10 @@ struct haf_engine {
     int flag_cap = 0;
     int flag0_cap = 0;      // screening pass: evaluations that go on to the three-pass kernel
     bool screen_active = true;   // default mode only: cleared (for good) once more than 60 % of a call's evaluations fell inside
-                                 // the screening band -- for such a model the single pass is wasted work
+                                 // the screening band even with the measured |w|_2 -- for such a model the single pass is wasted work
+    bool screen_sumsq = false;   // set (for good) once more than 25 % of a call's evaluations fell inside the band of the plain
+                                 // variant: from then on the kernel variant that measures |w|_2 = sqrt(sum (coef K)^2) runs
+                                 // (ill-conditioned models: large coefficients whose kernel values are small)
     ScreenParams screen{};
     size_t cells_cap = 0;   // B*R*H*W
 
@@ -234,6 +237,7 @@ struct haf_engine {
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64, d_part64;
     DevBuf<short> d_ev16;
+    DevBuf<float> d_margin;         // HAF_FLAG_KEEP_DEBUG, default mode: |dec^| / band of every evaluation the screening tier decided
     DevBuf<AttrRecord> d_attr;      // HAF_FLAG_KEEP_DEBUG: [max_evals][kKP] attribute records of the exact-form feature kernels
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
@@ -256,6 +260,7 @@ struct haf_engine {
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
     int last_evals = 0, last_flagged = 0, last_flagged2 = 0, last_flagged0 = 0;
+    bool last_screened = false;     // the last call's labels came through the screening tier (not its three-pass fallback)
     std::vector<haf_grasp_input> last_inputs;
 };
 
@@ -696,6 +701,7 @@ int build_tables(haf_engine *e)
         e->svm.as_max = (float)as_max;
     }
     e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
+    e->svm.sqrt_cmax = (float)(e->screen.sqrt_cmax * (1.0 + 1e-7));
     e->exact.gamma = m.gamma; e->exact.rho = m.rho;
     e->exact.lower = e->range.lower; e->exact.upper = e->range.upper;
     e->exact.n_sv = m.n_sv; e->exact.n_sv_pad = e->n_sv_pad; e->exact.kx = e->kx;
@@ -757,6 +763,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->list_cap);
     ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->list_cap);
+    if ((c.flags & HAF_FLAG_KEEP_DEBUG) && mode == MODE_SCREEN) ok &= hipSuccess == e->d_margin.alloc((size_t)e->max_evals_pad);
     if (c.flags & HAF_FLAG_KEEP_DEBUG) {
         // attribute records of the exact-form feature kernels (haf_debug_fetch_attr): 7.6 KB per evaluation, so only for
         // engines of reference size (up to 2 GiB); a larger debug engine runs without them and the fetch says so
@@ -837,7 +844,7 @@ void haf_destroy(haf_engine *e)
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
-    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
+    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
     e->d_sd.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -1036,16 +1043,17 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
     launch_compact(e->d_mask.p, e->d_rowcount.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
-    auto decide = [&](int mode) -> int {
+    auto decide = [&](int mode, bool reuse_operands) -> int {
         mark(e, HAF_ST_FEATURES);
         const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
         if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
-            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
+            if (!reuse_operands)
+                launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
+                                e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
             mark(e, HAF_ST_SVM);
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                              e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, s);
+                              e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p, e->screen_sumsq, s);
             mark(e, HAF_ST_REFINE);
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
@@ -1111,18 +1119,30 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     };
     int mode = contraction_mode(c);
     if (mode == MODE_SCREEN && !e->screen_active) mode = MODE_SPLIT;
-    int rc = decide(mode);
+    int rc = decide(mode, false);
     if (rc != HAF_OK) return rc;
     if (mode == MODE_SCREEN) {
-        const int f0 = e->h_counters[CNT_FLAGGED0], ne = e->h_counters[CNT_EVALS];
-        if (f0 > e->flag0_cap) {
-            // more undecided evaluations than the refinement list holds: this pass's labels are incomplete.  Redo the decision
-            // stage with the three-pass kernel for every evaluation (same labels by construction) and stay with it.
-            e->screen_active = false;
+        auto undecided = [&]() { return e->h_counters[CNT_FLAGGED0]; };
+        const int ne = e->h_counters[CNT_EVALS];
+        if (undecided() > e->flag0_cap && !e->screen_sumsq) {
+            // More undecided evaluations than the refinement list holds: this pass's labels are incomplete.  First remedy: the
+            // kernel variant that measures |w|_2 (same operand images, so only the decision stage is redone), and stay with it.
+            e->screen_sumsq = true;
             HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
-            rc = decide(MODE_SPLIT);
+            rc = decide(MODE_SCREEN, true);
             if (rc != HAF_OK) return rc;
-        } else if (ne >= 256 && (double)f0 > 0.6 * (double)ne) {
+        }
+        if (undecided() > e->flag0_cap) {
+            // Still too many: redo the decision stage with the three-pass kernel for every evaluation (same labels by
+            // construction) and serve this model without the screening pass from now on.
+            e->screen_active = false;
+            mode = MODE_SPLIT;
+            HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
+            rc = decide(MODE_SPLIT, false);
+            if (rc != HAF_OK) return rc;
+        } else if (ne >= 256 && !e->screen_sumsq && (double)undecided() > 0.25 * (double)ne) {
+            e->screen_sumsq = true;                      // from the next call on
+        } else if (ne >= 256 && e->screen_sumsq && (double)undecided() > 0.6 * (double)ne) {
             e->screen_active = false;
         }
     }
@@ -1135,6 +1155,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
+    e->last_screened = (mode == MODE_SCREEN) && e->last_flagged0 <= e->flag0_cap;
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
     if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
@@ -1327,6 +1348,22 @@ static int debug_fetch_impl(haf_engine *e, int32_t what, int32_t cloud, int32_t 
             for (size_t k = 0; k < ne; k++) {
                 size_t cb = (size_t)cell[k] / HW;
                 if (cb == br) g[(size_t)cell[k] - cb * HW] = d64[k];
+            }
+            return HAF_OK;
+        }
+        case HAF_DBG_SCREEN_MARGIN: {
+            if (!need(HW * 4)) break;
+            float *g = (float *)dst;
+            for (size_t i = 0; i < HW; i++) g[i] = NAN;
+            const size_t ne = (size_t)e->last_evals;
+            if (!ne || !e->d_margin.p || !e->last_screened) return HAF_OK;
+            std::vector<int> cell(ne);
+            std::vector<float> mg(ne);
+            HIPCHK(e, hipMemcpy(cell.data(), e->d_evalcell.p, ne * 4, hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(mg.data(), e->d_margin.p, ne * 4, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < ne; k++) {
+                size_t cb = (size_t)cell[k] / HW;
+                if (cb == br) g[(size_t)cell[k] - cb * HW] = mg[k];
             }
             return HAF_OK;
         }

@@ -127,7 +127,8 @@ struct ScrDesc3 {
 static_assert(sizeof(ScrDesc3) == 96, "ScrDesc3 layout");
 constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded
 // per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
-//   |dec^ - dec| <= min(gA * sqrt(S), gC * S) + (guard_acc0 + gB) * S + cm * (|dec^| + |rho|) + guard_abs,  S = sum|coef|K
+//   |dec^ - dec| <= min(gA * |w|_2, gC * S) + (guard_acc0 + gB) * S + cm * (|dec^| + |rho|) + guard_abs,  S = sum|coef|K,
+//   |w|_2 = sqrt(sum (coef K)^2), measured by the SUMSQ variant of k_svm_screen or bounded by sqrt(max|coef| * S)
 // with {gA, gB, gC, cm} per evaluation
 constexpr int kBandFloats = 4;
 
@@ -185,6 +186,7 @@ struct SvmParams {
     float guard_acc0;             // screening pass: single-level fp32 coefficient sum + exp2 + product, per unit of sum|coef|K
     float guard_acc_l;            // guard_acc of the three-pass kernel's list mode when the SV tiles are cut into ranges (k_svm_h_combine)
     int   gv0, gv1;               // grid values of label[0] / label[1] (atoi of the "%g" label text, server.cpp:843)
+    float sqrt_cmax;              // screening pass, plain variant: |w|_2 <= sqrt(max|coef| * S)
 };
 
 struct ExactParams {
@@ -222,7 +224,7 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
-                       int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s);
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, bool sumsq, hipStream_t s);
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);

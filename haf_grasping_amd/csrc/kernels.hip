@@ -649,7 +649,8 @@ __device__ __forceinline__ void screen_extra_norm(const ScreenParams &sp, int g,
 // (das_max), matrix-core accumulation generously (11 accumulating instructions, a few ulp of the largest partial sum each:
 // 2^-18 of |u||v^| + a_x + a_s).  The kernel measures S^ = 2^D sum|c_n| K_n 2^e_n: the true S is at most S^ * 2^(|D| + max|e_n|),
 // folded into the outputs.  Output {gA, gB, gC, cm} (kernels.h), scaled by sp.scale:
-//   |dec^ - dec| <= [min(gA sqrt(S^), gC S^) + (guard_acc0' + gB) S^ + cm (|dec^| + |rho|)] * 1.002
+//   |dec^ - dec| <= [min(gA |w|_2^, gC S^) + (guard_acc0' + gB) S^ + cm (|dec^| + |rho|)] * 1.002,
+//   |w|_2^ = sqrt(max|c_n| S^) or, in the kernel's SUMSQ variant, the measured sqrt(sum_n (c_n K_n)^2)
 // Upper bound of sqrt(x) to 1e-9 relative without a transcendental instruction (the guard band is never checked bit for
 // bit by a test, so nothing in it may hang on the v_exp/v_rsq result hazard described in screen.hip): 1/sqrt(x) by the
 // exponent-halving bit trick and four Newton steps r <- r (1.5 - 0.5 x r^2), which only multiply and add.
@@ -691,14 +692,15 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2
     const double D = (kF32Acc + 6.0e-8) * a_x + un_t * eta_t + 0.5 * eta_t * eta_t + 6.0e-7;
     const double e_max = d_max + sp.das_max + acc;
     const double infl = 1.0 + exp2m1_upper(e_max + D);   // meaningful below 0.05 only: beyond it the band is infinite anyway
-    const double gA = ln2 * (dn * sp.sigma_v + (un + dn) * sp.sigma_dv) * sp.sqrt_cmax;
+    const double gA = ln2 * (dn * sp.sigma_v + (un + dn) * sp.sigma_dv);   // per unit of |w|_2, which the contraction kernel supplies
     const double gB = ln2 * (sp.das_max + acc) + 0.6 * (ln2 * e_max) * (ln2 * e_max);
-    band[0] = (float)(gA * (1.0 + 0.5 * (infl - 1.0)) * sp.scale);   // sqrt(1+z) <= 1 + z/2; scale = 1.001: the roundings of these
-    band[1] = (float)(gB * infl * sp.scale);             // expressions and of the casts are far inside 0.1 %
+    band[0] = (float)(gA * infl * sp.scale);             // (|w|_2 measured: inflated like S; bounded through sqrt(S): sqrt(infl) <= infl)
+    band[1] = (float)(gB * infl * sp.scale);             // scale = 1.001: the roundings of these expressions and of the casts are far inside 0.1 %
     band[2] = (float)(ln2 * d_max * infl * sp.scale);
     band[3] = (float)(exp2m1_upper(D) * sp.scale);
     // outside the range the bounds were derived for, or a common factor 2^(a_x) that fp32 sums could overflow on: never trusted
-    if (!(e_max + D < 0.05) || !(a_x < 64.0)) band[1] = __builtin_inff();
+    // (2^(2 a_x) must stay finite in fp32 for the SUMSQ variant's sum of squares)
+    if (!(e_max + D < 0.05) || !(a_x < 30.0)) band[1] = __builtin_inff();
 }
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k

@@ -29,7 +29,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // MFMAs into two adds anyway -- and a tiny coefficient would put |t_n| ~ 12 into the accumulator, which the worst-case bound
 // of the matrix core's fp32 accumulation pays for with a 2x wider band: measured 2.9 % instead of 1.9 % refined.)
 // The result is only trusted outside a rigorous per-evaluation band
-//     |dec| > min(gA sqrt(S), gC S) + (guard_acc0 + gB) S + cm (|dec| + |rho|) + guard_abs,   S = sum|coef|K,
+//     |dec| > min(gA |w|_2, gC S) + (guard_acc0 + gB) S + cm (|dec| + |rho|) + guard_abs,   S = sum|coef|K,  w_n = coef_n K_n,
 // {gA, gB, gC, cm} from k_features (screen_finish),
 // which is ~20x wider than the three-pass kernel's, so a few per cent of the evaluations go on to that kernel (in list
 // mode) and from there to the fp64 tiers as before: the labels stay those of libsvm, the bulk costs a third.
@@ -81,16 +81,26 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // the block out of the MFMA stream (into the next basic block), and with two template instantiations in the arms of an
 // if/else it hoists the epilogue they have in common in front of the branch.  So every wave issues DMA in every block:
 // pieces 0..2 of the tile two ahead in column block 0, pieces 3..5 in column block 1 (FIRST = first piece, COUNT = how many).
-template <int FIRST, int COUNT>
+// SUMSQ (the variant for ill-conditioned models): the epilogue also accumulates q += (coef K)^2, so that the sqrt(S) form of the
+// band can use |w|_2^2 = sum_n (coef_n K_n)^2 itself instead of its bound max|coef| * S: three VALU instructions
+// per element behind the exp instead of one.
+// B fragments are read two k-steps ahead of their MFMAs, ACROSS the boundary between the two column blocks of a tile: block 0
+// (n = 0) reads its own first two fragments on entry and leaves those of block 1 in (b, b1) on exit, so that block 1's first
+// MFMA does not wait for an LDS round trip.  (Across tiles that is not possible: the next tile is only known to have landed
+// behind the barrier.)  SUMSQ: one step ahead -- the four registers go to the squares.
+template <int FIRST, int COUNT, bool SUMSQ>
 __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], f32x4 (&acc)[4],
-                                             const f32x4 (&old)[4], float t, float cf_old, float (&sum)[4][4], const TileDma &dma,
-                                             unsigned lane16)
+                                             const f32x4 (&old)[4], float t, float cf_old, float (&sum)[4][4], float (&sq)[4][4],
+                                             const TileDma &dma, unsigned lane16, half8 &b, half8 &b1)
 {
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
     const f32x4 t4 = {t, t, t, t};                                   // rows differ, the column (this lane's SV) is the same
-    half8 b = *reinterpret_cast<const half8 *>(bl);                  // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
-    half8 b1 = *reinterpret_cast<const half8 *>(bl + 2048);          // fragments are read two k-steps ahead of their MFMAs
+    constexpr bool kXBlock = !(SCREEN_VARIANT & 1);                  // (A/B builds: SCREEN_VARIANT bit 0 switches the hand-over off)
+    if (n == 0 || !kXBlock) {
+        b = *reinterpret_cast<const half8 *>(bl);                    // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
+        if (!SUMSQ) b1 = *reinterpret_cast<const half8 *>(bl + 2048);
+    }
     float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
     // The issue order of every k-step is pinned instruction by instruction (a scheduling barrier after each): B read of the
     // next step, then MFMA | exp | MFMA | exp | MFMA | fma | MFMA | fma, where the exps belong to pair s-1 and the fmas to
@@ -99,7 +109,16 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
 #pragma unroll
     for (int s = 0; s < kHFull; s++) {
         half8 b2 = b1;
-        if (s + 2 < kHFull && SCREEN_ABL != 5) b2 = *reinterpret_cast<const half8 *>(bl + (s + 2) * 2048);
+        // fragment s + 2 of this block, or -- in the last two steps of block 0 -- fragment s + 2 - 10 of block 1 (1 KiB further on)
+        constexpr bool kNoRead = SCREEN_ABL == 5;
+        if (!SUMSQ && !kNoRead) {
+            if (s + 2 < kHFull) b2 = *reinterpret_cast<const half8 *>(bl + (s + 2) * 2048);
+            else if (n == 0 && kXBlock) b2 = *reinterpret_cast<const half8 *>(bl + 1024 + (s + 2 - kHFull) * 2048);
+        }
+        if (SUMSQ && !kNoRead) {
+            if (s + 1 < kHFull) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
+            else if (n == 0 && kXBlock) b1 = *reinterpret_cast<const half8 *>(bl + 1024);
+        }
         HAF_SB();
         const bool ex = s >= 1 && s < 9, fm = s >= 2;
         const int e0 = 2 * (s - 1), e1 = e0 + 1, f0 = 2 * (s - 2), f1 = f0 + 1;
@@ -124,32 +143,51 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         HAF_SB();
         if (COUNT > 2 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 2], dma.l[FIRST + 2], lane16); HAF_SB(); }
 #if SCREEN_ABL != 2
-        if (fm) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
+        if (fm && !SUMSQ) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
+        if (fm && SUMSQ) {
+            const float ck = cf_old * k0;
+            HAF_SB();
+            sum[f0 >> 2][f0 & 3] += ck;
+            HAF_SB();
+            sq[f0 >> 2][f0 & 3] = fmaf(ck, ck, sq[f0 >> 2][f0 & 3]);
+            HAF_SB();
+        }
 #endif
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, s == 0 ? t4 : acc[3], 0, 0, 0);
         HAF_SB();
 #if SCREEN_ABL != 2
-        if (fm) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
+        if (fm && !SUMSQ) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
+        if (fm && SUMSQ) {
+            const float ck = cf_old * k1;
+            HAF_SB();
+            sum[f1 >> 2][f1 & 3] += ck;
+            HAF_SB();
+            sq[f1 >> 2][f1 & 3] = fmaf(ck, ck, sq[f1 >> 2][f1 & 3]);
+            HAF_SB();
+        }
 #endif
         k0 = q0;
         k1 = q1;
         b = b1;
-        b1 = b2;
+        if (!SUMSQ) b1 = b2;
     }
+    // (n == 0: b, b1 now hold fragments 0 and 1 of block 1 -- SUMSQ: b holds fragment 0)
 #undef HAF_SB
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
 
+template <bool SUMSQ>
 __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
                                                                const float *__restrict__ nax,
                                                                const char *__restrict__ svt0,
                                                                const int *__restrict__ evalcell,
                                                                const int *__restrict__ counters, SvmParams p,
                                                                float *__restrict__ dec, int8_t *__restrict__ labels,
-                                                               unsigned long long *__restrict__ flag0_words, Dims d)
+                                                               unsigned long long *__restrict__ flag0_words, Dims d,
+                                                               float *__restrict__ margin)
 {
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
-    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 2 * kS0Waves * kS0WaveEvals * 4];
+    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
     const int n_evals = counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
@@ -159,6 +197,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     const int nt = d.n_sv_tiles;
     float *pos = reinterpret_cast<float *>(lds + kS0Buffers * kS0SvTileBytes) + wave * kS0WaveEvals;
     float *fin = pos + kS0Waves * kS0WaveEvals;
+    float *qrow = fin + kS0Waves * kS0WaveEvals;                     // SUMSQ: sum of (coef K)^2 over both sweeps
 
     const unsigned lane16 = (unsigned)lane * 16u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -193,6 +232,11 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     __syncthreads();
 
     float sum[4][4];                                                 // rows 16m + 4(lane>>4) + r, this lane's columns
+    float sq[4][4];                                                  // SUMSQ only (dead otherwise): runs on across the two sweeps
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sq[m][r] = 0.0f;
     f32x4 acc0[4], acc1[4];
     // Two sweeps: the tile images hold the non-negative coefficients first, so the first sweep yields
     // P = sum_{coef>0} coef*K and the second N = sum_{coef<0} coef*K; dec = P + N - rho and the guard scale
@@ -216,8 +260,9 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
             const float t0 = tt[lane & 15], t1 = tt[16 + (lane & 15)];   // t_n of this lane's column in either block
             const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];   // and its coefficient (0 for padding SVs)
             // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0
-            screen_block<0, 3>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, dma, lane16);
-            screen_block<3, 3>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, dma, lane16);
+            half8 bf0, bf1;                                          // B fragments in flight, handed from block 0 to block 1
+            screen_block<0, 3, SUMSQ>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, sq, dma, lane16, bf0, bf1);
+            screen_block<3, 3, SUMSQ>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, sq, dma, lane16, bf0, bf1);
             cf_prev = cf1;
             // tile t+1 must have landed before anyone reads it; the six pieces just issued may stay in flight
 #if SCREEN_ABL == 3
@@ -243,12 +288,27 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = fmaf(cf_prev, acc1[m][r], sum[m][r]);
+                const float ck = cf_prev * acc1[m][r];
+                float v = ck + sum[m][r];
+                if (SUMSQ) sq[m][r] = fmaf(ck, ck, sq[m][r]);
                 v += __shfl_xor(v, 8, 64);
                 v += __shfl_xor(v, 4, 64);
                 v += __shfl_xor(v, 2, 64);
                 v += __shfl_xor(v, 1, 64);
                 if ((lane & 15) == 0) dst[16 * m + 4 * (lane >> 4) + r] = v;
+            }
+    }
+    if (SUMSQ) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = sq[m][r];
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 1, 64);
+                if ((lane & 15) == 0) qrow[16 * m + 4 * (lane >> 4) + r] = v;
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the refills past the last tile
@@ -272,9 +332,12 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         // {gA, gB, gC, cm} (screen_finish): linear term through the spectral norms (~sqrt(S)) or per SV (~S), whichever is
         // smaller; S-proportional terms; the common factor on (|dec^| + |rho|)
         const float adv = fabsf(dv);
-        const float lin = fminf(g.x * sqrtf(sabs), g.z * sabs);
+        // |w|_2 of w_n = coef_n K_n: measured (SUMSQ; the common factor enters squared) or bounded by sqrt(max|coef| * S)
+        const float w2 = SUMSQ ? sqrtf(qrow[lane]) * sc : p.sqrt_cmax * sqrtf(sabs);
+        const float lin = fminf(g.x * w2, g.z * sabs);
         const float err = (lin + (p.guard_acc0 * 1.04f + g.y) * sabs + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
         flagged = !(adv > err);                                     // also catches NaN
+        if (margin) margin[e] = flagged ? 0.0f : adv / err;         // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
     }
     // one 64-bit word per wave (64 consecutive evaluations): k_screen_compact turns the words into the ORDERED list of
     // undecided evaluations -- neighbours in the list are neighbours on the grid, so the feature kernel that follows reads
@@ -401,12 +464,16 @@ int probe_f16_subnormal_mfma(hipStream_t s)
 
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
-                       int flag0_cap, int *counters_rw, Dims d, long max_evals, hipStream_t s)
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, bool sumsq, hipStream_t s)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
-    hipLaunchKernelGGL(k_svm_screen, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax, (const char *)svt0,
-                       evalcell, counters, p, dec, labels, flag0_words, d);
+    if (sumsq)
+        hipLaunchKernelGGL(k_svm_screen<true>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,
+                           (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin);
+    else
+        hipLaunchKernelGGL(k_svm_screen<false>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,
+                           (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin);
     // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
     hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters);

@@ -185,7 +185,9 @@ int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_gr
  * HEIGHTS H*W f32, INTEGRAL (H+1)*(W+1) f32, MASK H*W u8, LABELS H*W i8 (-1 unmasked, else label text value),
  * DECISION H*W f64 (NaN unmasked), TRANSFORM 16 f32. */
 enum { HAF_DBG_HEIGHTS = 0, HAF_DBG_INTEGRAL = 1, HAF_DBG_MASK = 2, HAF_DBG_LABELS = 3, HAF_DBG_DECISION = 4,
-       HAF_DBG_TRANSFORM = 5 };
+       HAF_DBG_TRANSFORM = 5,
+       HAF_DBG_SCREEN_MARGIN = 6 };  /* H*W f32, default mode: |dec^| / guard band for the cells the screening tier decided
+                                        (> 1 by construction), 0 for the cells it handed on, NaN elsewhere */
 int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes);
 
 /* The attribute pipeline of the masked cells of one (cloud, roll) of the last scored batch, as the exact-form feature

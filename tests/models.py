@@ -53,3 +53,36 @@ def synthetic_cloud(grid=512, k=2, seed=0, cell=0.01):
     z = 0.05 + 0.20 * s + rng.uniform(0.0, 0.005, size=x.shape)
     pts = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
     return pts
+
+
+def write_replicated_model(path, base_model_path, copies=24, jitter=0.01, seed=0):
+    """An ILL-CONDITIONED model of bench size from a genuine one: every support vector of `base_model_path` (the committed
+    surrogate: libsvm-3.12 svm-train -c 512 on real feature rows, 172 SVs, most coefficients at the bound +-512) appears
+    `copies` times with its attribute values jittered by N(0, jitter) (printed %.8g like libsvm does) and its coefficient
+    kept.  The decision function is `copies` x the base model's up to the jitter, so the decisions keep crowding around
+    zero against sum|coef|K exactly as they do for the trained model -- the case the plain screening band cannot decide.
+    rho is scaled with the copies; labels and class order are the base model's."""
+    rng = np.random.RandomState(seed)
+    with open(base_model_path) as f:
+        text = f.read()
+    head, body = text.split("SV\n", 1)
+    keys = dict(line.split(" ", 1) for line in head.strip().splitlines())
+    n0, n1 = [int(t) for t in keys["nr_sv"].split()]
+    rows = []
+    for line in body.strip().splitlines():
+        t = line.split()
+        rows.append((float(t[0]), [(int(p.split(":")[0]), float(p.split(":")[1])) for p in t[1:]]))
+    assert len(rows) == n0 + n1
+    out = []
+    for cls_rows in (rows[:n0], rows[n0:]):                 # libsvm keeps the SVs grouped by class
+        for coef, pairs in cls_rows:
+            for _ in range(copies):
+                parts = ["%.16g " % coef]
+                for k, v in pairs:
+                    parts.append("%d:%.8g " % (k, v + rng.normal(0.0, jitter)))
+                out.append("".join(parts))
+    with open(path, "w") as f:
+        f.write("svm_type c_svc\nkernel_type rbf\ngamma %s\nnr_class 2\ntotal_sv %d\nrho %.9g\nlabel %s\nnr_sv %d %d\nSV\n"
+                % (keys["gamma"].strip(), len(out), float(keys["rho"]) * copies, keys["label"].strip(), n0 * copies, n1 * copies))
+        f.write("\n".join(out) + "\n")
+    return path

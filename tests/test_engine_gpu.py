@@ -26,6 +26,19 @@ DEC_ABS = 1e-6
 STATS = {}
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _dump_stats():
+    """What the tests measured on the way (refined shares, worst errors) goes to gpurun_out/test_stats.json."""
+    yield
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "test_stats.json"), "w") as f:
+            json.dump(STATS, f, indent=1, sort_keys=True, default=str)
+    except OSError:
+        pass
+
+
 def _files(data_dir):
     return os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures")
 
@@ -497,8 +510,9 @@ def test_screening_overflow_falls_back_to_three_passes(data_dir, surrogate, orc,
 def test_screening_tier_forced_and_reported(data_dir, surrogate, orc, monkeypatch, tmp_path):
     """Default mode: (1) on a well-conditioned model the screening pass decides most evaluations and reports how many it
     passed on; (2) on the surrogate model (C = 512: |dec| is tiny against sum|coef|K, nearly everything sits inside the
-    rigorous band) the labels are still the oracle's and the engine stops screening after the first call; (3) with the band
-    forced wide open every evaluation goes through the three-pass kernel in list mode and meets that kernel's bar."""
+    band of the plain variant) the labels are still the oracle's and the engine switches to the kernel variant that measures
+    |w|_2 = sqrt(sum (coef K)^2), which decides most evaluations again; (3) with the band forced wide open every evaluation
+    goes through the three-pass kernel in list mode and meets that kernel's bar."""
     xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
     inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
     f, r = _files(data_dir)
@@ -513,7 +527,17 @@ def test_screening_tier_forced_and_reported(data_dir, surrogate, orc, monkeypatc
     eng = make_engine(data_dir, surrogate)
     compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
     cnt = eng.last_counts()
-    assert cnt["n_refined"] > 0.6 * cnt["n_evals"]
+    assert cnt["n_refined"] > 0.25 * cnt["n_evals"]            # plain variant: the bound sqrt(max|coef| S) on |w|_2 is hopeless at C = 512
+    STATS["screen_refined_share_surrogate_plain"] = cnt["n_refined"] / max(1, cnt["n_evals"])
+    compare_full(eng, orc, xyz, dict(n_rolls=12), inp)          # the engine has switched to the variant that measures |w|_2
+    cnt2 = eng.last_counts()
+    # It helps, but not enough for a model of 172 SVs: the fp16 rounding of the operands alone bounds the error by
+    # |u^-u| sigma(W^) |w|_2 ~ 0.5 for this model, and most of its decision values are smaller than that.  Only the bound
+    # is large (the measured error is 20x smaller), but the labels are promised, not likely: the engine serves the model
+    # with the three-pass kernel from the third call on.  (Replicated to 4128 SVs the same model is decided to 96 % by
+    # the measuring variant: bench.py's hard_model line.)
+    assert 0 < cnt2["n_refined"] < cnt["n_refined"], (cnt, cnt2)
+    STATS["screen_refined_share_surrogate_sumsq"] = cnt2["n_refined"] / max(1, cnt2["n_evals"])
     compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
     assert eng.last_counts()["n_refined"] == 0                # screening switched off for this model
     eng.close()
@@ -847,3 +871,74 @@ def test_multi_rejects_bad_requests(data_dir, surrogate):
     with pytest.raises(capi.HafError):
         me.score_sharded(np.zeros((4, 3), np.float32), capi.default_input())      # wrong mode
     me.close()
+
+
+def test_bench_configuration_against_the_oracle_where_screening_was_closest(data_dir, tmp_path):
+    """The bench's own workload -- C5 (512 x 512, 36 rolls of 5 degrees, 524 288 points), seeded random model nSV = 4096
+    (seed 1234, as bench.py writes it), default mode -- against the oracle's feature / scale / decision chain
+    (hafo_feature_values, hafo_q4, hafo_scale_row, hafo_decision: libsvm's fp64 order) on >= 2 000 cells chosen where a
+    band hole would show first: the cells the screening tier decided with |dec^| / band closest to 1 (HAF_DBG_SCREEN_MARGIN),
+    plus the cells it handed on with the smallest |dec|, plus random ones.  Label identical; decision value inside the
+    tier's own band (which the margin makes checkable: |dec^ - dec| < |dec^| / margin)."""
+    nsv = 4096
+    path = str(tmp_path / "rand4096.model")
+    models.write_random_model(path, nsv, D=323, seed=1234, balanced=True)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, path)
+    xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
+    eng = make_engine(data_dir, path, 0, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+    assert not eng.cfg.flags & (capi.FLAG_SPLIT_F16 | capi.FLAG_FP32_MFMA)
+    inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
+    rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
+    cnt = eng.last_counts()
+    assert cnt["n_evals"] == int(rec["n_evals"].sum()) > 7800000 and 0 < cnt["n_refined"] < 0.1 * cnt["n_evals"]
+    # gather (roll, i, j, margin, dec) of every masked cell; keep the closest calls
+    close, handed, rnd = [], [], []
+    rng = np.random.RandomState(3)
+    n_decided = 0
+    for roll in range(36):
+        mg = eng.debug(capi.DBG_SCREEN_MARGIN, 0, roll)
+        dec = eng.debug(capi.DBG_DECISION, 0, roll)
+        ok = ~np.isnan(mg)
+        assert int(ok.sum()) == int(rec["n_evals"][roll])
+        decided = ok & (mg > 0)
+        assert (mg[decided] > 1.0).all()                       # the tier only decides outside its band
+        n_decided += int(decided.sum())
+        ii, jj = np.nonzero(decided)
+        order = np.argsort(mg[ii, jj])[:120]
+        close += [(roll, int(ii[k]), int(jj[k]), float(mg[ii[k], jj[k]])) for k in order]
+        hi, hj = np.nonzero(ok & (mg == 0))
+        if len(hi):
+            order = np.argsort(np.abs(dec[hi, hj]))[:10]
+            handed += [(roll, int(hi[k]), int(hj[k]), 0.0) for k in order]
+        pick = rng.choice(len(ii), 8, replace=False)
+        rnd += [(roll, int(ii[k]), int(jj[k]), float(mg[ii[k], jj[k]])) for k in pick]
+    assert n_decided == cnt["n_evals"] - cnt["n_refined"]
+    close.sort(key=lambda t: t[3])
+    sample = close[:1700] + handed + rnd
+    assert len(sample) >= 2000
+    m = o.model_arrays()
+    skip = np.zeros(325, np.uint8)
+    skip[324] = 1
+    by_roll = {}
+    for s in sample:
+        by_roll.setdefault(s[0], []).append(s)
+    worst = 0.0
+    for roll, items in by_roll.items():
+        ii = eng.debug(capi.DBG_INTEGRAL, 0, roll)
+        lab = eng.debug(capi.DBG_LABELS, 0, roll)
+        dec = eng.debug(capi.DBG_DECISION, 0, roll)
+        for _, i, j, mgv in items:
+            feats = o.feature_values(ii[i - 7:i + 8, j - 7:j + 8])
+            xs = o.scale_row(np.array([O.q4(v) for v in feats]), m["D"], skip)
+            d = o.decision(xs)
+            want = m["label"][0] if d > 0 else m["label"][1]
+            assert lab[i, j] == want, (roll, i, j, d, dec[i, j], mgv)
+            if mgv > 0:                                        # decided by the screening tier: its value, inside its band
+                assert abs(dec[i, j] - d) < abs(dec[i, j]) / mgv, (roll, i, j, d, dec[i, j], mgv)
+                worst = max(worst, abs(dec[i, j] - d) * mgv / abs(dec[i, j]))
+            else:                                              # handed on: an exact tier's value
+                assert abs(dec[i, j] - d) <= 6e-3, (roll, i, j, d, dec[i, j])     # three-pass tier: 2^-20 * S, S <= 4096
+    STATS["bench_config_oracle_check"] = {"cells": len(sample), "closest_margin": close[0][3],
+                                          "worst_error_as_fraction_of_band": worst}
+    eng.close()
