@@ -197,7 +197,10 @@ def reference_tools_baseline(o, O, rng_file, model_path, xyz, args):
     import subprocess
     ref = O.ref_dir()
     if not (os.path.exists(os.path.join(ref, "svm-scale")) and os.path.exists(os.path.join(ref, "svm-predict"))):
-        return None
+        return dict(kind="reference", value=None, unit="evals/s", cores=1,
+                    sample="NOT MEASURED: oracle/_ref/svm-scale and svm-predict are absent.  They are built from "
+                           "/root/reference/libsvm-3.12 by `make -C oracle ref` in the build container only (git-ignored, they "
+                           "travel to the GPU box with the snapshot); a clean checkout has the oracle port figure alone")
     c = 40
     half = c * 0.01 / 2
     sel = (np.abs(xyz[:, 0]) < half) & (np.abs(xyz[:, 1]) < half)

@@ -469,3 +469,33 @@ def test_hostile_files_return_errors_not_exceptions(data_dir, golden_dir, tmp_pa
         p.write_bytes((hdr % (sz, pts, pts, mode)).encode() + payload)
         rc = L.haf_pcd_load(str(p).encode(), C.byref(ptr), C.byref(n), err, 256)
         assert rc in (capi.HAF_E_IO, capi.HAF_E_INTERNAL) and err.value, (k, rc)
+
+
+def test_host_paths_under_address_and_ub_sanitizers(golden_dir, tmp_path):
+    """CPU sanitizer job (GPU sanitizers are not available on the pool): engine.cpp + parsers.cpp built with
+    -fsanitize=address,undefined by the ROCm clang (host only) and driven over the parsers with truncated / bit-flipped
+    files, the roll geometry, the cross-roll rule and the poses (tests/sanitize/host_paths.cpp).  Any report fails."""
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm clang")
+    csrc = os.path.join(ROOT, "haf_grasping_amd", "csrc")
+    objs = [os.path.join(csrc, o) for o in ("kernels.o", "screen.o", "multi.o")]
+    if not all(os.path.exists(o) for o in objs):
+        from haf_grasping_amd import build as b
+        b.build(force=True)
+    exe = str(tmp_path / "host_paths")
+    flags = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+             "-fno-omit-frame-pointer", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-DHAF_TESTING", "-I/opt/rocm/include"]
+    cmd = [clang] + flags + [os.path.join(csrc, "engine.cpp"), os.path.join(csrc, "parsers.cpp"),
+                             os.path.join(ROOT, "tests", "sanitize", "host_paths.cpp"), "-x", "none"] + objs + \
+          ["-fsanitize=address,undefined", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    scratch = tmp_path / "fuzz"
+    scratch.mkdir()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe, golden_dir, str(scratch)], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "sanitizer job ok" in p.stdout and "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, \
+        (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+    shutil.rmtree(str(scratch), ignore_errors=True)

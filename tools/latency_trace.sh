@@ -1,12 +1,15 @@
 # kernel-by-kernel timeline of one small request (C2) on the GPU box: bash tools/latency_trace.sh
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/lat
 rm -rf $O; mkdir -p $O
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/latency_breakdown.py --only C2 > $O/kt.log 2>&1
 python3 - <<'PY'
-import csv,glob
-f=glob.glob("/root/repo/gpurun_out/lat/kt/**/*kernel_trace.csv", recursive=True)[0]
+import csv,glob,os,sys
+fs=glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "lat/kt/**/*kernel_trace.csv"), recursive=True)
+if not fs: sys.exit("no rocprofv3 CSV under $GRAFT_REPO_ROOT/gpurun_out: did the profiled run fail? see the .log next to it")
+f=fs[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # last request = last occurrence of k_bin / k_bin_lds / k_fill to the end

@@ -1,4 +1,5 @@
 # quick per-kernel profile of the default bench workload (GPU box): kernel trace + SQ counters of the dominant kernel
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/quick
@@ -10,9 +11,11 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCL
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/sq2 -- python3 $B1 > $O/sq2.log 2>&1
 find $O -name "*kernel_stats.csv" | head -1 | xargs cat | cut -d, -f1-8 | head -20
 python3 - <<'PY'
-import csv,glob,collections
+import csv,glob,collections,os,sys
 for d in ("sq","sq2"):
-    for f in glob.glob("/root/repo/gpurun_out/quick/%s/**/*counter_collection.csv"%d, recursive=True):
+    fs=glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "quick", d, "**", "*counter_collection.csv"), recursive=True)
+    if not fs: print("no counter CSV for pass %s under $GRAFT_REPO_ROOT/gpurun_out/quick (see %s.log)" % (d, d), file=sys.stderr)
+    for f in fs:
         acc=collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
             if "k_svm_screen" in r["Kernel_Name"]:

@@ -1,4 +1,5 @@
 # Reproduces profiles/ for one round on the GPU box: bash tools/profile_round.sh   (about 4 GPU-minutes)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final
