@@ -84,7 +84,8 @@ NormalisedInput normalise(const haf_grasp_input &in)
 
 // mat_transform of generate_grid (423-483) when from_float_av, of transform_gp_in_wcs_and_publish (1276-1334) otherwise:
 // the two differ in whether atan2/sqrt see the float copy of the approach vector or the double message fields.
-Mat4 roll_transform(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, bool from_float_av)
+Mat4 roll_transform(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, bool from_float_av,
+                    Mat4 *pre_roll = nullptr, float *roll_cs = nullptr)
 {
     Mat4 scale = Mat4::identity(), to_orig = Mat4::identity(), rot_z = Mat4::identity(), rot_x = Mat4::identity(),
          from_orig = Mat4::identity(), rot = Mat4::identity();
@@ -120,13 +121,19 @@ Mat4 roll_transform(const haf_config &cfg, const haf_grasp_input &in, const Norm
     rot_z.a[1][0] = std::sin(about_z); rot_z.a[1][1] = std::cos(about_z);
     rot_x.a[1][1] = std::cos(about_x); rot_x.a[1][2] = -std::sin(about_x);
     rot_x.a[2][1] = std::sin(about_x); rot_x.a[2][2] = std::cos(about_x);
+    if (pre_roll) *pre_roll = from_orig * rot_x * rot_z * to_orig;   // (only a spatial pre-sort key for the binning kernels)
+    if (roll_cs) { roll_cs[0] = std::cos(angle); roll_cs[1] = std::sin(angle); roll_cs[2] = (float)n.width; }
     return scale * rot * from_orig * rot_x * rot_z * to_orig;
 }
 
-void fill_roll_geo(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, RollGeo &g)
+void fill_roll_geo(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, RollGeo &g, float *m0 = nullptr)
 {
-    Mat4 m = roll_transform(cfg, in, n, roll, true);
+    Mat4 pre;
+    float cs[3];
+    Mat4 m = roll_transform(cfg, in, n, roll, true, &pre, cs);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) g.m[i * 4 + j] = m.a[i][j];
+    g.rc = cs[0]; g.rs = cs[1]; g.rw = cs[2];
+    if (m0) for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) m0[i * 4 + j] = pre.a[i][j];
     // pnt_in_box scalars, server.cpp:679-696, with the reference's float/double mix
     const float boxrot_angle_init = 0.0f;                 // never assigned in the reference; zero in practice
     float alpha_deg = (float)(-roll * cfg.roll_step_deg - boxrot_angle_init * 180 / kPi);
@@ -145,7 +152,7 @@ void fill_roll_geo(const haf_config &cfg, const haf_grasp_input &in, const Norma
     g.cy3 = (float)(cy + std::cos(alpha + kPi / 2) * width_r);
     g.cx4 = (float)(cx + std::sin(alpha + kPi / 2) * width_r);
     g.cy4 = (float)(cy - std::cos(alpha + kPi / 2) * width_r);
-    g.pad[0] = g.pad[1] = 0;
+    g.pad = 0;
 }
 
 // 4x4 inverse: Gauss-Jordan with partial pivoting in double, rounded to float (Eigen's inverse() order is unpinned)
@@ -221,9 +228,13 @@ struct haf_engine {
 
     DevBuf<CloudDev> d_clouds;
     DevBuf<float> d_points;
+    DevBuf<float> d_sorted;         // bucket-sorted copy of the clouds (binning of large grids, kernels.hip)
+    DevBuf<int> d_bkt;              // 3 x max_clouds x kBktInts bucket counters / offsets / cursors
+    int bkt_ints = 0;
     DevBuf<RollGeo> d_geo;
     DevBuf<int> d_heights;          // ordered keys during binning, fp32 heights afterwards
-    DevBuf<double> d_rowsum;
+    DevBuf<double> d_rowsum;        // integral image: band totals of the parallel form / row sums of the sequential fallback
+    DevBuf<int> d_inexact;          // per (cloud, roll): the parallel integral image was not exact -> sequential order (kernels.hip)
     DevBuf<float> d_ii;
     DevBuf<uint8_t> d_mask;
     DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list, d_flag2_list;
@@ -259,7 +270,7 @@ struct haf_engine {
 
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
-    int last_evals = 0, last_flagged = 0, last_flagged2 = 0, last_flagged0 = 0;
+    int last_evals = 0, last_flagged = 0, last_flagged2 = 0, last_flagged0 = 0, last_inexact = 0;
     bool last_screened = false;     // the last call's labels came through the screening tier (not its three-pass fallback)
     std::vector<haf_grasp_input> last_inputs;
 };
@@ -727,9 +738,18 @@ int alloc_buffers(haf_engine *e)
     bool ok = true;
     ok &= hipSuccess == e->d_clouds.alloc(B);
     ok &= hipSuccess == e->d_points.alloc((size_t)c.max_points * 3);
+    {
+        const int nb = bin_bucket_grid(c.grid_h, nullptr);
+        e->bkt_ints = nb * nb + 1;
+        if ((size_t)c.grid_h * c.grid_w > 16384) {           // grids k_bin_lds cannot hold: the bucket-sorted binning path
+            ok &= hipSuccess == e->d_sorted.alloc((size_t)c.max_points * 3);
+            ok &= hipSuccess == e->d_bkt.alloc((size_t)3 * B * e->bkt_ints);
+        }
+    }
     ok &= hipSuccess == e->d_geo.alloc(B * R);
     ok &= hipSuccess == e->d_heights.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rowsum.alloc(e->cells_cap);
+    ok &= hipSuccess == e->d_inexact.alloc(B * R);
     ok &= hipSuccess == e->d_ii.alloc(B * R * (H + 1) * (W + 1));
     ok &= hipSuccess == e->d_mask.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rowcount.alloc(B * R * H);
@@ -839,7 +859,7 @@ void haf_destroy(haf_engine *e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->d_clouds.release(); e->d_points.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release();
+    e->d_clouds.release(); e->d_points.release(); e->d_sorted.release(); e->d_bkt.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release(); e->d_inexact.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
@@ -950,6 +970,13 @@ int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, in
     return HAF_OK;
 }
 
+int haf_last_prestage(const haf_engine *e, int64_t *n_inexact_grids)
+{
+    if (!e) return HAF_E_ARG;
+    if (n_inexact_grids) *n_inexact_grids = e->last_inexact;
+    return HAF_OK;
+}
+
 int haf_set_stream(haf_engine *e, void *s)
 {
     if (!e) return HAF_E_ARG;
@@ -986,10 +1013,16 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     }
     if (host_pts > (size_t)c.max_points) return fail(e, HAF_E_CAPACITY, "more host points than max_points");
     size_t off = 0;
+    long total_n = 0;
+    bool bucket_ok = true;
     for (int b = 0; b < B; b++) {
         NormalisedInput n = normalise(in[b]);
-        for (int r = 0; r < R; r++) fill_roll_geo(c, in[b], n, roll_first + r, e->h_geo[b * R + r]);
         CloudDev &cd = e->h_clouds[b];
+        for (int r = 0; r < R; r++) fill_roll_geo(c, in[b], n, roll_first + r, e->h_geo[b * R + r], r == 0 ? cd.m0 : nullptr);
+        if (n.width == 0) bucket_ok = false;             // x-scale 0: every point lands in row H/2, whatever its distance
+        cd.sorted_off = (int)total_n;
+        cd.bucket_off = b * e->bkt_ints;
+        total_n += (long)clouds[b].n_points;
         cd.n = (int)clouds[b].n_points;
         if (clouds[b].on_device) {
             cd.xyz = clouds[b].xyz;
@@ -1034,10 +1067,17 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     int key_m1;
     memcpy(&key_m1, &minus_one, 4);
     key_m1 ^= 0x7FFFFFFF;                                                // ordered key of -1.0f (499-501)
-    launch_fill_i32(e->d_heights.p, key_m1, cells, s);
-    launch_bin(e->d_clouds.p, max_n, e->d_geo.p, e->d_heights.p, d, r_row, r_col, s);
+    (void)key_m1;
+    {
+        BinScratch bs{};
+        bs.sorted = e->d_sorted.p; bs.sorted_cap = e->d_sorted.p ? (long)c.max_points : 0;
+        bs.bkt_count = e->d_bkt.p; bs.bkt_off = e->d_bkt.p ? e->d_bkt.p + (size_t)c.max_clouds * e->bkt_ints : nullptr;
+        bs.bkt_cursor = e->d_bkt.p ? e->d_bkt.p + (size_t)2 * c.max_clouds * e->bkt_ints : nullptr;
+        bs.bkt_cap = e->d_bkt.p ? c.max_clouds * e->bkt_ints : 0;
+        launch_bin(e->d_clouds.p, e->h_clouds, max_n, total_n, e->d_geo.p, e->d_heights.p, d, r_row, r_col, bucket_ok, bs, s);
+    }
     mark(e, HAF_ST_INTEGRAL);
-    launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, d, s);
+    launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, e->d_inexact.p, e->d_counters.p, d, s);
     mark(e, HAF_ST_MASK);
     launch_mask_count(e->d_ii.p, e->d_geo.p, e->d_mask.p, e->d_rowcount.p, d, s);
     launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
@@ -1121,6 +1161,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     if (mode == MODE_SCREEN && !e->screen_active) mode = MODE_SPLIT;
     int rc = decide(mode, false);
     if (rc != HAF_OK) return rc;
+    const int inexact_grids = e->h_counters[CNT_INEXACT];     // (a redo of the decision stage below resets the counters)
     if (mode == MODE_SCREEN) {
         auto undecided = [&]() { return e->h_counters[CNT_FLAGGED0]; };
         const int ne = e->h_counters[CNT_EVALS];
@@ -1155,6 +1196,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
+    e->last_inexact = inexact_grids;
     e->last_screened = (mode == MODE_SCREEN) && e->last_flagged0 <= e->flag0_cap;
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)

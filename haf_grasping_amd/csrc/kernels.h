@@ -136,6 +136,10 @@ struct CloudDev {
     const float *xyz;
     int n;
     int stride;      // floats per point
+    float m0[8];     // rows 0 and 1 of the transform WITHOUT roll and x-scale (T(0,0,z_shift) Rx Rz T(-centre), server.cpp:462-483):
+                     // where a point lands before the gripper roll -- only used to pre-sort the cloud into spatial buckets
+    int sorted_off;  // first point of this cloud in the bucket-sorted copy (points), bucket_off: its first bucket counter
+    int bucket_off;
 };
 
 // per (cloud, roll): rows 0..2 of the fp32 transform (server.cpp:483) and the rotated-rectangle scalars of
@@ -144,7 +148,8 @@ struct RollGeo {
     float m[12];
     float sa, ca;                 // sinf(alpha), cosf(alpha)
     float cx1, cy1, cx2, cy2, cx3, cy3, cx4, cy4;
-    float pad[2];
+    float rc, rs, rw;             // cos / sin of the roll angle and the x-scale of this roll's transform: m = S(rw) R(roll) m0
+    float pad;
 };
 
 // one HAF/SHAF feature (fv.cpp:141-199) with its svm-scale range (svm-scale.c:333-353)
@@ -198,7 +203,9 @@ struct ExactParams {
 };
 
 // counters[] slots in device memory
-enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAGGED0 = 4, CNT_COUNT = 8 };
+enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAGGED0 = 4,
+       CNT_INEXACT = 5,    // (cloud, roll) grids whose integral image needed the sequential summation order
+       CNT_COUNT = 8 };
 
 // fp64 model image for the rechecks: attribute-major [kM64Rows][n_sv_pad]; rows 0..323 attributes (model order of SVs),
 // row 324 |s|^2, row 325 coef
@@ -207,9 +214,20 @@ constexpr int kM64Rows = 326;
 struct RollRecordDev { int vote; short row, col; float h_locmax; int n_evals; };
 
 void launch_fill_i32(int *p, int v, size_t n, hipStream_t s);
-void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkeys, Dims d, float r_row, float r_col,
-                hipStream_t s);
-void launch_integral(int *hkeys_heights, double *rowsum, float *ii, Dims d, hipStream_t s);
+// scratch of the bucket-sorted binning path (large grids): see kernels.hip
+struct BinScratch {
+    float *sorted;       // [total points][3] the clouds' points grouped by bucket (original coordinates)
+    int *bkt_count;      // [B][nb*nb + 1]
+    int *bkt_off;        // [B][nb*nb + 1] exclusive scan of the counts (+ total)
+    int *bkt_cursor;     // [B][nb*nb + 1]
+    long sorted_cap;     // points the sorted copy holds
+    int bkt_cap;         // bucket counters per array
+};
+int bin_bucket_grid(int H, int *bucket_cells);     // buckets per side for a grid of H cells; bucket edge in cells
+// returns true when the bucket-sorted path ran (it also fills the empty cells: no separate fill launch needed)
+bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, long total_n, const RollGeo *geo, int *hkeys, Dims d,
+                float r_row, float r_col, bool bucket_ok, BinScratch bs, hipStream_t s);
+void launch_integral(int *hkeys_heights, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s);
 void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s);
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
 void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s);

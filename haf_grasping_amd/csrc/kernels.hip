@@ -139,22 +139,234 @@ __global__ __launch_bounds__(256) void k_bin_lds(const CloudDev *__restrict__ cl
     }
 }
 
-void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkeys, Dims d, float r_row, float r_col,
-                hipStream_t s)
+// Large grids (beyond what fits LDS) with a sizeable cloud: one global atomicMax per (point, roll) is what k_bin costs --
+// 19 M of them at C5, 0.40 ms, an order of magnitude above what the 75 MB they move would take.  The bucket-sorted path
+// removes every global atomic:
+//   once per request   k_bkt_count / k_bkt_scan / k_bkt_scatter: the cloud is grouped by WHERE ITS POINTS LAND BEFORE THE ROLL
+//                      (m0 = the transform without roll and x-scale) into square buckets of kBktCells x kBktCells grid cells
+//                      -- a counting sort, LDS-private histograms, the points keep their original coordinates;
+//   once per roll      k_bin_tiles: a workgroup owns a 64 x 64 tile of the output grid in LDS, walks the buckets whose image
+//                      under this roll can touch the tile (a conservative test with 2 mm of slack: the fp32 product
+//                      S R(roll) m0 and the full matrix differ by ~1e-6 m), transforms their points with the FULL matrix
+//                      exactly as k_bin does, keeps the cell maximum with ds_max, and stores the finished tile with plain
+//                      coalesced stores (empty cells included: no fill launch).
+// max is order independent and the cell of a point is computed by the same fp32 expression: the grid is k_bin's bit for bit.
+constexpr int kBinTile = 64;
+constexpr int kBktChunk = 2048;                  // points per workgroup in the counting-sort passes
+constexpr int kBktMaxBuckets = 4096;             // LDS histogram (16 KiB); bin_bucket_grid keeps nb*nb below it
+constexpr float kBktSlack = 0.002f;              // metres
+
+int bin_bucket_grid(int H, int *bucket_cells)
 {
-    if (max_n <= 0) return;
+    int bc = H / 32 > 16 ? H / 32 : 16;            // bucket edge in cells: nb stays ~ 1.414 * 32 + 3 for any grid size
+    const double r = 0.005 * H, bs = 0.01 * bc, Rb = r * 1.41422 + bs;
+    int nb = (int)(2.0 * Rb / bs) + 1;
+    if (bucket_cells) *bucket_cells = bc;
+    return nb;
+}
+
+struct BktGrid { float Rb, inv_bs, bs; int nb; };
+__host__ __device__ inline BktGrid bkt_grid(int H)
+{
+    int bc = H / 32 > 16 ? H / 32 : 16;
+    BktGrid g;
+    g.bs = 0.01f * (float)bc;
+    g.Rb = 0.005f * (float)H * 1.41422f + g.bs;
+    g.inv_bs = 1.0f / g.bs;
+    g.nb = (int)(2.0 * (0.005 * H * 1.41422 + 0.01 * bc) / (0.01 * bc)) + 1;
+    return g;
+}
+
+// bucket of a point (or -1): where m0 puts it; any consistent rule works, the test in k_bin_tiles is made for THIS one
+__device__ __forceinline__ int point_bucket(const CloudDev &c, const BktGrid &g, int i)
+{
+    const float *p = c.xyz + (size_t)i * c.stride;
+    const float x = p[0], y = p[1], z = p[2];
+    const float x0 = c.m0[0] * x + c.m0[1] * y + c.m0[2] * z + c.m0[3];
+    const float y0 = c.m0[4] * x + c.m0[5] * y + c.m0[6] * z + c.m0[7];
+    const float fx = (x0 + g.Rb) * g.inv_bs, fy = (y0 + g.Rb) * g.inv_bs;
+    if (!(fx >= 0.0f && fx < (float)g.nb && fy >= 0.0f && fy < (float)g.nb)) return -1;     // also NaN
+    return (int)fy * g.nb + (int)fx;
+}
+
+__global__ __launch_bounds__(256) void k_bkt_count(const CloudDev *__restrict__ clouds, int *__restrict__ bkt_count, Dims d)
+{
+    __shared__ int hist[kBktMaxBuckets];
+    const int b = blockIdx.y;
+    const CloudDev c = clouds[b];
+    const int first = blockIdx.x * kBktChunk;
+    if (first >= c.n) return;
+    const BktGrid g = bkt_grid(d.H);
+    const int nbk = g.nb * g.nb;
+    for (int k = threadIdx.x; k < nbk; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int last = min(c.n, first + kBktChunk);
+    for (int i = first + threadIdx.x; i < last; i += 256) {
+        const int q = point_bucket(c, g, i);
+        if (q >= 0) atomicAdd(&hist[q], 1);
+    }
+    __syncthreads();
+    int *out = bkt_count + c.bucket_off;
+    for (int k = threadIdx.x; k < nbk; k += 256)
+        if (hist[k]) atomicAdd(&out[k], hist[k]);
+}
+
+// exclusive scan of one cloud's bucket counts (<= 4096 of them): offsets (+ total at [nbk]) and the scatter cursors
+__global__ __launch_bounds__(1024) void k_bkt_scan(const CloudDev *__restrict__ clouds, const int *__restrict__ bkt_count,
+                                                   int *__restrict__ bkt_off, int *__restrict__ bkt_cursor, Dims d)
+{
+    __shared__ int part[1024];
+    const CloudDev c = clouds[blockIdx.x];
+    const BktGrid g = bkt_grid(d.H);
+    const int nbk = g.nb * g.nb, t = threadIdx.x;
+    const int per = (nbk + 1023) / 1024, lo = t * per, hi = min(nbk, lo + per);
+    int sum = 0;
+    for (int k = lo; k < hi; k++) sum += bkt_count[c.bucket_off + k];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int k = lo; k < hi; k++) {
+        bkt_off[c.bucket_off + k] = run;
+        bkt_cursor[c.bucket_off + k] = run;
+        run += bkt_count[c.bucket_off + k];
+    }
+    if (t == 1023) bkt_off[c.bucket_off + nbk] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_bkt_scatter(const CloudDev *__restrict__ clouds, int *__restrict__ bkt_cursor,
+                                                     float *__restrict__ sorted, Dims d)
+{
+    __shared__ int hist[kBktMaxBuckets];             // first the chunk's histogram, then each bucket's base in the sorted copy
+    const int b = blockIdx.y;
+    const CloudDev c = clouds[b];
+    const int first = blockIdx.x * kBktChunk;
+    if (first >= c.n) return;
+    const BktGrid g = bkt_grid(d.H);
+    const int nbk = g.nb * g.nb;
+    for (int k = threadIdx.x; k < nbk; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int last = min(c.n, first + kBktChunk);
+    for (int i = first + threadIdx.x; i < last; i += 256) {
+        const int q = point_bucket(c, g, i);
+        if (q >= 0) atomicAdd(&hist[q], 1);
+    }
+    __syncthreads();
+    // reserve this chunk's share of every bucket it touches: one global atomic per (chunk, bucket)
+    for (int k = threadIdx.x; k < nbk; k += 256) {
+        const int n = hist[k];
+        hist[k] = n ? atomicAdd(&bkt_cursor[c.bucket_off + k], n) : 0;
+    }
+    __syncthreads();
+    float *out = sorted + (size_t)c.sorted_off * 3;
+    for (int i = first + threadIdx.x; i < last; i += 256) {
+        const int q = point_bucket(c, g, i);
+        if (q < 0) continue;
+        const int pos = atomicAdd(&hist[q], 1);      // order inside a bucket is arbitrary: the cell maximum does not care
+        const float *p = c.xyz + (size_t)i * c.stride;
+        out[(size_t)pos * 3] = p[0];
+        out[(size_t)pos * 3 + 1] = p[1];
+        out[(size_t)pos * 3 + 2] = p[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
+                                                   const float *__restrict__ sorted, const int *__restrict__ bkt_off,
+                                                   int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty)
+{
+    __shared__ int cells[kBinTile * kBinTile];
+    __shared__ int blist[kBktMaxBuckets];
+    __shared__ int nlist;
+    const int br = blockIdx.y, b = br / d.R;
+    const CloudDev c = clouds[b];
+    const RollGeo &g = geo[br];
+    const int tiles_w = (d.W + kBinTile - 1) / kBinTile;
+    const int tx0 = (blockIdx.x / tiles_w) * kBinTile, ty0 = (blockIdx.x % tiles_w) * kBinTile;    // first row (x-bin) / column (y-bin)
+    const BktGrid bg = bkt_grid(d.H);
+    for (int k = threadIdx.x; k < kBinTile * kBinTile; k += 256) cells[k] = key_empty;
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
+    // ---- which buckets can reach this tile?  p = S(rw) R(roll) p0; tile = [xa, xb] x [ya, yb] in p (cell = floor(100 (p + r))) ----
+    const float xa = -r_row + 0.01f * (float)tx0, xb = -r_row + 0.01f * (float)min(tx0 + kBinTile, d.H);
+    const float ya = -r_col + 0.01f * (float)ty0, yb = -r_col + 0.01f * (float)min(ty0 + kBinTile, d.W);
+    const float cxm = 0.5f * (xa + xb), cym = 0.5f * (ya + yb);
+    const float rw = g.rw, hb = 0.70711f * bg.bs;                    // half diagonal of a bucket
+    const float hx = 0.5f * (xb - xa) + fabsf(rw) * hb + kBktSlack, hy = 0.5f * (yb - ya) + hb + kBktSlack;
+    const int nbk = bg.nb * bg.nb;
+    for (int q = threadIdx.x; q < nbk; q += 256) {
+        if (bkt_off[c.bucket_off + q + 1] == bkt_off[c.bucket_off + q]) continue;      // empty bucket
+        const float qx = -bg.Rb + ((float)(q % bg.nb) + 0.5f) * bg.bs, qy = -bg.Rb + ((float)(q / bg.nb) + 0.5f) * bg.bs;   // centre in p0
+        const float px = rw * (g.rc * qx - g.rs * qy), py = g.rs * qx + g.rc * qy;
+        if (fabsf(px - cxm) <= hx && fabsf(py - cym) <= hy) blist[atomicAdd(&nlist, 1)] = q;
+    }
+    __syncthreads();
+    const int nl = nlist;
+    const float *pts = sorted + (size_t)c.sorted_off * 3;
+    for (int l = 0; l < nl; l++) {
+        const int q = blist[l];
+        const int i0 = bkt_off[c.bucket_off + q], i1 = bkt_off[c.bucket_off + q + 1];
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+            // pcl::transformPointCloud (488): fp32, left to right, unfused -- the same expression as k_bin
+            float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
+            float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
+            float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
+            if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
+                const int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row))) - tx0;       // 513
+                const int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col))) - ty0;       // 514
+                if (ix >= 0 && ix < kBinTile && iy >= 0 && iy < kBinTile && ix + tx0 < d.H && iy + ty0 < d.W)
+                    atomicMax(&cells[ix * kBinTile + iy], f2key(pz));
+            }
+        }
+    }
+    __syncthreads();
+    int *out = hkeys + (size_t)br * d.H * d.W;
+    for (int k = threadIdx.x; k < kBinTile * kBinTile; k += 256) {
+        const int i = k / kBinTile, j = k % kBinTile;
+        if (tx0 + i < d.H && ty0 + j < d.W) out[(size_t)(tx0 + i) * d.W + ty0 + j] = cells[k];
+    }
+}
+
+bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, long total_n, const RollGeo *geo, int *hkeys, Dims d,
+                float r_row, float r_col, bool bucket_ok, BinScratch bs, hipStream_t s)
+{
     const int HW = d.H * d.W;
+    float minus_one = -1.0f;
+    int key_empty;
+    memcpy(&key_empty, &minus_one, 4);
+    key_empty ^= 0x7FFFFFFF;                                         // ordered key of -1.0f (499-501): an empty cell
+    int bc;
+    const int nb = bin_bucket_grid(d.H, &bc);
+    const long nbk1 = (long)nb * nb + 1;
+    // the bucket-sorted path: grids too large for k_bin_lds, enough points for the three sorting passes to pay, square grid
+    if (bucket_ok && HW > kBinLdsCells && total_n >= 32768 && d.H == d.W && nbk1 <= kBktMaxBuckets && total_n <= bs.sorted_cap &&
+        nbk1 * d.B <= bs.bkt_cap) {
+        (void)hipMemsetAsync(bs.bkt_count, 0, (size_t)nbk1 * d.B * sizeof(int), s);
+        dim3 grid((max_n + kBktChunk - 1) / kBktChunk, d.B);
+        hipLaunchKernelGGL(k_bkt_count, grid, dim3(256), 0, s, clouds, bs.bkt_count, d);
+        hipLaunchKernelGGL(k_bkt_scan, dim3(d.B), dim3(1024), 0, s, clouds, bs.bkt_count, bs.bkt_off, bs.bkt_cursor, d);
+        hipLaunchKernelGGL(k_bkt_scatter, grid, dim3(256), 0, s, clouds, bs.bkt_cursor, bs.sorted, d);
+        const int tiles = ((d.H + kBinTile - 1) / kBinTile) * ((d.W + kBinTile - 1) / kBinTile);
+        hipLaunchKernelGGL(k_bin_tiles, dim3(tiles, d.B * d.R), dim3(256), 0, s, clouds, geo, bs.sorted, bs.bkt_off, hkeys, d, r_row, r_col,
+                           key_empty);
+        return true;
+    }
+    (void)clouds_host;
+    launch_fill_i32(hkeys, key_empty, (size_t)d.B * d.R * HW, s);
+    if (max_n <= 0) return false;
     if (HW <= kBinLdsCells && max_n >= 4 * kBinChunk) {
-        float minus_one = -1.0f;
-        int key_empty;
-        memcpy(&key_empty, &minus_one, 4);
-        key_empty ^= 0x7FFFFFFF;                                     // ordered key of -1.0f: what the grid is filled with
         dim3 grid((max_n + kBinChunk - 1) / kBinChunk, d.B * d.R);
         hipLaunchKernelGGL(k_bin_lds, grid, dim3(256), (size_t)HW * sizeof(int), s, clouds, geo, hkeys, d, r_row, r_col, key_empty);
-        return;
+        return false;
     }
     dim3 grid((max_n + 255) / 256, d.B * d.R);
     hipLaunchKernelGGL(k_bin, grid, dim3(256), 0, s, clouds, geo, hkeys, d, r_row, r_col);
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -163,12 +375,15 @@ void launch_bin(const CloudDev *clouds, int max_n, const RollGeo *geo, int *hkey
 // fp64 partial sums and the fp32 narrowing (599-601) are bit-identical for any input, not only when the
 // sums happen to be exact.  Thread-per-row pass, then thread-per-column pass.
 // ---------------------------------------------------------------------------------------------------
-// Two launches: k_integral_rows (one thread per grid row: running sum along the row) and k_integral_cols (one thread per
-// column of the integral image: running sum down the column), 64 rows / columns per workgroup, so that a 36-roll request
-// occupies a few hundred workgroups instead of 36.
-__global__ __launch_bounds__(64) void k_integral_rows(int *hk, double *__restrict__ rowsum, Dims d)
+// The SEQUENTIAL form -- k_integral_rows (one thread per grid row: running sum along the row) and k_integral_cols (one thread
+// per column of the integral image: running sum down the column) -- is the definition of the result and, since round 2, the
+// fallback: it only runs for a grid whose parallel sums (k_integral_band, below) were not all exact.
+__global__ __launch_bounds__(64) void k_integral_rows(int *hk, double *__restrict__ rowsum, const int *__restrict__ inexact_flags,
+                                                      int *__restrict__ counters, Dims d)
 {
     const int br = blockIdx.y;
+    if (!inexact_flags[br]) return;                       // the parallel form was exact for this grid (the normal case)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CNT_INEXACT], 1);
     const int H = d.H, W = d.W;
     int *keys = hk + (size_t)br * H * W;
     float *hts = reinterpret_cast<float *>(keys);
@@ -185,8 +400,8 @@ __global__ __launch_bounds__(64) void k_integral_rows(int *hk, double *__restric
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             if (c0 + q < W) {
-                float h = key2f(kreg[q]);
-                if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare)
+                float h = __int_as_float(kreg[q]);        // already a finalised height (k_integral_band<true>), not a key
+                if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare; idempotent)
                 hts[row * W + c0 + q] = h;
                 s = __dadd_rn(s, (double)h);              // 589: widened before the integral
                 rs[row * W + c0 + q] = s;
@@ -195,9 +410,11 @@ __global__ __launch_bounds__(64) void k_integral_rows(int *hk, double *__restric
     }
 }
 
-__global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__ rowsum, float *__restrict__ ii, Dims d)
+__global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__ rowsum, float *__restrict__ ii,
+                                                      const int *__restrict__ inexact_flags, Dims d)
 {
     const int br = blockIdx.y;
+    if (!inexact_flags[br]) return;
     const int H = d.H, W = d.W, W1 = W + 1;
     const double *rs = rowsum + (size_t)br * H * W;
     float *I = ii + (size_t)br * (H + 1) * W1;
@@ -216,10 +433,132 @@ __global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__
     }
 }
 
-void launch_integral(int *hk, double *rowsum, float *ii, Dims d, hipStream_t s)
+// ---- the parallel form -----------------------------------------------------------------------------------------------
+// The reference's summed-area table is a SEQUENTIAL fp64 computation, and in general a different association rounds
+// differently.  But: if every addition of a parallel evaluation is EXACT (its TwoSum residual is zero), the parallel result is
+// the true 2-D prefix sum; all true prefix sums are then representable in fp64, so every addition of the sequential order is
+// exact as well and both give the same bits.  That is the normal case (heights are fp32 numbers of similar magnitude: a few
+// hundred thousand of them add up without rounding in 53 bits).  So the integral image is built with wave
+// scans and LDS tiles, every fp64 addition carries its residual into a per-(cloud, roll) flag, and only a grid whose flag
+// is set is redone by the sequential kernels above (k_integral_rows / k_integral_cols: they exit at once otherwise).
+//   k_integral_band<false>: per band of 16 grid rows the column totals of the row sums (one fp64 per column)
+//   k_integral_band<true> : row sums again, carry = totals of the bands above, column scan inside the band, fp32 store;
+//                           also writes the finalised heights (cells < -0.99 -> 0, 522-528) over the keys
+// Traffic per roll: keys read twice (L2), II and heights written once; the 2 MB fp64 row-sum scratch is gone.
+constexpr int kIBandRows = 16;
+constexpr int kIChunk = 512;                      // columns per pass: 64 lanes x 8, one thread per column in the column phase
+constexpr int kIThreads = 512;                    // 8 waves, two rows each
+
+// s = a + b with the flag raised when the sum is not exact (Knuth TwoSum residual)
+__device__ __forceinline__ double add_checked(double a, double b, bool &inexact)
 {
-    hipLaunchKernelGGL(k_integral_rows, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, hk, rowsum, d);
-    hipLaunchKernelGGL(k_integral_cols, dim3((d.W + 1 + 63) / 64, d.B * d.R), dim3(64), 0, s, rowsum, ii, d);
+    const double s = __dadd_rn(a, b);
+    const double bb = __dsub_rn(s, a);
+    const double err = __dadd_rn(__dsub_rn(a, __dsub_rn(s, bb)), __dsub_rn(b, bb));
+    inexact |= (err != 0.0);
+    return s;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, double *__restrict__ band_tot, float *__restrict__ ii,
+                                                             int *__restrict__ inexact_flags, Dims d)
+{
+    __shared__ double rs[kIBandRows][kIChunk];            // row sums of the band, one chunk of columns (64 KiB)
+    __shared__ double row_carry[kIBandRows];              // running row sum at the end of the previous chunk
+    const int band = blockIdx.x, br = blockIdx.y;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    const int n_bands = (H + kIBandRows - 1) / kIBandRows;
+    int *keys = hk + (size_t)br * H * W;
+    float *hts = reinterpret_cast<float *>(keys);
+    float *I = ii + (size_t)br * (H + 1) * W1;
+    double *tot = band_tot + ((size_t)br * n_bands) * W;  // [band][column]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = band * kIBandRows;
+    bool inexact = false;
+    if (tid < kIBandRows) row_carry[tid] = 0.0;
+    if (WRITE && band == 0)                               // first row and first column of the integral image are zero (cv::integral)
+        for (int c = tid; c < W1; c += kIThreads) I[c] = 0.0f;
+    if (WRITE && tid < kIBandRows && row0 + tid < H) I[(size_t)(row0 + tid + 1) * W1] = 0.0f;
+    __syncthreads();
+    for (int c0 = 0; c0 < W; c0 += kIChunk) {
+        // ---- row phase: wave w scans rows 2w, 2w + 1 of the band over columns c0 .. c0 + 511 (8 per lane) ----
+#pragma unroll
+        for (int q = 0; q < kIBandRows / 8; q++) {
+            const int rl = wave * (kIBandRows / 8) + q, row = row0 + rl;
+            double v[8];
+            const int cb = c0 + lane * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float h = 0.0f;
+                if (row < H && cb + k < W) {
+                    h = key2f(keys[(size_t)row * W + cb + k]);
+                    if ((double)h < -0.99) h = 0.0f;      // 524-526 (double compare)
+                }
+                v[k] = (double)h;                         // 589: widened before the integral
+            }
+            // inclusive prefix inside the lane, exclusive scan of the lane totals over the wave, carry of the earlier chunks
+#pragma unroll
+            for (int k = 1; k < 8; k++) v[k] = add_checked(v[k - 1], v[k], inexact);
+            double incl = v[7];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl = add_checked(up, incl, inexact);
+            }
+            double excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 0.0;
+            const double base = add_checked(row_carry[rl], excl, inexact);
+#pragma unroll
+            for (int k = 0; k < 8; k++) rs[rl][lane * 8 + k] = add_checked(base, v[k], inexact);
+        }
+        __syncthreads();
+        if (tid < kIBandRows) row_carry[tid] = rs[tid][kIChunk - 1];    // (columns past W hold the row's total: they added zeros)
+        // ---- column phase: thread t owns column c0 + t ----
+        const int c = c0 + tid;
+        if (c < W) {
+            if (!WRITE) {
+                double t = 0.0;
+#pragma unroll
+                for (int r = 0; r < kIBandRows; r++) t = add_checked(t, rs[r][tid], inexact);
+                tot[(size_t)band * W + c] = t;
+            } else {
+                double acc = 0.0;
+                for (int b = 0; b < band; b++) acc = add_checked(acc, tot[(size_t)b * W + c], inexact);
+#pragma unroll
+                for (int r = 0; r < kIBandRows; r++) {
+                    acc = add_checked(acc, rs[r][tid], inexact);
+                    if (row0 + r < H) I[(size_t)(row0 + r + 1) * W1 + c + 1] = (float)acc;     // 601
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (WRITE) {
+        // the finalised heights replace the keys (every key of the band has been read by now: both phases are behind a barrier)
+        for (int idx = tid; idx < kIBandRows * W; idx += kIThreads) {
+            const int row = row0 + idx / W;
+            if (row < H) {
+                const size_t a = (size_t)row * W + idx % W;
+                float h = key2f(keys[a]);
+                if ((double)h < -0.99) h = 0.0f;
+                hts[a] = h;
+            }
+        }
+    }
+    if (__syncthreads_or(inexact) && tid == 0) atomicOr(&inexact_flags[br], 1);
+}
+
+void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s)
+{
+    // rowsum doubles as the band-total scratch of the parallel form ([B*R][bands][W] doubles, far smaller) and as the row-sum
+    // scratch of the sequential fallback
+    const int n_bands = (d.H + kIBandRows - 1) / kIBandRows;
+    (void)hipMemsetAsync(inexact_flags, 0, (size_t)d.B * d.R * sizeof(int), s);
+    hipLaunchKernelGGL(k_integral_band<false>, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
+    hipLaunchKernelGGL(k_integral_band<true>, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
+    // sequential order for the grids whose parallel sums were not exact (practically never; the kernels exit at once otherwise)
+    hipLaunchKernelGGL(k_integral_rows, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, hk, rowsum, inexact_flags, counters, d);
+    hipLaunchKernelGGL(k_integral_cols, dim3((d.W + 1 + 63) / 64, d.B * d.R), dim3(64), 0, s, rowsum, ii, inexact_flags, d);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -222,6 +222,10 @@ int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked,
  * (they went through the three-pass kernel; 0 in the other modes), then the fp64 MFMA tier, then the strict tier. */
 int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, int64_t *n_rechecked, int64_t *n_strict);
 
+/* Pre-stages of the last scored batch: (cloud, roll) grids whose integral image had to be summed in the reference's
+ * sequential fp64 order because a parallel partial sum was not exact (normally 0; the result is bit-identical either way). */
+int haf_last_prestage(const haf_engine *e, int64_t *n_inexact_grids);
+
 /* Model facts for reporting: support vectors, attribute dimension, feature rows (incl. phantom rows). */
 int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_features);
 

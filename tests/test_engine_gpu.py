@@ -942,3 +942,42 @@ def test_bench_configuration_against_the_oracle_where_screening_was_closest(data
     STATS["bench_config_oracle_check"] = {"cells": len(sample), "closest_margin": close[0][3],
                                           "worst_error_as_fraction_of_band": worst}
     eng.close()
+
+
+def test_integral_image_falls_back_to_the_sequential_order_when_sums_are_inexact(data_dir, surrogate, orc):
+    """The integral image is built by parallel scans whose every fp64 addition is checked for exactness; exact sums are
+    order independent, so the result equals cv::integral's sequential order bit for bit (calc_intimage, server.cpp:577-613).
+    Heights that differ by more than 2^29 in magnitude make partial sums inexact: those grids must be flagged and redone
+    in the sequential order -- and still match the oracle bit for bit.  Ordinary clouds never take the fallback."""
+    rng = np.random.RandomState(21)
+    xyz = models.synthetic_cloud(grid=56, k=2, seed=3)
+    tiny = (-0.15 + rng.randint(1, 4000, size=len(xyz)) * 2.0 ** -26).astype(np.float32)      # heights of a few 2^-26 .. 2^-14
+    xyz[:, 2] = tiny
+    big = rng.choice(len(xyz), 40, replace=False)
+    xyz[big, 2] = (1.0e9 * (1.0 + rng.uniform(0, 1, size=40))).astype(np.float32)              # and some of ~2^30
+    inp = dict(grasp_area_length_x=56, grasp_area_length_y=56)
+    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16)
+    compare_full(eng, orc, xyz, dict(n_rolls=12), inp, check_dec=False)
+    assert eng.last_prestage()["n_inexact_grids"] > 0
+    ordinary = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    compare_full(eng, orc, ordinary, dict(n_rolls=12), inp)
+    assert eng.last_prestage()["n_inexact_grids"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("in_kw", [dict(), dict(approach_vector=(0.2, -0.1, 1.0)), dict(gripper_opening_width=2),
+                                   dict(grasp_area_center=(0.11, -0.07, 0.02), approach_vector=(-0.3, 0.2, 0.9), gripper_opening_width=3)],
+                         ids=["plain", "tilted", "width2", "shifted_tilted_width3"])
+def test_bucket_sorted_binning_of_large_grids(data_dir, surrogate, orc, in_kw):
+    """Grids beyond LDS size with a sizeable cloud are binned without global atomics: the cloud is counting-sorted into spatial
+    buckets once per request, then every (roll, 64 x 64 tile) gathers the buckets that can reach it (generate_grid,
+    server.cpp:406-529).  Height grids must equal the oracle's bit for bit for every roll -- with a tilted approach vector
+    (the pre-roll position then depends on z), an x-scale and a shifted centre (points outside the grid) as well."""
+    grid = 192
+    xyz = models.synthetic_cloud(grid=grid, k=2, seed=17)                      # 73 728 points: the bucket path (>= 32 768)
+    xyz[::7, 2] += 0.3                                                         # some relief, so that tilts move points across cells
+    kw = dict(grasp_area_length_x=grid, grasp_area_length_y=grid)
+    kw.update(in_kw)
+    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16, grid_h=grid, grid_w=grid, n_rolls=9, roll_step_deg=20, max_points=1 << 17)
+    compare_full(eng, orc, xyz, dict(n_rolls=9, roll_step_deg=20, grid_h=grid, grid_w=grid), kw, check_dec=False)
+    eng.close()
