@@ -792,7 +792,7 @@ int alloc_buffers(haf_engine *e)
     }
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rec.alloc(B * R);
-    ok &= hipSuccess == e->d_topkey.alloc(B * R);
+    ok &= hipSuccess == e->d_topkey.alloc(3 * B * R);          // top vote key, longest-run key, completion counter (k_vote_*)
     if (!ok) return fail(e, HAF_E_DEVICE, std::string("hipMalloc of working buffers failed: ") + hipGetErrorString(hipGetLastError()));
     HIPCHK(e, hipHostMalloc((void **)&e->h_clouds, B * sizeof(CloudDev)));
     HIPCHK(e, hipHostMalloc((void **)&e->h_geo, B * R * sizeof(RollGeo)));

@@ -153,12 +153,13 @@ __global__ __launch_bounds__(256) void k_bin_lds(const CloudDev *__restrict__ cl
 // max is order independent and the cell of a point is computed by the same fp32 expression: the grid is k_bin's bit for bit.
 constexpr int kBinTile = 64;
 constexpr int kBktChunk = 2048;                  // points per workgroup in the counting-sort passes
-constexpr int kBktMaxBuckets = 4096;             // LDS histogram (16 KiB); bin_bucket_grid keeps nb*nb below it
+constexpr int kBktMaxBuckets = 9216;             // LDS histogram (36 KiB); bin_bucket_grid keeps nb*nb below it
+constexpr int kBktListCap = 1024;                // candidate buckets of one tile (a 64-cell tile reaches ~120 buckets of 8 cells)
 constexpr float kBktSlack = 0.002f;              // metres
 
 int bin_bucket_grid(int H, int *bucket_cells)
 {
-    int bc = H / 32 > 16 ? H / 32 : 16;            // bucket edge in cells: nb stays ~ 1.414 * 32 + 3 for any grid size
+    int bc = H / 64 > 8 ? H / 64 : 8;              // bucket edge in cells: nb stays ~ 1.414 * 64 + 3 for any grid size
     const double r = 0.005 * H, bs = 0.01 * bc, Rb = r * 1.41422 + bs;
     int nb = (int)(2.0 * Rb / bs) + 1;
     if (bucket_cells) *bucket_cells = bc;
@@ -168,7 +169,7 @@ int bin_bucket_grid(int H, int *bucket_cells)
 struct BktGrid { float Rb, inv_bs, bs; int nb; };
 __host__ __device__ inline BktGrid bkt_grid(int H)
 {
-    int bc = H / 32 > 16 ? H / 32 : 16;
+    int bc = H / 64 > 8 ? H / 64 : 8;
     BktGrid g;
     g.bs = 0.01f * (float)bc;
     g.Rb = 0.005f * (float)H * 1.41422f + g.bs;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
                                                    int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty)
 {
     __shared__ int cells[kBinTile * kBinTile];
-    __shared__ int blist[kBktMaxBuckets];
+    __shared__ int blist[kBktListCap];
     __shared__ int nlist;
     const int br = blockIdx.y, b = br / d.R;
     const CloudDev c = clouds[b];
@@ -297,15 +298,31 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
     const float cxm = 0.5f * (xa + xb), cym = 0.5f * (ya + yb);
     const float rw = g.rw, hb = 0.70711f * bg.bs;                    // half diagonal of a bucket
     const float hx = 0.5f * (xb - xa) + fabsf(rw) * hb + kBktSlack, hy = 0.5f * (yb - ya) + hb + kBktSlack;
-    const int nbk = bg.nb * bg.nb;
-    for (int q = threadIdx.x; q < nbk; q += 256) {
+    // candidates: the buckets inside the bounding box (in p0) of the tile grown by the slack and a bucket's half diagonal ...
+    float bx_lo = 1e30f, bx_hi = -1e30f, by_lo = 1e30f, by_hi = -1e30f;
+    const float inv_rw = 1.0f / rw;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float px = ((k & 1) ? cxm + hx : cxm - hx) * inv_rw, py = (k & 2) ? cym + hy : cym - hy;
+        const float x0 = g.rc * px + g.rs * py, y0 = -g.rs * px + g.rc * py;          // p0 = R(-roll) S(1/rw) p
+        bx_lo = fminf(bx_lo, x0); bx_hi = fmaxf(bx_hi, x0); by_lo = fminf(by_lo, y0); by_hi = fmaxf(by_hi, y0);
+    }
+    const int ix0 = max(0, (int)floorf((bx_lo + bg.Rb) * bg.inv_bs) - 1), ix1 = min(bg.nb - 1, (int)floorf((bx_hi + bg.Rb) * bg.inv_bs) + 1);
+    const int iy0 = max(0, (int)floorf((by_lo + bg.Rb) * bg.inv_bs) - 1), iy1 = min(bg.nb - 1, (int)floorf((by_hi + bg.Rb) * bg.inv_bs) + 1);
+    const int nx = max(0, ix1 - ix0 + 1), ncand = nx * max(0, iy1 - iy0 + 1);
+    // ... whose centre's image lies within the tile's half extent + a bucket's half diagonal + slack (conservative both ways)
+    for (int k = threadIdx.x; k < ncand; k += 256) {
+        const int q = (iy0 + k / nx) * bg.nb + ix0 + k % nx;
         if (bkt_off[c.bucket_off + q + 1] == bkt_off[c.bucket_off + q]) continue;      // empty bucket
         const float qx = -bg.Rb + ((float)(q % bg.nb) + 0.5f) * bg.bs, qy = -bg.Rb + ((float)(q / bg.nb) + 0.5f) * bg.bs;   // centre in p0
         const float px = rw * (g.rc * qx - g.rs * qy), py = g.rs * qx + g.rc * qy;
-        if (fabsf(px - cxm) <= hx && fabsf(py - cym) <= hy) blist[atomicAdd(&nlist, 1)] = q;
+        if (fabsf(px - cxm) <= hx && fabsf(py - cym) <= hy) {
+            const int slot = atomicAdd(&nlist, 1);
+            if (slot < kBktListCap) blist[slot] = q;
+        }
     }
     __syncthreads();
-    const int nl = nlist;
+    const int nl = min(nlist, kBktListCap);     // (the cap is ~8x what a tile can reach; launch_bin checks the geometry it relies on)
     const float *pts = sorted + (size_t)c.sorted_off * 3;
     for (int l = 0; l < nl; l++) {
         const int q = blist[l];
@@ -441,9 +458,9 @@ __global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__
 // hundred thousand of them add up without rounding in 53 bits).  So the integral image is built with wave
 // scans and LDS tiles, every fp64 addition carries its residual into a per-(cloud, roll) flag, and only a grid whose flag
 // is set is redone by the sequential kernels above (k_integral_rows / k_integral_cols: they exit at once otherwise).
-//   k_integral_band<false>: per band of 16 grid rows the column totals of the row sums (one fp64 per column)
-//   k_integral_band<true> : row sums again, carry = totals of the bands above, column scan inside the band, fp32 store;
-//                           also writes the finalised heights (cells < -0.99 -> 0, 522-528) over the keys
+//   k_integral_totals: per band of 16 grid rows the column totals of the row sums (one fp64 per column)
+//   k_integral_band  : the band's row sums, carry = totals of the bands above, column scan inside the band, fp32 store;
+//                      also writes the finalised heights (cells < -0.99 -> 0, 522-528) over the keys
 // Traffic per roll: keys read twice (L2), II and heights written once; the 2 MB fp64 row-sum scratch is gone.
 constexpr int kIBandRows = 16;
 constexpr int kIChunk = 512;                      // columns per pass: 64 lanes x 8, one thread per column in the column phase
@@ -459,44 +476,118 @@ __device__ __forceinline__ double add_checked(double a, double b, bool &inexact)
     return s;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, double *__restrict__ band_tot, float *__restrict__ ii,
+constexpr int kIPitch = kIChunk + kIChunk / 32;   // row pitch of the LDS tile in doubles: one double of padding per 32 columns,
+                                                  // so that the 8-columns-per-lane stores of the row phase spread over all banks
+__device__ __forceinline__ int ipad(int c) { return c + (c >> 5); }
+
+__device__ __forceinline__ float final_height(int key)
+{
+    float h = key2f(key);
+    if ((double)h < -0.99) h = 0.0f;                      // 524-526 (double compare)
+    return h;
+}
+
+// Column totals of the row sums of one band: T[band][c] = sum_{rows of the band} sum_{b <= c} h[row][b]
+//                                                       = prefix over the columns of the band's COLUMN sums,
+// so one column sum per thread (coalesced) and one scan of the band's 512-wide vector instead of sixteen row scans.  Every
+// addition is checked: the totals are then the true values whatever the association.
+__global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__restrict__ hk, double *__restrict__ band_tot,
+                                                               int *__restrict__ inexact_flags, Dims d)
+{
+    __shared__ double wsum[kIThreads / 64];
+    __shared__ double carry;
+    const int band = blockIdx.x, br = blockIdx.y;
+    const int H = d.H, W = d.W;
+    const int n_bands = (H + kIBandRows - 1) / kIBandRows;
+    const int *keys = hk + (size_t)br * H * W;
+    double *tot = band_tot + ((size_t)br * n_bands + band) * W;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = band * kIBandRows;
+    bool inexact = false;
+    if (tid == 0) carry = 0.0;
+    __syncthreads();
+    for (int c0 = 0; c0 < W; c0 += kIThreads) {
+        const int c = c0 + tid;
+        double v = 0.0;
+        if (c < W) {
+            int kr[kIBandRows];
+#pragma unroll
+            for (int r = 0; r < kIBandRows; r++) kr[r] = (row0 + r < H) ? keys[(size_t)(row0 + r) * W + c] : 0;   // all loads first, then the dependent adds
+#pragma unroll
+            for (int r = 0; r < kIBandRows; r++)
+                if (row0 + r < H) v = add_checked(v, (double)final_height(kr[r]), inexact);
+        }
+        double incl = v;                                  // inclusive scan over the 512 columns of this pass
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = add_checked(up, incl, inexact);
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        double base = carry;
+        for (int w = 0; w < wave; w++) base = add_checked(base, wsum[w], inexact);
+        const double out = add_checked(base, incl, inexact);
+        if (c < W) tot[c] = out;
+        __syncthreads();
+        if (tid == kIThreads - 1) carry = out;            // (columns past W added zeros)
+        __syncthreads();
+    }
+    if (__syncthreads_or(inexact) && tid == 0) atomicOr(&inexact_flags[br], 1);
+}
+
+// Row sums of the band (wave scans), carry = totals of the bands above, column scan inside the band, fp32 store (601); also
+// writes the finalised heights over the keys.
+__global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, const double *__restrict__ band_tot, float *__restrict__ ii,
                                                              int *__restrict__ inexact_flags, Dims d)
 {
-    __shared__ double rs[kIBandRows][kIChunk];            // row sums of the band, one chunk of columns (64 KiB)
-    __shared__ double row_carry[kIBandRows];              // running row sum at the end of the previous chunk
+    __shared__ double rs[kIBandRows][kIPitch];            // row sums of the band, one pass of 512 columns (66 KiB)
+    __shared__ double row_carry[kIBandRows];              // running row sum at the end of the previous pass
     const int band = blockIdx.x, br = blockIdx.y;
     const int H = d.H, W = d.W, W1 = W + 1;
     const int n_bands = (H + kIBandRows - 1) / kIBandRows;
     int *keys = hk + (size_t)br * H * W;
     float *hts = reinterpret_cast<float *>(keys);
     float *I = ii + (size_t)br * (H + 1) * W1;
-    double *tot = band_tot + ((size_t)br * n_bands) * W;  // [band][column]
+    const double *tot = band_tot + ((size_t)br * n_bands) * W;  // [band][column]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row0 = band * kIBandRows;
     bool inexact = false;
     if (tid < kIBandRows) row_carry[tid] = 0.0;
-    if (WRITE && band == 0)                               // first row and first column of the integral image are zero (cv::integral)
+    if (band == 0)                                        // first row and first column of the integral image are zero (cv::integral)
         for (int c = tid; c < W1; c += kIThreads) I[c] = 0.0f;
-    if (WRITE && tid < kIBandRows && row0 + tid < H) I[(size_t)(row0 + tid + 1) * W1] = 0.0f;
+    if (tid < kIBandRows && row0 + tid < H) I[(size_t)(row0 + tid + 1) * W1] = 0.0f;
     __syncthreads();
     for (int c0 = 0; c0 < W; c0 += kIChunk) {
+        // ---- column carry of this pass: totals of the bands above, loaded eight at a time (independent loads, then the adds) ----
+        const int c = c0 + tid;
+        double acc = 0.0;
+        if (c < W)
+            for (int b0 = 0; b0 < band; b0 += 8) {
+                double t8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) t8[k] = (b0 + k < band) ? tot[(size_t)(b0 + k) * W + c] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc = add_checked(acc, t8[k], inexact);
+            }
         // ---- row phase: wave w scans rows 2w, 2w + 1 of the band over columns c0 .. c0 + 511 (8 per lane) ----
 #pragma unroll
         for (int q = 0; q < kIBandRows / 8; q++) {
             const int rl = wave * (kIBandRows / 8) + q, row = row0 + rl;
             double v[8];
             const int cb = c0 + lane * 8;
+            int kr[8];
+            if (row < H && cb + 7 < W && (W & 3) == 0) {  // two 16-byte loads (rows start 16-byte aligned when W % 4 == 0)
+                const int4 k0 = *reinterpret_cast<const int4 *>(keys + (size_t)row * W + cb);
+                const int4 k1 = *reinterpret_cast<const int4 *>(keys + (size_t)row * W + cb + 4);
+                kr[0] = k0.x; kr[1] = k0.y; kr[2] = k0.z; kr[3] = k0.w; kr[4] = k1.x; kr[5] = k1.y; kr[6] = k1.z; kr[7] = k1.w;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                float h = 0.0f;
-                if (row < H && cb + k < W) {
-                    h = key2f(keys[(size_t)row * W + cb + k]);
-                    if ((double)h < -0.99) h = 0.0f;      // 524-526 (double compare)
-                }
-                v[k] = (double)h;                         // 589: widened before the integral
+                for (int k = 0; k < 8; k++) v[k] = (double)final_height(kr[k]);                   // 589: widened before the integral
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = (row < H && cb + k < W) ? (double)final_height(keys[(size_t)row * W + cb + k]) : 0.0;
             }
-            // inclusive prefix inside the lane, exclusive scan of the lane totals over the wave, carry of the earlier chunks
+            // inclusive prefix inside the lane, exclusive scan of the lane totals over the wave, carry of the earlier passes
 #pragma unroll
             for (int k = 1; k < 8; k++) v[k] = add_checked(v[k - 1], v[k], inexact);
             double incl = v[7];
@@ -509,40 +600,26 @@ __global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, double *__
             if (lane == 0) excl = 0.0;
             const double base = add_checked(row_carry[rl], excl, inexact);
 #pragma unroll
-            for (int k = 0; k < 8; k++) rs[rl][lane * 8 + k] = add_checked(base, v[k], inexact);
+            for (int k = 0; k < 8; k++) rs[rl][ipad(lane * 8 + k)] = add_checked(base, v[k], inexact);
         }
         __syncthreads();
-        if (tid < kIBandRows) row_carry[tid] = rs[tid][kIChunk - 1];    // (columns past W hold the row's total: they added zeros)
+        if (tid < kIBandRows) row_carry[tid] = rs[tid][ipad(kIChunk - 1)];    // (columns past W hold the row's total: they added zeros)
         // ---- column phase: thread t owns column c0 + t ----
-        const int c = c0 + tid;
         if (c < W) {
-            if (!WRITE) {
-                double t = 0.0;
 #pragma unroll
-                for (int r = 0; r < kIBandRows; r++) t = add_checked(t, rs[r][tid], inexact);
-                tot[(size_t)band * W + c] = t;
-            } else {
-                double acc = 0.0;
-                for (int b = 0; b < band; b++) acc = add_checked(acc, tot[(size_t)b * W + c], inexact);
-#pragma unroll
-                for (int r = 0; r < kIBandRows; r++) {
-                    acc = add_checked(acc, rs[r][tid], inexact);
-                    if (row0 + r < H) I[(size_t)(row0 + r + 1) * W1 + c + 1] = (float)acc;     // 601
-                }
+            for (int r = 0; r < kIBandRows; r++) {
+                acc = add_checked(acc, rs[r][ipad(tid)], inexact);
+                if (row0 + r < H) I[(size_t)(row0 + r + 1) * W1 + c + 1] = (float)acc;     // 601
             }
         }
         __syncthreads();
     }
-    if (WRITE) {
-        // the finalised heights replace the keys (every key of the band has been read by now: both phases are behind a barrier)
-        for (int idx = tid; idx < kIBandRows * W; idx += kIThreads) {
-            const int row = row0 + idx / W;
-            if (row < H) {
-                const size_t a = (size_t)row * W + idx % W;
-                float h = key2f(keys[a]);
-                if ((double)h < -0.99) h = 0.0f;
-                hts[a] = h;
-            }
+    // the finalised heights replace the keys (every key of the band has been read by now: both phases are behind a barrier)
+    for (int idx = tid; idx < kIBandRows * W; idx += kIThreads) {
+        const int row = row0 + idx / W;
+        if (row < H) {
+            const size_t a = (size_t)row * W + idx % W;
+            hts[a] = final_height(keys[a]);
         }
     }
     if (__syncthreads_or(inexact) && tid == 0) atomicOr(&inexact_flags[br], 1);
@@ -554,8 +631,8 @@ void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int
     // scratch of the sequential fallback
     const int n_bands = (d.H + kIBandRows - 1) / kIBandRows;
     (void)hipMemsetAsync(inexact_flags, 0, (size_t)d.B * d.R * sizeof(int), s);
-    hipLaunchKernelGGL(k_integral_band<false>, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
-    hipLaunchKernelGGL(k_integral_band<true>, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
+    hipLaunchKernelGGL(k_integral_totals, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, inexact_flags, d);
+    hipLaunchKernelGGL(k_integral_band, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
     // sequential order for the grids whose parallel sums were not exact (practically never; the kernels exit at once otherwise)
     hipLaunchKernelGGL(k_integral_rows, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, hk, rowsum, inexact_flags, counters, d);
     hipLaunchKernelGGL(k_integral_cols, dim3((d.W + 1 + 63) / 64, d.B * d.R), dim3(64), 0, s, rowsum, ii, inexact_flags, d);
@@ -612,19 +689,39 @@ void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *
 // are written per cell through evalcell.
 // Exclusive scans of the per-row counts (n = B*R*H entries), single workgroup: rowoff[k] = start of row k's whole chunks,
 // rowoff[n + 1 + k] = start of its left-over chunk.
+// One workgroup per (cloud, roll): it sums the counts of all the rows in front of its grid (coalesced, a few loads per thread:
+// no atomics, so the offsets are deterministic), scans its own H rows in LDS and writes their offsets.  (One workgroup for
+// the whole request took 32 us at C5: eighteen dependent loads per thread and a 1024-wide scan on a single CU.)
+__device__ __forceinline__ unsigned long long row_pack(unsigned c) { return ((unsigned long long)(c & ~63u) << 32) | (c & 63u); }
+
 __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ rowcount, int *__restrict__ rowoff,
                                                int *__restrict__ brcount, int *__restrict__ counters, Dims d)
 {
     __shared__ unsigned long long part[1024];            // (whole-chunk cells << 32) | left-over cells
-    const int n = d.B * d.R * d.H;
-    const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk, hi = min(n, lo + chunk);
-    unsigned long long s = 0;
-    for (int k = lo; k < hi; k++) {
-        const unsigned c = (unsigned)rowcount[k];
-        s += ((unsigned long long)(c & ~63u) << 32) | (c & 63u);
+    __shared__ unsigned long long red[2][16];
+    const int n = d.B * d.R * d.H, br = blockIdx.x, H = d.H;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    // (1) everything in front of this grid, and everything at all (the left-over region starts behind ALL whole chunks)
+    unsigned long long before = 0, all = 0;
+    const int mine0 = br * H;
+    for (int k = t; k < n; k += 1024) {
+        const unsigned long long v = row_pack((unsigned)rowcount[k]);
+        all += v;
+        if (k < mine0) before += v;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = all; }
+    __syncthreads();
+    before = 0; all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { before += red[0][w]; all += red[1][w]; }
+    const int total_a = (int)(all >> 32), total = total_a + (int)(all & 0xffffffffu);
+    // (2) this grid's rows: chunk of consecutive rows per thread, LDS scan of the chunk sums
+    const int chunk = (H + 1023) / 1024;
+    const int lo = t * chunk, hi = min(H, lo + chunk);
+    unsigned long long s = 0;
+    for (int k = lo; k < hi; k++) s += row_pack((unsigned)rowcount[mine0 + k]);
     part[t] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -633,26 +730,22 @@ __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ rowcount,
         part[t] += v;
         __syncthreads();
     }
-    const unsigned long long tot = part[1023];
-    const int total_a = (int)(tot >> 32), total = total_a + (int)(tot & 0xffffffffu);
-    unsigned long long run = part[t] - s;
+    unsigned long long run = before + part[t] - s;
     for (int k = lo; k < hi; k++) {
-        const unsigned c = (unsigned)rowcount[k];
-        rowoff[k] = (int)(run >> 32);
-        rowoff[n + 1 + k] = total_a + (int)(run & 0xffffffffu);
-        run += ((unsigned long long)(c & ~63u) << 32) | (c & 63u);
+        rowoff[mine0 + k] = (int)(run >> 32);
+        rowoff[n + 1 + mine0 + k] = total_a + (int)(run & 0xffffffffu);
+        run += row_pack((unsigned)rowcount[mine0 + k]);
     }
-    if (t == 1023) { rowoff[n] = total_a; rowoff[2 * n + 1] = total; counters[CNT_EVALS] = total; }
-    __syncthreads();
-    for (int br = t; br < d.B * d.R; br += 1024) {       // cells of (cloud, roll) br: difference of the two prefixes, summed
-        const int k0 = br * d.H, k1 = k0 + d.H;
-        brcount[br] = (rowoff[k1] - rowoff[k0]) + (rowoff[n + 1 + k1] - rowoff[n + 1 + k0]);
+    if (t == 1023) {
+        const unsigned long long own = part[1023];
+        brcount[br] = (int)(own >> 32) + (int)(own & 0xffffffffu);
+        if (br == d.B * d.R - 1) { rowoff[n] = total_a; rowoff[2 * n + 1] = total; counters[CNT_EVALS] = total; }
     }
 }
 
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, rowcount, rowoff, brcount, counters, d);
+    hipLaunchKernelGGL(k_scan, dim3(d.B * d.R), dim3(1024), 0, s, rowcount, rowoff, brcount, counters, d);
 }
 
 __global__ __launch_bounds__(64) void k_compact(const uint8_t *__restrict__ mask, const int *__restrict__ rowcount,
@@ -2328,68 +2421,82 @@ __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ l
     if (t == 0 && red[0]) atomicMax(&topkey[br], red[0]);
 }
 
-// pass 2: longest-run centring on the roll's top value, z window, roll record.  One workgroup per (cloud, roll).
-__global__ __launch_bounds__(256) void k_vote_pick(const float *__restrict__ heights, const int *__restrict__ brcount,
-                                                   const short *__restrict__ ev16,
-                                                   const unsigned long long *__restrict__ topkey,
-                                                   RollRecordDev *__restrict__ rec, Dims d)
+// pass 2: longest-run centring on the roll's top value (904-932).  One wave per 64 grid rows, a thread per row: the row goes by
+// in 16-byte pieces (8 votes), and only a piece that holds the top value is looked at vote by vote -- hardly any does.  The
+// best (longest run, then smallest row) of the roll is a 64-bit atomicMax; the workgroup that finishes LAST (a completion
+// counter, no spinning) turns it into the roll record: run centre, z window of a11 (1342-1351), evaluation count.
+__global__ __launch_bounds__(64) void k_vote_pick(const float *__restrict__ heights, const int *__restrict__ brcount,
+                                                  const short *__restrict__ ev16, unsigned long long *__restrict__ keys3,
+                                                  RollRecordDev *__restrict__ rec, Dims d)
 {
-    __shared__ unsigned long long red[256];
-    __shared__ int s_row, s_col;
-    __shared__ unsigned int zred[256];
-    const int br = blockIdx.x, t = threadIdx.x;
-    const int H = d.H, W = d.W, HW = H * W;
+    const int br = blockIdx.y, lane = threadIdx.x;
+    const int H = d.H, W = d.W, HW = H * W, BR = d.B * d.R;
+    const unsigned long long *topkey = keys3;
+    unsigned long long *runkey = keys3 + BR, *done = keys3 + 2 * (size_t)BR;
     const short *ev = ev16 + (size_t)br * HW;
     const int top = (int)(topkey[br] >> 32) - 32768;
-    // longest horizontal run of `top` per row (904-932): first longest run wins, column = run end - len/2
+    const int row = blockIdx.x * 64 + lane;
     unsigned long long rbest = 0;
-    for (int row = t; row < H; row += 256) {
+    if (row < H) {
         int cur = 0, longest = 0, endc = 0;
-#pragma unroll 8
-        for (int col = 0; col < W; col++) {
-            if (ev[row * W + col] == top) {
+        const short *er = ev + (size_t)row * W;
+        auto step = [&](int v, int col) {
+            if (v == top) {
                 cur++;
                 if (cur > longest) { longest = cur; endc = col; }
             } else cur = 0;
+        };
+        if ((W & 7) == 0) {
+            typedef short short8 __attribute__((ext_vector_type(8)));
+            for (int c0 = 0; c0 < W; c0 += 8) {
+                const short8 v = *reinterpret_cast<const short8 *>(er + c0);
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) any |= (v[k] == top);
+                if (!any) { cur = 0; continue; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) step(v[k], c0 + k);
+            }
+        } else {
+            for (int col = 0; col < W; col++) step(er[col], col);
         }
         if (longest > 0) {
-            int bc = endc - longest / 2;
-            unsigned long long key = ((unsigned long long)(unsigned)longest << 40) |
-                                     ((unsigned long long)(unsigned)(0xFFFF - row) << 20) | (unsigned)bc;
-            if (key > rbest) rbest = key;                             // longer run, then smaller row
+            const int bc = endc - longest / 2;            // first longest run wins, column = run end - len/2 (926-932)
+            rbest = ((unsigned long long)(unsigned)longest << 40) | ((unsigned long long)(unsigned)(0xFFFF - row) << 20) | (unsigned)bc;
         }
     }
-    red[t] = rbest;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(rbest, o, 64);
+        if (other > rbest) rbest = other;                 // longer run, then smaller row
     }
-    if (t == 0) {
-        s_row = 0xFFFF - (int)((red[0] >> 20) & 0xFFFFF);
-        s_col = (int)(red[0] & 0xFFFFF);
+    unsigned long long finished = 0;
+    if (lane == 0) {
+        if (rbest) atomicMax(&runkey[br], rbest);
+        __threadfence();
+        finished = atomicAdd(&done[br], 1ull);
     }
-    __syncthreads();
-    const int brow = s_row, bcol = s_col;
+    finished = __shfl(finished, 0, 64);
+    if (finished != gridDim.x - 1) return;
+    // ---- the last workgroup of this (cloud, roll): everybody's atomicMax is visible (fence before the counter) ----
+    __threadfence();
+    const unsigned long long best = atomicMax(&runkey[br], 0ull);
+    const int brow = 0xFFFF - (int)((best >> 20) & 0xFFFFF), bcol = (int)(best & 0xFFFFF);
     // z estimate window rows brow-4..brow+4, cols bcol-4..bcol+3 (1342-1351), as an ordered-key max
     int zk = f2key(-10.0f);
-    if (t < 72) {
-        int rr = brow + (t / 8) - 4, cc = bcol + (t % 8) - 4;
+    for (int t = lane; t < 72; t += 64) {
+        const int rr = brow + (t / 8) - 4, cc = bcol + (t % 8) - 4;
         if (rr >= 0 && cc >= 0 && rr < H && cc < W) {
-            float h = heights[(size_t)br * HW + rr * W + cc];
-            if (-10.0f < h) zk = f2key(h);
+            const float h = heights[(size_t)br * HW + rr * W + cc];
+            if (-10.0f < h) zk = max(zk, f2key(h));
         }
     }
-    zred[t] = (unsigned)(zk ^ 0x80000000);
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o && zred[t + o] > zred[t]) zred[t] = zred[t + o];
-        __syncthreads();
-    }
-    if (t == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zk = max(zk, __shfl_xor(zk, o, 64));
+    if (lane == 0) {
         RollRecordDev r;
         r.vote = top; r.row = (short)brow; r.col = (short)bcol;
-        r.h_locmax = key2f((int)(zred[0] ^ 0x80000000));
+        r.h_locmax = key2f(zk);
         r.n_evals = brcount[br];
         rec[br] = r;
     }
@@ -2398,11 +2505,12 @@ __global__ __launch_bounds__(256) void k_vote_pick(const float *__restrict__ hei
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
                  RollRecordDev *rec, Dims d, hipStream_t s)
 {
-    (void)hipMemsetAsync(topkey, 0, (size_t)d.B * d.R * sizeof(unsigned long long), s);
+    // topkey: three arrays of B*R 64-bit words (top vote key, longest-run key, completion counter)
+    (void)hipMemsetAsync(topkey, 0, (size_t)3 * d.B * d.R * sizeof(unsigned long long), s);
     const int HW = d.H * d.W;
     hipLaunchKernelGGL(k_vote_cells, dim3((HW + kVoteCellsPerBlock - 1) / kVoteCellsPerBlock, d.B * d.R), dim3(256), 0, s, labels, ev16,
                        topkey, d);
-    hipLaunchKernelGGL(k_vote_pick, dim3(d.B * d.R), dim3(256), 0, s, heights, brcount, ev16, topkey, rec, d);
+    hipLaunchKernelGGL(k_vote_pick, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, heights, brcount, ev16, topkey, rec, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
