@@ -2,7 +2,7 @@
 //
 // Stage -> reference function it replaces (src/calc_grasppoints_action_server.cpp unless noted):
 //   k_bin            generate_grid 406-529 (transform + max-z binning)
-//   k_integral_rows / k_integral_cols   generate_grid 522-528 (empty cells -> 0) + calc_intimage 577-613
+//   k_integral_totals / k_integral_band (k_integral_seq as fallback)   generate_grid 522-528 (empty cells -> 0) + calc_intimage 577-613
 //   k_mask_count / k_scan / k_compact   pnt_in_box 666-749 + the row-major cell order of calc_featurevectors 637-643
 //   k_features_serial / k_features   CIntImage_to_Featurevec::calc_featurevalue (fv.cpp:141-199), the "%.4g" text
 //                    round trip (fv.cpp:133 -> svm-scale.c:270), svm-scale restore+output (svm-scale.c:333-353) and
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
                                                    int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty)
 {
     __shared__ int cells[kBinTile * kBinTile];
-    __shared__ int blist[kBktListCap];
+    __shared__ int lstart[kBktListCap], lend[kBktListCap];         // point ranges of the candidate buckets
     __shared__ int nlist;
     const int br = blockIdx.y, b = br / d.R;
     const CloudDev c = clouds[b];
@@ -313,32 +313,42 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
     // ... whose centre's image lies within the tile's half extent + a bucket's half diagonal + slack (conservative both ways)
     for (int k = threadIdx.x; k < ncand; k += 256) {
         const int q = (iy0 + k / nx) * bg.nb + ix0 + k % nx;
-        if (bkt_off[c.bucket_off + q + 1] == bkt_off[c.bucket_off + q]) continue;      // empty bucket
+        const int i0 = bkt_off[c.bucket_off + q], i1 = bkt_off[c.bucket_off + q + 1];
+        if (i1 == i0) continue;                                                        // empty bucket
         const float qx = -bg.Rb + ((float)(q % bg.nb) + 0.5f) * bg.bs, qy = -bg.Rb + ((float)(q / bg.nb) + 0.5f) * bg.bs;   // centre in p0
         const float px = rw * (g.rc * qx - g.rs * qy), py = g.rs * qx + g.rc * qy;
         if (fabsf(px - cxm) <= hx && fabsf(py - cym) <= hy) {
             const int slot = atomicAdd(&nlist, 1);
-            if (slot < kBktListCap) blist[slot] = q;
+            if (slot < kBktListCap) { lstart[slot] = i0; lend[slot] = i1; }
         }
     }
     __syncthreads();
     const int nl = min(nlist, kBktListCap);     // (the cap is ~8x what a tile can reach; launch_bin checks the geometry it relies on)
     const float *pts = sorted + (size_t)c.sorted_off * 3;
-    for (int l = 0; l < nl; l++) {
-        const int q = blist[l];
-        const int i0 = bkt_off[c.bucket_off + q], i1 = bkt_off[c.bucket_off + q + 1];
-        for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-            const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
-            // pcl::transformPointCloud (488): fp32, left to right, unfused -- the same expression as k_bin
-            float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
-            float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
-            float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
-            if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
-                const int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row))) - tx0;       // 513
-                const int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col))) - ty0;       // 514
-                if (ix >= 0 && ix < kBinTile && iy >= 0 && iy < kBinTile && ix + tx0 < d.H && iy + ty0 < d.W)
-                    atomicMax(&cells[ix * kBinTile + iy], f2key(pz));
+    // a wave per candidate bucket (a bucket of 8 x 8 cells holds ~128 points: two per lane), both loads of a trip in flight
+    // before either point is processed; the ranges come from LDS, so nothing in this loop waits on a dependent global load
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    auto bin_point = [&](float x, float y, float z) {
+        // pcl::transformPointCloud (488): fp32, left to right, unfused -- the same expression as k_bin
+        float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
+        float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
+        if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col)) {                 // 510-511
+            const int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row))) - tx0;       // 513
+            const int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col))) - ty0;       // 514
+            if (ix >= 0 && ix < kBinTile && iy >= 0 && iy < kBinTile && ix + tx0 < d.H && iy + ty0 < d.W) {
+                float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
+                if (pz == pz) atomicMax(&cells[ix * kBinTile + iy], f2key(pz));              // NaN z never wins (515)
             }
+        }
+    };
+    for (int l = wave; l < nl; l += 4) {
+        const int i0 = lstart[l], i1 = lend[l];
+        for (int i = i0 + lane; i < i1; i += 128) {
+            const int j = (i + 64 < i1) ? i + 64 : i;
+            const float x1 = pts[(size_t)i * 3], y1 = pts[(size_t)i * 3 + 1], z1 = pts[(size_t)i * 3 + 2];
+            const float x2 = pts[(size_t)j * 3], y2 = pts[(size_t)j * 3 + 1], z2 = pts[(size_t)j * 3 + 2];
+            bin_point(x1, y1, z1);
+            if (j != i) bin_point(x2, y2, z2);
         }
     }
     __syncthreads();
@@ -392,60 +402,54 @@ bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, 
 // fp64 partial sums and the fp32 narrowing (599-601) are bit-identical for any input, not only when the
 // sums happen to be exact.  Thread-per-row pass, then thread-per-column pass.
 // ---------------------------------------------------------------------------------------------------
-// The SEQUENTIAL form -- k_integral_rows (one thread per grid row: running sum along the row) and k_integral_cols (one thread
-// per column of the integral image: running sum down the column) -- is the definition of the result and, since round 2, the
-// fallback: it only runs for a grid whose parallel sums (k_integral_band, below) were not all exact.
-__global__ __launch_bounds__(64) void k_integral_rows(int *hk, double *__restrict__ rowsum, const int *__restrict__ inexact_flags,
-                                                      int *__restrict__ counters, Dims d)
+// The SEQUENTIAL form -- k_integral_seq: a thread per grid row (running sum along the row), then a thread per column of the
+// integral image (running sum down the column), one workgroup per grid -- is the definition of the result and, since round 2,
+// the fallback: it only runs for a grid whose parallel sums (k_integral_band, below) were not all exact.
+__global__ __launch_bounds__(256) void k_integral_seq(int *hk, double *__restrict__ rowsum, float *__restrict__ ii,
+                                                      const int *__restrict__ inexact_flags, int *__restrict__ counters, Dims d)
 {
-    const int br = blockIdx.y;
+    const int br = blockIdx.x;
     if (!inexact_flags[br]) return;                       // the parallel form was exact for this grid (the normal case)
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[CNT_INEXACT], 1);
-    const int H = d.H, W = d.W;
+    if (threadIdx.x == 0) atomicAdd(&counters[CNT_INEXACT], 1);
+    const int H = d.H, W = d.W, W1 = W + 1;
     int *keys = hk + (size_t)br * H * W;
     float *hts = reinterpret_cast<float *>(keys);
     double *rs = rowsum + (size_t)br * H * W;
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= H) return;
-    double s = 0.0;
-    // the running sum is sequential by definition; the loads are not: fetch 8 keys ahead of the dependent chain
-    // (keys and heights share storage, so the compiler cannot hoist the loads itself)
-    for (int c0 = 0; c0 < W; c0 += 8) {
-        int kreg[8];
+    float *I = ii + (size_t)br * (H + 1) * W1;
+    // rows: one thread per grid row, running sum along the row
+    for (int row = threadIdx.x; row < H; row += 256) {
+        double s = 0.0;
+        // the running sum is sequential by definition; the loads are not: fetch 8 values ahead of the dependent chain
+        for (int c0 = 0; c0 < W; c0 += 8) {
+            int kreg[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) kreg[q] = (c0 + q < W) ? keys[row * W + c0 + q] : 0;
+            for (int q = 0; q < 8; q++) kreg[q] = (c0 + q < W) ? keys[row * W + c0 + q] : 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (c0 + q < W) {
-                float h = __int_as_float(kreg[q]);        // already a finalised height (k_integral_band<true>), not a key
-                if ((double)h < -0.99) h = 0.0f;          // 524-526 (double compare; idempotent)
-                hts[row * W + c0 + q] = h;
-                s = __dadd_rn(s, (double)h);              // 589: widened before the integral
-                rs[row * W + c0 + q] = s;
+            for (int q = 0; q < 8; q++) {
+                if (c0 + q < W) {
+                    float h = __int_as_float(kreg[q]);    // already a finalised height (k_integral_band), not a key
+                    if ((double)h < -0.99) h = 0.0f;      // 524-526 (double compare; idempotent)
+                    hts[row * W + c0 + q] = h;
+                    s = __dadd_rn(s, (double)h);          // 589: widened before the integral
+                    rs[row * W + c0 + q] = s;
+                }
             }
         }
     }
-}
-
-__global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__ rowsum, float *__restrict__ ii,
-                                                      const int *__restrict__ inexact_flags, Dims d)
-{
-    const int br = blockIdx.y;
-    if (!inexact_flags[br]) return;
-    const int H = d.H, W = d.W, W1 = W + 1;
-    const double *rs = rowsum + (size_t)br * H * W;
-    float *I = ii + (size_t)br * (H + 1) * W1;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= W1) return;
-    I[c] = 0.0f;
-    if (c == 0) {
-        for (int r = 0; r < H; r++) I[(r + 1) * W1] = 0.0f;
-    } else {
-        double acc = 0.0;
+    __threadfence_block();
+    __syncthreads();                                      // every row sum of this grid is in place (one workgroup per grid)
+    // columns: one thread per column of the integral image, running sum down the column
+    for (int c = threadIdx.x; c < W1; c += 256) {
+        I[c] = 0.0f;
+        if (c == 0) {
+            for (int r = 0; r < H; r++) I[(r + 1) * W1] = 0.0f;
+        } else {
+            double acc = 0.0;
 #pragma unroll 8
-        for (int r = 0; r < H; r++) {
-            acc = __dadd_rn(acc, rs[r * W + (c - 1)]);
-            I[(r + 1) * W1 + c] = (float)acc;     // 601
+            for (int r = 0; r < H; r++) {
+                acc = __dadd_rn(acc, rs[r * W + (c - 1)]);
+                I[(r + 1) * W1 + c] = (float)acc;         // 601
+            }
         }
     }
 }
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(64) void k_integral_cols(const double *__restrict__
 // exact as well and both give the same bits.  That is the normal case (heights are fp32 numbers of similar magnitude: a few
 // hundred thousand of them add up without rounding in 53 bits).  So the integral image is built with wave
 // scans and LDS tiles, every fp64 addition carries its residual into a per-(cloud, roll) flag, and only a grid whose flag
-// is set is redone by the sequential kernels above (k_integral_rows / k_integral_cols: they exit at once otherwise).
+// is set is redone by the sequential kernel above (k_integral_seq: its workgroups exit at once otherwise).
 //   k_integral_totals: per band of 16 grid rows the column totals of the row sums (one fp64 per column)
 //   k_integral_band  : the band's row sums, carry = totals of the bands above, column scan inside the band, fp32 store;
 //                      also writes the finalised heights (cells < -0.99 -> 0, 522-528) over the keys
@@ -634,8 +638,7 @@ void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int
     hipLaunchKernelGGL(k_integral_totals, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, inexact_flags, d);
     hipLaunchKernelGGL(k_integral_band, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
     // sequential order for the grids whose parallel sums were not exact (practically never; the kernels exit at once otherwise)
-    hipLaunchKernelGGL(k_integral_rows, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, hk, rowsum, inexact_flags, counters, d);
-    hipLaunchKernelGGL(k_integral_cols, dim3((d.W + 1 + 63) / 64, d.B * d.R), dim3(64), 0, s, rowsum, ii, inexact_flags, d);
+    hipLaunchKernelGGL(k_integral_seq, dim3(d.B * d.R), dim3(256), 0, s, hk, rowsum, ii, inexact_flags, counters, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
