@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void k_bkt_scatter(const CloudDev *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
+constexpr int kBinTileThreads = 512;
+__global__ __launch_bounds__(kBinTileThreads) void k_bin_tiles(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
                                                    const float *__restrict__ sorted, const int *__restrict__ bkt_off,
                                                    int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty)
 {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
     const int tiles_w = (d.W + kBinTile - 1) / kBinTile;
     const int tx0 = (blockIdx.x / tiles_w) * kBinTile, ty0 = (blockIdx.x % tiles_w) * kBinTile;    // first row (x-bin) / column (y-bin)
     const BktGrid bg = bkt_grid(d.H);
-    for (int k = threadIdx.x; k < kBinTile * kBinTile; k += 256) cells[k] = key_empty;
+    for (int k = threadIdx.x; k < kBinTile * kBinTile; k += kBinTileThreads) cells[k] = key_empty;
     if (threadIdx.x == 0) nlist = 0;
     __syncthreads();
     // ---- which buckets can reach this tile?  p = S(rw) R(roll) p0; tile = [xa, xb] x [ya, yb] in p (cell = floor(100 (p + r))) ----
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
     const int iy0 = max(0, (int)floorf((by_lo + bg.Rb) * bg.inv_bs) - 1), iy1 = min(bg.nb - 1, (int)floorf((by_hi + bg.Rb) * bg.inv_bs) + 1);
     const int nx = max(0, ix1 - ix0 + 1), ncand = nx * max(0, iy1 - iy0 + 1);
     // ... whose centre's image lies within the tile's half extent + a bucket's half diagonal + slack (conservative both ways)
-    for (int k = threadIdx.x; k < ncand; k += 256) {
+    for (int k = threadIdx.x; k < ncand; k += kBinTileThreads) {
         const int q = (iy0 + k / nx) * bg.nb + ix0 + k % nx;
         const int i0 = bkt_off[c.bucket_off + q], i1 = bkt_off[c.bucket_off + q + 1];
         if (i1 == i0) continue;                                                        // empty bucket
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
             }
         }
     };
-    for (int l = wave; l < nl; l += 4) {
+    for (int l = wave; l < nl; l += kBinTileThreads / 64) {
         const int i0 = lstart[l], i1 = lend[l];
         for (int i = i0 + lane; i < i1; i += 128) {
             const int j = (i + 64 < i1) ? i + 64 : i;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void k_bin_tiles(const CloudDev *__restrict__ 
     }
     __syncthreads();
     int *out = hkeys + (size_t)br * d.H * d.W;
-    for (int k = threadIdx.x; k < kBinTile * kBinTile; k += 256) {
+    for (int k = threadIdx.x; k < kBinTile * kBinTile; k += kBinTileThreads) {
         const int i = k / kBinTile, j = k % kBinTile;
         if (tx0 + i < d.H && ty0 + j < d.W) out[(size_t)(tx0 + i) * d.W + ty0 + j] = cells[k];
     }
@@ -379,7 +380,7 @@ bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, 
         hipLaunchKernelGGL(k_bkt_scan, dim3(d.B), dim3(1024), 0, s, clouds, bs.bkt_count, bs.bkt_off, bs.bkt_cursor, d);
         hipLaunchKernelGGL(k_bkt_scatter, grid, dim3(256), 0, s, clouds, bs.bkt_cursor, bs.sorted, d);
         const int tiles = ((d.H + kBinTile - 1) / kBinTile) * ((d.W + kBinTile - 1) / kBinTile);
-        hipLaunchKernelGGL(k_bin_tiles, dim3(tiles, d.B * d.R), dim3(256), 0, s, clouds, geo, bs.sorted, bs.bkt_off, hkeys, d, r_row, r_col,
+        hipLaunchKernelGGL(k_bin_tiles, dim3(tiles, d.B * d.R), dim3(kBinTileThreads), 0, s, clouds, geo, bs.sorted, bs.bkt_off, hkeys, d, r_row, r_col,
                            key_empty);
         return true;
     }
@@ -585,11 +586,22 @@ __global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, const doub
                 const int4 k0 = *reinterpret_cast<const int4 *>(keys + (size_t)row * W + cb);
                 const int4 k1 = *reinterpret_cast<const int4 *>(keys + (size_t)row * W + cb + 4);
                 kr[0] = k0.x; kr[1] = k0.y; kr[2] = k0.z; kr[3] = k0.w; kr[4] = k1.x; kr[5] = k1.y; kr[6] = k1.z; kr[7] = k1.w;
+                float hf[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = (double)final_height(kr[k]);                   // 589: widened before the integral
+                for (int k = 0; k < 8; k++) { hf[k] = final_height(kr[k]); v[k] = (double)hf[k]; }   // 589: widened before the integral
+                // the finalised heights replace the keys right here: nobody else reads these eight cells (k_integral_totals has run)
+                *reinterpret_cast<float4 *>(hts + (size_t)row * W + cb) = float4{hf[0], hf[1], hf[2], hf[3]};
+                *reinterpret_cast<float4 *>(hts + (size_t)row * W + cb + 4) = float4{hf[4], hf[5], hf[6], hf[7]};
             } else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = (row < H && cb + k < W) ? (double)final_height(keys[(size_t)row * W + cb + k]) : 0.0;
+                for (int k = 0; k < 8; k++) {
+                    v[k] = 0.0;
+                    if (row < H && cb + k < W) {
+                        const float hfk = final_height(keys[(size_t)row * W + cb + k]);
+                        hts[(size_t)row * W + cb + k] = hfk;
+                        v[k] = (double)hfk;
+                    }
+                }
             }
             // inclusive prefix inside the lane, exclusive scan of the lane totals over the wave, carry of the earlier passes
 #pragma unroll
@@ -617,14 +629,6 @@ __global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, const doub
             }
         }
         __syncthreads();
-    }
-    // the finalised heights replace the keys (every key of the band has been read by now: both phases are behind a barrier)
-    for (int idx = tid; idx < kIBandRows * W; idx += kIThreads) {
-        const int row = row0 + idx / W;
-        if (row < H) {
-            const size_t a = (size_t)row * W + idx % W;
-            hts[a] = final_height(keys[a]);
-        }
     }
     if (__syncthreads_or(inexact) && tid == 0) atomicOr(&inexact_flags[br], 1);
 }
@@ -2397,6 +2401,35 @@ __device__ __forceinline__ int vote_at(const int8_t *__restrict__ g, int W, int 
 // key (vote, then smallest linear index): max is order independent, so the result is deterministic.
 constexpr int kVoteCellsPerBlock = 2048;
 
+// W % 4 == 0 (every grid the engine is normally used with): a thread computes FOUR horizontally adjacent cells from fifteen
+// aligned 4-byte loads (5 rows x 12 labels) instead of 4 x 29 single-byte loads -- the kernel was bound by the texture
+// addresser, not by arithmetic.  Same integer sum, same first-wins key.
+__device__ __forceinline__ void vote_quad(const int8_t *__restrict__ g, int W, int row, int c, int (&v)[4])
+{
+    int b[5][12];
+#pragma unroll
+    for (int dr = 0; dr < 5; dr++) {
+        const int *p = reinterpret_cast<const int *>(g + (size_t)(row + dr - 2) * W + c - 4);
+#pragma unroll
+        for (int w = 0; w < 3; w++) {
+            const int x = p[w];
+#pragma unroll
+            for (int k = 0; k < 4; k++) b[dr][4 * w + k] = (int)(int8_t)(x >> (8 * k));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = 4 + k;
+        v[k] = 1 * b[0][j - 2] + 2 * b[0][j - 1] + 3 * b[0][j] + 2 * b[0][j + 1] + 1 * b[0][j + 2] +
+               2 * b[1][j - 2] + 3 * b[1][j - 1] + 4 * b[1][j] + 3 * b[1][j + 1] + 2 * b[1][j + 2] +
+               2 * b[2][j - 4] + 2 * b[2][j - 3] + 3 * b[2][j - 2] + 4 * b[2][j - 1] + 55 * b[2][j] + 4 * b[2][j + 1] + 3 * b[2][j + 2] +
+               2 * b[2][j + 3] + 2 * b[2][j + 4] +
+               2 * b[3][j - 2] + 3 * b[3][j - 1] + 4 * b[3][j] + 3 * b[3][j + 1] + 2 * b[3][j + 2] +
+               1 * b[4][j - 2] + 2 * b[4][j - 1] + 3 * b[4][j] + 2 * b[4][j + 1] + 1 * b[4][j + 2];       // 873-878
+        if (b[2][j] < 0) v[k] = 0;                                   // 870-871: a cell without a positive label scores 0
+    }
+}
+
 __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ labels, short *__restrict__ ev16,
                                                     unsigned long long *__restrict__ topkey, Dims d)
 {
@@ -2407,13 +2440,28 @@ __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ l
     short *ev = ev16 + (size_t)br * HW;
     unsigned long long best = 0;
     const int lo = blockIdx.x * kVoteCellsPerBlock, hi = min(HW, lo + kVoteCellsPerBlock);
-    for (int idx = lo + t; idx < hi; idx += 256) {
-        int row = idx / W, col = idx - row * W;
-        int v = 0;
-        if (g[idx] >= 0 && row >= 2 && row < H - 2 && col >= 4 && col < W - 4) v = vote_at(g, W, row, col);   // 870-879
-        ev[idx] = (short)v;
-        unsigned long long key = ((unsigned long long)(unsigned)(v + 32768) << 32) | (unsigned)(0x7FFFFFFF - idx);
-        if (key > best) best = key;                                   // larger vote, then smaller index (first wins, 882)
+    if ((W & 3) == 0) {
+        for (int idx = lo + 4 * t; idx < hi; idx += 4 * 256) {       // (kVoteCellsPerBlock and W are multiples of 4: a quad never straddles)
+            const int row = idx / W, col = idx - row * W;
+            int v[4] = {0, 0, 0, 0};
+            if (row >= 2 && row < H - 2 && col >= 4 && col + 4 <= W - 4) vote_quad(g, W, row, col, v);   // 870-879 (the border scores 0)
+            typedef short short4v __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<short4v *>(ev + idx) = short4v{(short)v[0], (short)v[1], (short)v[2], (short)v[3]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long key = ((unsigned long long)(unsigned)(v[k] + 32768) << 32) | (unsigned)(0x7FFFFFFF - (idx + k));
+                if (key > best) best = key;                           // larger vote, then smaller index (first wins, 882)
+            }
+        }
+    } else {
+        for (int idx = lo + t; idx < hi; idx += 256) {
+            int row = idx / W, col = idx - row * W;
+            int v = 0;
+            if (g[idx] >= 0 && row >= 2 && row < H - 2 && col >= 4 && col < W - 4) v = vote_at(g, W, row, col);   // 870-879
+            ev[idx] = (short)v;
+            unsigned long long key = ((unsigned long long)(unsigned)(v + 32768) << 32) | (unsigned)(0x7FFFFFFF - idx);
+            if (key > best) best = key;                               // larger vote, then smaller index (first wins, 882)
+        }
     }
     red[t] = best;
     __syncthreads();
