@@ -152,7 +152,12 @@ def pmc_traffic(args, kernel):
             t = json.load(f)
         w = t["workload"]
         if (w["grid"], w["rolls"], w["n_sv"]) == (args.grid, args.rolls, args.nsv):
-            return t["kernels"][kernel]["hbm_bytes"]
+            ks = t["kernels"]
+            if kernel in ks:
+                return ks[kernel]["hbm_bytes"]
+            for k in sorted(ks):                       # template instances: k_svm_screen<false>
+                if k.startswith(kernel + "<"):
+                    return ks[k]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     return None

@@ -252,6 +252,7 @@ struct haf_engine {
     DevBuf<AttrRecord> d_attr;      // HAF_FLAG_KEEP_DEBUG: [max_evals][kKP] attribute records of the exact-form feature kernels
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
+    DevBuf<int> d_rowmax;           // best vote per grid row (k_vote_cells -> k_vote_pick)
     DevBuf<FeatDesc> d_fd, d_fd_slot;
     DevBuf<ScrDesc> d_sd;
     DevBuf<float> d_part1;
@@ -792,6 +793,7 @@ int alloc_buffers(haf_engine *e)
     }
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rec.alloc(B * R);
+    ok &= hipSuccess == e->d_rowmax.alloc(B * R * H);
     ok &= hipSuccess == e->d_topkey.alloc(3 * B * R);          // top vote key, longest-run key, completion counter (k_vote_*)
     if (!ok) return fail(e, HAF_E_DEVICE, std::string("hipMalloc of working buffers failed: ") + hipGetErrorString(hipGetLastError()));
     HIPCHK(e, hipHostMalloc((void **)&e->h_clouds, B * sizeof(CloudDev)));
@@ -864,7 +866,7 @@ void haf_destroy(haf_engine *e)
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
-    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_rec.release(); e->d_topkey.release(); e->d_fd.release();
+    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_rec.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
@@ -1129,7 +1131,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         // the counters come back with the roll records: a second window costs nothing unless it is needed
         auto vote = [&]() -> int {
             mark(e, HAF_ST_VOTE);
-            launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rec.p, d, s);
+            launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rowmax.p, e->d_rec.p, d, s);
             mark(e, HAF_ST_DOWNLOAD);
             HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
             HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));

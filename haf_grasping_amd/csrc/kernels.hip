@@ -2431,15 +2431,19 @@ __device__ __forceinline__ void vote_quad(const int8_t *__restrict__ g, int W, i
 }
 
 __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ labels, short *__restrict__ ev16,
-                                                    unsigned long long *__restrict__ topkey, Dims d)
+                                                    unsigned long long *__restrict__ topkey, int *__restrict__ rowmax, Dims d)
 {
     __shared__ unsigned long long red[256];
+    __shared__ int rmax[kVoteCellsPerBlock / 8 + 2];                  // best vote of every grid row this block touches (W >= 15)
     const int br = blockIdx.y, t = threadIdx.x;
     const int H = d.H, W = d.W, HW = H * W;
     const int8_t *g = labels + (size_t)br * HW;
     short *ev = ev16 + (size_t)br * HW;
     unsigned long long best = 0;
     const int lo = blockIdx.x * kVoteCellsPerBlock, hi = min(HW, lo + kVoteCellsPerBlock);
+    const int row_lo = lo / W, n_rows = (hi - 1) / W - row_lo + 1;
+    for (int k = t; k < n_rows; k += 256) rmax[k] = 0;
+    __syncthreads();
     if ((W & 3) == 0) {
         for (int idx = lo + 4 * t; idx < hi; idx += 4 * 256) {       // (kVoteCellsPerBlock and W are multiples of 4: a quad never straddles)
             const int row = idx / W, col = idx - row * W;
@@ -2447,6 +2451,8 @@ __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ l
             if (row >= 2 && row < H - 2 && col >= 4 && col + 4 <= W - 4) vote_quad(g, W, row, col, v);   // 870-879 (the border scores 0)
             typedef short short4v __attribute__((ext_vector_type(4)));
             *reinterpret_cast<short4v *>(ev + idx) = short4v{(short)v[0], (short)v[1], (short)v[2], (short)v[3]};
+            const int vm = max(max(v[0], v[1]), max(v[2], v[3]));
+            if (vm > 0) atomicMax(&rmax[row - row_lo], vm);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const unsigned long long key = ((unsigned long long)(unsigned)(v[k] + 32768) << 32) | (unsigned)(0x7FFFFFFF - (idx + k));
@@ -2459,12 +2465,16 @@ __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ l
             int v = 0;
             if (g[idx] >= 0 && row >= 2 && row < H - 2 && col >= 4 && col < W - 4) v = vote_at(g, W, row, col);   // 870-879
             ev[idx] = (short)v;
+            if (v > 0) atomicMax(&rmax[row - row_lo], v);
             unsigned long long key = ((unsigned long long)(unsigned)(v + 32768) << 32) | (unsigned)(0x7FFFFFFF - idx);
             if (key > best) best = key;                               // larger vote, then smaller index (first wins, 882)
         }
     }
     red[t] = best;
     __syncthreads();
+    // per-row maxima for k_vote_pick (a row may be shared with the neighbouring blocks: atomicMax, votes are >= 0)
+    for (int k = t; k < n_rows; k += 256)
+        if (rmax[k] > 0) atomicMax(&rowmax[(size_t)br * H + row_lo + k], rmax[k]);
     for (int o = 128; o > 0; o >>= 1) {
         if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
         __syncthreads();
@@ -2478,7 +2488,7 @@ __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ l
 // counter, no spinning) turns it into the roll record: run centre, z window of a11 (1342-1351), evaluation count.
 __global__ __launch_bounds__(64) void k_vote_pick(const float *__restrict__ heights, const int *__restrict__ brcount,
                                                   const short *__restrict__ ev16, unsigned long long *__restrict__ keys3,
-                                                  RollRecordDev *__restrict__ rec, Dims d)
+                                                  const int *__restrict__ rowmax, RollRecordDev *__restrict__ rec, Dims d)
 {
     const int br = blockIdx.y, lane = threadIdx.x;
     const int H = d.H, W = d.W, HW = H * W, BR = d.B * d.R;
@@ -2488,7 +2498,9 @@ __global__ __launch_bounds__(64) void k_vote_pick(const float *__restrict__ heig
     const int top = (int)(topkey[br] >> 32) - 32768;
     const int row = blockIdx.x * 64 + lane;
     unsigned long long rbest = 0;
-    if (row < H) {
+    // only a row whose best vote IS the roll's top can hold a run of it (k_vote_cells left the row maxima; top = 0 means every
+    // row qualifies: the run of zeros of row 0 wins then, and the scan below finds it)
+    if (row < H && rowmax[(size_t)br * H + row] == top) {
         int cur = 0, longest = 0, endc = 0;
         const short *er = ev + (size_t)row * W;
         auto step = [&](int v, int col) {
@@ -2554,14 +2566,15 @@ __global__ __launch_bounds__(64) void k_vote_pick(const float *__restrict__ heig
 }
 
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
-                 RollRecordDev *rec, Dims d, hipStream_t s)
+                 int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s)
 {
+    (void)hipMemsetAsync(rowmax, 0, (size_t)d.B * d.R * d.H * sizeof(int), s);
     // topkey: three arrays of B*R 64-bit words (top vote key, longest-run key, completion counter)
     (void)hipMemsetAsync(topkey, 0, (size_t)3 * d.B * d.R * sizeof(unsigned long long), s);
     const int HW = d.H * d.W;
     hipLaunchKernelGGL(k_vote_cells, dim3((HW + kVoteCellsPerBlock - 1) / kVoteCellsPerBlock, d.B * d.R), dim3(256), 0, s, labels, ev16,
-                       topkey, d);
-    hipLaunchKernelGGL(k_vote_pick, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, heights, brcount, ev16, topkey, rec, d);
+                       topkey, rowmax, d);
+    hipLaunchKernelGGL(k_vote_pick, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, heights, brcount, ev16, topkey, rowmax, rec, d);
 }
 
 // ---------------------------------------------------------------------------------------------------

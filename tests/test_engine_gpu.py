@@ -433,6 +433,37 @@ def test_cli_and_server_mirror(data_dir, golden_dir, surrogate):
     np.testing.assert_allclose(res.graspPoint2, g["gp2"], atol=1e-4)
     assert res.hypothesis_string().split()[0] == str(g["eval"])
     srv.close()
+    # ---- ros_shim/shim_core.h through the CLI: the per-roll hypotheses of show_predicted_gps (server.cpp:962-969) and the
+    # exact text of /haf_grasping/grasp_hypothesis_with_eval (1384), against the oracle-derived goldens ----
+    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+        gold = json.load(f)
+    for name, key, extra in (("plastic_mug2", "plastic_mug2/default", []), ("pcd2", "pcd2/default", []),
+                             ("plastic_mug2", "plastic_mug2/C2best", ["--search-size", "18", "18", "--show-only-best"])):
+        w = gold[key]
+        args = [cli, "--features", f_, "--range", r_, "--model", surrogate, "--hypotheses"] + (extra or ["--search-size", "18", "30"])
+        out = subprocess.run(args + [os.path.join(data_dir, name + ".pcd")], check=True, capture_output=True, text=True)
+        lines = out.stdout.strip().splitlines()
+        hyp = [l.split()[1:] for l in lines if l.startswith("hypothesis ")]
+        final = lines[-1].split()
+        show_best = "--show-only-best" in args
+        want = [] if show_best else [(max(v[2] - 20, 10), r * 15) for r, v in enumerate(w["roll_best"][:w["rolls_done"]]) if v[2] > 70]
+        assert [(int(h[0]), int(h[13])) for h in hyp] == want, (key, hyp, want)
+        assert int(final[0]) == w["eval"] and int(final[13]) == w["roll_idx"] * 15
+        np.testing.assert_allclose([float(t) for t in final[1:7]], list(w["gp1"]) + list(w["gp2"]), atol=1e-4)
+        np.testing.assert_allclose([float(t) for t in final[7:10]], w["av"], atol=1e-6)
+        # the text itself: floats streamed with 6 significant digits, like the reference's stringstream
+        eng = make_engine(data_dir, surrogate)
+        o = eng.score(capi.load_pcd(os.path.join(data_dir, name + ".pcd")),
+                      capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32 if show_best else 44, show_only_best_grasp=int(show_best)))
+        eng.close()
+        f32 = lambda v: "%g" % float(np.float32(v))
+        text = " ".join(["%d" % o["eval"]] + [f32(v) for v in o["grasp_point1"] + o["grasp_point2"] + o["approach_vector"]] +
+                        ["%g" % v for v in o["averaged_grasp_point"]] + ["%d" % (o["best_roll"] * 15)])
+        assert lines[-1] == text, (lines[-1], text)
+    # --gpus 1: the same request through haf_create_multi / haf_score_sharded (one RCCL rank)
+    out1 = subprocess.run([cli, "--features", f_, "--range", r_, "--model", surrogate, "--search-size", "18", "18", "--gpus", "1",
+                           os.path.join(data_dir, "pcd2.pcd")], check=True, capture_output=True, text=True)
+    assert out1.stdout.split() == tok and "1 shards on 1 RCCL ranks" in out1.stderr
 
 
 def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/ktimes
 rm -rf $O; mkdir -p $O
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side "$@" > $O/kt.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side "$@" > $O/kt.log 2>&1
 python3 - <<'PY'
 import csv,glob,os,sys
 fs=glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "ktimes/kt/**/*kernel_stats.csv"), recursive=True)

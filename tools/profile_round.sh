@@ -5,8 +5,8 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/final
 rm -rf $O; mkdir -p $O
 timeout 700 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side"
-B1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-f32-side"
+B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side"
+B1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side"
 # default (screened) mode: kernel trace + PMC passes (counters in their own runs)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/kt.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $B1 > $O/fetch.log 2>&1
