@@ -463,7 +463,8 @@ def test_cli_and_server_mirror(data_dir, golden_dir, surrogate):
     # --gpus 1: the same request through haf_create_multi / haf_score_sharded (one RCCL rank)
     out1 = subprocess.run([cli, "--features", f_, "--range", r_, "--model", surrogate, "--search-size", "18", "18", "--gpus", "1",
                            os.path.join(data_dir, "pcd2.pcd")], check=True, capture_output=True, text=True)
-    assert out1.stdout.split() == tok and "1 shards on 1 RCCL ranks" in out1.stderr
+    # (RCCL may print its version banner to stdout when NCCL_DEBUG is set on the box: the result is the last line)
+    assert out1.stdout.strip().splitlines()[-1].split() == tok and "1 shards on 1 RCCL ranks" in out1.stderr
 
 
 def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
