@@ -75,15 +75,21 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for r, p in enumerate(procs):
-        code = p.wait()
-        if code != 0 and rc == 0:
-            rc = code or 1
-            sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
-            for q in procs:
-                if q.poll() is None:
-                    q.terminate()
+    # poll ALL ranks: when one dies the others would sit in a collective until its timeout -- stop them at once
+    rc, alive = 0, set(range(len(procs)))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for q in alive:
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.2)
     return rc
 
 
@@ -135,7 +141,7 @@ def run_cabi_side(args, world):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                            "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, text=True)
         if p.returncode != 0:
             return {"error": "child exited with %d: %s" % (p.returncode, p.stderr.strip()[-400:])}
         return json.loads(p.stdout.strip().splitlines()[-1])

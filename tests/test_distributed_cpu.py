@@ -6,6 +6,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 import pcdio
@@ -73,3 +74,22 @@ def test_roll_shards_and_batch_election_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus N` without a launcher starts one rank process per GPU itself, before anything in the parent
+    touches a GPU, and exits non-zero as soon as any rank fails (here: no GPU in the container) instead of leaving the other
+    ranks waiting in a collective."""
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the ranks would run the benchmark")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert p.returncode != 0 and "stopping the other ranks" in p.stderr and time.time() - t0 < 120
+    assert p.stdout.strip() == ""                              # no JSON line from a failed run
