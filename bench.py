@@ -34,8 +34,8 @@ D_ATTR = 323                       # algorithmic work 2*D*nSV 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nsv", type=int, default=4096, help="support vectors of the seeded random model")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rolls", type=int, default=36)

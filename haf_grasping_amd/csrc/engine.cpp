@@ -703,7 +703,11 @@ int build_tables(haf_engine *e)
     // HAF_GUARD0_REL scales the whole screening band (this term and the per-evaluation one) for experiments.
     double guard0_scale = 1.0;
     if (const char *g = test_env("HAF_GUARD0_REL")) guard0_scale = atof(g);
-    e->svm.guard_acc0 = (float)(guard0_scale * ((2.0 * e->n_sv_tiles + 4.0 + 2.0 + 6.0) * u));
+    // (plain variant: two levels -- a term passes through at most 16 fmas of the lower level, one fold, and the folds of its
+    // sweep, <= tiles/8 + 1; then the final fma and add, the 4-step lane reduction, the class split, exp2 + product, the two
+    // products with the common factor.  SUMSQ variant: one level, 2 fmas per tile.)
+    e->svm.guard_acc0 = (float)(guard0_scale * ((16.0 + 1.0 + (e->n_sv_tiles / 8.0 + 1.0) + 2.0 + 4.0 + 2.0 + 6.0 + 2.0) * u));
+    e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * e->n_sv_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {

@@ -188,7 +188,8 @@ struct SvmParams {
     float guard_abs;
     float as_max;                 // max_n gamma*log2(e)*|s_n|^2
     float guard_dot_p;            // the same for the three-pass kernel's PRECISE form (list mode behind the screening pass)
-    float guard_acc0;             // screening pass: single-level fp32 coefficient sum + exp2 + product, per unit of sum|coef|K
+    float guard_acc0;             // screening pass, plain variant: two-level fp32 coefficient sum + exp2 + product, per unit of sum|coef|K
+    float guard_acc0_s;           // screening pass, SUMSQ variant: single-level sum
     float guard_acc_l;            // guard_acc of the three-pass kernel's list mode when the SV tiles are cut into ranges (k_svm_h_combine)
     int   gv0, gv1;               // grid values of label[0] / label[1] (atoi of the "%g" label text, server.cpp:843)
     float sqrt_cmax;              // screening pass, plain variant: |w|_2 <= sqrt(max|coef| * S)

@@ -84,10 +84,11 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // SUMSQ (the variant for ill-conditioned models): the epilogue also accumulates q += (coef K)^2, so that the sqrt(S) form of the
 // band can use |w|_2^2 = sum_n (coef_n K_n)^2 itself instead of its bound max|coef| * S: three VALU instructions
 // per element behind the exp instead of one.
-// B fragments are read two k-steps ahead of their MFMAs, ACROSS the boundary between the two column blocks of a tile: block 0
-// (n = 0) reads its own first two fragments on entry and leaves those of block 1 in (b, b1) on exit, so that block 1's first
-// MFMA does not wait for an LDS round trip.  (Across tiles that is not possible: the next tile is only known to have landed
-// behind the barrier.)  SUMSQ: one step ahead -- the four registers go to the squares.
+// B fragments are read one k-step ahead of their MFMAs, ACROSS the boundary between the two column blocks of a tile: block 0
+// (n = 0) reads its own first fragment on entry and leaves that of block 1 in b on exit, so that block 1's first MFMA does not
+// wait for an LDS round trip.  (Across tiles that is not possible: the next tile is only known to have landed behind the
+// barrier.)  Two steps ahead -- round 1, SCREEN_VARIANT bit 1 -- measured the same and costs four VGPRs, which now hold a
+// second level of the coefficient sum.
 template <int FIRST, int COUNT, bool SUMSQ>
 __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], f32x4 (&acc)[4],
                                              const f32x4 (&old)[4], float t, float cf_old, float (&sum)[4][4], float (&sq)[4][4],
@@ -97,9 +98,10 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
     const f32x4 t4 = {t, t, t, t};                                   // rows differ, the column (this lane's SV) is the same
     constexpr bool kXBlock = !(SCREEN_VARIANT & 1);                  // (A/B builds: SCREEN_VARIANT bit 0 switches the hand-over off)
+    constexpr bool kDeep = (SCREEN_VARIANT & 2) != 0;                // B fragments two k-steps ahead (four more VGPRs) instead of one
     if (n == 0 || !kXBlock) {
         b = *reinterpret_cast<const half8 *>(bl);                    // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
-        if (!SUMSQ) b1 = *reinterpret_cast<const half8 *>(bl + 2048);
+        if (kDeep) b1 = *reinterpret_cast<const half8 *>(bl + 2048);
     }
     float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
     // The issue order of every k-step is pinned instruction by instruction (a scheduling barrier after each): B read of the
@@ -111,11 +113,11 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         half8 b2 = b1;
         // fragment s + 2 of this block, or -- in the last two steps of block 0 -- fragment s + 2 - 10 of block 1 (1 KiB further on)
         constexpr bool kNoRead = SCREEN_ABL == 5;
-        if (!SUMSQ && !kNoRead) {
+        if (kDeep && !kNoRead) {
             if (s + 2 < kHFull) b2 = *reinterpret_cast<const half8 *>(bl + (s + 2) * 2048);
             else if (n == 0 && kXBlock) b2 = *reinterpret_cast<const half8 *>(bl + 1024 + (s + 2 - kHFull) * 2048);
         }
-        if (SUMSQ && !kNoRead) {
+        if (!kDeep && !kNoRead) {
             if (s + 1 < kHFull) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
             else if (n == 0 && kXBlock) b1 = *reinterpret_cast<const half8 *>(bl + 1024);
         }
@@ -169,9 +171,9 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         k0 = q0;
         k1 = q1;
         b = b1;
-        if (!SUMSQ) b1 = b2;
+        if (kDeep) b1 = b2;
     }
-    // (n == 0: b, b1 now hold fragments 0 and 1 of block 1 -- SUMSQ: b holds fragment 0)
+    // (n == 0: b now holds fragment 0 of block 1 -- and b1 fragment 1 when the read-ahead is two steps deep)
 #undef HAF_SB
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
@@ -232,6 +234,11 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     __syncthreads();
 
     float sum[4][4];                                                 // rows 16m + 4(lane>>4) + r, this lane's columns
+    // Plain variant: TWO-LEVEL coefficient sum.  `sum` takes the products of at most eight tiles (16 fmas), then folds into
+    // `part`: a term passes through 16 + tiles/8 roundings instead of 2 * tiles, and the worst-case bound of this fp32 sum --
+    // guard_acc0, the largest single term of the screening band at 4096 SVs -- shrinks from 268 u to 41 u (refined share at C5:
+    // 2.05 % -> see DESIGN.md 5).  The SUMSQ variant has no registers for it (its 16 go to the squares): single level there.
+    float part[4][4];
     float sq[4][4];                                                  // SUMSQ only (dead otherwise): runs on across the two sweeps
 #pragma unroll
     for (int m = 0; m < 4; m++)
@@ -247,8 +254,9 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         for (int m = 0; m < 4; m++) {
             acc1[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < 4; r++) sum[m][r] = 0.0f;
+            for (int r = 0; r < 4; r++) { sum[m][r] = 0.0f; part[m][r] = 0.0f; }
         }
+        int fold = 0;
         float cf_prev = 0.0f;                                        // the first deferred epilogue adds 0 * exp2(0)
         for (int t = ph ? d.sv_tile_neg : 0; t < t_end; t++) {
             const char *cur = lds + (t % kS0Buffers) * kS0SvTileBytes;
@@ -264,6 +272,13 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
             screen_block<0, 3, SUMSQ>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, sq, dma, lane16, bf0, bf1);
             screen_block<3, 3, SUMSQ>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, sq, dma, lane16, bf0, bf1);
             cf_prev = cf1;
+            if (!SUMSQ && ++fold == 8) {                             // wave-uniform, outside the MFMA stream
+                fold = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { part[m][r] += sum[m][r]; sum[m][r] = 0.0f; }
+            }
             // tile t+1 must have landed before anyone reads it; the six pieces just issued may stay in flight
 #if SCREEN_ABL == 3
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -290,6 +305,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
             for (int r = 0; r < 4; r++) {
                 const float ck = cf_prev * acc1[m][r];
                 float v = ck + sum[m][r];
+                if (!SUMSQ) v += part[m][r];
                 if (SUMSQ) sq[m][r] = fmaf(ck, ck, sq[m][r]);
                 v += __shfl_xor(v, 8, 64);
                 v += __shfl_xor(v, 4, 64);
@@ -335,7 +351,8 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         // |w|_2 of w_n = coef_n K_n: measured (SUMSQ; the common factor enters squared) or bounded by sqrt(max|coef| * S)
         const float w2 = SUMSQ ? sqrtf(qrow[lane]) * sc : p.sqrt_cmax * sqrtf(sabs);
         const float lin = fminf(g.x * w2, g.z * sabs);
-        const float err = (lin + (p.guard_acc0 * 1.04f + g.y) * sabs + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
+        const float gacc = SUMSQ ? p.guard_acc0_s : p.guard_acc0;   // single- / two-level coefficient sum
+        const float err = (lin + (gacc * 1.04f + g.y) * sabs + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
         flagged = !(adv > err);                                     // also catches NaN
         if (margin) margin[e] = flagged ? 0.0f : adv / err;         // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
     }
