@@ -20,7 +20,7 @@ LIB_TESTING = os.path.join(HERE, "libhafgrasp_testing.so")
 SOURCES = ["kernels.hip", "screen.hip", "engine.cpp", "parsers.cpp", "multi.cpp"]
 # per-file extra flags (screen.hip: see its header)
 EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["kernels.h", "parsers.h", "decq.h", "engine_internal.h", os.path.join("..", "..", "include", "hafgrasp.h"),
+HEADERS = ["kernels.h", "parsers.h", "decq.h", "engine_internal.h", "testkernels.hip", os.path.join("..", "..", "include", "hafgrasp.h"),
            os.path.join("..", "cli", "haf_grasp_cli.cpp"), os.path.join("..", "..", "ros_shim", "shim_core.h")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -154,10 +154,11 @@ def build(force=False, verbose=False):
 
     objs = {src: compile_one(src) for src in SOURCES}
     engine_testing = compile_one("engine.cpp", "_testing", ["-DHAF_TESTING"])
+    test_kernels = compile_one("testkernels.hip")                  # device code of the testing build only
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"]
     libs = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     for out, eng in ((LIB, objs["engine.cpp"]), (LIB_TESTING, engine_testing)):
-        cmd = link + [eng if s == "engine.cpp" else objs[s] for s in SOURCES] + libs + ["-o", out]
+        cmd = link + [eng if s == "engine.cpp" else objs[s] for s in SOURCES] + ([test_kernels] if out == LIB_TESTING else []) + libs + ["-o", out]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

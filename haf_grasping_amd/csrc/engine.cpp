@@ -1639,6 +1639,23 @@ double haf_test_decq4_scr(float v)
     return hafq::decq4_float_scr(v, st);
 }
 
+// runs the screening kernel's MFMA chain on host-chosen data (testkernels.hip); a, b: fp16 bit patterns
+int haf_test_mfma_accum(const uint16_t *a, const uint16_t *b, const float *c0, float *out, int trials)
+{
+    void *da = nullptr, *db = nullptr;
+    float *dc = nullptr, *dout = nullptr;
+    const size_t na = (size_t)trials * 16 * 320 * 2, nc = (size_t)trials * 16 * 4, no = (size_t)trials * 256 * 4;
+    if (hipMalloc(&da, na) != hipSuccess || hipMalloc(&db, na) != hipSuccess || hipMalloc((void **)&dc, nc) != hipSuccess ||
+        hipMalloc((void **)&dout, no) != hipSuccess) return HAF_E_DEVICE;
+    (void)hipMemcpy(da, a, na, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, na, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dc, c0, nc, hipMemcpyHostToDevice);
+    haf::launch_mfma_accum_test(da, db, dc, dout, trials, nullptr);
+    const hipError_t rc = hipMemcpy(out, dout, no, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
+    return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
+
 int haf_test_decq_device(const double *in, double *out, int n, int digits)
 {
     double *di = nullptr, *dout = nullptr;

@@ -1013,3 +1013,41 @@ def test_bucket_sorted_binning_of_large_grids(data_dir, surrogate, orc, in_kw):
     eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16, grid_h=grid, grid_w=grid, n_rolls=9, roll_step_deg=20, max_points=1 << 17)
     compare_full(eng, orc, xyz, dict(n_rolls=9, roll_step_deg=20, grid_h=grid, grid_w=grid), kw, check_dec=False)
     eng.close()
+
+
+def test_matrix_core_accumulation_stays_inside_the_band_assumption():
+    """The one assumption about undocumented hardware behaviour in the screening band: a chain of ten
+    v_mfma_f32_16x16x32_f16 that starts from C deviates from the exact C + sum a_k b_k by at most 2^-18 (|C| + sum |a_k b_k|).
+    The products are exact in fp32; how the matrix core adds them is not documented.  Evidence, not proof: the chain of
+    k_svm_screen (same builtin, same operand layout, same start-value mechanism) on 2 048 trials x 256 outputs of operands
+    made to hurt -- magnitudes over the whole fp16 range the operands can take, signs arranged for near-total cancellation,
+    start values like t_n -- against an fp64 evaluation.  The worst observed error is reported as a fraction of the budget."""
+    L = capi.testlib()
+    rng = np.random.RandomState(77)
+    trials = 2048
+    a = np.zeros((trials, 16, 320), np.float16)
+    b = np.zeros((trials, 320, 16), np.float16)
+    c0 = np.zeros((trials, 16), np.float32)
+    for t in range(trials):
+        kind = t % 4
+        if kind == 0:                       # what the engine feeds: |u|, |w| ~ 0.05, start -0.5 .. 0
+            a[t] = rng.uniform(-0.1, 0.1, (16, 320)); b[t] = rng.uniform(-0.1, 0.1, (320, 16)); c0[t] = rng.uniform(-0.6, 0, 16)
+        elif kind == 1:                     # wide magnitudes: 2^-14 .. 2^3
+            a[t] = rng.choice([-1, 1], (16, 320)) * 2.0 ** rng.uniform(-14, 3, (16, 320))
+            b[t] = rng.choice([-1, 1], (320, 16)) * 2.0 ** rng.uniform(-14, 3, (320, 16)); c0[t] = rng.uniform(-20, 20, 16)
+        elif kind == 2:                     # cancellation: pairs of equal products with opposite signs, then a small rest
+            x = rng.uniform(0.5, 4.0, (16, 160)); y = rng.uniform(0.5, 4.0, (160, 16))
+            a[t, :, 0::2] = x; a[t, :, 1::2] = -x; b[t, 0::2, :] = y; b[t, 1::2, :] = y
+            a[t, :, :8] = rng.uniform(-1e-3, 1e-3, (16, 8)); c0[t] = rng.uniform(-1e-3, 1e-3, 16)
+        else:                               # one huge term early, many tiny ones after it
+            a[t] = rng.uniform(-2.0 ** -10, 2.0 ** -10, (16, 320)); b[t] = rng.uniform(-1, 1, (320, 16))
+            a[t, :, 0] = 60.0; b[t, 0, :] = 60.0; c0[t] = -3600.0 + rng.uniform(-1, 1, 16)
+    out = np.zeros((trials, 16, 16), np.float32)
+    assert L.haf_test_mfma_accum(a.ctypes.data, b.ctypes.data, c0.ctypes.data, out.ctypes.data, trials) == 0
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    exact = np.einsum("trk,tkc->trc", a64, b64) + c0[:, None, :].astype(np.float64)
+    scale = np.einsum("trk,tkc->trc", np.abs(a64), np.abs(b64)) + np.abs(c0[:, None, :].astype(np.float64))
+    ratio = np.abs(out.astype(np.float64) - exact) / (2.0 ** -18 * scale)
+    assert np.isfinite(out).all() and ratio.max() <= 1.0, float(ratio.max())
+    STATS["mfma_accumulation_error_as_fraction_of_the_2^-18_budget"] = {"max": float(ratio.max()),
+                                                                          "by_kind": [float(ratio[k::4].max()) for k in range(4)]}
