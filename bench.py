@@ -395,9 +395,9 @@ def main():
             "prestages_hbm": (lambda ms, b: {"kernels": "k_bin + k_integral + k_mask_count/k_scan/k_compact + k_vote_cells/k_vote_pick",
                                              "algorithmic_bytes": b, "ms": ms, "GBps": b / ms / 1e6, "peak_GBps": 8000.0,
                                              "frac": b / ms / 1e6 / 8000.0,
-                                             "note": "SURVEY 8(d): 12 B per cell per roll + 12 B per point per roll; these launches are "
-                                                     "latency- and atomic-bound (sequential row/column sums, 19 M scattered "
-                                                     "atomics), 4 % of the step"})(
+                                             "note": "SURVEY 8(d): 12 B per cell per roll + 12 B per point per roll.  About twenty launches of "
+                                                     "5-50 us (bucket sort + tile binning without global atomics, exactness-checked parallel "
+                                                     "integral image, mask/scan/compact, vote) with 4-5 us gaps: 1.5 % of the step"})(
                 res["stage_ms"]["bin"] + res["stage_ms"]["integral"] + res["stage_ms"]["mask"] + res["stage_ms"]["vote"],
                 12.0 * args.rolls * (G * G + xyz.shape[0])),
             "rechecked_per_step": {"three_pass_tier": res["refined"], "fp64_mfma_tier": res["rechecked"],
