@@ -2484,16 +2484,14 @@ __global__ __launch_bounds__(256) void k_vote_cells(const int8_t *__restrict__ l
 
 // pass 2: longest-run centring on the roll's top value (904-932).  One wave per 64 grid rows, a thread per row: the row goes by
 // in 16-byte pieces (8 votes), and only a piece that holds the top value is looked at vote by vote -- hardly any does.  The
-// best (longest run, then smallest row) of the roll is a 64-bit atomicMax; the workgroup that finishes LAST (a completion
-// counter, no spinning) turns it into the roll record: run centre, z window of a11 (1342-1351), evaluation count.
-__global__ __launch_bounds__(64) void k_vote_pick(const float *__restrict__ heights, const int *__restrict__ brcount,
-                                                  const short *__restrict__ ev16, unsigned long long *__restrict__ keys3,
-                                                  const int *__restrict__ rowmax, RollRecordDev *__restrict__ rec, Dims d)
+// best (longest run, then smallest row) of the roll is a 64-bit atomicMax; k_vote_record turns it into the roll record.
+__global__ __launch_bounds__(64) void k_vote_pick(const short *__restrict__ ev16, unsigned long long *__restrict__ keys3,
+                                                  const int *__restrict__ rowmax, Dims d)
 {
     const int br = blockIdx.y, lane = threadIdx.x;
     const int H = d.H, W = d.W, HW = H * W, BR = d.B * d.R;
     const unsigned long long *topkey = keys3;
-    unsigned long long *runkey = keys3 + BR, *done = keys3 + 2 * (size_t)BR;
+    unsigned long long *runkey = keys3 + BR;
     const short *ev = ev16 + (size_t)br * HW;
     const int top = (int)(topkey[br] >> 32) - 32768;
     const int row = blockIdx.x * 64 + lane;
@@ -2533,17 +2531,19 @@ __global__ __launch_bounds__(64) void k_vote_pick(const float *__restrict__ heig
         const unsigned long long other = __shfl_xor(rbest, o, 64);
         if (other > rbest) rbest = other;                 // longer run, then smaller row
     }
-    unsigned long long finished = 0;
-    if (lane == 0) {
-        if (rbest) atomicMax(&runkey[br], rbest);
-        __threadfence();
-        finished = atomicAdd(&done[br], 1ull);
-    }
-    finished = __shfl(finished, 0, 64);
-    if (finished != gridDim.x - 1) return;
-    // ---- the last workgroup of this (cloud, roll): everybody's atomicMax is visible (fence before the counter) ----
-    __threadfence();
-    const unsigned long long best = atomicMax(&runkey[br], 0ull);
+    if (lane == 0 && rbest) atomicMax(&runkey[br], rbest);
+}
+
+// pass 3: the roll record from the longest-run key: run centre, z window of a11 (1342-1351), evaluation count.  Its own tiny
+// launch: finishing the record inside k_vote_pick behind a completion counter needs a device-scope fence per workgroup, and
+// on this chip each of those is an L2 write-back -- the 288 fences of a C5 request cost more than this launch.
+__global__ __launch_bounds__(64) void k_vote_record(const float *__restrict__ heights, const int *__restrict__ brcount,
+                                                    const unsigned long long *__restrict__ keys3, RollRecordDev *__restrict__ rec, Dims d)
+{
+    const int br = blockIdx.x, lane = threadIdx.x;
+    const int H = d.H, W = d.W, HW = H * W, BR = d.B * d.R;
+    const int top = (int)(keys3[br] >> 32) - 32768;
+    const unsigned long long best = keys3[BR + br];
     const int brow = 0xFFFF - (int)((best >> 20) & 0xFFFFF), bcol = (int)(best & 0xFFFFF);
     // z estimate window rows brow-4..brow+4, cols bcol-4..bcol+3 (1342-1351), as an ordered-key max
     int zk = f2key(-10.0f);
@@ -2569,12 +2569,13 @@ void launch_vote(const int8_t *labels, const float *heights, const int *brcount,
                  int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s)
 {
     (void)hipMemsetAsync(rowmax, 0, (size_t)d.B * d.R * d.H * sizeof(int), s);
-    // topkey: three arrays of B*R 64-bit words (top vote key, longest-run key, completion counter)
-    (void)hipMemsetAsync(topkey, 0, (size_t)3 * d.B * d.R * sizeof(unsigned long long), s);
+    // topkey: two arrays of B*R 64-bit words (top vote key, longest-run key)
+    (void)hipMemsetAsync(topkey, 0, (size_t)2 * d.B * d.R * sizeof(unsigned long long), s);
     const int HW = d.H * d.W;
     hipLaunchKernelGGL(k_vote_cells, dim3((HW + kVoteCellsPerBlock - 1) / kVoteCellsPerBlock, d.B * d.R), dim3(256), 0, s, labels, ev16,
                        topkey, rowmax, d);
-    hipLaunchKernelGGL(k_vote_pick, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, heights, brcount, ev16, topkey, rowmax, rec, d);
+    hipLaunchKernelGGL(k_vote_pick, dim3((d.H + 63) / 64, d.B * d.R), dim3(64), 0, s, ev16, topkey, rowmax, d);
+    hipLaunchKernelGGL(k_vote_record, dim3(d.B * d.R), dim3(64), 0, s, heights, brcount, topkey, rec, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
