@@ -633,8 +633,58 @@ __global__ __launch_bounds__(kIThreads) void k_integral_band(int *hk, const doub
     if (__syncthreads_or(inexact) && tid == 0) atomicOr(&inexact_flags[br], 1);
 }
 
+// Small grids (the reference's 56 x 56, up to ~70 x 70): the whole grid of a roll fits LDS, and three launches cost more than the
+// work.  One workgroup per (cloud, roll) does the SEQUENTIAL summation itself -- a thread per row, then a thread per column,
+// fp64, in LDS -- which is the reference's order by construction (no exactness check needed), in one launch.
+constexpr int kISmallCells = 8192;               // H * W up to this is worth checking; the LDS need decides (launch_integral)
+__global__ __launch_bounds__(256) void k_integral_small(int *hk, float *__restrict__ ii, Dims d)
+{
+    extern __shared__ double s_rs[];                      // [H][pitch] row sums, then the heights as floats
+    const int br = blockIdx.x, tid = threadIdx.x;
+    const int H = d.H, W = d.W, W1 = W + 1;
+    const int pitch = ((W + 15) / 16) * 16 + 1;           // = 1 (mod 16) doubles: the 64 rows of a column read hit distinct banks
+    float *s_h = reinterpret_cast<float *>(s_rs + (size_t)H * pitch);
+    int *keys = hk + (size_t)br * H * W;
+    float *hts = reinterpret_cast<float *>(keys);
+    float *I = ii + (size_t)br * (H + 1) * W1;
+    for (int k = tid; k < H * W; k += 256) {              // coalesced: finalise the heights (522-528), keep a copy in LDS
+        const float h = final_height(keys[k]);
+        s_h[k] = h;
+        hts[k] = h;
+    }
+    __syncthreads();
+    for (int row = tid; row < H; row += 256) {            // running sum along the row (589-595)
+        double s = 0.0;
+        for (int c = 0; c < W; c++) {
+            s = __dadd_rn(s, (double)s_h[row * W + c]);
+            s_rs[(size_t)row * pitch + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < W1; c += 256) {                 // running sum down the column, fp32 store (601)
+        I[c] = 0.0f;
+        if (c == 0) {
+            for (int r = 0; r < H; r++) I[(size_t)(r + 1) * W1] = 0.0f;
+        } else {
+            double acc = 0.0;
+            for (int r = 0; r < H; r++) {
+                acc = __dadd_rn(acc, s_rs[(size_t)r * pitch + (c - 1)]);
+                I[(size_t)(r + 1) * W1 + c] = (float)acc;
+            }
+        }
+    }
+}
+
 void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s)
 {
+    if (d.H * d.W <= kISmallCells) {
+        const int pitch = ((d.W + 15) / 16) * 16 + 1;
+        const size_t lds = (size_t)d.H * pitch * sizeof(double) + (size_t)d.H * d.W * sizeof(float);
+        if (lds <= 64 * 1024) {                               // (the default dynamic-LDS limit: grids up to ~70 x 70)
+            hipLaunchKernelGGL(k_integral_small, dim3(d.B * d.R), dim3(256), lds, s, hk, ii, d);
+            return;
+        }
+    }
     // rowsum doubles as the band-total scratch of the parallel form ([B*R][bands][W] doubles, far smaller) and as the row-sum
     // scratch of the sequential fallback
     const int n_bands = (d.H + kIBandRows - 1) / kIBandRows;
@@ -2565,9 +2615,97 @@ __global__ __launch_bounds__(64) void k_vote_record(const float *__restrict__ he
     }
 }
 
+// Small grids: labels, votes, argmax, run centring, z window and the record of one (cloud, roll) in ONE workgroup and one launch
+// (five launches and two memsets otherwise: more than the work at 56 x 56).
+constexpr int kVoteSmallCells = 16384;
+__global__ __launch_bounds__(256) void k_vote_small(const int8_t *__restrict__ labels, const float *__restrict__ heights,
+                                                    const int *__restrict__ brcount, short *__restrict__ ev16,
+                                                    RollRecordDev *__restrict__ rec, Dims d)
+{
+    extern __shared__ short s_ev[];                       // [H*W] votes, then [H*W] labels as bytes
+    __shared__ unsigned long long red[256];
+    __shared__ int s_top, s_row, s_col;
+    const int br = blockIdx.x, t = threadIdx.x;
+    const int H = d.H, W = d.W, HW = H * W;
+    int8_t *s_g = reinterpret_cast<int8_t *>(s_ev + HW);
+    const int8_t *g = labels + (size_t)br * HW;
+    short *ev = ev16 + (size_t)br * HW;
+    for (int k = t; k < HW; k += 256) s_g[k] = g[k];
+    __syncthreads();
+    unsigned long long best = 0;
+    for (int idx = t; idx < HW; idx += 256) {
+        const int row = idx / W, col = idx - row * W;
+        int v = 0;
+        if (s_g[idx] >= 0 && row >= 2 && row < H - 2 && col >= 4 && col < W - 4) v = vote_at(s_g, W, row, col);   // 870-879
+        s_ev[idx] = (short)v;
+        ev[idx] = (short)v;
+        const unsigned long long key = ((unsigned long long)(unsigned)(v + 32768) << 32) | (unsigned)(0x7FFFFFFF - idx);
+        if (key > best) best = key;                       // larger vote, then smaller index (first wins, 882)
+    }
+    red[t] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) s_top = (int)(red[0] >> 32) - 32768;
+    __syncthreads();
+    const int top = s_top;
+    // longest horizontal run of `top` per row (904-932): first longest run wins, column = run end - len/2
+    unsigned long long rbest = 0;
+    for (int row = t; row < H; row += 256) {
+        int cur = 0, longest = 0, endc = 0;
+        for (int col = 0; col < W; col++) {
+            if (s_ev[row * W + col] == top) {
+                cur++;
+                if (cur > longest) { longest = cur; endc = col; }
+            } else cur = 0;
+        }
+        if (longest > 0) {
+            const int bc = endc - longest / 2;
+            const unsigned long long key = ((unsigned long long)(unsigned)longest << 40) | ((unsigned long long)(unsigned)(0xFFFF - row) << 20) | (unsigned)bc;
+            if (key > rbest) rbest = key;                 // longer run, then smaller row
+        }
+    }
+    __syncthreads();
+    red[t] = rbest;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && red[t + o] > red[t]) red[t] = red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) { s_row = 0xFFFF - (int)((red[0] >> 20) & 0xFFFFF); s_col = (int)(red[0] & 0xFFFFF); }
+    __syncthreads();
+    const int brow = s_row, bcol = s_col;
+    // z estimate window rows brow-4..brow+4, cols bcol-4..bcol+3 (1342-1351), as an ordered-key max
+    if (t < 64) {
+        int zk = f2key(-10.0f);
+        for (int q = t; q < 72; q += 64) {
+            const int rr = brow + (q / 8) - 4, cc = bcol + (q % 8) - 4;
+            if (rr >= 0 && cc >= 0 && rr < H && cc < W) {
+                const float h = heights[(size_t)br * HW + rr * W + cc];
+                if (-10.0f < h) zk = max(zk, f2key(h));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) zk = max(zk, __shfl_xor(zk, o, 64));
+        if (t == 0) {
+            RollRecordDev r;
+            r.vote = top; r.row = (short)brow; r.col = (short)bcol;
+            r.h_locmax = key2f(zk);
+            r.n_evals = brcount[br];
+            rec[br] = r;
+        }
+    }
+}
+
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
                  int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s)
 {
+    if (d.H * d.W <= kVoteSmallCells) {                   // 3 bytes of LDS per cell: 48 KiB at most
+        hipLaunchKernelGGL(k_vote_small, dim3(d.B * d.R), dim3(256), (size_t)d.H * d.W * 3 + 16, s, labels, heights, brcount, ev16, rec, d);
+        return;
+    }
     (void)hipMemsetAsync(rowmax, 0, (size_t)d.B * d.R * d.H * sizeof(int), s);
     // topkey: two arrays of B*R 64-bit words (top vote key, longest-run key)
     (void)hipMemsetAsync(topkey, 0, (size_t)2 * d.B * d.R * sizeof(unsigned long long), s);

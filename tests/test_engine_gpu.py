@@ -977,24 +977,27 @@ def test_bench_configuration_against_the_oracle_where_screening_was_closest(data
 
 
 def test_integral_image_falls_back_to_the_sequential_order_when_sums_are_inexact(data_dir, surrogate, orc):
-    """The integral image is built by parallel scans whose every fp64 addition is checked for exactness; exact sums are
-    order independent, so the result equals cv::integral's sequential order bit for bit (calc_intimage, server.cpp:577-613).
-    Heights that differ by more than 2^29 in magnitude make partial sums inexact: those grids must be flagged and redone
-    in the sequential order -- and still match the oracle bit for bit.  Ordinary clouds never take the fallback."""
+    """Beyond ~70 x 70 cells the integral image is built by parallel scans whose every fp64 addition is checked for exactness;
+    exact sums are order independent, so the result equals cv::integral's sequential order bit for bit (calc_intimage,
+    server.cpp:577-613).  Heights that differ by more than 2^29 in magnitude make partial sums inexact: those grids must be
+    flagged and redone in the sequential order -- and still match the oracle bit for bit.  Ordinary clouds never take the
+    fallback; small grids (the reference's 56 x 56) are summed sequentially in LDS in the first place."""
     rng = np.random.RandomState(21)
-    xyz = models.synthetic_cloud(grid=56, k=2, seed=3)
-    tiny = (-0.15 + rng.randint(1, 4000, size=len(xyz)) * 2.0 ** -26).astype(np.float32)      # heights of a few 2^-26 .. 2^-14
-    xyz[:, 2] = tiny
-    big = rng.choice(len(xyz), 40, replace=False)
-    xyz[big, 2] = (1.0e9 * (1.0 + rng.uniform(0, 1, size=40))).astype(np.float32)              # and some of ~2^30
-    inp = dict(grasp_area_length_x=56, grasp_area_length_y=56)
-    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16)
-    compare_full(eng, orc, xyz, dict(n_rolls=12), inp, check_dec=False)
-    assert eng.last_prestage()["n_inexact_grids"] > 0
-    ordinary = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
-    compare_full(eng, orc, ordinary, dict(n_rolls=12), inp)
-    assert eng.last_prestage()["n_inexact_grids"] == 0
-    eng.close()
+    for grid in (96, 56):
+        xyz = models.synthetic_cloud(grid=grid, k=2, seed=3)
+        tiny = (-0.15 + rng.randint(1, 4000, size=len(xyz)) * 2.0 ** -26).astype(np.float32)   # heights of a few 2^-26 .. 2^-14
+        xyz[:, 2] = tiny
+        big = rng.choice(len(xyz), 40, replace=False)
+        xyz[big, 2] = (1.0e9 * (1.0 + rng.uniform(0, 1, size=40))).astype(np.float32)           # and some of ~2^30
+        inp = dict(grasp_area_length_x=grid, grasp_area_length_y=grid)
+        eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16, grid_h=grid, grid_w=grid, n_rolls=6, roll_step_deg=30)
+        cfg = dict(n_rolls=6, roll_step_deg=30, grid_h=grid, grid_w=grid)
+        compare_full(eng, orc, xyz, cfg, inp, check_dec=False)
+        assert (eng.last_prestage()["n_inexact_grids"] > 0) == (grid == 96)
+        ordinary = models.synthetic_cloud(grid=grid, k=2, seed=4)
+        compare_full(eng, orc, ordinary, cfg, inp)
+        assert eng.last_prestage()["n_inexact_grids"] == 0
+        eng.close()
 
 
 @pytest.mark.parametrize("in_kw", [dict(), dict(approach_vector=(0.2, -0.1, 1.0)), dict(gripper_opening_width=2),
