@@ -13,6 +13,7 @@
 //   --gpus N [--shard rolls|clouds]   N GPUs of this node in ONE process through haf_create_multi: the rolls of every request
 //                                     sharded with one RCCL all-gather of the roll records (default), or the clouds given on
 //                                     the command line sharded with one RCCL all-reduce(max) electing the best grasp
+//   --shards-per-gpu K                K shards on every GPU (they share its RCCL rank)
 //   --hypotheses                      also print the per-roll hypotheses the server publishes when show_only_best is off
 //                                     (server.cpp:962-969), in its string format
 #include "../../include/hafgrasp.h"
@@ -28,10 +29,14 @@
 static void usage();
 
 // --gpus N: the same requests through the multi-device front end of the C-ABI
-static int run_multi(haf_config cfg, const haf_grasp_input &in, int gpus, const std::string &shard, int argc, char **argv, int first_cloud)
+static int run_multi(haf_config cfg, const haf_grasp_input &in, int gpus, int shards_per_gpu, const std::string &shard, int argc, char **argv,
+                     int first_cloud)
 {
-    std::vector<int32_t> devices((size_t)gpus);
-    for (int g = 0; g < gpus; g++) devices[(size_t)g] = g;
+    // shards_per_gpu > 1: every GPU carries several shards (they share its RCCL rank): also how a one-GPU machine runs sharded
+    std::vector<int32_t> devices;
+    for (int k = 0; k < shards_per_gpu; k++)
+        for (int g = 0; g < gpus; g++) devices.push_back(g);
+    gpus = (int)devices.size();
     const bool by_cloud = shard == "clouds";
     const int n_clouds = argc - first_cloud;
     if (by_cloud) cfg.max_clouds = n_clouds;
@@ -80,7 +85,7 @@ static void usage()
             "usage: haf_grasp_cli --features F --range R --model M [options] cloud.pcd [cloud2.pcd ...]\n"
             "  --center x y z  --search-size x y  --approach x y z  --max-time s  --show-only-best  --gripper-width w\n"
             "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll  --hypotheses\n"
-            "  --gpus N [--shard rolls|clouds]\n");
+            "  --gpus N [--shard rolls|clouds] [--shards-per-gpu K]\n");
 }
 
 int main(int argc, char **argv)
@@ -91,7 +96,7 @@ int main(int argc, char **argv)
     haf_grasp_input_default(&in);
     double sx = 18, sy = 30;                       // launch defaults (launch/haf_grasping_all.launch:25-65)
     bool per_roll = false, hypotheses = false;
-    int gpus = 0;
+    int gpus = 0, shards_per_gpu = 1;
     std::string shard = "rolls";
     std::string features, range, model;
     int first_cloud = argc;
@@ -115,6 +120,7 @@ int main(int argc, char **argv)
         else if (a == "--hypotheses") hypotheses = true;
         else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--shard") { need(1); shard = argv[++i]; }
+        else if (a == "--shards-per-gpu") { need(1); shards_per_gpu = atoi(argv[++i]); if (shards_per_gpu < 1) shards_per_gpu = 1; }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { first_cloud = i; break; }
     }
@@ -126,7 +132,7 @@ int main(int argc, char **argv)
     cfg.model_file = model.c_str();
     cfg.max_points = 1 << 22;
 
-    if (gpus > 0) return run_multi(cfg, in, gpus, shard, argc, argv, first_cloud);
+    if (gpus > 0) return run_multi(cfg, in, gpus, shards_per_gpu, shard, argc, argv, first_cloud);
 
     haf_engine *eng = nullptr;
     if (haf_create(&cfg, &eng) != HAF_OK) { fprintf(stderr, "haf_create: %s\n", haf_last_error(nullptr)); return 1; }

@@ -465,6 +465,14 @@ def test_cli_and_server_mirror(data_dir, golden_dir, surrogate):
                            os.path.join(data_dir, "pcd2.pcd")], check=True, capture_output=True, text=True)
     # (RCCL may print its version banner to stdout when NCCL_DEBUG is set on the box: the result is the last line)
     assert out1.stdout.strip().splitlines()[-1].split() == tok and "1 shards on 1 RCCL ranks" in out1.stderr
+    # rolls of pcd2/C2 sharded 3 ways (4 + 4 + 4) on this box's one GPU, and -- where the box has more -- over two GPUs
+    out3 = subprocess.run([cli, "--features", f_, "--range", r_, "--model", surrogate, "--search-size", "18", "18", "--gpus", "1",
+                           "--shards-per-gpu", "3", os.path.join(data_dir, "pcd2.pcd")], check=True, capture_output=True, text=True)
+    assert out3.stdout.strip().splitlines()[-1].split() == tok and "3 shards on 1 RCCL ranks" in out3.stderr
+    if _n_gpus() >= 2:
+        out2 = subprocess.run([cli, "--features", f_, "--range", r_, "--model", surrogate, "--search-size", "18", "18", "--gpus", "2",
+                               os.path.join(data_dir, "pcd2.pcd")], check=True, capture_output=True, text=True)
+        assert out2.stdout.strip().splitlines()[-1].split() == tok and "2 shards on 2 RCCL ranks" in out2.stderr
 
 
 def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
