@@ -60,7 +60,8 @@ constexpr int kS0BlockEvals = kS0Waves * kS0WaveEvals;
 constexpr int kS0K = 320;                             // slots
 constexpr int kS0Groups = kS0K / 8;                   // 40 groups of 8 slots (feature kernels)
 constexpr int kS0MatBytes = kHFull * 2048;            // one 32 x 320 fp16 operand image = 20 KiB (h_image_offset, k < 320)
-constexpr int kS0WavePieces = 6;                      // LDS-DMA pieces a wave stages per tile (4 x 6 = 24 >= 21: three go twice)
+constexpr int kS0WavePieces = 5;                      // LDS-DMA pieces of the operand image a wave stages per tile (4 x 5 = 20 KiB);
+                                                      // the 21st piece (t_n, coefficients) is wave 0's
 constexpr int kS0SvTileBytes = 21504;                 // fp16 image (20480 B) + 32 floats t_n = -|v_n|^2/2 + 32 coefficients, padded to 21 KiB
 constexpr int kS0Pieces = kS0SvTileBytes / 1024;      // 21 LDS-DMA wave instructions
 constexpr int kS0Buffers = 3;

@@ -48,7 +48,9 @@ __device__ __forceinline__ void dma_piece(const char *gbase, unsigned lds_dst, u
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(lane16), "s"(gbase) : "memory", "m0");
 }
 
-// the six pieces of one SV tile this wave stages (21 pieces over 4 waves x 6: pieces 0..2 go twice)
+// the five pieces of one SV tile's operand image this wave stages (20 pieces over 4 waves; round 1 spread 22 pieces as 4 x 6 with
+// two of them staged twice -- an eighth of the DMA instructions for nothing).  The 21st piece (t_n and the coefficients, 256
+// bytes of it used) is staged by wave 0 alone, outside the MFMA stream.
 struct TileDma {
     const char *g[kS0WavePieces];
     unsigned l[kS0WavePieces];
@@ -75,12 +77,12 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // it (wrong sums on some waves of some launches; hipcc pads one wait state, which is not enough).  Every exp result
 // here is consumed one whole k-step (>= 4 MFMAs, >= 8 instructions) after it was issued; haf_grasping_amd/build.py checks
 // that distance in the ISA of every build.
-// The wave's three LDS-DMA pieces of the tile two ahead are issued behind the first MFMAs of k-step 0 (which carries no
+// The wave's LDS-DMA pieces of the tile two ahead are issued behind the first MFMAs of k-step 0 (which carries no
 // epilogue work), inside the MFMA stream instead of all waves paying for them together behind the tile barrier.
 // No branch may sit inside this stream: with the DMA under a wave-uniform `if`, hipcc's code motion carries the epilogue of
 // the block out of the MFMA stream (into the next basic block), and with two template instantiations in the arms of an
-// if/else it hoists the epilogue they have in common in front of the branch.  So every wave issues DMA in every block:
-// pieces 0..2 of the tile two ahead in column block 0, pieces 3..5 in column block 1 (FIRST = first piece, COUNT = how many).
+// if/else it hoists the epilogue they have in common in front of the branch.  So every wave issues the same DMA in every block:
+// its pieces 0..2 of the tile two ahead in column block 0, its pieces 3..4 in column block 1 (FIRST = first piece, COUNT = how many).
 // SUMSQ (the variant for ill-conditioned models): the epilogue also accumulates q += (coef K)^2, so that the sqrt(S) form of the
 // band can use |w|_2^2 = sum_n (coef_n K_n)^2 itself instead of its bound max|coef| * S: three VALU instructions
 // per element behind the exp instead of one.
@@ -203,15 +205,16 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
 
     const unsigned lane16 = (unsigned)lane * 16u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int poff[kS0WavePieces];                                         // byte offsets of this wave's six pieces inside a tile
+    int poff[kS0WavePieces];                                         // byte offsets of this wave's five image pieces inside a tile
 #pragma unroll
-    for (int q = 0; q < kS0WavePieces; q++) {
-        int pq = wave_u + kS0Waves * q;
-        if (pq >= kS0Pieces) pq -= kS0Pieces;
-        poff[q] = pq * 1024;
-    }
+    for (int q = 0; q < kS0WavePieces; q++) poff[q] = (wave_u + kS0Waves * q) * 1024;    // pieces 0..19, each exactly once
+    static_assert(kS0Waves * kS0WavePieces * 1024 == kS0MatBytes && kS0MatBytes + 1024 == kS0SvTileBytes, "20 image pieces + 1 tail piece");
     stage_sv_tile_s0(tile_dma(svt0, lds0, poff), lane16);                                                      // tile 0
-    if (nt > 1) stage_sv_tile_s0(tile_dma(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, poff), lane16);   // tile 1
+    if (wave_u == 0) dma_piece(svt0 + kS0MatBytes, lds0 + kS0MatBytes, lane16);
+    if (nt > 1) {                                                                                              // tile 1
+        stage_sv_tile_s0(tile_dma(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, poff), lane16);
+        if (wave_u == 0) dma_piece(svt0 + (size_t)kS0SvTileBytes + kS0MatBytes, lds0 + kS0SvTileBytes + kS0MatBytes, lane16);
+    }
 
     // A fragments: row block m = 0..3 (rows 16m..16m+15 of the wave's 64); lane holds A[16m + (lane&15)][32s + 8(lane>>4) + j]
     // read once, with the nt hint: 5 GB of operands stream past the 2.8 MB of SV tiles that every workgroup re-reads from L2
@@ -260,17 +263,20 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         float cf_prev = 0.0f;                                        // the first deferred epilogue adds 0 * exp2(0)
         for (int t = ph ? d.sv_tile_neg : 0; t < t_end; t++) {
             const char *cur = lds + (t % kS0Buffers) * kS0SvTileBytes;
-            // always six DMA pieces per wave and tile, so the wait below is one constant: past the last tile the ring
-            // slot that nobody reads any more is refilled with tile (t+2) mod nt
+            // always the same DMA pieces per wave and tile, so the wait below is one constant per wave: past the last tile the
+            // ring slot that nobody reads any more is refilled with tile (t+2) mod nt
             const int tn = (t + 2) % nt;
             const TileDma dma = tile_dma(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, poff);
+            // wave 0: the tail piece of that tile, here -- in front of the MFMA stream, where a branch does no harm
+            if (wave_u == 0) dma_piece(svt0 + (size_t)tn * kS0SvTileBytes + kS0MatBytes,
+                                       lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes + kS0MatBytes, lane16);
             const float *tt = reinterpret_cast<const float *>(cur + kS0MatBytes);
             const float t0 = tt[lane & 15], t1 = tt[16 + (lane & 15)];   // t_n of this lane's column in either block
             const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];   // and its coefficient (0 for padding SVs)
             // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0
             half8 bf0, bf1;                                          // B fragments in flight, handed from block 0 to block 1
             screen_block<0, 3, SUMSQ>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, sq, dma, lane16, bf0, bf1);
-            screen_block<3, 3, SUMSQ>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, sq, dma, lane16, bf0, bf1);
+            screen_block<3, 2, SUMSQ>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, sq, dma, lane16, bf0, bf1);
             cf_prev = cf1;
             if (!SUMSQ && ++fold == 8) {                             // wave-uniform, outside the MFMA stream
                 fold = 0;
@@ -279,11 +285,13 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
 #pragma unroll
                     for (int r = 0; r < 4; r++) { part[m][r] += sum[m][r]; sum[m][r] = 0.0f; }
             }
-            // tile t+1 must have landed before anyone reads it; the six pieces just issued may stay in flight
+            // tile t+1 must have landed before anyone reads it; the five image pieces just issued may stay in flight.  (Wave 0
+            // has a sixth in the queue, the tail piece: it went out first, a whole tile ago, so waiting for it too costs
+            // nothing and keeps this one constant -- a branch here makes hipcc reschedule the epilogue behind it.)
 #if SCREEN_ABL == 3
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
 #endif
 #if SCREEN_ABL != 4
             __builtin_amdgcn_s_barrier();
