@@ -181,7 +181,7 @@ hafo_model *hafo_model_load(const char *path)
     hafo_model *m = (hafo_model *)calloc(1, sizeof(*m));
     m->svm_type = -1; m->kernel_type = -1;
     char cmd[81];
-    int ok = 1, have_sv = 0;
+    int ok = 1, have_sv = 0, have_a = 0, have_b = 0;
     while (ok) {
         if (fscanf(fp, "%80s", cmd) != 1) { ok = 0; break; }
         if (!strcmp(cmd, "svm_type")) {
@@ -203,7 +203,8 @@ hafo_model *hafo_model_load(const char *path)
         } else if (!strcmp(cmd, "label")) {
             if (m->nr_class != 2) { ok = 0; break; }
             ok = fscanf(fp, "%d %d", &m->label[0], &m->label[1]) == 2;
-        } else if (!strcmp(cmd, "probA") || !strcmp(cmd, "probB")) { double d; ok = fscanf(fp, "%lf", &d) == 1; }
+        } else if (!strcmp(cmd, "probA")) { ok = m->nr_class == 2 && fscanf(fp, "%lf", &m->probA) == 1; have_a = 1; }   /* 2811-2817 */
+        else if (!strcmp(cmd, "probB")) { ok = m->nr_class == 2 && fscanf(fp, "%lf", &m->probB) == 1; have_b = 1; }     /* 2818-2824 */
         else if (!strcmp(cmd, "nr_sv")) {
             if (m->nr_class != 2) { ok = 0; break; }
             ok = fscanf(fp, "%d %d", &m->nSV[0], &m->nSV[1]) == 2;
@@ -217,6 +218,7 @@ hafo_model *hafo_model_load(const char *path)
     if (!ok || !have_sv || m->nr_class != 2 || m->kernel_type != 2 || m->svm_type > 1 || m->l <= 0) {
         fclose(fp); free(m); return NULL;
     }
+    m->has_prob = have_a && have_b;
     long pos = ftell(fp);
     fseek(fp, 0, SEEK_END);
     long end = ftell(fp);
@@ -572,6 +574,132 @@ int hafo_label_gridval(int label)
 }
 
 /* ------------------------------------------------------------------ */
+/* f4: probability output (svm.cpp:1818-1888, 2550-2587)               */
+/* ------------------------------------------------------------------ */
+static double sigmoid_predict(double decision_value, double A, double B)     /* svm.cpp:1818-1826 */
+{
+    double fApB = decision_value * A + B;
+    if (fApB >= 0) return exp(-fApB) / (1.0 + exp(-fApB));
+    else return 1.0 / (1 + exp(fApB));
+}
+
+/* multiclass_probability (svm.cpp:1829-1888), k = 2, same operations in the same order */
+static void multiclass_probability2(double r[2][2], double p[2])
+{
+    const int k = 2;
+    int t, j, iter = 0, max_iter = 100;                                       /* max(100, k) */
+    double Q[2][2], Qp[2], pQp, eps = 0.005 / k;
+    for (t = 0; t < k; t++) {
+        p[t] = 1.0 / k;
+        Q[t][t] = 0;
+        for (j = 0; j < t; j++) { Q[t][t] += r[j][t] * r[j][t]; Q[t][j] = Q[j][t]; }
+        for (j = t + 1; j < k; j++) { Q[t][t] += r[j][t] * r[j][t]; Q[t][j] = -r[j][t] * r[t][j]; }
+    }
+    for (iter = 0; iter < max_iter; iter++) {
+        pQp = 0;
+        for (t = 0; t < k; t++) {
+            Qp[t] = 0;
+            for (j = 0; j < k; j++) Qp[t] += Q[t][j] * p[j];
+            pQp += p[t] * Qp[t];
+        }
+        double max_error = 0;
+        for (t = 0; t < k; t++) {
+            double error = fabs(Qp[t] - pQp);
+            if (error > max_error) max_error = error;
+        }
+        if (max_error < eps) break;
+        for (t = 0; t < k; t++) {
+            double diff = (-Qp[t] + pQp) / Q[t][t];
+            p[t] += diff;
+            pQp = (pQp + diff * (diff * Q[t][t] + 2 * Qp[t])) / (1 + diff) / (1 + diff);
+            for (j = 0; j < k; j++) {
+                Qp[j] = (Qp[j] + diff * Q[t][j]) / (1 + diff);
+                p[j] /= (1 + diff);
+            }
+        }
+    }
+}
+
+int hafo_probability(const hafo_model *m, double dec, double prob[2])            /* svm.cpp:2550-2587 */
+{
+    if (!m->has_prob) return 0;
+    const double min_prob = 1e-7;
+    double r[2][2] = {{0, 0}, {0, 0}};
+    double s = sigmoid_predict(dec, m->probA, m->probB);
+    s = s > min_prob ? s : min_prob;                                              /* max(.., min_prob) */
+    s = s < 1 - min_prob ? s : 1 - min_prob;                                      /* min(.., 1 - min_prob) */
+    r[0][1] = s;
+    r[1][0] = 1 - r[0][1];
+    multiclass_probability2(r, prob);
+    return prob[1] > prob[0] ? m->label[1] : m->label[0];                         /* first maximum */
+}
+
+/* server.cpp:831-841 on one line of the output file: int res = atof(line.substr(0,2)); the first or (res > 0) second number
+ * behind the label; float prob = atof(...); the cell gets res*prob.  std::string::find's npos becomes -1 in the reference's
+ * `int` variables and a huge length in substr(pos, len): "to the end of the line". */
+float hafo_probability_gridval(const char *line)
+{
+    const int len = (int)strlen(line);
+    char two[3] = {0, 0, 0};
+    for (int i = 0; i < 2 && i < len; i++) two[i] = line[i];
+    int res = (int)atof(two);
+    int start = -1, end = -1;
+    for (int i = 0; i < len; i++) if (line[i] == ' ') { start = i; break; }
+    if (start >= 0) for (int i = start + 1; i < len; i++) if (line[i] == ' ') { end = i; break; }
+    if (res > 0) {
+        start = end;
+        end = -1;
+        if (start >= 0) for (int i = start + 1; i < len; i++) if (line[i] == ' ') { end = i; break; }
+    }
+    if (start < 0 || start > len) return NAN;               /* the reference would throw std::out_of_range here */
+    char tmp[128];
+    int n = end < 0 ? len - start : end;                     /* substr(pos, LEN): `end` is used as a length */
+    if (n > len - start) n = len - start;
+    if (n > (int)sizeof tmp - 1) n = (int)sizeof tmp - 1;
+    memcpy(tmp, line + start, (size_t)n);
+    tmp[n] = 0;
+    float prob = (float)atof(tmp);
+    return res * prob;
+}
+
+/* server.cpp:865-932 with the float cell values of the probability branch: the 29 products and their sum in fp32, left to
+ * right; topval_gp is an int, so every assignment truncates and every comparison converts it back */
+void hafo_vote_f(const hafo_cfg *cfg, const float *g, float *ev, int best[3])
+{
+    const int H = cfg->H, W = cfg->W;
+    const int w1 = 1, w2 = 2, w3 = 3, w4 = 4, w5 = 55;
+    int topval = -1000, id_row = -1, id_col = -1;
+#define G(r, c) (g[(r) * W + (c)])
+    for (int row = 0; row < H; row++)
+        for (int col = 0; col < W; col++) {
+            float v;
+            if (G(row, col) < 0 || row < 2 || row >= H - 2 || col < 4 || col >= W - 4) {
+                v = 0;
+            } else {
+                v = w1 * G(row - 2, col - 2) + w2 * G(row - 2, col - 1) + w3 * G(row - 2, col) + w2 * G(row - 2, col + 1) + w1 * G(row - 2, col + 2) +
+                    w2 * G(row - 1, col - 2) + w3 * G(row - 1, col - 1) + w4 * G(row - 1, col) + w3 * G(row - 1, col + 1) + w2 * G(row - 1, col + 2) +
+                    w2 * G(row, col - 4) + w2 * G(row, col - 3) + w3 * G(row, col - 2) + w4 * G(row, col - 1) + w5 * G(row, col) + w4 * G(row, col + 1) + w3 * G(row, col + 2) + w2 * G(row, col + 3) + w2 * G(row, col + 4) +
+                    w2 * G(row + 1, col - 2) + w3 * G(row + 1, col - 1) + w4 * G(row + 1, col) + w3 * G(row + 1, col + 1) + w2 * G(row + 1, col + 2) +
+                    w1 * G(row + 2, col - 2) + w2 * G(row + 2, col - 1) + w3 * G(row + 2, col) + w2 * G(row + 2, col + 1) + w1 * G(row + 2, col + 2);
+            }
+            ev[row * W + col] = v;
+            if (v > topval) { topval = (int)v; id_row = row; id_col = col; }   /* 882-885 */
+        }
+#undef G
+    int longest = 0;                                                           /* 904-932 */
+    for (int row = 0; row < H; row++) {
+        int cur = 0;
+        for (int col = 0; col < W; col++) {
+            if (ev[row * W + col] == topval) {
+                cur++;
+                if (cur > longest) { longest = cur; id_row = row; id_col = col - cur / 2; }
+            } else cur = 0;
+        }
+    }
+    best[0] = id_row; best[1] = id_col; best[2] = topval;
+}
+
+/* ------------------------------------------------------------------ */
 /* a10: vote, argmax, run centring (server.cpp:865-932)                */
 /* ------------------------------------------------------------------ */
 void hafo_vote(const hafo_cfg *cfg, const signed char *g, float *ev, int best[3])
@@ -708,6 +836,8 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
     const int nx = nf > m->D ? nf : m->D;
     double *xs = (double *)malloc(sizeof(double) * (size_t)nx);
     const int gv0 = hafo_label_gridval(m->label[0]), gv1 = hafo_label_gridval(m->label[1]);
+    if (cfg->probability && !m->has_prob) return -2;
+    float *gridf = cfg->probability ? (float *)malloc(sizeof(float) * (size_t)H * W) : NULL;
 
     int o_row = -1, o_col = -1, o_roll = -1, o_top = -1000;       /* 322-326 */
     long n_evals = 0;
@@ -731,6 +861,8 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
 
         for (int i = 0; i < H * W; i++) grid[i] = -1;              /* 828-829 */
         if (dbg && dbg->dec) for (int i = 0; i < H * W; i++) dbg->dec[(size_t)roll * H * W + i] = NAN;
+        double *row_prob = cfg->probability ? (double *)malloc(sizeof(double) * 2 * (size_t)(rows > 0 ? rows : 1)) : NULL;
+        int *row_label = cfg->probability ? (int *)malloc(sizeof(int) * (size_t)(rows > 0 ? rows : 1)) : NULL;
         /* rows are independent: the only parallel region of the oracle (HAFO_THREADS, default 1), used by the
          * all-cores CPU baseline of bench.py; per-row arithmetic and its order are untouched */
 #pragma omp parallel num_threads(hafo_threads())
@@ -743,16 +875,44 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
                 double dec = decision_nx2(m, xs_t, nx, &sabs);
                 if (dbg && dbg->sabs) dbg->sabs[(size_t)roll * H * W + cells[r]] = sabs;
                 int label = dec > 0 ? m->label[0] : m->label[1];       /* svm.cpp:2516-2531 */
+                if (cfg->probability) {                                /* svm-predict -b 1: svm-predict.c:111-118 */
+                    label = hafo_probability(m, dec, row_prob + 2 * r);
+                    row_label[r] = label;
+                }
                 grid[cells[r]] = (signed char)(label == m->label[0] ? gv0 : gv1);
                 if (dbg && dbg->dec) dbg->dec[(size_t)roll * H * W + cells[r]] = dec;
             }
             free(xs_t);
         }
         n_evals += rows;
-        free(q4); free(cells); free(fmin); free(fmax);
-
         int best[3];
-        hafo_vote(cfg, grid, ev, best);
+        if (cfg->probability) {
+            /* show_predicted_gps 815-816, 824-848: ONE getline before the loops, so the k-th masked cell (row-major) is filled
+             * from line k of the output file -- and line 0 is the "labels" header (svm-predict.c:60-64): every cell holds the
+             * prediction of the masked cell BEFORE it, the first one what the header parses to, the last row is never read */
+            char line[160];
+            snprintf(line, sizeof line, "labels %d %d", m->label[0], m->label[1]);
+            for (int i = 0; i < H * W; i++) gridf[i] = -1;             /* 828-829 */
+            if (dbg && dbg->prob) for (int i = 0; i < 2 * H * W; i++) dbg->prob[(size_t)roll * 2 * H * W + i] = NAN;
+            for (long r = 0; r < rows; r++) {                          /* cells[] is row-major (a4) */
+                gridf[cells[r]] = hafo_probability_gridval(line);
+                char t0[32], t1[32], tl[32];
+                snprintf(tl, sizeof tl, "%g", (double)row_label[r]);   /* svm-predict.c:114-117 */
+                snprintf(t0, sizeof t0, "%g", row_prob[2 * r]);
+                snprintf(t1, sizeof t1, "%g", row_prob[2 * r + 1]);
+                snprintf(line, sizeof line, "%s %s %s", tl, t0, t1);
+                if (dbg && dbg->prob) {
+                    dbg->prob[((size_t)roll * H * W + cells[r]) * 2] = strtod(t0, NULL);
+                    dbg->prob[((size_t)roll * H * W + cells[r]) * 2 + 1] = strtod(t1, NULL);
+                }
+            }
+            hafo_vote_f(cfg, gridf, ev, best);
+            if (dbg && dbg->graspsgrid) memcpy(dbg->graspsgrid + (size_t)roll * H * W, gridf, sizeof(float) * (size_t)H * W);
+        } else {
+            hafo_vote(cfg, grid, ev, best);
+        }
+        free(q4); free(cells); free(fmin); free(fmax); free(row_prob); free(row_label);
+
         if (best[2] > o_top) { o_row = best[0]; o_col = best[1]; o_roll = roll; o_top = best[2]; }   /* 953-960 */
         rolls_done++;
 
@@ -805,7 +965,7 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
         out->av[0] = M_last[8]; out->av[1] = M_last[9]; out->av[2] = M_last[10];   /* 1370-1374, 1398-1400 */
         out->roll = (float)((o_roll * cfg->roll_step_deg * HAFO_PI) / 180);       /* 1401 */
     }
-    free(heights_all); free(ii); free(mask); free(grid); free(ev); free(xs);
+    free(heights_all); free(ii); free(mask); free(grid); free(ev); free(xs); free(gridf);
     return 0;
 }
 

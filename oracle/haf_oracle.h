@@ -58,6 +58,8 @@ typedef struct {
     int    D;                 /* max attribute index seen in the SVs */
     double *coef;             /* [l]                                  */
     double *sv;               /* dense [l][D], attribute k at column k-1 */
+    int    has_prob;          /* probA and probB both present (svm.cpp:2811-2824): svm_check_probability_model, 3098-3104 */
+    double probA, probB;      /* the pair (0,1) sigmoid of a 2-class model */
 } hafo_model;
 
 hafo_features *hafo_features_load(const char *path);
@@ -77,6 +79,7 @@ typedef struct {
     int   graspval_top;      /* 119 (203) */
     int   nshaf;             /* nr_features_without_shaf = 302 (224) */
     int   skip_text;         /* test knob: 0 = go through both decimal text round trips (reference behaviour) */
+    int   probability;       /* svm_with_probability (server.cpp:383, 791, 831-841): "svm-predict -b 1" and the float vote */
 } hafo_cfg;
 
 typedef struct {
@@ -107,6 +110,9 @@ typedef struct {
     int           *roll_best;  /* [R][3] row, col, val after run-centring */
     float         *M;          /* [R][16] row-major transform */
     double        *sabs;       /* [R][H][W] sum_n |coef_n| K_n: the cancellation scale of the decision value */
+    double        *prob;       /* [R][H][W][2] probability mode: the two "%g" probabilities svm-predict -b 1 prints for the
+                                  cell's own row, as strtod reads them back; NaN where unmasked */
+    float         *graspsgrid; /* [R][H][W] probability mode: the value show_predicted_gps stores for the cell (831-841) */
 } hafo_debug;
 
 /* ---- stage functions (each cites the reference lines it follows) ---- */
@@ -131,6 +137,14 @@ double hafo_q4(float v);   /* float -> "%.4g" -> strtod   (fv.cpp:133, svm-scale
 double hafo_q6(double v);  /* double -> "%g"  -> strtod   (svm-scale.c:350, svm-predict.c:108) */
 double hafo_decision(const hafo_model *m, const double *xs /* dense [m->D] */);
 int    hafo_label_gridval(int label); /* atoi(first two chars of "%g" of label) (svm-predict.c:127, server.cpp:843) */
+/* svm_predict_probability (svm.cpp:2550-2587) of a 2-class model with probA/probB on a decision value: the two
+ * probability estimates (sigmoid_predict 1818-1826, clamp to [1e-7, 1-1e-7], multiclass_probability 1829-1888 for k = 2)
+ * and the label it returns (the first maximum).  Returns 0 when the model has no probability information. */
+int    hafo_probability(const hafo_model *m, double dec, double prob[2]);
+/* the value show_predicted_gps (server.cpp:831-841) extracts from one line of "svm-predict -b 1" output */
+float  hafo_probability_gridval(const char *line);
+/* a10 with float cell values (probability mode): server.cpp:865-932 on res*prob instead of labels */
+void   hafo_vote_f(const hafo_cfg *cfg, const float *grid, float *graspseval, int best[3]);
 void hafo_vote(const hafo_cfg *cfg, const signed char *grid, float *graspseval, int best[3]);
 
 int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg, const hafo_model *m,

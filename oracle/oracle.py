@@ -20,7 +20,8 @@ def build():
 
 class Cfg(C.Structure):
     _fields_ = [("H", C.c_int), ("W", C.c_int), ("n_rolls", C.c_int), ("roll_step_deg", C.c_int),
-                ("z_shift", C.c_float), ("graspval_top", C.c_int), ("nshaf", C.c_int), ("skip_text", C.c_int)]
+                ("z_shift", C.c_float), ("graspval_top", C.c_int), ("nshaf", C.c_int), ("skip_text", C.c_int),
+                ("probability", C.c_int)]
 
 
 class Input(C.Structure):
@@ -37,7 +38,7 @@ class Output(C.Structure):
 class Debug(C.Structure):
     _fields_ = [("heights", C.c_void_p), ("integral", C.c_void_p), ("mask", C.c_void_p), ("labels", C.c_void_p),
                 ("dec", C.c_void_p), ("graspseval", C.c_void_p), ("roll_best", C.c_void_p), ("M", C.c_void_p),
-                ("sabs", C.c_void_p)]
+                ("sabs", C.c_void_p), ("prob", C.c_void_p), ("graspsgrid", C.c_void_p)]
 
 
 class Features(C.Structure):
@@ -53,7 +54,8 @@ class Range(C.Structure):
 class Model(C.Structure):
     _fields_ = [("svm_type", C.c_int), ("kernel_type", C.c_int), ("gamma", C.c_double), ("rho", C.c_double),
                 ("nr_class", C.c_int), ("l", C.c_int), ("nSV", C.c_int * 2), ("label", C.c_int * 2),
-                ("D", C.c_int), ("coef", C.POINTER(C.c_double)), ("sv", C.POINTER(C.c_double))]
+                ("D", C.c_int), ("coef", C.POINTER(C.c_double)), ("sv", C.POINTER(C.c_double)),
+                ("has_prob", C.c_int), ("probA", C.c_double), ("probB", C.c_double)]
 
 
 def lib():
@@ -86,6 +88,11 @@ def lib():
         L.hafo_feature_line.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
         L.hafo_scale_row.argtypes = [C.POINTER(Range), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.hafo_vote.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hafo_vote_f.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hafo_probability.restype = C.c_int
+        L.hafo_probability.argtypes = [C.POINTER(Model), C.c_double, C.POINTER(C.c_double)]
+        L.hafo_probability_gridval.restype = C.c_float
+        L.hafo_probability_gridval.argtypes = [C.c_char_p]
         L.hafo_transform.argtypes = [C.POINTER(Cfg), C.POINTER(Input), C.c_int, C.c_int, C.c_void_p]
         L.hafo_height_grid.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.hafo_integral.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_void_p]
@@ -108,8 +115,8 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_cfg(H=56, W=56, n_rolls=12, roll_step_deg=15, z_shift=0.15, graspval_top=119, nshaf=302, skip_text=0):
-    return Cfg(H, W, n_rolls, roll_step_deg, z_shift, graspval_top, nshaf, skip_text)
+def make_cfg(H=56, W=56, n_rolls=12, roll_step_deg=15, z_shift=0.15, graspval_top=119, nshaf=302, skip_text=0, probability=0):
+    return Cfg(H, W, n_rolls, roll_step_deg, z_shift, graspval_top, nshaf, skip_text, probability)
 
 
 def make_input(center=(0, 0, 0), length_x=32, length_y=32, approach=(0, 0, 1), show_only_best=0, gripper_width=1):
@@ -184,6 +191,12 @@ class Oracle:
         lib().hafo_decision_rows(self.m, _p(xs), xs.shape[0], _p(dec))
         return dec
 
+    def probability(self, dec):
+        """svm_predict_probability on a decision value: (label, p0, p1); None without probA/probB."""
+        pr = (C.c_double * 2)()
+        lab = lib().hafo_probability(self.m, float(dec), pr)
+        return (lab, pr[0], pr[1]) if self.m.contents.has_prob else None
+
     def run(self, xyz, cfg, inp, debug=True):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)
         assert xyz.ndim == 2 and xyz.shape[1] >= 3
@@ -197,8 +210,11 @@ class Oracle:
                           dec=np.full((R, H, W), np.nan, np.float64), graspseval=np.zeros((R, H, W), np.float32),
                           roll_best=np.full((R, 3), -1, np.int32), M=np.zeros((R, 16), np.float32),
                           sabs=np.zeros((R, H, W), np.float64))
-            dbg = Debug(*[_p(arrays[k]) for k in ("heights", "integral", "mask", "labels", "dec", "graspseval",
-                                                  "roll_best", "M", "sabs")])
+            if cfg.probability:
+                arrays.update(prob=np.full((R, H, W, 2), np.nan, np.float64), graspsgrid=np.full((R, H, W), -1, np.float32))
+            dbg = Debug(*[_p(arrays[k]) if k in arrays else None
+                          for k in ("heights", "integral", "mask", "labels", "dec", "graspseval", "roll_best", "M", "sabs",
+                                    "prob", "graspsgrid")])
         rc = lib().hafo_run(C.byref(cfg), self.ft, self.rg, self.m, _p(xyz), xyz.shape[0], xyz.shape[1],
                             C.byref(inp), C.byref(out), C.byref(dbg) if dbg else None)
         if rc != 0:

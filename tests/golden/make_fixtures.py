@@ -12,6 +12,10 @@ Outputs (all data, no code):
                           printed, and fp64 decision values from the REAL svm_predict_values (libsvm_ref.so).
   heart_scale*, g5_heart.npz  libsvm known-answer: reference svm-train -c 2 -g 0.5 heart_scale -> model, labels,
                           decision values (190 SVs, 259/270).
+  heart_scale_prob.model, g5_heart_prob.npz   probability output: reference svm-train -b 1 / svm-predict -b 1
+                          on heart_scale: printed labels and probabilities, unrounded svm_predict_probability estimates.
+  surrogate_prob.json, g23p_<cloud>_r<roll>.npz  probA/probB of the surrogate from the reference svm-train -b 1 (same SVs), and
+                          the reference svm-predict -b 1 output lines for the g23 rows.
   g6_end_to_end.json      per-roll (row, col, val), overall best and GraspOutput of the ORACLE for every cloud x
                           configuration: regression goldens for the GPU engine.
 """
@@ -192,6 +196,100 @@ def make_g5():
     np.savez_compressed(os.path.join(HERE, "g5_heart.npz"), X=X, y=y, labels=labels.astype(np.int8), dec=dec)
 
 
+def ref_probabilities(model_path, scaled_path):
+    """Unrounded probability estimates and labels straight from the reference svm_predict_probability (svm.cpp:2550)."""
+    L = C.CDLL(os.path.join(REF, "libsvm_ref.so"))
+
+    class Node(C.Structure):
+        _fields_ = [("index", C.c_int), ("value", C.c_double)]
+    L.svm_load_model.restype = C.c_void_p
+    L.svm_load_model.argtypes = [C.c_char_p]
+    L.svm_predict_probability.restype = C.c_double
+    L.svm_predict_probability.argtypes = [C.c_void_p, C.POINTER(Node), C.POINTER(C.c_double)]
+    m = L.svm_load_model(model_path.encode())
+    assert m
+    probs, labs = [], []
+    with open(scaled_path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            nodes = (Node * len(t))()
+            for i, tok in enumerate(t[1:]):
+                k, v = tok.split(":")
+                nodes[i].index = int(k)
+                nodes[i].value = float(v)
+            nodes[len(t) - 1].index = -1
+            pr = (C.c_double * 2)()
+            labs.append(L.svm_predict_probability(m, nodes, pr))
+            probs.append((pr[0], pr[1]))
+    return np.array(probs), np.array(labs)
+
+
+def read_prob_output(path):
+    """svm-predict -b 1 output: header 'labels a b', then 'label p(a) p(b)' per row (svm-predict.c:60-64, 111-118)."""
+    with open(path) as f:
+        lines = f.read().splitlines()
+    assert lines[0].split()[0] == "labels"
+    rows = [ln.split() for ln in lines[1:]]
+    return (lines[0], np.array([float(r[0]) for r in rows]), np.array([[float(r[1]), float(r[2])] for r in rows]),
+            [" ".join(r) for r in rows])
+
+
+def make_g5p():
+    """f4, libsvm side: reference svm-train -b 1 on heart_scale, svm-predict -b 1 on the same rows."""
+    dst = os.path.join(HERE, "heart_scale")
+    model = os.path.join(HERE, "heart_scale_prob.model")
+    run([os.path.join(REF, "svm-train"), "-b", "1", "-c", "2", "-g", "0.5", "-q", dst, model])
+    out = os.path.join(TMP, "heart_prob.out")
+    os.makedirs(TMP, exist_ok=True)
+    run([os.path.join(REF, "svm-predict"), "-b", "1", dst, model, out], stdout=subprocess.DEVNULL)
+    header, labels, prob_text, _ = read_prob_output(out)
+    dec, _ = ref_decisions(model, dst)
+    raw, lab2 = ref_probabilities(model, dst)
+    assert (labels == lab2).all()
+    np.savez_compressed(os.path.join(HERE, "g5_heart_prob.npz"), labels=labels.astype(np.int8), prob_text=prob_text, prob_raw=raw,
+                        dec=dec, header=np.array(header))
+    print("g5p:", header, "| +1:", int((labels > 0).sum()), "of", len(labels))
+
+
+def make_g23p(model):
+    """f4, hot path: the surrogate's training set through the reference svm-train -b 1 gives probA/probB for the SAME support
+    vectors (checked); the g23 rows through the reference svm-predict -b 1 give the lines show_predicted_gps would read."""
+    train = os.path.join(TMP, "train.txt")
+    if not os.path.exists(train):
+        sys.exit("run the 'surrogate' step first: it leaves the training rows in " + train)
+    pm = os.path.join(TMP, "surrogate_prob.model")
+    run([os.path.join(REF, "svm-train"), "-b", "1", "-c", "512", "-g", "0.0031", "-q", train, pm])
+    with open(pm) as f:
+        ptxt = f.read()
+    with open(model) as f:
+        mtxt = f.read()
+    assert ptxt.split("SV\n", 1)[1] == mtxt.split("SV\n", 1)[1], "svm-train -b 1 ended on other support vectors"
+    toks = {ln.split()[0]: ln.split()[1] for ln in ptxt.split("SV\n", 1)[0].splitlines() if ln.startswith("prob")}
+    with open(os.path.join(HERE, "surrogate_prob.json"), "w") as f:
+        json.dump(dict(probA=toks["probA"], probB=toks["probB"],
+                       note="printed by the reference svm-train -b 1 -c 512 -g 0.0031 on the surrogate's training rows; "
+                            "tests insert them into surrogate.model (tests/models.py: write_probability_model)"), f, indent=1)
+    orc = O.Oracle(FEATURES, RANGE, model)
+    cfg = O.make_cfg()
+    inp = O.make_input()
+    for name, roll in [("pcd2", 0), ("pcd2", 5), ("pcd3", 2), ("plastic_mug2", 7)]:
+        xyz = pcdio.load_pcd(os.path.join(DATA, name + ".pcd"))
+        fpath = os.path.join(TMP, "g_%s_%d.txt" % (name, roll))
+        orc.dump_feature_file(xyz, cfg, inp, roll, fpath)
+        with open(fpath + ".scale", "w") as out:
+            run([os.path.join(REF, "svm-scale"), "-r", RANGE, fpath], stdout=out)
+        run([os.path.join(REF, "svm-predict"), "-b", "1", fpath + ".scale", pm, fpath + ".pout"], stdout=subprocess.DEVNULL)
+        header, labels, prob_text, lines = read_prob_output(fpath + ".pout")
+        raw, lab2 = ref_probabilities(pm, fpath + ".scale")
+        assert (labels == lab2).all()
+        sel = slice(0, None, 3)     # the rows g23 keeps
+        np.savez_compressed(os.path.join(HERE, "g23p_%s_r%d.npz" % (name, roll)), labels=labels.astype(np.int8)[sel],
+                            prob_text=prob_text[sel], prob_raw=raw[sel], lines=np.array(lines[sel]), header=np.array(header))
+        print("g23p", name, roll, len(labels), "rows; +1:", int((labels > 0).sum()), "probA/B", toks)
+
+
 CONFIGS = {
     "C1": dict(cfg=dict(n_rolls=1), inp=dict(length_x=32, length_y=32)),
     "C2": dict(cfg=dict(n_rolls=12), inp=dict(length_x=32, length_y=32)),
@@ -237,7 +335,7 @@ def make_g6(model):
 
 if __name__ == "__main__":
     O.build()
-    what = sys.argv[1:] or ["surrogate", "g23", "g5", "g6"]
+    what = sys.argv[1:] or ["surrogate", "g23", "g5", "g6", "g5p", "g23p"]
     model = os.path.join(HERE, "surrogate.model")
     if "surrogate" in what:
         make_surrogate()
@@ -249,3 +347,7 @@ if __name__ == "__main__":
         make_g5()
     if "g6" in what:
         make_g6(model)
+    if "g5p" in what:
+        make_g5p()
+    if "g23p" in what:
+        make_g23p(model)

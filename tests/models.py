@@ -86,3 +86,13 @@ def write_replicated_model(path, base_model_path, copies=24, jitter=0.01, seed=0
                 % (keys["gamma"].strip(), len(out), float(keys["rho"]) * copies, keys["label"].strip(), n0 * copies, n1 * copies))
         f.write("\n".join(out) + "\n")
     return path
+
+
+def write_probability_model(dst, src, probA, probB):
+    """Copy of the libsvm model `src` with `probA` / `probB` header lines (text tokens) in svm_save_model's place for them
+    (svm.cpp:2641-2655: behind `label`, before `nr_sv`): what `svm-train -b 1` writes for the same support vectors."""
+    with open(src) as f:
+        head, body = f.read().split("nr_sv", 1)
+    with open(dst, "w") as f:
+        f.write(head + "probA %s\nprobB %s\nnr_sv" % (probA, probB) + body)
+    return dst

@@ -168,3 +168,117 @@ def test_live_against_reference_binaries(orc, data_dir, golden_dir, tmp_path):
         labels = np.loadtxt(f + ".out").astype(int).reshape(-1)
         mine = res["labels"][roll][res["mask"][roll] == 1]
         assert (labels == mine).all()
+
+
+# ---- probability output: svm_predict_probability, svm-predict -b 1, show_predicted_gps 831-841 ----------
+
+def _surrogate_prob_model(golden_dir, tmp_path):
+    import models
+    with open(os.path.join(golden_dir, "surrogate_prob.json")) as f:
+        pj = json.load(f)
+    return models.write_probability_model(str(tmp_path / "surrogate_prob.model"), os.path.join(golden_dir, "surrogate.model"),
+                                          pj["probA"], pj["probB"])
+
+
+def _g(x):
+    return float("%g" % x)
+
+
+def test_probability_known_answer_heart(golden_dir):
+    """The restated sigmoid + pairwise coupling against the reference library's svm_predict_probability (unrounded doubles,
+    bit for bit) and against what the reference svm-predict -b 1 printed, on heart_scale with a model from svm-train -b 1."""
+    g = np.load(os.path.join(golden_dir, "g5_heart_prob.npz"))
+    L = O.lib()
+    m = L.hafo_model_load(os.path.join(golden_dir, "heart_scale_prob.model").encode())
+    assert m and m.contents.has_prob
+    assert str(g["header"]) == "labels %d %d" % (m.contents.label[0], m.contents.label[1])
+    pr = (O.C.c_double * 2)()
+    for r in range(270):
+        lab = L.hafo_probability(m, float(g["dec"][r]), pr)
+        assert (pr[0], pr[1]) == tuple(g["prob_raw"][r]), r
+        assert lab == g["labels"][r]
+        assert (_g(pr[0]), _g(pr[1])) == tuple(g["prob_text"][r])
+    # a model without probA/probB has no probability output (svm_check_probability_model, svm.cpp:3098-3104)
+    m0 = L.hafo_model_load(os.path.join(golden_dir, "heart_scale.model").encode())
+    assert m0 and not m0.contents.has_prob and L.hafo_probability(m0, 0.5, pr) == 0
+
+
+@pytest.mark.parametrize("name", ["pcd2_r0", "pcd2_r5", "pcd3_r2", "plastic_mug2_r7"])
+def test_probability_rows_match_reference_tools(golden_dir, tmp_path, name):
+    """The g23 rows (decision values from the reference library) through the restated probability output: the reference's
+    unrounded estimates bit for bit, its printed line character for character, and the cell value show_predicted_gps takes
+    from such a line."""
+    g, gp = np.load(os.path.join(golden_dir, "g23_%s.npz" % name)), np.load(os.path.join(golden_dir, "g23p_%s.npz" % name))
+    L = O.lib()
+    m = L.hafo_model_load(_surrogate_prob_model(golden_dir, tmp_path).encode())
+    assert m and m.contents.has_prob and (m.contents.label[0], m.contents.label[1]) == (-1, 1)
+    pr = (O.C.c_double * 2)()
+    assert len(g["dec"]) == len(gp["labels"])
+    for r in range(len(gp["labels"])):
+        lab = L.hafo_probability(m, float(g["dec"][r]), pr)
+        assert (pr[0], pr[1]) == tuple(gp["prob_raw"][r]), r
+        assert lab == gp["labels"][r]
+        line = "%g %g %g" % (lab, pr[0], pr[1])
+        assert line == str(gp["lines"][r])
+        want = np.float32(lab) * np.float32(gp["prob_text"][r][1 if lab > 0 else 0])      # server.cpp:831-841
+        assert L.hafo_probability_gridval(line.encode()) == want
+    assert L.hafo_probability_gridval(str(gp["header"]).encode()) == 0.0                    # what the first cell gets
+
+
+def test_probability_mode_end_to_end_quirks(data_dir, golden_dir, tmp_path):
+    """show_predicted_gps with svm_with_probability: each masked cell holds the PREVIOUS masked cell's prediction (the one getline
+    in front of the loops reads the "labels" header), the first one 0; the vote is an fp32 sum and topval an int."""
+    mp = _surrogate_prob_model(golden_dir, tmp_path)
+    o = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"), mp)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    cfg, inp = O.make_cfg(probability=1), O.make_input()
+    r = o.run(xyz, cfg, inp)
+    r0 = o.run(xyz, O.make_cfg(), inp)
+    assert (r["mask"] == r0["mask"]).all() and np.array_equal(r["dec"], r0["dec"], equal_nan=True)
+    for roll in range(cfg.n_rolls):
+        cells = np.argwhere(r["mask"][roll] == 1)                 # row-major
+        g = r["graspsgrid"][roll]
+        assert (g[r["mask"][roll] == 0] == -1).all()
+        assert g[tuple(cells[0])] == 0
+        for k in range(1, len(cells)):
+            lab, p0, p1 = o.probability(r["dec"][roll][tuple(cells[k - 1])])
+            assert r["labels"][roll][tuple(cells[k - 1])] == lab
+            assert tuple(r["prob"][roll][tuple(cells[k - 1])]) == (_g(p0), _g(p1))
+            assert g[tuple(cells[k])] == np.float32(lab) * np.float32(_g(p1 if lab > 0 else p0))
+        ev = np.zeros((56, 56), np.float32)
+        best = np.zeros(3, np.int32)
+        O.lib().hafo_vote_f(O.C.byref(cfg), g.ctypes.data, ev.ctypes.data, best.ctypes.data)
+        assert (ev == r["graspseval"][roll]).all() and tuple(best) == tuple(r["roll_best"][roll])
+        assert best[2] == int(ev.max()) or ev.max() < 0
+    # a model without probA/probB cannot serve this mode
+    o0 = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"),
+                  os.path.join(golden_dir, "surrogate.model"))
+    with pytest.raises(RuntimeError):
+        o0.run(xyz, cfg, inp)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(O.ref_dir(), "svm-predict")), reason="oracle/_ref not built")
+def test_probability_live_against_reference_binary(data_dir, golden_dir, tmp_path):
+    """One roll's feature text through the REAL svm-scale and svm-predict -b 1: the oracle's lines, character for character."""
+    mp = _surrogate_prob_model(golden_dir, tmp_path)
+    o = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"), mp)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd12.pcd"))
+    cfg, inp = O.make_cfg(probability=1), O.make_input(length_y=44)
+    res = o.run(xyz, cfg, inp)
+    roll = 3
+    f = str(tmp_path / "f.txt")
+    o.dump_feature_file(xyz, cfg, inp, roll, f)
+    with open(f + ".scale", "w") as out:
+        subprocess.run([os.path.join(O.ref_dir(), "svm-scale"), "-r", os.path.join(data_dir, "range21062012_allfeatures"), f],
+                       stdout=out, check=True)
+    subprocess.run([os.path.join(O.ref_dir(), "svm-predict"), "-b", "1", f + ".scale", mp, f + ".out"],
+                   stdout=subprocess.DEVNULL, check=True)
+    with open(f + ".out") as fh:
+        lines = fh.read().splitlines()
+    cells = np.argwhere(res["mask"][roll] == 1)
+    assert lines[0] == "labels -1 1" and len(lines) == len(cells) + 1
+    for k, c in enumerate(cells):
+        lab = res["labels"][roll][tuple(c)]
+        p0, p1 = res["prob"][roll][tuple(c)]
+        assert lines[k + 1] == "%g %g %g" % (lab, p0, p1)
+        assert res["graspsgrid"][roll][tuple(c)] == O.lib().hafo_probability_gridval(lines[k].encode())
