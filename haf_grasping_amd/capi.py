@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("HAF_LIB", os.path.join(HERE, "libhafgrasp.so"))   # H
 TESTLIB_PATH = os.path.join(HERE, "libhafgrasp_testing.so")
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
-FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16 = 1, 2, 4, 8
-DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM, DBG_SCREEN_MARGIN = range(7)
+FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16, FLAG_PROBABILITY = 1, 2, 4, 8, 16
+DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM, DBG_SCREEN_MARGIN, DBG_PROBABILITY, DBG_GRASPSGRID = range(9)
 SHARD_ROLLS, SHARD_CLOUDS = 0, 1
 STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "refine", "recheck", "vote", "download"]
 
@@ -315,7 +315,8 @@ class Engine:
         H, W = self.cfg.grid_h, self.cfg.grid_w
         shape, dt = {DBG_HEIGHTS: ((H, W), np.float32), DBG_INTEGRAL: ((H + 1, W + 1), np.float32),
                      DBG_MASK: ((H, W), np.uint8), DBG_LABELS: ((H, W), np.int8), DBG_DECISION: ((H, W), np.float64),
-                     DBG_TRANSFORM: ((4, 4), np.float32), DBG_SCREEN_MARGIN: ((H, W), np.float32)}[what]
+                     DBG_TRANSFORM: ((4, 4), np.float32), DBG_SCREEN_MARGIN: ((H, W), np.float32),
+                     DBG_PROBABILITY: ((H, W, 2), np.float64), DBG_GRASPSGRID: ((H, W), np.float32)}[what]
         a = np.zeros(shape, dt)
         self._check(self._L.haf_debug_fetch(self._h, what, cloud, roll, a.ctypes.data, a.nbytes))
         return a

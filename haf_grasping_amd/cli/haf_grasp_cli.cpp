@@ -14,6 +14,7 @@
 //                                     sharded with one RCCL all-gather of the roll records (default), or the clouds given on
 //                                     the command line sharded with one RCCL all-reduce(max) electing the best grasp
 //   --shards-per-gpu K                K shards on every GPU (they share its RCCL rank)
+//   --probability                     svm_with_probability: "svm-predict -b 1" output as show_predicted_gps reads it (model with probA/probB)
 //   --hypotheses                      also print the per-roll hypotheses the server publishes when show_only_best is off
 //                                     (server.cpp:962-969), in its string format
 #include "../../include/hafgrasp.h"
@@ -84,7 +85,7 @@ static void usage()
     fprintf(stderr,
             "usage: haf_grasp_cli --features F --range R --model M [options] cloud.pcd [cloud2.pcd ...]\n"
             "  --center x y z  --search-size x y  --approach x y z  --max-time s  --show-only-best  --gripper-width w\n"
-            "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll  --hypotheses\n"
+            "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll  --hypotheses  --probability\n"
             "  --gpus N [--shard rolls|clouds] [--shards-per-gpu K]\n");
 }
 
@@ -118,6 +119,7 @@ int main(int argc, char **argv)
         else if (a == "--device") { need(1); cfg.device = atoi(argv[++i]); }
         else if (a == "--per-roll") per_roll = true;
         else if (a == "--hypotheses") hypotheses = true;
+        else if (a == "--probability") cfg.flags |= HAF_FLAG_PROBABILITY;     // svm_with_probability (server.cpp:383, 791, 831-841)
         else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--shard") { need(1); shard = argv[++i]; }
         else if (a == "--shards-per-gpu") { need(1); shards_per_gpu = atoi(argv[++i]); if (shards_per_gpu < 1) shards_per_gpu = 1; }

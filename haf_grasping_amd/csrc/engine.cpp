@@ -253,6 +253,12 @@ struct haf_engine {
     DevBuf<RollRecordDev> d_rec;
     DevBuf<unsigned long long> d_topkey;
     DevBuf<int> d_rowmax;           // best vote per grid row (k_vote_cells -> k_vote_pick)
+    // probability-output mode (HAF_FLAG_PROBABILITY, prob.hip): per-cell value of the cell's own output line, the grid
+    // show_predicted_gps builds from them, the fp32 votes, and the two "%g" probabilities per evaluation
+    DevBuf<float> d_own, d_gridf, d_evf;
+    DevBuf<double> d_ptext;
+    ProbParams prob{};
+    bool prob_mode = false;
     DevBuf<FeatDesc> d_fd, d_fd_slot;
     DevBuf<ScrDesc> d_sd;
     DevBuf<float> d_part1;
@@ -319,6 +325,21 @@ template <class F> int guarded(std::string *err, F &&f)
     return HAF_E_INTERNAL;
 }
 
+
+// What show_predicted_gps (server.cpp:831-841) makes of the FIRST line of "svm-predict -b 1" output, the header
+// "labels a b" (svm-predict.c:60-64), which the getline in front of its loops hands to the first masked cell:
+// res = (int)atof("la") = 0, prob = atof(" a b") = a, value res*prob = 0 with the sign of a.
+static float header_grid_value(int label0, int label1)
+{
+    char line[96];
+    snprintf(line, sizeof line, "labels %d %d", label0, label1);
+    const std::string ln(line);
+    const int res = (int)atof(ln.substr(0, 2).c_str());
+    int start = (int)ln.find(" ", 0), end = (int)ln.find(" ", (size_t)start + 1);
+    if (res > 0) { start = end; end = (int)ln.find(" ", (size_t)start + 1); }
+    const float prob = (float)atof(ln.substr((size_t)start, (size_t)end).c_str());
+    return res * prob;
+}
 
 int label_grid_value(int label)
 {
@@ -666,6 +687,15 @@ int build_tables(haf_engine *e)
     e->gv0 = label_grid_value(m.label[0]);
     e->gv1 = label_grid_value(m.label[1]);
     if (e->gv0 < -128 || e->gv0 > 127 || e->gv1 < -128 || e->gv1 > 127) return fail(e, HAF_E_ARG, "model labels out of range");
+    e->prob_mode = (c.flags & HAF_FLAG_PROBABILITY) != 0;
+    if (e->prob_mode) {
+        // svm-predict -b 1 on a model without probA/probB exits ("Model does not support probabiliy estimates",
+        // svm-predict.c:219-224) and the reference then votes on a stale or missing file; the engine says so instead
+        if (!m.has_prob) return fail(e, HAF_E_ARG, "HAF_FLAG_PROBABILITY needs a model with probA and probB (svm-train -b 1)");
+        e->prob.A = m.probA; e->prob.B = m.probB;
+        e->prob.gv0 = e->gv0; e->prob.gv1 = e->gv1;       // (int)atof(two characters) == atoi(two characters) for "%g" of an int
+        e->prob.hdr = header_grid_value(m.label[0], m.label[1]);
+    }
 
     e->svm.two_gamma2 = (float)(2.0 * m.gamma * log2e);
     e->svm.neg_gamma2 = (float)(-m.gamma * log2e);
@@ -796,6 +826,12 @@ int alloc_buffers(haf_engine *e)
         if (bytes <= (2ull << 30)) ok &= hipSuccess == e->d_attr.alloc((size_t)e->max_evals * kKP);
     }
     ok &= hipSuccess == e->d_ev16.alloc(e->cells_cap);
+    if (e->prob_mode) {
+        ok &= hipSuccess == e->d_own.alloc(e->cells_cap);
+        ok &= hipSuccess == e->d_gridf.alloc(e->cells_cap);
+        ok &= hipSuccess == e->d_evf.alloc(e->cells_cap);
+        ok &= hipSuccess == e->d_ptext.alloc(2 * (size_t)e->list_cap);
+    }
     ok &= hipSuccess == e->d_rec.alloc(B * R);
     ok &= hipSuccess == e->d_rowmax.alloc(B * R * H);
     ok &= hipSuccess == e->d_topkey.alloc(3 * B * R);          // top vote key, longest-run key, completion counter (k_vote_*)
@@ -870,6 +906,7 @@ void haf_destroy(haf_engine *e)
     e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
+    e->d_own.release(); e->d_gridf.release(); e->d_evf.release(); e->d_ptext.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_rec.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
@@ -1163,12 +1200,31 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         }
         return HAF_OK;
     };
+    // probability-output mode: every evaluation through the strict tier (libsvm's own order), then svm_predict_probability,
+    // the output lines as show_predicted_gps reads them, the fp32 vote (prob.hip)
+    auto decide_probability = [&]() -> int {
+        mark(e, HAF_ST_FEATURES); mark(e, HAF_ST_SVM); mark(e, HAF_ST_REFINE); mark(e, HAF_ST_RECHECK);
+        launch_prob_list(e->d_counters.p, e->d_flag2_list.p, e->list_cap, s);
+        launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
+                       e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+        mark(e, HAF_ST_VOTE);
+        launch_probability(e->d_dec_exact2.p, e->d_evalcell.p, e->d_counters.p, e->prob, e->d_labels.p, e->d_mask.p, e->d_rowcount.p,
+                           e->d_brcount.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_own.p, e->d_ptext.p, e->d_gridf.p,
+                           e->d_evf.p, e->d_rec.p, evals_cap, d, s);
+        mark(e, HAF_ST_DOWNLOAD);
+        HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+        mark(e, HAF_ST_COUNT);
+        HIPCHK(e, hipStreamSynchronize(s));
+        HIPCHK(e, hipGetLastError());
+        return HAF_OK;
+    };
     int mode = contraction_mode(c);
     if (mode == MODE_SCREEN && !e->screen_active) mode = MODE_SPLIT;
-    int rc = decide(mode, false);
+    int rc = e->prob_mode ? decide_probability() : decide(mode, false);
     if (rc != HAF_OK) return rc;
     const int inexact_grids = e->h_counters[CNT_INEXACT];     // (a redo of the decision stage below resets the counters)
-    if (mode == MODE_SCREEN) {
+    if (mode == MODE_SCREEN && !e->prob_mode) {
         auto undecided = [&]() { return e->h_counters[CNT_FLAGGED0]; };
         const int ne = e->h_counters[CNT_EVALS];
         if (undecided() > e->flag0_cap && !e->screen_sumsq) {
@@ -1203,7 +1259,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
     e->last_inexact = inexact_grids;
-    e->last_screened = (mode == MODE_SCREEN) && e->last_flagged0 <= e->flag0_cap;
+    e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && e->last_flagged0 <= e->flag0_cap;
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
     if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
@@ -1323,7 +1379,9 @@ static int get_roll_grid_impl(haf_engine *e, int32_t cloud, int32_t roll, float 
     const int rl = roll - e->last_roll_first;
     if (cloud < 0 || cloud >= e->last_B || rl < 0 || rl >= e->last_R) return fail(e, HAF_E_ARG, "haf_get_roll_grid: (cloud, roll) not in the last scored batch");
     const size_t HW = (size_t)e->cfg.grid_h * e->cfg.grid_w, base = ((size_t)cloud * e->last_R + rl) * HW;
-    if (eval_grid) {
+    if (eval_grid && e->prob_mode) {
+        HIPCHK(e, hipMemcpy(eval_grid, e->d_evf.p + base, HW * sizeof(float), hipMemcpyDeviceToHost));
+    } else if (eval_grid) {
         std::vector<short> tmp(HW);
         HIPCHK(e, hipMemcpy(tmp.data(), e->d_ev16.p + base, HW * sizeof(short), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < HW; i++) eval_grid[i] = (float)tmp[i];
@@ -1396,6 +1454,28 @@ static int debug_fetch_impl(haf_engine *e, int32_t what, int32_t cloud, int32_t 
             for (size_t k = 0; k < ne; k++) {
                 size_t cb = (size_t)cell[k] / HW;
                 if (cb == br) g[(size_t)cell[k] - cb * HW] = d64[k];
+            }
+            return HAF_OK;
+        }
+        case HAF_DBG_GRASPSGRID:
+            if (!e->prob_mode) return fail(e, HAF_E_ARG, "haf_debug_fetch: HAF_DBG_GRASPSGRID needs HAF_FLAG_PROBABILITY");
+            if (!need(HW * 4)) break;
+            HIPCHK(e, hipMemcpy(dst, e->d_gridf.p + br * HW, HW * 4, hipMemcpyDeviceToHost));
+            return HAF_OK;
+        case HAF_DBG_PROBABILITY: {
+            if (!e->prob_mode) return fail(e, HAF_E_ARG, "haf_debug_fetch: HAF_DBG_PROBABILITY needs HAF_FLAG_PROBABILITY");
+            if (!need(HW * 16)) break;
+            double *g = (double *)dst;
+            for (size_t i = 0; i < 2 * HW; i++) g[i] = NAN;
+            const size_t ne = (size_t)e->last_evals;
+            if (!ne) return HAF_OK;
+            std::vector<int> cell(ne);
+            std::vector<double> pt(2 * ne);
+            HIPCHK(e, hipMemcpy(cell.data(), e->d_evalcell.p, ne * 4, hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(pt.data(), e->d_ptext.p, 2 * ne * 8, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < ne; k++) {
+                size_t cb = (size_t)cell[k] / HW;
+                if (cb == br) { g[2 * ((size_t)cell[k] - cb * HW)] = pt[2 * k]; g[2 * ((size_t)cell[k] - cb * HW) + 1] = pt[2 * k + 1]; }
             }
             return HAF_OK;
         }

@@ -215,6 +215,17 @@ constexpr int kM64Rows = 326;
 
 struct RollRecordDev { int vote; short row, col; float h_locmax; int n_evals; };
 
+// probability-output mode (prob.hip)
+struct ProbParams {
+    double A, B;          // probA, probB of the model
+    int gv0, gv1;         // (int)atof(first two characters of "%g" of label[0] / label[1])  (server.cpp:833)
+    float hdr;            // what the "labels a b" header line parses to: the value of the first masked cell of a roll
+};
+void launch_prob_list(int *counters, int *list, int cap, hipStream_t s);
+void launch_probability(const double *dec_exact, const int *evalcell, const int *counters, ProbParams P, int8_t *labels,
+                        const uint8_t *mask, const int *rowcount, const int *brcount, const float *heights, float *own,
+                        double *ptext, float *gridf, float *evf, RollRecordDev *rec, long evals_cap, Dims d, hipStream_t s);
+
 void launch_fill_i32(int *p, int v, size_t n, hipStream_t s);
 // scratch of the bucket-sorted binning path (large grids): see kernels.hip
 struct BinScratch {

@@ -132,7 +132,7 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
 
     std::string key, val;
     int nr_class = -1;
-    bool body = false;
+    bool body = false, have_a = false, have_b = false;
     while (token(key)) {
         if (key == "svm_type") {
             if (!token(val) || (val != "c_svc" && val != "nu_svc")) { err = "model: svm_type '" + val + "' is not a classifier the server path uses"; return false; }
@@ -145,7 +145,8 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
         else if (key == "total_sv") { if (!integer(m.n_sv) || m.n_sv <= 0 || m.n_sv > kMaxSupportVectors) { err = "model: bad total_sv (must be in [1, " + std::to_string(kMaxSupportVectors) + "])"; return false; } }
         else if (key == "rho") { if (nr_class != 2 || !number(m.rho)) { err = "model: bad rho"; return false; } }
         else if (key == "label") { if (nr_class != 2 || !integer(m.label[0]) || !integer(m.label[1])) { err = "model: bad label"; return false; } }
-        else if (key == "probA" || key == "probB") { double d; if (!number(d)) { err = "model: bad prob"; return false; } }
+        else if (key == "probA") { if (nr_class != 2 || !number(m.probA)) { err = "model: bad probA"; return false; } have_a = true; }
+        else if (key == "probB") { if (nr_class != 2 || !number(m.probB)) { err = "model: bad probB"; return false; } have_b = true; }
         else if (key == "nr_sv") { if (nr_class != 2 || !integer(m.n_sv_class[0]) || !integer(m.n_sv_class[1])) { err = "model: bad nr_sv"; return false; } }
         else if (key == "SV") {
             while (pos < text.size() && text[pos] != '\n') pos++;     // rest of the SV line (svm.cpp:2834-2838)
@@ -155,6 +156,7 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
         } else { err = "model: unknown text in model file: [" + key + "]"; return false; }   // svm.cpp:2841-2852
     }
     if (!body || nr_class != 2 || m.n_sv <= 0) { err = "model: incomplete header"; return false; }
+    m.has_prob = have_a && have_b;
     if (m.n_sv_class[0] + m.n_sv_class[1] != m.n_sv) { err = "model: nr_sv does not add up to total_sv"; return false; }
 
     // body: one line per SV: coef idx:val idx:val ...   (svm.cpp:2890-2916)

@@ -33,6 +33,8 @@ struct SvmModel {
     double gamma = 0, rho = 0;
     int n_sv = 0, dim = 0;                 // dim = largest attribute index
     int n_sv_class[2] = {0, 0};
+    bool has_prob = false;          // probA and probB both present (svm.cpp:2811-2824; svm_check_probability_model 3098-3104)
+    double probA = 0.0, probB = 0.0;
     int label[2] = {0, 0};
     std::vector<double> coef;              // [n_sv]
     std::vector<double> sv;                // dense [n_sv][dim], attribute k in column k-1

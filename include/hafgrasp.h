@@ -69,6 +69,12 @@ typedef struct haf_config {
                                         the rest goes through the three-pass kernel and the fp64 tiers: same labels, same
                                         grasps, about 2.5x the rate                                                       */
 
+#define HAF_FLAG_PROBABILITY 16u     /* svm_with_probability (server.cpp:383 passes false; 791, 831-841): labels and cell values
+                                        from "svm-predict -b 1" (svm_predict_probability, svm.cpp:2550-2587) as
+                                        show_predicted_gps reads them -- each masked cell takes the prediction of the masked cell
+                                        before it -- and the fp32 vote with an int topval.  Needs a model with probA/probB
+                                        (svm-train -b 1).  Every decision value comes from the strict tier: complete, not fast */
+
 /* GraspInput (reference msg/GraspInput.msg:3-15) minus the cloud and the frame id: the cloud is passed
  * separately, already in the base frame (server.cpp:316). */
 typedef struct haf_grasp_input {
@@ -186,8 +192,11 @@ int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_gr
  * DECISION H*W f64 (NaN unmasked), TRANSFORM 16 f32. */
 enum { HAF_DBG_HEIGHTS = 0, HAF_DBG_INTEGRAL = 1, HAF_DBG_MASK = 2, HAF_DBG_LABELS = 3, HAF_DBG_DECISION = 4,
        HAF_DBG_TRANSFORM = 5,
-       HAF_DBG_SCREEN_MARGIN = 6 };  /* H*W f32, default mode: |dec^| / guard band for the cells the screening tier decided
+       HAF_DBG_SCREEN_MARGIN = 6,    /* H*W f32, default mode: |dec^| / guard band for the cells the screening tier decided
                                         (> 1 by construction), 0 for the cells it handed on, NaN elsewhere */
+       HAF_DBG_PROBABILITY = 7,      /* HAF_FLAG_PROBABILITY: H*W*2 f64, the two probabilities of the cell's own output line as
+                                        atof reads them ("%g" text), NaN unmasked */
+       HAF_DBG_GRASPSGRID = 8 };     /* HAF_FLAG_PROBABILITY: H*W f32, the grid show_predicted_gps builds (831-841) */
 int haf_debug_fetch(haf_engine *e, int32_t what, int32_t cloud, int32_t roll, void *dst, size_t dst_bytes);
 
 /* The attribute pipeline of the masked cells of one (cloud, roll) of the last scored batch, as the exact-form feature

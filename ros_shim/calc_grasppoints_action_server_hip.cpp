@@ -39,6 +39,9 @@ public:
         nh_.param("range_file_path", range_file_, pkg + "/data/range21062012_allfeatures");                  // 767-769
         nh_.param("svmmodel_file_path", model_file_, pkg + "/data/all_features.txt.scale.model");            // 771-773
         nh_.param("nr_features_without_shaf", cfg_.nr_features_without_shaf, 302);
+        bool svm_with_probability = false;                 // the reference passes a literal `false` (383); a parameter here
+        nh_.param("svm_with_probability", svm_with_probability, false);
+        if (svm_with_probability) cfg_.flags |= HAF_FLAG_PROBABILITY;
         cfg_.feature_file = feature_file_.c_str();
         cfg_.range_file = range_file_.c_str();
         cfg_.model_file = model_file_.c_str();

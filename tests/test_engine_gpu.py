@@ -1062,3 +1062,120 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption():
     assert np.isfinite(out).all() and ratio.max() <= 1.0, float(ratio.max())
     STATS["mfma_accumulation_error_as_fraction_of_the_2^-18_budget"] = {"max": float(ratio.max()),
                                                                           "by_kind": [float(ratio[k::4].max()) for k in range(4)]}
+
+
+# ---- probability-output mode (HAF_FLAG_PROBABILITY) -----------------------------------------------------
+
+def _prob_model(golden_dir, tmp_path):
+    with open(os.path.join(golden_dir, "surrogate_prob.json")) as f:
+        pj = json.load(f)
+    return models.write_probability_model(str(tmp_path / "surrogate_prob.model"), os.path.join(golden_dir, "surrogate.model"),
+                                          pj["probA"], pj["probB"])
+
+
+def compare_probability(eng, orc, xyz, cfg_kw, in_kw):
+    """Probability mode against the oracle: the grids of the common stages bit for bit, the labels svm_predict_probability returns,
+    the two "%g" probabilities of every cell, the shifted res*prob grid, the fp32 vote grid, per-roll winners, the grasp."""
+    ocfg = O.make_cfg(**{k: v for k, v in cfg_kw.items() if k in ("n_rolls", "roll_step_deg")},
+                      H=cfg_kw.get("grid_h", 56), W=cfg_kw.get("grid_w", 56), probability=1)
+    want = orc.run(xyz, ocfg, oracle_input(in_kw))
+    got = eng.score(xyz, capi.default_input(**in_kw))
+    for roll in range(want["rolls_done"]):
+        assert (eng.debug(capi.DBG_HEIGHTS, 0, roll).view(np.uint32) == want["heights"][roll].view(np.uint32)).all()
+        assert (eng.debug(capi.DBG_MASK, 0, roll) == want["mask"][roll]).all()
+        msk = want["mask"][roll] == 1
+        d = eng.debug(capi.DBG_DECISION, 0, roll)
+        assert np.isnan(d[~msk]).all()
+        if msk.any():                                    # strict tier: libsvm's order; device exp vs glibc exp is the residual
+            assert (np.abs(d[msk] - want["dec"][roll][msk]) <= 1e-12 * want["sabs"][roll][msk] + 1e-300).all()
+        assert (eng.debug(capi.DBG_LABELS, 0, roll) == want["labels"][roll]).all(), ("labels", roll)
+        p = eng.debug(capi.DBG_PROBABILITY, 0, roll)
+        assert np.isnan(p[~msk]).all()
+        assert (p[msk] == want["prob"][roll][msk]).all(), ("probabilities", roll, int((p[msk] != want["prob"][roll][msk]).sum()))
+        g = eng.debug(capi.DBG_GRASPSGRID, 0, roll)
+        assert (g.view(np.uint32) == want["graspsgrid"][roll].view(np.uint32)).all(), ("graspsgrid", roll)
+        ev, _ = eng.roll_grid(0, roll)
+        assert (ev.view(np.uint32) == want["graspseval"][roll].view(np.uint32)).all(), ("vote grid", roll)
+    for k_e, k_o in [("eval", "eval"), ("best_row", "row"), ("best_col", "col"), ("best_roll", "roll_idx"),
+                     ("best_vote", "top"), ("rolls_done", "rolls_done"), ("n_evals", "n_evals")]:
+        assert got[k_e] == want[k_o], (k_e, got[k_e], want[k_o])
+    np.testing.assert_allclose(got["grasp_point1"], want["gp1"], atol=1e-4)
+    np.testing.assert_allclose(got["grasp_point2"], want["gp2"], atol=1e-4)
+    assert got["roll"] == want["roll"]
+    return got, want
+
+
+def test_probability_mode_against_oracle(data_dir, golden_dir, tmp_path):
+    """svm_with_probability end to end (dead in the reference, server.cpp:383; restated because SURVEY.md §8 lists it): pcd2 at
+    C2, a table cloud at C3, a 96 x 96 synthetic grid, and requests with tilted approach vectors."""
+    mp = _prob_model(golden_dir, tmp_path)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, mp)
+    eng = make_engine(data_dir, mp, capi.FLAG_PROBABILITY)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    got, want = compare_probability(eng, o, xyz, {}, dict(grasp_area_length_x=32, grasp_area_length_y=32))
+    assert want["n_evals"] > 3000 and (want["labels"] > 0).any() and (want["graspsgrid"] > 0).any()
+    compare_probability(eng, o, xyz, {}, dict(grasp_area_length_x=32, grasp_area_length_y=44, approach_vector=(0.2, -0.1, 1.0)))
+    compare_probability(eng, o, pcdio.load_pcd(os.path.join(data_dir, "pcd12.pcd")), {}, dict(show_only_best_grasp=1))
+    compare_probability(eng, o, np.zeros((0, 3), np.float32), {}, {})                  # nothing masked: votes all 0
+    eng.close()
+    eng = make_engine(data_dir, mp, capi.FLAG_PROBABILITY, n_rolls=20, roll_step_deg=9, max_points=1 << 17)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    compare_probability(eng, o, xyz, dict(n_rolls=20, roll_step_deg=9),
+                        dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)))
+    eng.close()
+    eng = make_engine(data_dir, mp, capi.FLAG_PROBABILITY, grid_h=96, grid_w=96, n_rolls=5, roll_step_deg=36)
+    compare_probability(eng, o, models.synthetic_cloud(grid=96, k=2, seed=11), dict(n_rolls=5, roll_step_deg=36, grid_h=96, grid_w=96),
+                        dict(grasp_area_length_x=96, grasp_area_length_y=70))
+    eng.close()
+
+
+def test_probability_mode_needs_a_probability_model(data_dir, surrogate):
+    with pytest.raises(capi.HafError, match="probA"):
+        make_engine(data_dir, surrogate, capi.FLAG_PROBABILITY)
+
+
+def test_probability_mode_randomised(data_dir, tmp_path):
+    """Random requests x random models with random sigmoid parameters (label order "1 -1", so the header parses to +0 and the
+    positive label takes the SECOND probability, that of label -1: the reference's own quirk), probability mode against the oracle."""
+    f, r = _files(data_dir)
+    rng = np.random.RandomState(4242)
+    for case in range(6):
+        base = str(tmp_path / ("r%d.model" % case))
+        models.write_random_model(base, int(rng.choice([3, 40, 300])), seed=int(rng.randint(1 << 30)), balanced=True,
+                                  gamma=float(rng.choice([1.0 / 323, 0.02])))
+        mp = models.write_probability_model(str(tmp_path / ("rp%d.model" % case)), base, "%g" % rng.uniform(-40, 40),
+                                            "%g" % rng.uniform(-2, 2))
+        o = O.Oracle(f, r, mp)
+        n_rolls, step = [(12, 15), (5, 36), (3, 60)][case % 3]
+        eng = make_engine(data_dir, mp, capi.FLAG_PROBABILITY, n_rolls=n_rolls, roll_step_deg=step, max_points=1 << 16)
+        for _ in range(3):
+            n = int(rng.choice([200, 5000]))
+            pts = [rng.uniform(-0.1, 0.1, 3) * [1, 1, 0.3] + [0, 0, 0.05] + rng.standard_normal((n, 3)) * rng.uniform(0.005, 0.05, 3)
+                   for _ in range(rng.randint(1, 4))]
+            xy = rng.uniform(-0.3, 0.3, (n, 2))
+            pts.append(np.column_stack([xy, 0.02 + 0.1 * xy[:, 0] - 0.05 * xy[:, 1]]))
+            xyz = np.concatenate(pts).astype(np.float32)
+            kw = dict(grasp_area_center=tuple(rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]),
+                      grasp_area_length_x=float(rng.choice([20, 32, 44, 56])), grasp_area_length_y=float(rng.choice([18, 32, 44, 56])),
+                      gripper_opening_width=int(rng.choice([1, 1, 2])), show_only_best_grasp=int(rng.rand() < 0.3))
+            if rng.rand() < 0.5:
+                kw["approach_vector"] = tuple(rng.standard_normal(3) * [0.3, 0.3, 1.0] + [0, 0, 1.0])
+            compare_probability(eng, o, xyz, dict(n_rolls=n_rolls, roll_step_deg=step), kw)
+        eng.close()
+
+
+def test_probability_mode_through_the_cli(data_dir, golden_dir, tmp_path):
+    """haf_grasp_cli --probability prints the oracle's grasp for pcd2 at C2."""
+    mp = _prob_model(golden_dir, tmp_path)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, mp)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    want = o.run(xyz, O.make_cfg(probability=1), O.make_input())
+    import subprocess
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "haf_grasp_cli")
+    out = subprocess.run([cli, "--features", f, "--range", r, "--model", mp, "--search-size", "18", "18", "--probability",
+                          os.path.join(data_dir, "pcd2.pcd")], capture_output=True, text=True, check=True)
+    line = out.stdout.strip().splitlines()[-1].split()
+    assert int(line[0]) == want["eval"], (out.stdout, out.stderr)
+    np.testing.assert_allclose([float(v) for v in line[1:4]], want["gp1"], atol=1e-4)

@@ -7,6 +7,6 @@ cd "$(dirname "$0")/../haf_grasping_amd"
 N=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-inline-asm -fno-slp-vectorize \
     -DSCREEN_VARIANT=$N "$@" -c csrc/screen.hip -o /tmp/screen_v$N.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC csrc/kernels.o /tmp/screen_v$N.o csrc/engine.o csrc/parsers.o csrc/multi.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC csrc/kernels.o /tmp/screen_v$N.o csrc/prob.o csrc/engine.o csrc/parsers.o csrc/multi.o \
     -L/opt/rocm/lib -lrccl -lpthread -Wl,-rpath,/opt/rocm/lib -o libhafgrasp_v$N.so
 echo built libhafgrasp_v$N.so
