@@ -1179,3 +1179,19 @@ def test_probability_mode_through_the_cli(data_dir, golden_dir, tmp_path):
     line = out.stdout.strip().splitlines()[-1].split()
     assert int(line[0]) == want["eval"], (out.stdout, out.stderr)
     np.testing.assert_allclose([float(v) for v in line[1:4]], want["gp1"], atol=1e-4)
+
+
+def test_probability_mode_roll_sharded(data_dir, golden_dir, tmp_path):
+    """The probability mode behind haf_score_sharded: three shards (on one GPU here) give the oracle's grasp and roll records."""
+    mp = _prob_model(golden_dir, tmp_path)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, mp)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd12.pcd"))
+    want = o.run(xyz, O.make_cfg(probability=1), O.make_input(length_y=44))
+    me = capi.MultiEngine(f, r, mp, [0, 0, 0], capi.SHARD_ROLLS, flags=capi.FLAG_PROBABILITY)
+    got = me.score_sharded(xyz, capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44))
+    assert (got["eval"], got["best_row"], got["best_col"], got["best_roll"]) == (want["eval"], want["row"], want["col"], want["roll_idx"])
+    rec = me.last_records(0)
+    for roll in range(12):
+        assert [int(rec["row"][roll]), int(rec["col"][roll]), int(rec["vote"][roll])] == list(want["roll_best"][roll])
+    me.close()
