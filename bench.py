@@ -141,7 +141,7 @@ def run_cabi_side(args, world):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                            "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, text=True)
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, text=True)
         if p.returncode != 0:
             return {"error": "child exited with %d: %s" % (p.returncode, p.stderr.strip()[-400:])}
         return json.loads(p.stdout.strip().splitlines()[-1])
