@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--per-model", type=int, default=6)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget", type=float, default=600.0, help="seconds")
+    ap.add_argument("--probability", action="store_true",
+                    help="every third model with random probA/probB, served in the probability-output mode (HAF_FLAG_PROBABILITY)")
     ap.add_argument("--big", action="store_true", help="also grids beyond 128 x 128 (bucket-sorted binning, banded integral "
                                                        "image, large-grid vote) and models of a few thousand support vectors")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"))
@@ -92,6 +94,12 @@ def main():
         H, W = sizes[rng.randint(len(sizes))]
         n_rolls, step = [(12, 15), (5, 36), (7, 25), (3, 60), (20, 9)][rng.randint(5)]
         mode, mname = mode_list[mi % 3] if mi % 2 else mode_list[2]           # two thirds of the models through the default path
+        prob = a.probability and mi % 3 == 0
+        if prob:
+            path = models.write_probability_model(os.path.join(tmp, "p%d.model" % mi), path, "%g" % rng.uniform(-30, 30), "%g" % rng.uniform(-2, 2))
+            orc = O.Oracle(os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_allfeatures"), path)
+            mode, mname = capi.FLAG_PROBABILITY, "probability"
+            by_mode.setdefault(mname, 0)
         eng = T.make_engine(DATA, path, mode, grid_h=H, grid_w=W, n_rolls=n_rolls, roll_step_deg=step, max_points=1 << 17)
         n_here = 0
         for _ in range(a.per_model):
@@ -109,6 +117,13 @@ def main():
             if rng.rand() < 0.5:
                 kw["approach_vector"] = tuple(rng.standard_normal(3) * [0.3, 0.3, 1.0] + [0, 0, 1.0])
             try:
+                if prob:
+                    got, want = T.compare_probability(eng, orc, xyz, dict(n_rolls=n_rolls, roll_step_deg=step, grid_h=H, grid_w=W), kw)
+                    done += 1
+                    n_here += 1
+                    evals += int(want["n_evals"])
+                    by_mode[mname] += 1
+                    continue
                 got, want = T.compare_full(eng, orc, xyz, dict(n_rolls=n_rolls, roll_step_deg=step, grid_h=H, grid_w=W), kw,
                                            check_dec=False)
                 # decision values: recorded, not gated -- the tests' bound (2^-20 S, 2^-8 S for screened values) is for attributes
