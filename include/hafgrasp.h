@@ -184,7 +184,8 @@ haf_engine *haf_multi_engine(haf_multi *m, int32_t shard);      /* the shard's e
 int haf_multi_last_records(const haf_multi *m, int32_t rank, haf_roll_record *records);
 
 /* Per-roll vote grid and mask of the LAST scored batch, for the marker grid the ROS shim publishes
- * (publish_grasp_grid, server.cpp:901-902, 979-1016).  eval_grid: H*W floats, mask: H*W bytes; either may be NULL. */
+ * (publish_grasp_grid, server.cpp:901-902, 979-1016).  eval_grid: H*W floats, mask: H*W bytes; either may be NULL.
+ * (Integer-valued votes; with HAF_FLAG_PROBABILITY the fp32 votes of the probability branch.) */
 int haf_get_roll_grid(haf_engine *e, int32_t cloud, int32_t roll, float *eval_grid, uint8_t *mask);
 
 /* Intermediates of the last scored batch (needs HAF_FLAG_KEEP_DEBUG).  dst sizes per (cloud, roll):
