@@ -62,7 +62,10 @@ class CalcGraspPointsServer:
     server.cpp:217-225), then execute(goal) per GraspInput.  No ROS here: the catkin shim that forwards the real
     action to the C-ABI is shown in INTEGRATION.md."""
 
-    def __init__(self, feature_file_path, range_file_path, svmmodel_file_path, nr_features_without_shaf=302, **cfg):
+    def __init__(self, feature_file_path, range_file_path, svmmodel_file_path, nr_features_without_shaf=302,
+                 svm_with_probability=False, **cfg):
+        if svm_with_probability:                     # the literal `false` of server.cpp:383, as a parameter (HAF_FLAG_PROBABILITY)
+            cfg["flags"] = cfg.get("flags", 0) | capi.FLAG_PROBABILITY
         self.engine = capi.Engine(feature_file_path, range_file_path, svmmodel_file_path,
                                   nr_features_without_shaf=nr_features_without_shaf, **cfg)
         self.base_frame_id = "/base_link"            # server.cpp:294-301
