@@ -5,14 +5,8 @@
 
 namespace haf {
 
-#ifndef SCREEN_VARIANT
-#define SCREEN_VARIANT 0
-#endif
-// SCREEN_ABL: timing experiments only (results are wrong; never defined in a product or testing build): 2 = no epilogue VALU
-// at all, 3 = no LDS-DMA inside the loop, 4 = no tile barrier, 5 = no B-fragment LDS reads inside the k loop
-#ifndef SCREEN_ABL
-#define SCREEN_ABL 0
-#endif
+// (The A/B and ablation switches the measurements of DESIGN.md §5 were taken with are not part of this file:
+// tools/screen_experiments.patch puts them back, tools/build_variant.sh builds such a variant next to the product library.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -89,8 +83,8 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // B fragments are read one k-step ahead of their MFMAs, ACROSS the boundary between the two column blocks of a tile: block 0
 // (n = 0) reads its own first fragment on entry and leaves that of block 1 in b on exit, so that block 1's first MFMA does not
 // wait for an LDS round trip.  (Across tiles that is not possible: the next tile is only known to have landed behind the
-// barrier.)  Two steps ahead -- round 1, SCREEN_VARIANT bit 1 -- measured the same and costs four VGPRs, which now hold a
-// second level of the coefficient sum.
+// barrier.)  Two steps ahead measured the same (round 1) and costs four VGPRs, which now hold a second level of the
+// coefficient sum.
 template <int FIRST, int COUNT, bool SUMSQ>
 __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], f32x4 (&acc)[4],
                                              const f32x4 (&old)[4], float t, float cf_old, float (&sum)[4][4], float (&sq)[4][4],
@@ -99,12 +93,7 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
     const f32x4 t4 = {t, t, t, t};                                   // rows differ, the column (this lane's SV) is the same
-    constexpr bool kXBlock = !(SCREEN_VARIANT & 1);                  // (A/B builds: SCREEN_VARIANT bit 0 switches the hand-over off)
-    constexpr bool kDeep = (SCREEN_VARIANT & 2) != 0;                // B fragments two k-steps ahead (four more VGPRs) instead of one
-    if (n == 0 || !kXBlock) {
-        b = *reinterpret_cast<const half8 *>(bl);                    // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
-        if (kDeep) b1 = *reinterpret_cast<const half8 *>(bl + 2048);
-    }
+    if (n == 0) b = *reinterpret_cast<const half8 *>(bl);            // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
     float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
     // The issue order of every k-step is pinned instruction by instruction (a scheduling barrier after each): B read of the
     // next step, then MFMA | exp | MFMA | exp | MFMA | fma | MFMA | fma, where the exps belong to pair s-1 and the fmas to
@@ -112,41 +101,24 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
 #define HAF_SB() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int s = 0; s < kHFull; s++) {
-        half8 b2 = b1;
-        // fragment s + 2 of this block, or -- in the last two steps of block 0 -- fragment s + 2 - 10 of block 1 (1 KiB further on)
-        constexpr bool kNoRead = SCREEN_ABL == 5;
-        if (kDeep && !kNoRead) {
-            if (s + 2 < kHFull) b2 = *reinterpret_cast<const half8 *>(bl + (s + 2) * 2048);
-            else if (n == 0 && kXBlock) b2 = *reinterpret_cast<const half8 *>(bl + 1024 + (s + 2 - kHFull) * 2048);
-        }
-        if (!kDeep && !kNoRead) {
-            if (s + 1 < kHFull) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
-            else if (n == 0 && kXBlock) b1 = *reinterpret_cast<const half8 *>(bl + 1024);
-        }
+        // fragment s + 1 of this block, or -- in the last step of block 0 -- fragment 0 of block 1 (1 KiB further on)
+        if (s + 1 < kHFull) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
+        else if (n == 0) b1 = *reinterpret_cast<const half8 *>(bl + 1024);
         HAF_SB();
         const bool ex = s >= 1 && s < 9, fm = s >= 2;
         const int e0 = 2 * (s - 1), e1 = e0 + 1, f0 = 2 * (s - 2), f1 = f0 + 1;
         float q0 = 0.0f, q1 = 0.0f;
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, s == 0 ? t4 : acc[0], 0, 0, 0);
         HAF_SB();
-        if (COUNT > 0 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST], dma.l[FIRST], lane16); HAF_SB(); }
-#if SCREEN_ABL == 2
-        if (ex) { asm volatile("" ::"v"(old[e0 >> 2][e0 & 3])); HAF_SB(); }
-#else
+        if (COUNT > 0 && s == 0) { dma_piece(dma.g[FIRST], dma.l[FIRST], lane16); HAF_SB(); }
         if (ex) { q0 = __builtin_amdgcn_exp2f(old[e0 >> 2][e0 & 3]); HAF_SB(); }
-#endif
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, s == 0 ? t4 : acc[1], 0, 0, 0);
         HAF_SB();
-        if (COUNT > 1 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 1], dma.l[FIRST + 1], lane16); HAF_SB(); }
-#if SCREEN_ABL == 2
-        if (ex) { asm volatile("" ::"v"(old[e1 >> 2][e1 & 3])); HAF_SB(); }
-#else
+        if (COUNT > 1 && s == 0) { dma_piece(dma.g[FIRST + 1], dma.l[FIRST + 1], lane16); HAF_SB(); }
         if (ex) { q1 = __builtin_amdgcn_exp2f(old[e1 >> 2][e1 & 3]); HAF_SB(); }
-#endif
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, s == 0 ? t4 : acc[2], 0, 0, 0);
         HAF_SB();
-        if (COUNT > 2 && s == 0 && SCREEN_ABL != 3) { dma_piece(dma.g[FIRST + 2], dma.l[FIRST + 2], lane16); HAF_SB(); }
-#if SCREEN_ABL != 2
+        if (COUNT > 2 && s == 0) { dma_piece(dma.g[FIRST + 2], dma.l[FIRST + 2], lane16); HAF_SB(); }
         if (fm && !SUMSQ) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
         if (fm && SUMSQ) {
             const float ck = cf_old * k0;
@@ -156,10 +128,8 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             sq[f0 >> 2][f0 & 3] = fmaf(ck, ck, sq[f0 >> 2][f0 & 3]);
             HAF_SB();
         }
-#endif
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, s == 0 ? t4 : acc[3], 0, 0, 0);
         HAF_SB();
-#if SCREEN_ABL != 2
         if (fm && !SUMSQ) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
         if (fm && SUMSQ) {
             const float ck = cf_old * k1;
@@ -169,13 +139,11 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             sq[f1 >> 2][f1 & 3] = fmaf(ck, ck, sq[f1 >> 2][f1 & 3]);
             HAF_SB();
         }
-#endif
         k0 = q0;
         k1 = q1;
         b = b1;
-        if (kDeep) b1 = b2;
     }
-    // (n == 0: b now holds fragment 0 of block 1 -- and b1 fragment 1 when the read-ahead is two steps deep)
+    // (n == 0: b now holds fragment 0 of block 1)
 #undef HAF_SB
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
@@ -288,14 +256,8 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
             // tile t+1 must have landed before anyone reads it; the five image pieces just issued may stay in flight.  (Wave 0
             // has a sixth in the queue, the tail piece: it went out first, a whole tile ago, so waiting for it too costs
             // nothing and keeps this one constant -- a branch here makes hipcc reschedule the epilogue behind it.)
-#if SCREEN_ABL == 3
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-#endif
-#if SCREEN_ABL != 4
             __builtin_amdgcn_s_barrier();
-#endif
             asm volatile("" ::: "memory");                          // no LDS read of the next tile may move above the barrier
         }
         // epilogue of the sweep's last block, then the sum over the 16 column lanes
