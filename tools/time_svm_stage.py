@@ -16,7 +16,7 @@ d = torch.from_numpy(xyz).cuda()
 eng = capi.Engine(feat, rng, mp, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20, flags=capi.FLAG_PROFILE)
 inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
 ts = []
-for i in range(4):
+for i in range(int(os.environ.get('HAF_ITERS', '4'))):
     try:
         eng.score_rolls([(d.data_ptr(), xyz.shape[0], 3)], [inp], 0, 36)
     except capi.HafError:
