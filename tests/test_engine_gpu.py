@@ -1195,3 +1195,27 @@ def test_probability_mode_roll_sharded(data_dir, golden_dir, tmp_path):
     for roll in range(12):
         assert [int(rec["row"][roll]), int(rec["col"][roll]), int(rec["vote"][roll])] == list(want["roll_best"][roll])
     me.close()
+
+
+def test_probability_mode_batch_and_roll_shards(data_dir, golden_dir, tmp_path):
+    """Probability mode: a batch of eight clouds == eight single calls (per-cloud grids and records do not leak into each other),
+    and roll shards + haf_finalize == the unsharded call."""
+    mp = _prob_model(golden_dir, tmp_path)
+    names = ["pcd%d" % i for i in range(1, 9)]
+    clouds = [capi.load_pcd(os.path.join(data_dir, n + ".pcd")) for n in names]
+    inputs = [capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44) for _ in names]
+    inputs[6] = capi.default_input(grasp_area_center=(0.30, 0.46, 0.0))
+    eng = make_engine(data_dir, mp, capi.FLAG_PROBABILITY, n_rolls=20, roll_step_deg=9, max_clouds=8)
+    batch = eng.score_batch(clouds, inputs)
+    grids = [eng.debug(capi.DBG_GRASPSGRID, b, 7).copy() for b in range(8)]
+    singles = []
+    for b, (c, i) in enumerate(zip(clouds, inputs)):
+        singles.append(eng.score(c, i))
+        assert (eng.debug(capi.DBG_GRASPSGRID, 0, 7).view(np.uint32) == grids[b].view(np.uint32)).all(), b
+    for b, s in zip(batch, singles):
+        for k in ("eval", "best_row", "best_col", "best_roll", "best_vote", "n_evals", "grasp_point1", "roll"):
+            assert b[k] == s[k], k
+    full = eng.score_rolls(clouds[:3], inputs[:3], 0, 20)
+    parts = [eng.score_rolls(clouds[:3], inputs[:3], a, n) for a, n in ((0, 5), (5, 5), (10, 7), (17, 3))]
+    assert (np.concatenate(parts, axis=1) == full).all()
+    eng.close()
