@@ -715,11 +715,14 @@ __device__ __forceinline__ bool cell_in_box(const float *__restrict__ I, int W1,
     return ((double)t1 < 0.00001) && ((double)t2 > -0.00001) && ((double)t3 > -0.00001) && ((double)t4 < 0.00001);
 }
 
-__global__ __launch_bounds__(64) void k_mask_count(const float *__restrict__ ii, const RollGeo *__restrict__ geo,
-                                                   uint8_t *__restrict__ mask, int *__restrict__ rowcount, Dims d)
+// (a wave per grid row, kRowsPerWg rows per workgroup: 18 432 one-wave workgroups at C5 spent more on dispatch than on their rows)
+constexpr int kRowsPerWg = 4;
+__global__ __launch_bounds__(64 * kRowsPerWg) void k_mask_count(const float *__restrict__ ii, const RollGeo *__restrict__ geo,
+                                                                uint8_t *__restrict__ mask, int *__restrict__ rowcount, Dims d)
 {
-    const int i = blockIdx.x, br = blockIdx.y, lane = threadIdx.x;
+    const int i = blockIdx.x * kRowsPerWg + (threadIdx.x >> 6), br = blockIdx.y, lane = threadIdx.x & 63;
     const int H = d.H, W = d.W, W1 = W + 1;
+    if (i >= H) return;
     const float *I = ii + (size_t)br * (H + 1) * W1;
     const RollGeo &g = geo[br];
     uint8_t *mrow = mask + ((size_t)br * H + i) * W;
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(64) void k_mask_count(const float *__restrict__ ii,
 
 void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mask_count, dim3(d.H, d.B * d.R), dim3(64), 0, s, ii, geo, mask, rowcount, d);
+    hipLaunchKernelGGL(k_mask_count, dim3((d.H + kRowsPerWg - 1) / kRowsPerWg, d.B * d.R), dim3(64 * kRowsPerWg), 0, s, ii, geo, mask, rowcount, d);
 }
 
 // Evaluation order.  The evaluations of a grid row are its masked cells from left to right, cut into chunks of 64: the
@@ -805,11 +808,12 @@ void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, 
     hipLaunchKernelGGL(k_scan, dim3(d.B * d.R), dim3(1024), 0, s, rowcount, rowoff, brcount, counters, d);
 }
 
-__global__ __launch_bounds__(64) void k_compact(const uint8_t *__restrict__ mask, const int *__restrict__ rowcount,
-                                                const int *__restrict__ rowoff, int *__restrict__ evalcell, Dims d)
+__global__ __launch_bounds__(64 * kRowsPerWg) void k_compact(const uint8_t *__restrict__ mask, const int *__restrict__ rowcount,
+                                                             const int *__restrict__ rowoff, int *__restrict__ evalcell, Dims d)
 {
-    const int i = blockIdx.x, br = blockIdx.y, lane = threadIdx.x;
+    const int i = blockIdx.x * kRowsPerWg + (threadIdx.x >> 6), br = blockIdx.y, lane = threadIdx.x & 63;
     const int H = d.H, W = d.W, n = d.B * d.R * H;
+    if (i >= H) return;
     const uint8_t *mrow = mask + ((size_t)br * H + i) * W;
     const int whole = rowcount[br * H + i] & ~63;
     const int base_a = rowoff[br * H + i], base_b = rowoff[n + 1 + br * H + i] - whole;
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(64) void k_compact(const uint8_t *__restrict__ mask
 
 void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_compact, dim3(d.H, d.B * d.R), dim3(64), 0, s, mask, rowcount, rowoff, evalcell, d);
+    hipLaunchKernelGGL(k_compact, dim3((d.H + kRowsPerWg - 1) / kRowsPerWg, d.B * d.R), dim3(64 * kRowsPerWg), 0, s, mask, rowcount, rowoff, evalcell, d);
 }
 
 // ---------------------------------------------------------------------------------------------------
