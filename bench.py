@@ -14,6 +14,7 @@ A step = one pass of the whole hot path (bin -> integral -> mask -> features+tex
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -405,6 +406,27 @@ def main():
             "best": {"eval": res["out"]["eval"], "row": res["out"]["best_row"], "col": res["out"]["best_col"],
                      "roll": res["out"]["best_roll"]},
         }
+        if args.precision == "f16s":
+            # Context for `roofline.frac`: what THIS GPU sustains on a bare loop of the same MFMA instruction (random operands in
+            # registers, two 4-wave workgroups per CU, ~20 ms; libhafgrasp_testing.so, testkernels.hip).  The chip runs the matrix
+            # pipe at the clock it can hold under the load, and that differs between the boxes of a pool.
+            try:
+                tl = capi.testlib()
+                probe = []
+                tf = C.c_double()
+                for _ in range(3):
+                    if tl.haf_test_mfma_rate(local_rank, 36000, C.byref(tf)) == 0:
+                        probe.append(tf.value)
+                if probe:
+                    bare = float(np.median(probe))
+                    line["roofline"]["box_bare_mfma_tflops"] = bare
+                    line["roofline"]["executed_over_box_bare"] = line["roofline"]["executed_tflops"] / bare
+                    line["roofline"]["box_note"] = ("bare v_mfma_f32_16x16x32_f16 loop on this GPU in this run: the executed rate of "
+                                                    "k_svm_screen (MFMA + one v_exp_f32 and one fma per evaluation x SV + LDS/DMA "
+                                                    "traffic) against what the matrix pipe alone sustains here")
+            except Exception as ex:      # noqa: BLE001 -- context only
+                line["roofline"]["box_bare_mfma_tflops"] = None
+                line["roofline"]["box_note"] = "probe unavailable: %r" % (ex,)
         if world == 1 and not args.no_f32_side:
             for other in [m for m in ("f16x3", "f32") if m != args.precision]:
                 e2 = make_engine(other)

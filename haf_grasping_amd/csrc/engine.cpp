@@ -1736,6 +1736,40 @@ int haf_test_mfma_accum(const uint16_t *a, const uint16_t *b, const float *c0, f
     return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
 }
 
+// bare v_mfma_f32_16x16x32_f16 loop on `device` for about `iters` * 0.55 us: executed TFLOP/s by HIP events (bench.py context)
+int haf_test_mfma_rate(int device, int iters, double *tflops)
+{
+    if (!tflops || iters < 1) return HAF_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return HAF_E_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HAF_E_DEVICE;
+    const int blocks = 2 * prop.multiProcessorCount;
+    std::vector<uint16_t> h(65536 * 8);
+    uint32_t x = 12345u;
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3000u | ((x >> 9) & 0x83FFu)); }   // +-[0.125, 0.25): random mantissas and signs
+    void *din = nullptr;
+    float *dout = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = HAF_E_DEVICE;
+    float ms = 0.0f;
+    if (hipMalloc(&din, h.size() * 2) == hipSuccess && hipMalloc((void **)&dout, (size_t)blocks * 256 * 4) == hipSuccess &&
+        hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+        hipEventCreate(&e1) == hipSuccess) {
+        haf::launch_mfma_rate_test(din, dout, blocks, 64, nullptr);                      // warm the code path
+        (void)hipEventRecord(e0, nullptr);
+        haf::launch_mfma_rate_test(din, dout, blocks, iters, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f) {
+            *tflops = (double)blocks * 4.0 * iters * 32.0 * 16384.0 / (ms * 1e-3) / 1e12;
+            rc = HAF_OK;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(din); (void)hipFree(dout);
+    return rc;
+}
+
 int haf_test_decq_device(const double *in, double *out, int n, int digits)
 {
     double *di = nullptr, *dout = nullptr;

@@ -34,6 +34,34 @@ __global__ __launch_bounds__(64) void k_mfma_accum(const _Float16 *__restrict__ 
     for (int r = 0; r < 4; r++) out[(size_t)t * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];   // D[row = 4 (lane >> 4) + r][col = lane & 15]
 }
 
+// haf_test_mfma_rate: what THIS GPU sustains on the instruction the screening kernel is made of, for bench.py's context line
+// (the fp16 MFMA pipe runs at the clock the chip holds under the load, which differs from box to box).  Random
+// fp16 operands in registers, eight independent accumulators, nothing but v_mfma_f32_16x16x32_f16 in the loop; two 4-wave
+// workgroups per CU like k_svm_screen.  flop = blocks * 4 waves * iters * 32 * 16384.
+__global__ __launch_bounds__(256, 2) void k_mfma_rate(const half8 *__restrict__ in, float *__restrict__ out, int iters)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    half8 a[8], b[8];
+    for (int i = 0; i < 8; i++) { a[i] = in[(tid * 16 + i) & 65535]; b[i] = in[(tid * 16 + 8 + i) & 65535]; }
+    f32x4 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[(i * 4 + j) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[(i + j) & 7], acc[(i * 4 + j) & 7], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) s += acc[i][j];
+    out[tid] = s;
+}
+
+void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mfma_rate, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, iters);
+}
+
 void launch_mfma_accum_test(const void *a, const void *b, const float *c0, float *out, int trials, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mfma_accum, dim3(trials), dim3(64), 0, s, (const _Float16 *)a, (const _Float16 *)b, c0, out);
