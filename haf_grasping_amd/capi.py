@@ -128,6 +128,7 @@ def _bind(path, testing):
         L.haf_test_decq_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.haf_test_mfma_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.haf_test_mfma_rate.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.haf_test_mfma_model.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.haf_test_scale_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
                                             C.c_int]
         L.haf_test_feature_table.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int]

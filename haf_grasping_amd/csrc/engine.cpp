@@ -1770,6 +1770,40 @@ int haf_test_mfma_rate(int device, int iters, double *tflops)
     return rc;
 }
 
+// timing model of the screening kernel's inner loop with mb = 4 or 8 row blocks per wave (testkernels.hip): executed TFLOP/s
+int haf_test_mfma_model(int device, int mb, int tiles, double *tflops)
+{
+    if (!tflops || tiles < 1 || (mb != 4 && mb != 8)) return HAF_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return HAF_E_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HAF_E_DEVICE;
+    const int blocks = (mb == 8 ? 1 : 2) * prop.multiProcessorCount * 8;          // eight rounds of workgroups
+    std::vector<uint16_t> h(65536 * 8);
+    uint32_t x = 777u;
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x2800u | ((x >> 9) & 0x83FFu)); }
+    void *din = nullptr;
+    float *dout = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = HAF_E_DEVICE;
+    float ms = 0.0f;
+    if (hipMalloc(&din, h.size() * 2) == hipSuccess && hipMalloc((void **)&dout, (size_t)blocks * 256 * 4) == hipSuccess &&
+        hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+        hipEventCreate(&e1) == hipSuccess) {
+        haf::launch_mfma_model_test(din, dout, mb, blocks, 2, nullptr);
+        (void)hipEventRecord(e0, nullptr);
+        haf::launch_mfma_model_test(din, dout, mb, blocks, tiles, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f) {
+            *tflops = (double)blocks * 4.0 * tiles * 20.0 * mb * 16384.0 / (ms * 1e-3) / 1e12;
+            rc = HAF_OK;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(din); (void)hipFree(dout);
+    return rc;
+}
+
 int haf_test_decq_device(const double *in, double *out, int n, int digits)
 {
     double *di = nullptr, *dout = nullptr;

@@ -274,6 +274,7 @@ void launch_vote(const int8_t *labels, const float *heights, const int *brcount,
                  int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s);
 void launch_mfma_accum_test(const void *a, const void *b, const float *c0, float *out, int trials, hipStream_t s);   // testkernels.hip (testing build)
 void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hipStream_t s);                       // testkernels.hip (testing build)
+void launch_mfma_model_test(const void *in, float *out, int mb, int blocks, int tiles, hipStream_t s);             // testkernels.hip (testing build)
 void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s);
 void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
                        int n, hipStream_t s);

@@ -62,6 +62,71 @@ void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hi
     hipLaunchKernelGGL(k_mfma_rate, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, iters);
 }
 
+// Feasibility model of the screening kernel's inner loop for MB row blocks of 16 evaluations per wave (4 = the shipped tiling at
+// two workgroups per CU, 8 = one 512-register wave per SIMD): static SV tile images in LDS (no DMA), A fragments in registers,
+// per k-step one B fragment read and MB MFMAs, the epilogue (one v_exp_f32 + one fma per accumulator value of the previous column
+// block) left to hipcc's scheduling, a barrier per tile.  Timing only.
+template <int MB>
+__global__ __launch_bounds__(256, MB == 8 ? 1 : 2) void k_mfma_model(const half8 *__restrict__ in, float *__restrict__ out, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) char lds[3 * 21504];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 3 * 21504 / 16; i += 256) reinterpret_cast<half8 *>(lds)[i] = in[(blockIdx.x * 977 + i) & 65535];
+    half8 a[10][MB];
+#pragma unroll
+    for (int s = 0; s < 10; s++)
+#pragma unroll
+        for (int m = 0; m < MB; m++) a[s][m] = in[(blockIdx.x * 256 + tid + 131 * (s * MB + m)) & 65535];
+    __syncthreads();
+    f32x4 acc0[MB], acc1[MB];
+    float sum[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+        acc0[m] = f32x4{0, 0, 0, 0}; acc1[m] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) sum[m][r] = 0.0f;
+    }
+    const float cf = 0.37f;
+    for (int t = 0; t < tiles; t++) {
+        const char *cur = lds + (t % 3) * 21504 + lane * 16;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            f32x4 *acc = n ? acc1 : acc0;
+            f32x4 *old = n ? acc0 : acc1;
+            half8 b = *reinterpret_cast<const half8 *>(cur + n * 1024);
+#pragma unroll
+            for (int s = 0; s < 10; s++) {
+                half8 b1 = b;
+                if (s + 1 < 10) b1 = *reinterpret_cast<const half8 *>(cur + n * 1024 + (s + 1) * 2048);
+#pragma unroll
+                for (int m = 0; m < MB; m++) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][m], b, s == 0 ? f32x4{-1.0f, -1.0f, -1.0f, -1.0f} : acc[m], 0, 0, 0);
+                    // epilogue of the previous column block: MB * 4 values over the ten k-steps
+                    const int v0 = (s * MB * 4) / 10 + (m * (((s + 1) * MB * 4) / 10 - (s * MB * 4) / 10)) / MB;
+                    const int v1 = (s * MB * 4) / 10 + ((m + 1) * (((s + 1) * MB * 4) / 10 - (s * MB * 4) / 10)) / MB;
+#pragma unroll
+                    for (int v = v0; v < v1; v++) sum[v >> 2][v & 3] = fmaf(cf, __builtin_amdgcn_exp2f(old[v >> 2][v & 3] * 1e-3f), sum[v >> 2][v & 3]);
+                }
+                b = b1;
+            }
+        }
+        __syncthreads();
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) r += sum[m][q] + acc0[m][q] + acc1[m][q];
+    out[blockIdx.x * 256 + tid] = r;
+}
+
+// returns nothing; flop = blocks * 4 waves * tiles * 20 * MB * 16384
+void launch_mfma_model_test(const void *in, float *out, int mb, int blocks, int tiles, hipStream_t s)
+{
+    if (mb == 8) hipLaunchKernelGGL(k_mfma_model<8>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
+    else hipLaunchKernelGGL(k_mfma_model<4>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
+}
+
 void launch_mfma_accum_test(const void *a, const void *b, const float *c0, float *out, int trials, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mfma_accum, dim3(trials), dim3(64), 0, s, (const _Float16 *)a, (const _Float16 *)b, c0, out);
