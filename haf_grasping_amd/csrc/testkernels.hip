@@ -120,10 +120,76 @@ __global__ __launch_bounds__(256, MB == 8 ? 1 : 2) void k_mfma_model(const half8
     out[blockIdx.x * 256 + tid] = r;
 }
 
+// The same model for 8 row blocks per wave with the register classes chosen by hand: the A fragments of k-steps 3..9 (56 of
+// 80) are loaded straight into AccVGPRs and named as such to the MFMA (inline asm, "a" constraint); accumulators, sums and B
+// fragments stay in VGPRs, so nothing is copied between the two files inside the loop.
+__global__ __launch_bounds__(256, 1) void k_mfma_model8a(const half8 *__restrict__ in, float *__restrict__ out, int tiles)
+{
+    constexpr int MB = 8, KV = 3;                        // k-steps whose A fragments live in VGPRs
+    __shared__ __attribute__((aligned(16))) char lds[3 * 21504];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 3 * 21504 / 16; i += 256) reinterpret_cast<half8 *>(lds)[i] = in[(blockIdx.x * 977 + i) & 65535];
+    half8 av[KV][MB], aa[10 - KV][MB];
+#pragma unroll
+    for (int s = 0; s < KV; s++)
+#pragma unroll
+        for (int m = 0; m < MB; m++) av[s][m] = in[(blockIdx.x * 256 + tid + 131 * (s * MB + m)) & 65535];
+#pragma unroll
+    for (int s = KV; s < 10; s++)
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+            const half8 *p = in + ((blockIdx.x * 256 + tid + 131 * (s * MB + m)) & 65535);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(aa[s - KV][m]) : "v"(p) : "memory");
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 acc0[MB], acc1[MB];
+    float sum[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+        acc0[m] = f32x4{0, 0, 0, 0}; acc1[m] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) sum[m][r] = 0.0f;
+    }
+    const float cf = 0.37f;
+    for (int t = 0; t < tiles; t++) {
+        const char *cur = lds + (t % 3) * 21504 + lane * 16;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            f32x4 *acc = n ? acc1 : acc0;
+            f32x4 *old = n ? acc0 : acc1;
+            half8 b = *reinterpret_cast<const half8 *>(cur + n * 1024);
+#pragma unroll
+            for (int s = 0; s < 10; s++) {
+                half8 b1 = b;
+                if (s + 1 < 10) b1 = *reinterpret_cast<const half8 *>(cur + n * 1024 + (s + 1) * 2048);
+#pragma unroll
+                for (int m = 0; m < MB; m++) {
+                    if (s < KV) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[s][m], b, s == 0 ? f32x4{-1.0f, -1.0f, -1.0f, -1.0f} : acc[m], 0, 0, 0);
+                    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(aa[s - KV][m]), "v"(b));
+                    const int v0 = (s * MB * 4) / 10 + (m * (((s + 1) * MB * 4) / 10 - (s * MB * 4) / 10)) / MB;
+                    const int v1 = (s * MB * 4) / 10 + ((m + 1) * (((s + 1) * MB * 4) / 10 - (s * MB * 4) / 10)) / MB;
+#pragma unroll
+                    for (int v = v0; v < v1; v++) sum[v >> 2][v & 3] = fmaf(cf, __builtin_amdgcn_exp2f(old[v >> 2][v & 3] * 1e-3f), sum[v >> 2][v & 3]);
+                }
+                b = b1;
+            }
+        }
+        __syncthreads();
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) r += sum[m][q] + acc0[m][q] + acc1[m][q];
+    out[blockIdx.x * 256 + tid] = r;
+}
+
 // returns nothing; flop = blocks * 4 waves * tiles * 20 * MB * 16384
 void launch_mfma_model_test(const void *in, float *out, int mb, int blocks, int tiles, hipStream_t s)
 {
-    if (mb == 8) hipLaunchKernelGGL(k_mfma_model<8>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
+    if (mb == 9) hipLaunchKernelGGL(k_mfma_model8a, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);   // 8 row blocks, hand-placed AccVGPRs
+    else if (mb == 8) hipLaunchKernelGGL(k_mfma_model<8>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
     else hipLaunchKernelGGL(k_mfma_model<4>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
 }
 
