@@ -1773,12 +1773,12 @@ int haf_test_mfma_rate(int device, int iters, double *tflops)
 // timing model of the screening kernel's inner loop with mb = 4 or 8 row blocks per wave (testkernels.hip): executed TFLOP/s
 int haf_test_mfma_model(int device, int mb, int tiles, double *tflops)
 {
-    if (!tflops || tiles < 1 || (mb != 4 && mb != 8 && mb != 9)) return HAF_E_ARG;
+    if (!tflops || tiles < 1 || (mb != 4 && mb != 5 && mb != 8 && mb != 9)) return HAF_E_ARG;
     if (hipSetDevice(device) != hipSuccess) return HAF_E_DEVICE;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HAF_E_DEVICE;
-    const int blocks = (mb >= 8 ? 1 : 2) * prop.multiProcessorCount * 8;          // eight rounds of workgroups
-    const int mbe = mb == 9 ? 8 : mb;                                              // (9 = the hand-placed form of 8)
+    const int blocks = (mb >= 5 ? 1 : 2) * prop.multiProcessorCount * 8;          // eight rounds of workgroups
+    const int mbe = mb == 9 ? 8 : (mb == 5 ? 8 : mb);                              // (9 = the hand-placed form of 8; 5 = 4 row blocks x 8 waves: same flop per workgroup as 8)
     std::vector<uint16_t> h(65536 * 8);
     uint32_t x = 777u;
     for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x2800u | ((x >> 9) & 0x83FFu)); }
@@ -1787,7 +1787,8 @@ int haf_test_mfma_model(int device, int mb, int tiles, double *tflops)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = HAF_E_DEVICE;
     float ms = 0.0f;
-    if (hipMalloc(&din, h.size() * 2) == hipSuccess && hipMalloc((void **)&dout, (size_t)blocks * 256 * 4) == hipSuccess &&
+    // (out holds one float per thread of the widest form: 512 threads per workgroup)
+    if (hipMalloc(&din, h.size() * 2) == hipSuccess && hipMalloc((void **)&dout, (size_t)blocks * 512 * 4) == hipSuccess &&
         hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
         hipEventCreate(&e1) == hipSuccess) {
         haf::launch_mfma_model_test(din, dout, mb, blocks, 2, nullptr);

@@ -66,12 +66,12 @@ void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hi
 // two workgroups per CU, 8 = one 512-register wave per SIMD): static SV tile images in LDS (no DMA), A fragments in registers,
 // per k-step one B fragment read and MB MFMAs, the epilogue (one v_exp_f32 + one fma per accumulator value of the previous column
 // block) left to hipcc's scheduling, a barrier per tile.  Timing only.
-template <int MB>
-__global__ __launch_bounds__(256, MB == 8 ? 1 : 2) void k_mfma_model(const half8 *__restrict__ in, float *__restrict__ out, int tiles)
+template <int MB, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, (MB == 8 || THREADS == 512) ? 1 : 2) void k_mfma_model(const half8 *__restrict__ in, float *__restrict__ out, int tiles)
 {
     __shared__ __attribute__((aligned(16))) char lds[3 * 21504];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 3 * 21504 / 16; i += 256) reinterpret_cast<half8 *>(lds)[i] = in[(blockIdx.x * 977 + i) & 65535];
+    for (int i = tid; i < 3 * 21504 / 16; i += THREADS) reinterpret_cast<half8 *>(lds)[i] = in[(blockIdx.x * 977 + i) & 65535];
     half8 a[10][MB];
 #pragma unroll
     for (int s = 0; s < 10; s++)
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, MB == 8 ? 1 : 2) void k_mfma_model(const half8
     for (int m = 0; m < MB; m++)
 #pragma unroll
         for (int q = 0; q < 4; q++) r += sum[m][q] + acc0[m][q] + acc1[m][q];
-    out[blockIdx.x * 256 + tid] = r;
+    out[blockIdx.x * THREADS + tid] = r;
 }
 
 // The same model for 8 row blocks per wave with the register classes chosen by hand: the A fragments of k-steps 3..9 (56 of
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, 1) void k_mfma_model8a(const half8 *__restrict
 // returns nothing; flop = blocks * 4 waves * tiles * 20 * MB * 16384
 void launch_mfma_model_test(const void *in, float *out, int mb, int blocks, int tiles, hipStream_t s)
 {
-    if (mb == 9) hipLaunchKernelGGL(k_mfma_model8a, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);   // 8 row blocks, hand-placed AccVGPRs
+    if (mb == 5) hipLaunchKernelGGL((k_mfma_model<4, 512>), dim3(blocks), dim3(512), 0, s, (const half8 *)in, out, tiles);   // ONE 8-wave workgroup per CU
+    else if (mb == 9) hipLaunchKernelGGL(k_mfma_model8a, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);   // 8 row blocks, hand-placed AccVGPRs
     else if (mb == 8) hipLaunchKernelGGL(k_mfma_model<8>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
     else hipLaunchKernelGGL(k_mfma_model<4>, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, tiles);
 }
