@@ -261,6 +261,7 @@ struct haf_engine {
     bool prob_mode = false;
     DevBuf<FeatDesc> d_fd, d_fd_slot;
     DevBuf<ScrDesc> d_sd;
+    DevBuf<ScrCorr> d_corr;         // per-slot constants of the centred screening band
     DevBuf<float> d_part1;
     long part1_stride = 0;
     // requests with at least this many evaluation slots take the thread-per-evaluation feature kernel: its floor is one thread's
@@ -614,7 +615,7 @@ int build_tables(haf_engine *e)
             }
         sp.v_max = sp.dv_max = sp.das_max = sp.as_max = 0.0;
         std::vector<char> img((size_t)e->n_sv_tiles * kS0SvTileBytes, 0);
-        std::vector<double> Wh((size_t)m.n_sv * kS0K, 0.0), Wd((size_t)m.n_sv * kS0K, 0.0);
+        std::vector<double> Wh((size_t)m.n_sv * kS0K, 0.0), Wd((size_t)m.n_sv * kS0K, 0.0), tns((size_t)m.n_sv, 0.0);
         for (int n = 0; n < m.n_sv; n++) {
             const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
             char *tile = img.data() + (size_t)t * kS0SvTileBytes;
@@ -634,6 +635,7 @@ int build_tables(haf_engine *e)
             double vv = 0;
             for (int k = 0; k < m.dim; k++) { const double v = m.sv[(size_t)n * m.dim + k] * sp.c; vv += v * v; }
             const double tn = -0.5 * vv;
+            tns[(size_t)n] = tn;
             const float tf = (float)tn;
             reinterpret_cast<float *>(tile + kS0MatBytes)[j] = tf;                          // padding columns: t = 0, coef = 0
             reinterpret_cast<float *>(tile + kS0MatBytes)[kTile + j] = (float)m.coef[(size_t)n];
@@ -650,6 +652,60 @@ int build_tables(haf_engine *e)
             double cmax = 0.0;
             for (int n = 0; n < m.n_sv; n++) cmax = std::max(cmax, std::fabs(m.coef[(size_t)n]));
             sp.sqrt_cmax = std::sqrt(cmax) * (1.0 + 1e-12);
+        }
+        // ---- centred form of the bilinear band term (kernels.h: ScreenParams) ----
+        // Reference operand ubar = the |c_n| 2^(t_n)-weighted centroid of the fp16 support vectors in slot space (for a model whose
+        // support vectors are spread evenly around the origin it is ~0 and kappa_n is the kernel value at u.w_n = 0; for a trained
+        // model, whose support vectors are themselves data points, it sits where the data does).  Any ubar gives a rigorous band;
+        // this one only has to be a good guess.  All model constants in fp64, rounded UP where they feed the band.
+        {
+            std::vector<double> ub((size_t)kS0K, 0.0), ckap((size_t)m.n_sv, 0.0), G((size_t)kS0K, 0.0), Hd((size_t)kS0K, 0.0);
+            double wsum = 0.0;
+            for (int n = 0; n < m.n_sv; n++) {
+                const double wgt = std::fabs(m.coef[(size_t)n]) * std::exp2(tns[(size_t)n]);
+                wsum += wgt;
+                for (int sl = 0; sl < kS0K; sl++) ub[(size_t)sl] += wgt * Wh[(size_t)n * kS0K + sl];
+            }
+            if (wsum > 0.0) for (auto &x : ub) x /= wsum;
+            // the kernel reads ubar as fp32: use exactly those values everywhere
+            for (auto &x : ub) x = (double)(float)x;
+            sp.ubar2 = 0.0;
+            for (double x : ub) sp.ubar2 += x * x;
+            sp.ck_max = 0.0;
+            std::vector<double> DW((size_t)m.n_sv * kS0K, 0.0);
+            for (int n = 0; n < m.n_sv; n++) {
+                double mn = 0.0;
+                for (int sl = 0; sl < kS0K; sl++) mn += ub[(size_t)sl] * Wh[(size_t)n * kS0K + sl];
+                const double ck = m.coef[(size_t)n] * std::exp2(tns[(size_t)n] + mn);
+                ckap[(size_t)n] = ck;
+                sp.ck_max = std::max(sp.ck_max, std::fabs(ck));
+                for (int sl = 0; sl < kS0K; sl++) {
+                    G[(size_t)sl] += ck * Wh[(size_t)n * kS0K + sl];
+                    Hd[(size_t)sl] += ck * Wd[(size_t)n * kS0K + sl];
+                    DW[(size_t)n * kS0K + sl] = ck * Wh[(size_t)n * kS0K + sl];
+                }
+            }
+            sp.sigma_dk = sigma_upper_bound(DW.data(), m.n_sv, kS0K) * (1.0 + 1e-9);
+            std::vector<ScrCorr> sc((size_t)kS0K);
+            sp.g_norm = sp.hd_norm = 0.0;
+            for (int sl = 0; sl < kS0K; sl++) {
+                sc[(size_t)sl].g = (float)G[(size_t)sl];
+                sc[(size_t)sl].hd = (float)Hd[(size_t)sl];
+                sc[(size_t)sl].ub = (float)ub[(size_t)sl];
+                sc[(size_t)sl].pad = 0.0f;
+                sp.g_norm += G[(size_t)sl] * G[(size_t)sl];
+                sp.hd_norm += Hd[(size_t)sl] * Hd[(size_t)sl];
+            }
+            sp.g_norm = std::sqrt(sp.g_norm) * (1.0 + 1e-6);       // (also covers the fp32 rounding of the stored constants)
+            sp.hd_norm = std::sqrt(sp.hd_norm) * (1.0 + 1e-6);
+            sp.ck_max *= 1.0 + 1e-12;
+            sp.ubar2 *= 1.0 + 1e-12;
+            if (!std::isfinite(sp.sigma_dk) || !std::isfinite(sp.g_norm) || !std::isfinite(sp.hd_norm) || sp.g_norm > 1e30 ||
+                test_env("HAF_SCREEN_NO_CENTRE"))
+                sp.sigma_dk = INFINITY;                          // centred estimate never chosen (A/B runs; degenerate models)
+            if (hipSuccess != e->d_corr.alloc(sc.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening corrections)");
+            HIPCHK(e, hipMemcpy(e->d_corr.p, sc.data(), sc.size() * sizeof(ScrCorr), hipMemcpyHostToDevice));
+            sp.corr = e->d_corr.p;
         }
         // the bounds feed a rigorous band: round them up past their own fp64 rounding
         sp.v_max *= 1.0 + 1e-12; sp.dv_max *= 1.0 + 1e-12; sp.das_max = sp.das_max * (1.0 + 1e-12) + 1e-300;
@@ -908,7 +964,7 @@ void haf_destroy(haf_engine *e)
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_own.release(); e->d_gridf.release(); e->d_evf.release(); e->d_ptext.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_rec.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
-    e->d_sd.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
+    e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     if (e->h_clouds) (void)hipHostFree(e->h_clouds);
     if (e->h_geo) (void)hipHostFree(e->h_geo);
     if (e->h_rec) (void)hipHostFree(e->h_rec);

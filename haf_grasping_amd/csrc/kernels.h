@@ -98,6 +98,17 @@ struct ScreenParams {
     double sqrt_cmax;             // sqrt(max_n |coef_n|)
     double scale;                 // 1.001 (roundings of the band expression itself) x HAF_GUARD0_REL
     double eta_abs;               // |u' - u| beyond the relative part: fp64 roundings of the screening attribute formula (norm)
+    // ---- centred form of the bilinear band term ----
+    // w_n = c_n K_n is split into c_n kappa_n sc + c_n (k_n - kappa_n) sc with kappa_n = 2^(t_n + ubar.w^_n) -- the raw kernel value at
+    // a reference operand ubar (the |c| kappa-weighted centroid of the support vectors; sc = the common factor 2^(-|u|^2/2)).  The first
+    // part does not depend on the evaluation: its first-order error is the dot product of the operand residuals with the model constants
+    // G = W^'(c kappa), Hd = (W^ - W)'(c kappa) and is CORRECTED; only the second part is bounded through the spectral norms, with
+    // |c (k - kappa)|_2 <= ln2 2^zmax (sigma_dk |u^ - ubar| + ck_max |e|_2), zmax = |u^ - ubar| max|w^_n| + max|e_n|.
+    double sigma_dk;              // upper bound of the largest singular value of diag(c kappa) W^   (inf: centred form switched off)
+    double ck_max;                // max_n |c_n kappa_n|
+    double ubar2;                 // |ubar|^2
+    double g_norm, hd_norm;       // |G|_2, |Hd|_2 (the fp32 roundings of the correction and of u' against u are bounded through them)
+    const struct ScrCorr *corr;   // kS0K per-slot constants {G, Hd, ubar} (device)
     const struct ScrDesc *sd;     // kS0K compact descriptors (device), one per SLOT, for the two-region groups
     const struct ScrDesc3 *sd3;   // kS0K general descriptors (device), one per slot
     const struct FeatDesc *fd_slot;   // kS0K feature descriptors (device): the representative attribute of every slot
@@ -116,6 +127,8 @@ struct ScrDesc {
     float  pad;
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
+// per-slot constants of the centred band (ScreenParams): one 16-byte scalar load
+struct ScrCorr { float g, hd, ub, pad; };
 // The same for any feature (three regions, HAF or SHAF rule): the groups that are not in ScreenParams::fast_groups
 struct ScrDesc3 {
     int    off[12];               // band BYTE offsets of the corners of regions 0..2
@@ -130,8 +143,11 @@ constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image 
 // per-evaluation guard band of the screening pass, written by the feature kernel (4 floats per evaluation):
 //   |dec^ - dec| <= min(gA * |w|_2, gC * S) + (guard_acc0 + gB) * S + cm * (|dec^| + |rho|) + guard_abs,  S = sum|coef|K,
 //   |w|_2 = sqrt(sum (coef K)^2), measured by the SUMSQ variant of k_svm_screen or bounded by sqrt(max|coef| * S)
-// with {gA, gB, gC, cm} per evaluation
-constexpr int kBandFloats = 4;
+// with {gA, gB, gC, cm} per evaluation, and for the CENTRED estimate dec^ - corr * sc (ScreenParams):
+//   |dec^ - corr sc - dec| <= abs_c * sc + (guard_acc0 + gB) * S + cm (|dec^ - corr sc| + |corr sc| + |rho|) + guard_abs
+// {corr, abs_c} in raw space (the contraction kernel applies the common factor sc); the kernel decides from whichever of the
+// two estimates has the narrower band.  8 floats per evaluation: {gA, gB, gC, cm, corr, abs_c, 0, 0}
+constexpr int kBandFloats = 8;
 
 struct CloudDev {
     const float *xyz;

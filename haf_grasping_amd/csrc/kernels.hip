@@ -1096,7 +1096,12 @@ __device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 h
 }
 
 // screening operand of one attribute: u' in fp64 (screen_attribute / screen_quad), u^ = fp16(fl32(u')); accumulates |fl32(u')|^2 and |u^ - fl32(u')|^2 in fp32, the two norms the guard band of the screening pass is made of
-__device__ __forceinline__ _Float16 screen_operand(double ud, float &su2, float &sd2)
+// Centred form of the band (kernels.h: ScreenParams): three more fp32 sums over the slots -- cr = (u^ - u').G + u'.Hd, the first-order
+// error of the evaluation-independent part of the coefficient-weighted kernel vector, which the contraction kernel SUBTRACTS, and
+// ub = u'.ubar for |u' - ubar|.  (u^ - u' is exact in fp32, so the first dot product does not cancel.)
+struct ScreenSums { float su2, sd2, cr, ub; };
+template <class Corr>
+__device__ __forceinline__ _Float16 screen_operand(double ud, ScreenSums &a, const Corr &k)
 {
     const float f = (float)ud;                       // fl32(u'): |f - u'| <= 2^-24 |u'|
     _Float16 h = (_Float16)f;                        // subnormal results stay: the matrix core multiplies them as they are
@@ -1104,10 +1109,15 @@ __device__ __forceinline__ _Float16 screen_operand(double ud, float &su2, float 
     if (fabsf((float)h) < kF16MinNormal) h = (_Float16)0.0f;
 #endif
     const float du = (float)h - f;                   // exact in fp32 (h is f rounded to fewer bits, or 0)
-    su2 = fmaf(f, f, su2);                           // both sums in fp32: screen_finish() carries the 326 roundings
-    sd2 = fmaf(du, du, sd2);
+    a.su2 = fmaf(f, f, a.su2);                       // all sums in fp32: screen_finish() carries the 326 roundings
+    a.sd2 = fmaf(du, du, a.sd2);
+    a.cr = fmaf(du, k.g, a.cr);
+    a.cr = fmaf(f, k.hd, a.cr);
+    a.ub = fmaf(f, k.ub, a.ub);
     return h;
 }
+typedef const ScrCorr __attribute__((address_space(4))) *ScrCorrK;
+__device__ __forceinline__ ScrCorrK constant_ptr(const ScrCorr *p) { return (ScrCorrK)(unsigned long long)p; }
 
 // attributes that share a slot beyond the first count once more in |u|^2 (the common factor), not in the operand: sx gets
 // extra * u'^2 for the slots of group g that have any (wave-uniform; three slots of the reference's feature file)
@@ -1158,7 +1168,8 @@ __device__ __forceinline__ double sqrt_upper(double x)
 // 2^z - 1 <= ln2 z + 0.26 z^2 for 0 <= z < 0.05 (y = z ln2: e^y - 1 <= y + y^2/2 e^y)
 __device__ __forceinline__ double exp2m1_upper(double z) { return 0.69314718056 * z + 0.26 * z * z; }
 
-__device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2, const ScreenParams &sp, float *band, float &nax)
+__device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2, double cr, double ubd, const ScreenParams &sp, float *band,
+                                              float &nax)
 {
     // su2 = sum over the SLOTS of fl32(u')^2 and sd2 = sum over the slots of (u^ - fl32(u'))^2: the two norms of the operand the
     // contraction sees (kernels.h: attributes that share a slot are one operand).  sx2 = su2 + the squares of the attributes
@@ -1194,6 +1205,39 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2
     // outside the range the bounds were derived for, or a common factor 2^(a_x) that fp32 sums could overflow on: never trusted
     // (2^(2 a_x) must stay finite in fp32 for the SUMSQ variant's sum of squares)
     if (!(e_max + D < 0.05) || !(a_x < 30.0)) band[1] = __builtin_inff();
+    // ---- the centred estimate dec^ - corr * sc (kernels.h: ScreenParams; derivation in DESIGN.md 2) ----
+    // w_n = c_n K_n = sc c_n kappa_n + sc c_n (k_n - kappa_n), kappa_n = 2^(t_n + ubar.w^_n), k_n = 2^(t_n + u.w_n) (raw space, TRUE
+    // operands).  First-order error of the first part: ln2 sc [(u^-u).G + u.Hd], known up to u' - u and fp32 roundings: corrected.
+    // Second part: k_n - kappa_n = kappa_n (2^zeta_n - 1), zeta_n = u.w_n - ubar.w^_n = (u^ - ubar).w^_n - e_n with e_n the bilinear
+    // part of the exp2 argument's error, |e|_2 <= |u^-u| sigma(W^) + |u| sigma(dW) =: e2 and |e_n| <= d_max.  With
+    // |2^zeta - 1| <= ln2 |zeta| 2^|zeta|:   |c (k - kappa)|_2 <= ln2 2^zmax (sigma(diag(c kappa) W^) |u^ - ubar| + max|c kappa| e2).
+    band[4] = 0.0f; band[5] = __builtin_inff(); band[6] = 0.0f; band[7] = 0.0f;
+    if (sp.sigma_dk < 1e300) {
+        // |fl32(u') - ubar|^2 from the fp32 sums: each is off by at most kF32Acc of the sum of its terms' magnitudes
+        const double ubn = sqrt_upper(sp.ubar2);
+        double du2 = su2 - 2.0 * ubd + sp.ubar2 + kF32Acc * (su2 + 2.0 * un1 * ubn) + 1e-30;
+        if (!(du2 > 0.0)) du2 = (du2 == du2) ? 0.0 : du2;                        // (NaN stays NaN: never trusted)
+        const double dun = sqrt_upper(du2) + dn1;                                // |u^ - ubar| <= |fl32(u') - ubar| + |u^ - fl32(u')|
+        const double e2 = dn * sp.sigma_v + (un + dn) * sp.sigma_dv;
+        const double zmax = dun * sp.v_max + e_max;                              // sup_n |zeta_n|
+        const double zf = floor(zmax);
+        // 2^zmax <= (1 + frac) 2^floor: the chord of the convex 2^x over [0, 1] (no transcendental instruction: see sqrt_upper)
+        const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();
+        const double dev = ln2 * p2 * (sp.sigma_dk * dun + sp.ck_max * e2);
+        // what the computed correction misses: u' against u in both dot products ((u'-u).(G - Hd)), the 2 x 320 fp32 roundings of
+        // its accumulation and the fp32 rounding of the constants
+        const double cerr = ln2 * (eta * (sp.g_norm + sp.hd_norm) + 4.2e-5 * (dn1 * sp.g_norm + un1 * sp.hd_norm));
+        band[4] = (float)(ln2 * cr);
+        band[5] = (float)((ln2 * e2 * dev * infl + cerr) * sp.scale);
+        if (!(e_max + D < 0.05) || !(a_x < 30.0) || !(zmax < 60.0)) band[5] = __builtin_inff();
+    }
+}
+
+__device__ __forceinline__ void store_band(float *dst, const float *band)
+{
+    static_assert(kBandFloats == 8, "two 16-byte stores");
+    reinterpret_cast<float4 *>(dst)[0] = float4{band[0], band[1], band[2], band[3]};
+    reinterpret_cast<float4 *>(dst)[1] = float4{band[4], band[5], band[6], band[7]};
 }
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
@@ -1255,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         } else {
             for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
         }
-        if (MODE == XMODE_SCREEN) { *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{0.0f, 0.0f, 0.0f, 0.0f}; ax2[e] = 0.0f; }
+        if (MODE == XMODE_SCREEN) { const float zb[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; store_band(ax + kBandFloats * e, zb); ax2[e] = 0.0f; }
         else ax[e] = 0.0f;
         return;
     }
@@ -1265,7 +1309,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     AttrRecord *rec = (MODE != XMODE_SCREEN && dbg) ? dbg + (size_t)e_src * kKP : nullptr;   // KEEP_DEBUG only
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
-        float su2 = 0.0f, sd2 = 0.0f, sx = 0.0f;
+        ScreenSums acc{0.0f, 0.0f, 0.0f, 0.0f};
+        float sx = 0.0f;
         for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
             double ud[8];
             if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
@@ -1283,13 +1328,13 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             }
             half8 hi;
 #pragma unroll
-            for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], su2, sd2);
+            for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], acc, constant_ptr(sp.corr)[g * 8 + q]);
             screen_extra_norm(sp, g, ud, sx);
             store_group_img(xtile, r, g, hi);
         }
         float band[kBandFloats], nax;
-        screen_finish((double)su2, (double)sd2, (double)su2 + (double)sx, sp, band, nax);
-        *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
+        screen_finish((double)acc.su2, (double)acc.sd2, (double)acc.su2 + (double)sx, (double)acc.cr, (double)acc.ub, sp, band, nax);
+        store_band(ax + kBandFloats * e, band);
         ax2[e] = nax;
         return;
     }
@@ -1345,6 +1390,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     __shared__ unsigned s_w0[kFeatEvals];
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     __shared__ double red3[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
+    __shared__ float red4[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals], red5[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
@@ -1384,7 +1430,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0;
-    float su2 = 0.0f, sd2 = 0.0f, sx = 0.0f;                           // screening form: fp32 partial norms of this wave's groups
+    ScreenSums acc{0.0f, 0.0f, 0.0f, 0.0f};                            // screening form: fp32 partial sums of this wave's groups
+    float sx = 0.0f;
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
         double udv[8];
@@ -1401,7 +1448,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             udv[q] = xd;
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
-                hi[q] = screen_operand(xd, su2, sd2);
+                hi[q] = screen_operand(xd, acc, constant_ptr(sp.corr)[f]);
             } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -1420,19 +1467,19 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             store_group_img(xtile, r, g, hi);
         }
     }
-    red[gl][ev] = (MODE == XMODE_SCREEN) ? (double)su2 : xx;
-    if (MODE == XMODE_SCREEN) { red2[gl][ev] = (double)sd2; red3[gl][ev] = (double)sx; }
+    red[gl][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
+    if (MODE == XMODE_SCREEN) { red2[gl][ev] = (double)acc.sd2; red3[gl][ev] = (double)sx; red4[gl][ev] = acc.cr; red5[gl][ev] = acc.ub; }
     __syncthreads();
     if (gl == kFeatFinisher) {
-        double t = 0.0, t2 = 0.0, t3 = 0.0;
+        double t = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
 #pragma unroll
         for (int k = 0; k < kFeatWaves; k++) t += red[k][ev];         // fixed order: deterministic
         if (MODE == XMODE_SCREEN) {
 #pragma unroll
-            for (int k = 0; k < kFeatWaves; k++) { t2 += red2[k][ev]; t3 += red3[k][ev]; }
-            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f}, nax = 0.0f;
-            if (live) screen_finish(t, t2, t + t3, sp, band, nax);
-            *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
+            for (int k = 0; k < kFeatWaves; k++) { t2 += red2[k][ev]; t3 += red3[k][ev]; t4 += (double)red4[k][ev]; t5 += (double)red5[k][ev]; }
+            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, nax = 0.0f;
+            if (live) screen_finish(t, t2, t + t3, t4, t5, sp, band, nax);
+            store_band(ax + kBandFloats * e, band);
             ax2[e] = nax;
         } else {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
@@ -1466,6 +1513,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __shared__ double red[kSmSlots][kSmEvals];
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
     __shared__ double red3[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
+    __shared__ float red4[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals], red5[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
     __shared__ float s_win[kSmEvals * kWinPitch];
     __shared__ unsigned s_w0[kSmEvals];
     const int n_evals = counters[CNT_EVALS];
@@ -1498,7 +1546,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0;
-    float su2 = 0.0f, sd2 = 0.0f, sx = 0.0f;
+    ScreenSums acc{0.0f, 0.0f, 0.0f, 0.0f};
+    float sx = 0.0f;
     half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
     const int g = slot;
     const bool has_group = g < n_groups;
@@ -1517,7 +1566,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
-                hi[q] = screen_operand(xd, su2, sd2);
+                hi[q] = screen_operand(xd, acc, sp.corr[f]);           // (per quarter wave: a 16-byte vector load)
             } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -1533,19 +1582,19 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
         if (MODE == XMODE_SCREEN) store_group_img(xtile, r, g, hi);
     }
-    red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)su2 : xx;
-    if (MODE == XMODE_SCREEN) { red2[slot][ev] = (double)sd2; red3[slot][ev] = (double)sx; }
+    red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
+    if (MODE == XMODE_SCREEN) { red2[slot][ev] = (double)acc.sd2; red3[slot][ev] = (double)sx; red4[slot][ev] = acc.cr; red5[slot][ev] = acc.ub; }
     __syncthreads();
     if (slot == kFinisher) {
-        double t = 0.0, t2 = 0.0, t3 = 0.0;
+        double t = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
 #pragma unroll
         for (int k = 0; k < kSmSlots; k++) t += red[k][ev];            // fixed order: deterministic
         if (MODE == XMODE_SCREEN) {
 #pragma unroll
-            for (int k = 0; k < kSmSlots; k++) { t2 += red2[k][ev]; t3 += red3[k][ev]; }
-            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f}, nax = 0.0f;
-            if (live) screen_finish(t, t2, t + t3, sp, band, nax);
-            *reinterpret_cast<float4 *>(ax + kBandFloats * e) = float4{band[0], band[1], band[2], band[3]};
+            for (int k = 0; k < kSmSlots; k++) { t2 += red2[k][ev]; t3 += red3[k][ev]; t4 += (double)red4[k][ev]; t5 += (double)red5[k][ev]; }
+            float band[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, nax = 0.0f;
+            if (live) screen_finish(t, t2, t + t3, t4, t5, sp, band, nax);
+            store_band(ax + kBandFloats * e, band);
             ax2[e] = nax;
         } else {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument

@@ -24,7 +24,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // of the matrix core's fp32 accumulation pays for with a 2x wider band: measured 2.9 % instead of 1.9 % refined.)
 // The result is only trusted outside a rigorous per-evaluation band
 //     |dec| > min(gA |w|_2, gC S) + (guard_acc0 + gB) S + cm (|dec| + |rho|) + guard_abs,   S = sum|coef|K,  w_n = coef_n K_n,
-// {gA, gB, gC, cm} from k_features (screen_finish),
+// {gA, gB, gC, cm} from k_features (screen_finish) -- or, for the CENTRED estimate dec - corr (the first-order error of the part of
+// w that does not depend on the evaluation, computed by k_features and subtracted here), outside
+//     abs_c + (guard_acc0 + gB) S + cm (|dec - corr| + |corr| + |rho|) + guard_abs, whichever band is narrower (kernels.h),
 // which is ~20x wider than the three-pass kernel's, so a few per cent of the evaluations go on to that kernel (in list
 // mode) and from there to the fp64 tiers as before: the labels stay those of libsvm, the bulk costs a third.
 //   * a wave keeps 64 evals x 320 slots in 160 VGPRs (twice the rows of the three-pass kernel: every B fragment read
@@ -308,13 +310,12 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         // the LDS reads and their wait sit in between)
         float sc = __builtin_amdgcn_exp2f(nax[e]);
         const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
+        const float4 g2 = *reinterpret_cast<const float4 *>(gband + kBandFloats * e + 4);
         const float Ps = pos[lane], Ns = fin[lane];
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
         const float P = Ps * sc, N = Ns * sc;
         const float dv = (P + N) - p.rho;
         const float sabs = P - N;                                   // sum |coef| K
-        dec[e] = dv;
-        labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
         // {gA, gB, gC, cm} (screen_finish): linear term through the spectral norms (~sqrt(S)) or per SV (~S), whichever is
         // smaller; S-proportional terms; the common factor on (|dec^| + |rho|)
         const float adv = fabsf(dv);
@@ -322,9 +323,19 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         const float w2 = SUMSQ ? sqrtf(qrow[lane]) * sc : p.sqrt_cmax * sqrtf(sabs);
         const float lin = fminf(g.x * w2, g.z * sabs);
         const float gacc = SUMSQ ? p.guard_acc0_s : p.guard_acc0;   // single- / two-level coefficient sum
-        const float err = (lin + (gacc * 1.04f + g.y) * sabs + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
-        flagged = !(adv > err);                                     // also catches NaN
-        if (margin) margin[e] = flagged ? 0.0f : adv / err;         // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
+        const float sterm = (gacc * 1.04f + g.y) * sabs;
+        const float err1 = (lin + sterm + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
+        // the centred estimate (kernels.h): the first-order error of the evaluation-independent part of w is subtracted, the rest
+        // of the bilinear term is the absolute bound g2.y; the two fp32 operations here go with the common factor's term
+        const float corr = g2.x * sc;
+        const float dvc = dv - corr;
+        const float err2 = (g2.y * sc + sterm + (g.w + 2.4e-7f) * (fabsf(dvc) + fabsf(corr) + fabsf(p.rho))) * 1.002f + p.guard_abs;
+        const bool centred = err2 < err1;                           // decide from the estimate with the narrower band
+        const float val = centred ? dvc : dv, err = centred ? err2 : err1;
+        dec[e] = val;
+        labels[evalcell[e]] = (int8_t)(val > 0.0f ? p.gv0 : p.gv1);
+        flagged = !(fabsf(val) > err);                              // also catches NaN
+        if (margin) margin[e] = flagged ? 0.0f : fabsf(val) / err;  // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
     }
     // one 64-bit word per wave (64 consecutive evaluations): k_screen_compact turns the words into the ORDERED list of
     // undecided evaluations -- neighbours in the list are neighbours on the grid, so the feature kernel that follows reads

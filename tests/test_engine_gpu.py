@@ -62,7 +62,8 @@ DEC_REL_SCREEN = 2.0 ** -8
 
 
 # environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
-TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW")
+TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
+              "HAF_SCREEN_NO_CENTRE")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
