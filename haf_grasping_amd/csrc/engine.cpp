@@ -226,18 +226,26 @@ struct haf_engine {
     ScreenParams screen{};
     size_t cells_cap = 0;   // B*R*H*W
 
-    DevBuf<CloudDev> d_clouds;
-    DevBuf<float> d_points;
+    // ONE input block per request: [CloudDev x B][RollGeo x B*R][host clouds' points], packed at call time so that a single
+    // host-to-device copy carries everything (a small request is bound by the number of stream operations); the
+    // pinned staging block h_in has the same layout
+    DevBuf<char> d_in;
+    char *h_in = nullptr;
+    size_t in_hdr_cap = 0;          // bytes reserved for the two header arrays
+    // ONE output block: [counters][roll records], fetched with a single device-to-host copy (d_counters / d_rec point into it)
+    DevBuf<char> d_out;
+    char *h_out = nullptr;
+    bool counters_clean = false;    // the counters were zeroed behind the previous request's copy-out (off the next request's critical path)
     DevBuf<float> d_sorted;         // bucket-sorted copy of the clouds (binning of large grids, kernels.hip)
     DevBuf<int> d_bkt;              // 3 x max_clouds x kBktInts bucket counters / offsets / cursors
     int bkt_ints = 0;
-    DevBuf<RollGeo> d_geo;
     DevBuf<int> d_heights;          // ordered keys during binning, fp32 heights afterwards
     DevBuf<double> d_rowsum;        // integral image: band totals of the parallel form / row sums of the sequential fallback
     DevBuf<int> d_inexact;          // per (cloud, roll): the parallel integral image was not exact -> sequential order (kernels.hip)
     DevBuf<float> d_ii;
     DevBuf<uint8_t> d_mask;
-    DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_counters, d_evalcell, d_flag_list, d_flag2_list;
+    DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_evalcell, d_flag_list, d_flag2_list;
+    struct View { int *p = nullptr; } d_counters;      // inside d_out
     DevBuf<float> d_X, d_ax, d_dec, d_svt;
     DevBuf<char> d_svt_h;            // split-fp16 SV tile images
     DevBuf<char> d_svt0;             // screening-pass SV tile images
@@ -250,7 +258,7 @@ struct haf_engine {
     DevBuf<short> d_ev16;
     DevBuf<float> d_margin;         // HAF_FLAG_KEEP_DEBUG, default mode: |dec^| / band of every evaluation the screening tier decided
     DevBuf<AttrRecord> d_attr;      // HAF_FLAG_KEEP_DEBUG: [max_evals][kKP] attribute records of the exact-form feature kernels
-    DevBuf<RollRecordDev> d_rec;
+    struct RecView { RollRecordDev *p = nullptr; } d_rec;   // inside d_out, behind the counters
     DevBuf<unsigned long long> d_topkey;
     DevBuf<int> d_rowmax;           // best vote per grid row (k_vote_cells -> k_vote_pick)
     // probability-output mode (HAF_FLAG_PROBABILITY, prob.hip): per-cell value of the cell's own output line, the grid
@@ -269,12 +277,13 @@ struct haf_engine {
     long large_evals = 1L << 18;
     DevBuf<ScrDesc3> d_sd3;
 
-    // pinned host staging
-    CloudDev *h_clouds = nullptr;
-    RollGeo *h_geo = nullptr;
+    // pinned host staging (views into h_in / h_out; the input views are set per request)
     RollRecordDev *h_rec = nullptr;
     int *h_counters = nullptr;
-    float *h_points = nullptr;
+    // requests whose whole SVM work (evaluations x support vectors) is at most this go straight to the fp64 MFMA tier: its three
+    // launches then cost less than a fast tier's launches plus the rechecks behind it (C2: 3 760 x 172)
+    long direct_work = 1L << 20;
+    bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
@@ -293,6 +302,8 @@ namespace {
             return HAF_E_DEVICE;                                                                          \
         }                                                                                                 \
     } while (0)
+
+constexpr size_t kCntBytes = (CNT_COUNT * sizeof(int) + 15) / 16 * 16;      // the counters' share of the output block (d_out)
 
 // contraction mode: default = screening pass + three-pass refinement; HAF_FLAG_SPLIT_F16 = three passes for everything;
 // HAF_FLAG_FP32_MFMA = one fp32 MFMA pass for everything
@@ -827,8 +838,13 @@ int alloc_buffers(haf_engine *e)
     // the three-pass kernel alone from then on (haf_score_rolls)
     e->flag0_cap = mode == MODE_SCREEN ? (int)std::min<long>(std::max<long>(4096, (e->max_evals / 2 + 255) / 256 * 256), 1L << 23) : 0;
     bool ok = true;
-    ok &= hipSuccess == e->d_clouds.alloc(B);
-    ok &= hipSuccess == e->d_points.alloc((size_t)c.max_points * 3);
+    e->in_hdr_cap = (B * sizeof(CloudDev) + 15) / 16 * 16 + (B * R * sizeof(RollGeo) + 15) / 16 * 16;
+    ok &= hipSuccess == e->d_in.alloc(e->in_hdr_cap + (size_t)c.max_points * 3 * sizeof(float));
+    ok &= hipSuccess == e->d_out.alloc(kCntBytes + B * R * sizeof(RollRecordDev));
+    if (ok) {
+        e->d_counters.p = reinterpret_cast<int *>(e->d_out.p);
+        e->d_rec.p = reinterpret_cast<RollRecordDev *>(e->d_out.p + kCntBytes);
+    }
     {
         const int nb = bin_bucket_grid(c.grid_h, nullptr);
         e->bkt_ints = nb * nb + 1;
@@ -837,7 +853,6 @@ int alloc_buffers(haf_engine *e)
             ok &= hipSuccess == e->d_bkt.alloc((size_t)3 * B * e->bkt_ints);
         }
     }
-    ok &= hipSuccess == e->d_geo.alloc(B * R);
     ok &= hipSuccess == e->d_heights.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rowsum.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_inexact.alloc(B * R);
@@ -846,7 +861,6 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_rowcount.alloc(B * R * H);
     ok &= hipSuccess == e->d_rowoff.alloc(2 * (B * R * H + 1));      // whole-chunk and left-over starts (k_scan)
     ok &= hipSuccess == e->d_brcount.alloc(B * R);
-    ok &= hipSuccess == e->d_counters.alloc(CNT_COUNT);
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->list_cap);
     if (mode == MODE_SCREEN) {
@@ -888,15 +902,15 @@ int alloc_buffers(haf_engine *e)
         ok &= hipSuccess == e->d_evf.alloc(e->cells_cap);
         ok &= hipSuccess == e->d_ptext.alloc(2 * (size_t)e->list_cap);
     }
-    ok &= hipSuccess == e->d_rec.alloc(B * R);
     ok &= hipSuccess == e->d_rowmax.alloc(B * R * H);
     ok &= hipSuccess == e->d_topkey.alloc(3 * B * R);          // top vote key, longest-run key, completion counter (k_vote_*)
     if (!ok) return fail(e, HAF_E_DEVICE, std::string("hipMalloc of working buffers failed: ") + hipGetErrorString(hipGetLastError()));
-    HIPCHK(e, hipHostMalloc((void **)&e->h_clouds, B * sizeof(CloudDev)));
-    HIPCHK(e, hipHostMalloc((void **)&e->h_geo, B * R * sizeof(RollGeo)));
-    HIPCHK(e, hipHostMalloc((void **)&e->h_rec, B * R * sizeof(RollRecordDev)));
-    HIPCHK(e, hipHostMalloc((void **)&e->h_counters, CNT_COUNT * sizeof(int)));
-    HIPCHK(e, hipHostMalloc((void **)&e->h_points, (size_t)c.max_points * 3 * sizeof(float)));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_in, e->d_in.n));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_out, e->d_out.n));
+    e->h_counters = reinterpret_cast<int *>(e->h_out);
+    e->h_rec = reinterpret_cast<RollRecordDev *>(e->h_out + kCntBytes);
+    HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), e->stream));
+    e->counters_clean = true;
     return HAF_OK;
 }
 
@@ -957,19 +971,16 @@ void haf_destroy(haf_engine *e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->d_clouds.release(); e->d_points.release(); e->d_sorted.release(); e->d_bkt.release(); e->d_geo.release(); e->d_heights.release(); e->d_rowsum.release(); e->d_inexact.release();
+    e->d_in.release(); e->d_out.release(); e->d_sorted.release(); e->d_bkt.release(); e->d_heights.release(); e->d_rowsum.release(); e->d_inexact.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
-    e->d_counters.release(); e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
+    e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_own.release(); e->d_gridf.release(); e->d_evf.release(); e->d_ptext.release();
-    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_rec.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
+    e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
-    if (e->h_clouds) (void)hipHostFree(e->h_clouds);
-    if (e->h_geo) (void)hipHostFree(e->h_geo);
-    if (e->h_rec) (void)hipHostFree(e->h_rec);
-    if (e->h_counters) (void)hipHostFree(e->h_counters);
-    if (e->h_points) (void)hipHostFree(e->h_points);
+    if (e->h_in) (void)hipHostFree(e->h_in);
+    if (e->h_out) (void)hipHostFree(e->h_out);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1032,6 +1043,11 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
     }
 #endif
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
+    // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
+    if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_LARGE_EVALS") ||
+        test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE"))
+        e->direct_work = 0;
+    if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
     rc = alloc_buffers(e);
@@ -1079,7 +1095,8 @@ int haf_last_prestage(const haf_engine *e, int64_t *n_inexact_grids)
 int haf_set_stream(haf_engine *e, void *s)
 {
     if (!e) return HAF_E_ARG;
-    if (e->own_stream && e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    if (e->stream) (void)hipStreamSynchronize(e->stream);          // (the counters of the next request are zeroed on the old stream)
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     e->stream = (hipStream_t)s;
     e->own_stream = false;
     return HAF_OK;
@@ -1111,13 +1128,22 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         max_n = std::max(max_n, (int)clouds[b].n_points);
     }
     if (host_pts > (size_t)c.max_points) return fail(e, HAF_E_CAPACITY, "more host points than max_points");
+    // the request's input block (d_in / h_in): [CloudDev x B][RollGeo x B*R][points of the host clouds], one copy
+    const size_t geo_off = ((size_t)B * sizeof(CloudDev) + 15) / 16 * 16;
+    const size_t pts_off = geo_off + ((size_t)B * R * sizeof(RollGeo) + 15) / 16 * 16;
+    CloudDev *h_clouds = reinterpret_cast<CloudDev *>(e->h_in);
+    RollGeo *h_geo = reinterpret_cast<RollGeo *>(e->h_in + geo_off);
+    float *h_points = reinterpret_cast<float *>(e->h_in + pts_off);
+    const CloudDev *d_clouds = reinterpret_cast<const CloudDev *>(e->d_in.p);
+    const RollGeo *d_geo = reinterpret_cast<const RollGeo *>(e->d_in.p + geo_off);
+    const float *d_points = reinterpret_cast<const float *>(e->d_in.p + pts_off);
     size_t off = 0;
     long total_n = 0;
     bool bucket_ok = true;
     for (int b = 0; b < B; b++) {
         NormalisedInput n = normalise(in[b]);
-        CloudDev &cd = e->h_clouds[b];
-        for (int r = 0; r < R; r++) fill_roll_geo(c, in[b], n, roll_first + r, e->h_geo[b * R + r], r == 0 ? cd.m0 : nullptr);
+        CloudDev &cd = h_clouds[b];
+        for (int r = 0; r < R; r++) fill_roll_geo(c, in[b], n, roll_first + r, h_geo[b * R + r], r == 0 ? cd.m0 : nullptr);
         if (n.width == 0) bucket_ok = false;             // x-scale 0: every point lands in row H/2, whatever its distance
         cd.sorted_off = (int)total_n;
         cd.bucket_off = b * e->bkt_ints;
@@ -1127,27 +1153,25 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             cd.xyz = clouds[b].xyz;
             cd.stride = (int)clouds[b].stride_floats;
         } else {
-            float *dst = e->h_points + off * 3;
+            float *dst = h_points + off * 3;
             const float *src = clouds[b].xyz;
             const size_t st = clouds[b].stride_floats;
             if (clouds[b].n_points == 0) { /* nothing to stage */ }
             else if (st == 3) memcpy(dst, src, clouds[b].n_points * 3 * sizeof(float));
             else for (size_t i = 0; i < clouds[b].n_points; i++) { dst[i * 3] = src[i * st]; dst[i * 3 + 1] = src[i * st + 1]; dst[i * 3 + 2] = src[i * st + 2]; }
-            cd.xyz = e->d_points.p + off * 3;
+            cd.xyz = d_points + off * 3;
             cd.stride = 3;
             off += clouds[b].n_points;
         }
     }
     hipStream_t s = e->stream;
     mark(e, 0);
-    if (off) HIPCHK(e, hipMemcpyAsync(e->d_points.p, e->h_points, off * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipMemcpyAsync(e->d_clouds.p, e->h_clouds, (size_t)B * sizeof(CloudDev), hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipMemcpyAsync(e->d_geo.p, e->h_geo, (size_t)B * R * sizeof(RollGeo), hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s));
+    HIPCHK(e, hipMemcpyAsync(e->d_in.p, e->h_in, pts_off + off * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    // (the counters were zeroed behind the previous request's copy-out; after an error they may not have been)
+    if (!e->counters_clean) HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s));
+    e->counters_clean = false;
     const size_t cells = (size_t)B * R * H * W;
-    HIPCHK(e, hipMemsetAsync(e->d_labels.p, 0xFF, cells, s));            // -1: no feature vector for this cell (server.cpp:828-829)
     if (e->d_attr.p) HIPCHK(e, hipMemsetAsync(e->d_attr.p, 0xFF, e->d_attr.n * sizeof(AttrRecord), s));   // debug: "not computed"
-    mark(e, HAF_ST_BIN);
 
     Dims d;
     d.H = H; d.W = W; d.R = R; d.B = B; d.nf = e->nf; d.n_sv = e->model.n_sv; d.n_sv_tiles = e->n_sv_tiles; d.sv_tile_neg = e->sv_tile_neg;
@@ -1161,31 +1185,49 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         const long a2 = std::max(0, 2 * ((int)in[b].grasp_area_length_x / 2 - 7)) + 2, b2 = std::max(0, 2 * ((int)in[b].grasp_area_length_y / 2 - 7)) + 2;
         evals_sel += (long)R * std::min<long>((long)(H - 14) * (W - 14), a2 * b2);
     }
-
-    float minus_one = -1.0f;
-    int key_m1;
-    memcpy(&key_m1, &minus_one, 4);
-    key_m1 ^= 0x7FFFFFFF;                                                // ordered key of -1.0f (499-501)
-    (void)key_m1;
-    {
+    // A request whose whole SVM work is tiny goes straight to the fp64 MFMA tier (every evaluation enters its list): same
+    // labels by construction -- the tier decides outside its own band and hands the rest to the strict tier -- and three
+    // launches instead of a feature kernel, a contraction kernel and the rechecks behind them.
+    const bool direct = !e->prob_mode && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= e->direct_work && evals_sel <= e->flag_cap;
+    const bool short_request = evals_sel * (long)e->n_sv_pad <= (1L << 26) && total_n <= (1L << 20);
+    // small grids: a1 (tail) + a2 + a3 + a4 in ONE launch (k_small_pre); the probability branch needs k_scan's row-major order
+    bool fused_pre = false;
+    mark(e, HAF_ST_BIN);
+    if (!e->prob_mode && !e->no_fused_pre)
+        fused_pre = launch_small_pre(d_clouds, d_geo, max_n, e->d_heights.p, e->d_ii.p, e->d_mask.p, e->d_rowcount.p, e->d_brcount.p,
+                                     e->d_labels.p, e->d_evalcell.p, e->d_counters.p, e->d_flag_list.p, direct, d, r_row, r_col, s);
+    if (fused_pre) {
+        mark(e, HAF_ST_INTEGRAL);
+        mark(e, HAF_ST_MASK);
+    } else {
+        HIPCHK(e, hipMemsetAsync(e->d_labels.p, 0xFF, cells, s));        // -1: no feature vector for this cell (server.cpp:828-829)
         BinScratch bs{};
         bs.sorted = e->d_sorted.p; bs.sorted_cap = e->d_sorted.p ? (long)c.max_points : 0;
         bs.bkt_count = e->d_bkt.p; bs.bkt_off = e->d_bkt.p ? e->d_bkt.p + (size_t)c.max_clouds * e->bkt_ints : nullptr;
         bs.bkt_cursor = e->d_bkt.p ? e->d_bkt.p + (size_t)2 * c.max_clouds * e->bkt_ints : nullptr;
         bs.bkt_cap = e->d_bkt.p ? c.max_clouds * e->bkt_ints : 0;
-        launch_bin(e->d_clouds.p, e->h_clouds, max_n, total_n, e->d_geo.p, e->d_heights.p, d, r_row, r_col, bucket_ok, bs, s);
+        launch_bin(d_clouds, h_clouds, max_n, total_n, d_geo, e->d_heights.p, d, r_row, r_col, bucket_ok, bs, s);
+        mark(e, HAF_ST_INTEGRAL);
+        launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, e->d_inexact.p, e->d_counters.p, d, s);
+        mark(e, HAF_ST_MASK);
+        launch_mask_count(e->d_ii.p, d_geo, e->d_mask.p, e->d_rowcount.p, d, s);
+        launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
+        launch_compact(e->d_mask.p, e->d_rowcount.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
+        if (direct) launch_prob_list(e->d_counters.p, CNT_FLAGGED, e->d_flag_list.p, e->list_cap, s);
     }
-    mark(e, HAF_ST_INTEGRAL);
-    launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, e->d_inexact.p, e->d_counters.p, d, s);
-    mark(e, HAF_ST_MASK);
-    launch_mask_count(e->d_ii.p, e->d_geo.p, e->d_mask.p, e->d_rowcount.p, d, s);
-    launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
-    launch_compact(e->d_mask.p, e->d_rowcount.p, e->d_rowoff.p, e->d_evalcell.p, d, s);
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
     auto decide = [&](int mode, bool reuse_operands) -> int {
         mark(e, HAF_ST_FEATURES);
         const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
-        if (mode == MODE_SCREEN) {
+        if (direct) {
+            // tiny request: every evaluation is on the fp64 tier's list already (k_small_pre / k_prob_list); the feature kernel
+            // writes that tier's fp64 attribute image for all of them
+            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, reinterpret_cast<float *>(e->d_x64.p), nullptr, d,
+                            e->range.lower, e->range.upper, 0.0f, std::min<long>(evals_cap, e->flag_cap), XMODE_F64, e->screen, nullptr, 0, 0,
+                            false, evals_sel, e->d_attr.p, nullptr, s);
+            mark(e, HAF_ST_SVM);
+            mark(e, HAF_ST_REFINE);
+        } else if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
             if (!reuse_operands)
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
@@ -1220,20 +1262,27 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         }
         mark(e, HAF_ST_RECHECK);
         // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
-        // is still within 2^-40 of zero (practically nothing).  Window 0 of the tier-2 list goes with every request.
+        // is still within 2^-40 of zero (practically nothing).  Window 0 of the tier-2 list goes with every request; the
+        // strict tier is launched only when the counters that come back with the roll records say it has work (never so far).
         launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, 0, e->d_counters.p,
-                            e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s);
-        launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
-                       e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+                            e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s,
+                            nullptr, direct);
         // the counters come back with the roll records: a second window costs nothing unless it is needed
         auto vote = [&]() -> int {
             mark(e, HAF_ST_VOTE);
             launch_vote(e->d_labels.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_brcount.p, e->d_ev16.p, e->d_topkey.p, e->d_rowmax.p, e->d_rec.p, d, s);
             mark(e, HAF_ST_DOWNLOAD);
-            HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
-            HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(e, hipMemcpyAsync(e->h_out, e->d_out.p, kCntBytes + (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));   // counters + records
             mark(e, HAF_ST_COUNT);
-            HIPCHK(e, hipStreamSynchronize(s));
+            // a short request (tens to hundreds of microseconds on the device) is waited for by polling: the wake-up of a
+            // blocked host thread costs more than the request's last kernels
+            if (short_request) {
+                hipError_t q;
+                while ((q = hipStreamQuery(s)) == hipErrorNotReady) { }
+                HIPCHK(e, q);
+            } else {
+                HIPCHK(e, hipStreamSynchronize(s));
+            }
             HIPCHK(e, hipGetLastError());
             return HAF_OK;
         };
@@ -1253,6 +1302,11 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
                            e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();
             if (rc != HAF_OK) return rc;
+        } else if (e->h_counters[CNT_FLAGGED2] > 0) {
+            launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
+                           e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+            rc = vote();
+            if (rc != HAF_OK) return rc;
         }
         return HAF_OK;
     };
@@ -1260,7 +1314,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     // the output lines as show_predicted_gps reads them, the fp32 vote (prob.hip)
     auto decide_probability = [&]() -> int {
         mark(e, HAF_ST_FEATURES); mark(e, HAF_ST_SVM); mark(e, HAF_ST_REFINE); mark(e, HAF_ST_RECHECK);
-        launch_prob_list(e->d_counters.p, e->d_flag2_list.p, e->list_cap, s);
+        launch_prob_list(e->d_counters.p, CNT_FLAGGED2, e->d_flag2_list.p, e->list_cap, s);
         launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
                        e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
         mark(e, HAF_ST_VOTE);
@@ -1268,8 +1322,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
                            e->d_brcount.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_own.p, e->d_ptext.p, e->d_gridf.p,
                            e->d_evf.p, e->d_rec.p, evals_cap, d, s);
         mark(e, HAF_ST_DOWNLOAD);
-        HIPCHK(e, hipMemcpyAsync(e->h_rec, e->d_rec.p, (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
-        HIPCHK(e, hipMemcpyAsync(e->h_counters, e->d_counters.p, CNT_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipMemcpyAsync(e->h_out, e->d_out.p, kCntBytes + (size_t)B * R * sizeof(RollRecordDev), hipMemcpyDeviceToHost, s));
         mark(e, HAF_ST_COUNT);
         HIPCHK(e, hipStreamSynchronize(s));
         HIPCHK(e, hipGetLastError());
@@ -1280,7 +1333,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     int rc = e->prob_mode ? decide_probability() : decide(mode, false);
     if (rc != HAF_OK) return rc;
     const int inexact_grids = e->h_counters[CNT_INEXACT];     // (a redo of the decision stage below resets the counters)
-    if (mode == MODE_SCREEN && !e->prob_mode) {
+    if (mode == MODE_SCREEN && !e->prob_mode && !direct) {
         auto undecided = [&]() { return e->h_counters[CNT_FLAGGED0]; };
         const int ne = e->h_counters[CNT_EVALS];
         if (undecided() > e->flag0_cap && !e->screen_sumsq) {
@@ -1315,7 +1368,9 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
     e->last_inexact = inexact_grids;
-    e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && e->last_flagged0 <= e->flag0_cap;
+    e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->last_flagged0 <= e->flag0_cap;
+    // zero the counters for the next request now, behind this one's copy-out: off that request's critical path
+    if (hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s) == hipSuccess) e->counters_clean = true;
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
     if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");

@@ -237,7 +237,7 @@ struct ProbParams {
     int gv0, gv1;         // (int)atof(first two characters of "%g" of label[0] / label[1])  (server.cpp:833)
     float hdr;            // what the "labels a b" header line parses to: the value of the first masked cell of a roll
 };
-void launch_prob_list(int *counters, int *list, int cap, hipStream_t s);
+void launch_prob_list(int *counters, int slot, int *list, int cap, hipStream_t s);
 void launch_probability(const double *dec_exact, const int *evalcell, const int *counters, ProbParams P, int8_t *labels,
                         const uint8_t *mask, const int *rowcount, const int *brcount, const float *heights, float *own,
                         double *ptext, float *gridf, float *evf, RollRecordDev *rec, long evals_cap, Dims d, hipStream_t s);
@@ -256,18 +256,25 @@ int bin_bucket_grid(int H, int *bucket_cells);     // buckets per side for a gri
 // returns true when the bucket-sorted path ran (it also fills the empty cells: no separate fill launch needed)
 bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, long total_n, const RollGeo *geo, int *hkeys, Dims d,
                 float r_row, float r_col, bool bucket_ok, BinScratch bs, hipStream_t s);
+// small grids: a1 (tail) + a2 + a3 + a4 in one launch, one workgroup per (cloud, roll); false when the grid does not fit LDS
+bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int *hkeys, float *ii, uint8_t *mask, int *rowcount,
+                      int *brcount, int8_t *labels, int *evalcell, int *counters, int *flag_list, bool direct, Dims d, float r_row,
+                      float r_col, hipStream_t s);
+size_t small_pre_lds(int H, int W);
 void launch_integral(int *hkeys_heights, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s);
 void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s);
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
 void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
 // operand image the feature kernels write
-enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2 };
+enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2,
+       XMODE_F64 = 3 };   // the fp64 attribute image of the fp64 MFMA tier (X = double *, [group of 16][324][16]); no ax
 // idx_list == nullptr: evaluations 0..counters[CNT_EVALS]; otherwise slot j takes evaluation idx_list[j],
 // j < min(counters[list_counter], list_cap) (the screened evaluations that go on to the three-pass kernel)
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
                      const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
-                     float *ax2, hipStream_t s);   // ax2: screening form only, -|u|^2/2 per evaluation
+                     float *ax2, hipStream_t s,    // ax2: screening form only, -|u|^2/2 per evaluation
+                     int list_off = 0);            // list mode: idx_list points at entry list_off of the list counted by list_counter
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
@@ -284,7 +291,9 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
                          const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
-                         double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s);
+                         double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s,
+                         AttrRecord *dbg = nullptr,    // dbg: attribute records of a request that went straight to this tier
+                         bool have_x64 = false);       // the attribute image is in place already (launch_features XMODE_F64)
 constexpr int kRecheckPartRows = 2 * 8 + 1;       // part64: [2 * kMSplit + 1][flag_cap] doubles (partial sums + |x|^2)
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
                  int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s);

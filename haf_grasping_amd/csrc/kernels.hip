@@ -14,7 +14,7 @@
 //   k_svm_rbf_h      the same as three fp16 MFMA passes on the hi/lo halves of the fp32 operands, exp epilogue, guard
 //                    band (tier 1: on the list in the default mode, on everything with HAF_FLAG_SPLIT_F16)
 //   k_svm_rbf        the same as one fp32 MFMA pass (HAF_FLAG_FP32_MFMA)
-//   k_recheck_x / k_recheck_mfma / k_recheck_combine   guard-band evaluations again as an fp64 MFMA contraction (tier 2)
+//   k_features<XMODE_F64> / k_recheck_mfma / k_recheck_combine   guard-band evaluations again as an fp64 MFMA contraction (tier 2)
 //   k_recheck        what is still within 2^-40 of zero, in libsvm's exact fp64 summation order (tier 3)
 //   k_vote_cells / k_vote_pick   show_predicted_gps 865-932 (29-tap vote, first-wins argmax, longest-run centring) and the
 //                    z window of transform_gp_in_wcs_and_publish 1342-1351
@@ -41,6 +41,9 @@ __device__ __forceinline__ float key2f(int k)
 {
     return __int_as_float(k >= 0 ? k : (k ^ 0x7FFFFFFF));
 }
+
+// entries of a list of `total` that fall into the window [off, off + cap)
+__device__ __forceinline__ int window_count(int total, int off, int cap) { return max(0, min(total - off, cap)); }
 
 __global__ void k_fill_i32(int *p, int v, size_t n)
 {
@@ -836,6 +839,166 @@ void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small grids, ONE launch for a1 (tail) + a2 + a3 + a4: the reference's own 56 x 56 grid fits LDS with everything derived from it,
+// and a small request is bound by the number of dependent launches (fill, bin, integral, mask, scan, compact: six launches of
+// 4-7 us each for ~10 us of work).  One workgroup per (cloud, roll):
+//   cells <- -1 keys; [BIN: transform + ds_max of the cloud's points, exactly k_bin_lds's arithmetic]  or  cells <- the keys a
+//   binning kernel left in global memory (clouds too large for one workgroup per roll); heights finalised (522-528);
+//   SEQUENTIAL fp64 row sums, then column sums (the reference's order by construction, as k_integral_small); mask and row counts
+//   (k_mask_count's cell_in_box on the LDS copy); the roll's evaluations appended to the global list in row-major order.
+// The list segment of a roll is reserved with ONE atomicAdd on counters[CNT_EVALS]: the order of the rolls inside the list
+// depends on which workgroup gets there first, nothing else does (labels, decision values and votes are written per cell through
+// evalcell).  The labels of the roll's grid are initialised here too (-1: no feature vector, server.cpp:828-829).
+// DIRECT: also enter every evaluation into the fp64 tier's list (requests so small that the exact tier costs less than the
+// fast ones' launches: engine.cpp).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSmallPreThreads = 1024;
+constexpr int kSmallPreMaxPoints = 16384;        // BIN inside the kernel up to this many points per cloud (one workgroup per roll reads them all)
+
+__host__ __device__ inline int small_pre_pitch(int W) { return ((W + 15) / 16) * 16 + 1; }
+size_t small_pre_lds(int H, int W)
+{
+    return (size_t)H * small_pre_pitch(W) * sizeof(double) + (size_t)H * W * 4 + (size_t)(H + 1) * (W + 1) * 4 + (size_t)H * 4;
+}
+
+template <bool BIN>
+__global__ __launch_bounds__(kSmallPreThreads) void k_small_pre(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
+                                                                int *hk, float *__restrict__ ii, uint8_t *__restrict__ mask,
+                                                                int *__restrict__ rowcount, int *__restrict__ brcount,
+                                                                int8_t *__restrict__ labels, int *__restrict__ evalcell,
+                                                                int *__restrict__ counters, int *__restrict__ flag_list, int direct,
+                                                                Dims d, float r_row, float r_col, int key_empty)
+{
+    extern __shared__ double s_rs[];                      // [H][pitch] fp64 row sums | [H*W] keys -> heights | [(H+1)*(W+1)] II | [H] counts
+    __shared__ int s_base;
+    const int br = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int H = d.H, W = d.W, W1 = W + 1, HW = H * W;
+    const int pitch = small_pre_pitch(W);
+    int *cells = reinterpret_cast<int *>(s_rs + (size_t)H * pitch);
+    float *s_h = reinterpret_cast<float *>(cells);
+    float *s_I = reinterpret_cast<float *>(cells + HW);
+    int *s_cnt = reinterpret_cast<int *>(s_I + (size_t)(H + 1) * W1);
+    int *keys = hk + (size_t)br * HW;
+    float *hts = reinterpret_cast<float *>(keys);
+    float *I = ii + (size_t)br * (H + 1) * W1;
+    const RollGeo &g = geo[br];
+    int8_t *lab = labels + (size_t)br * HW;
+    for (int k = tid; k < HW; k += kSmallPreThreads) {
+        cells[k] = BIN ? key_empty : keys[k];
+        lab[k] = (int8_t)-1;
+    }
+    __syncthreads();
+    if (BIN) {
+        const CloudDev c = clouds[br / d.R];
+        for (int i = tid; i < c.n; i += kSmallPreThreads) {
+            const float *p = c.xyz + (size_t)i * c.stride;
+            const float x = p[0], y = p[1], z = p[2];
+            // pcl::transformPointCloud (488): fp32, left to right, unfused
+            float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
+            float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
+            float pz = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[8], x), __fmul_rn(g.m[9], y)), __fmul_rn(g.m[10], z)), g.m[11]);
+            if ((px > -r_row) && (px < r_row) && (py > -r_col) && (py < r_col) && (pz == pz)) {   // 510-511; NaN z never wins 515
+                int ix = (int)floorf(__fmul_rn(100.0f, __fadd_rn(px, r_row)));                   // 513
+                int iy = (int)floorf(__fmul_rn(100.0f, __fadd_rn(py, r_col)));                   // 514
+                if (ix >= 0 && ix < H && iy >= 0 && iy < W) atomicMax(&cells[ix * W + iy], f2key(pz));
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < HW; k += kSmallPreThreads) {     // finalise the heights (522-528): LDS copy + the grid a11 and the debug fetch read
+        const float h = final_height(cells[k]);
+        s_h[k] = h;
+        hts[k] = h;
+    }
+    __syncthreads();
+    for (int row = tid; row < H; row += kSmallPreThreads) {   // running sum along the row (589-595)
+        double s = 0.0;
+        for (int c = 0; c < W; c++) {
+            s = __dadd_rn(s, (double)s_h[row * W + c]);
+            s_rs[(size_t)row * pitch + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < W1; c += kSmallPreThreads) {        // running sum down the column, fp32 store (601)
+        s_I[c] = 0.0f;
+        I[c] = 0.0f;
+        if (c == 0) {
+            for (int r = 0; r < H; r++) { s_I[(size_t)(r + 1) * W1] = 0.0f; I[(size_t)(r + 1) * W1] = 0.0f; }
+        } else {
+            double acc = 0.0;
+            for (int r = 0; r < H; r++) {
+                acc = __dadd_rn(acc, s_rs[(size_t)r * pitch + (c - 1)]);
+                const float v = (float)acc;
+                s_I[(size_t)(r + 1) * W1 + c] = v;
+                I[(size_t)(r + 1) * W1 + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // mask (666-749) and row counts: a wave per grid row
+    uint8_t *mgrid = mask + (size_t)br * HW;
+    for (int i = wave; i < H; i += kSmallPreThreads / 64) {
+        int cnt = 0;
+        for (int j0 = 0; j0 < W; j0 += 64) {
+            const int j = j0 + lane;
+            const bool m = (j < W) && cell_in_box(s_I, W1, H, i, j, g);
+            if (j < W) mgrid[i * W + j] = m ? 1 : 0;
+            cnt += __popcll(__ballot(m));
+        }
+        if (lane == 0) { s_cnt[i] = cnt; rowcount[br * H + i] = cnt; }
+    }
+    __syncthreads();
+    if (tid == 0) {                                        // exclusive prefix over the rows (H <= a few dozen), segment reservation
+        int run = 0;
+        for (int i = 0; i < H; i++) { const int c = s_cnt[i]; s_cnt[i] = run; run += c; }
+        brcount[br] = run;
+        s_base = run ? atomicAdd(&counters[CNT_EVALS], run) : 0;
+        if (direct && run) atomicAdd(&counters[CNT_FLAGGED], run);
+    }
+    __syncthreads();
+    const int base = s_base;
+    for (int i = wave; i < H; i += kSmallPreThreads / 64) {   // (each lane re-reads the mask bytes it wrote itself)
+        int done = s_cnt[i];
+        for (int j0 = 0; j0 < W; j0 += 64) {
+            const int j = j0 + lane;
+            const bool m = (j < W) && mgrid[i * W + j];
+            const unsigned long long bal = __ballot(m);
+            if (m) {
+                const int e = base + done + __popcll(bal & ((1ull << lane) - 1ull));
+                evalcell[e] = (br * H + i) * W + j;
+                if (direct) flag_list[e] = e;
+            }
+            done += __popcll(bal);
+        }
+    }
+}
+
+// true when the fused form ran (then nothing else of a1 tail / a2 / a3 / a4 has to be launched, and the labels are initialised)
+bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int *hkeys, float *ii, uint8_t *mask, int *rowcount,
+                      int *brcount, int8_t *labels, int *evalcell, int *counters, int *flag_list, bool direct, Dims d, float r_row,
+                      float r_col, hipStream_t s)
+{
+    const size_t lds = small_pre_lds(d.H, d.W);
+    if (lds > 64 * 1024) return false;                    // (the default dynamic-LDS limit: grids up to ~58 x 58)
+    float minus_one = -1.0f;
+    int key_empty;
+    memcpy(&key_empty, &minus_one, 4);
+    key_empty ^= 0x7FFFFFFF;                              // ordered key of -1.0f (499-501): an empty cell
+    if (max_n <= kSmallPreMaxPoints) {
+        hipLaunchKernelGGL(k_small_pre<true>, dim3(d.B * d.R), dim3(kSmallPreThreads), lds, s, clouds, geo, hkeys, ii, mask, rowcount, brcount,
+                           labels, evalcell, counters, flag_list, direct ? 1 : 0, d, r_row, r_col, key_empty);
+    } else {
+        // a large cloud: many workgroups bin it (k_bin_lds: LDS-private grids, one global atomicMax per touched cell), then the rest
+        launch_fill_i32(hkeys, key_empty, (size_t)d.B * d.R * d.H * d.W, s);
+        dim3 grid((max_n + kBinChunk - 1) / kBinChunk, d.B * d.R);
+        hipLaunchKernelGGL(k_bin_lds, grid, dim3(256), (size_t)d.H * d.W * sizeof(int), s, clouds, geo, hkeys, d, r_row, r_col, key_empty);
+        hipLaunchKernelGGL(k_small_pre<false>, dim3(d.B * d.R), dim3(kSmallPreThreads), lds, s, clouds, geo, hkeys, ii, mask, rowcount, brcount,
+                           labels, evalcell, counters, flag_list, direct ? 1 : 0, d, r_row, r_col, key_empty);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // a5/a6: one feature value from the 15x15 integral window (fv.cpp:141-199).  fp32, strict order, unfused.
 // ---------------------------------------------------------------------------------------------------
 // Integral-image reads go through a buffer descriptor: address = descriptor base + 32-bit VGPR byte offset (the window
@@ -1381,9 +1544,11 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
                                                   const int *__restrict__ idx_list, int list_counter, int list_cap,
-                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2)
+                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2, int list_off)
 {
-    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
+    // XMODE_F64: the fp64 attribute image of the fp64 MFMA tier (k_recheck_mfma), [group of 16 slots][324][16] doubles, for a
+    // window [list_off, list_off + list_cap) of the tier's list (idx_list already points at entry list_off)
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64) ? 64 : kSvmBlockEvals;
     constexpr int kFeatFinisher = 0;                          // the wave that sums up the partial norms
     __shared__ double red[kFeatWaves][kFeatEvals];
     __shared__ float s_win[kFeatEvals * kWinPitch];
@@ -1391,7 +1556,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     __shared__ double red3[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     __shared__ float red4[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals], red5[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
-    const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
+    const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
@@ -1409,7 +1574,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
+    const int n_groups = (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
+    double *x64 = reinterpret_cast<double *>(X) + (size_t)(e >> 4) * kKP * 16 + (e & 15);
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
     const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;  // the evaluation this slot holds
@@ -1456,6 +1622,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                 lo[q] = l;
                 const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
                 xx = fma((double)xe, (double)xe, xx);
+            } else if (MODE == XMODE_F64) {
+                if (f < kKP) x64[(size_t)f * 16] = xd;                  // unused slots and attributes beyond the feature file: zeros
             } else {
                 if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
                 xx = fma((double)xf, (double)xf, xx);
@@ -1481,7 +1649,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             if (live) screen_finish(t, t2, t + t3, t4, t5, sp, band, nax);
             store_band(ax + kBandFloats * e, band);
             ax2[e] = nax;
-        } else {
+        } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
     }
@@ -1505,9 +1673,10 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
-                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2)
+                                                  AttrRecord *__restrict__ dbg, float *__restrict__ ax2,
+                                                  const int *__restrict__ idx_list, int list_counter, int list_cap, int list_off)
 {
-    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64) ? 64 : kSvmBlockEvals;
     constexpr int kFinisher = 40;                     // the quarter wave that sums up the partial norms (one without a group of its own in the screening form)
     static_assert(kSmSlots >= 2 * kHSteps && kFinisher < kSmSlots, "slots cover the groups");
     __shared__ double red[kSmSlots][kSmEvals];
@@ -1516,7 +1685,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __shared__ float red4[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals], red5[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
     __shared__ float s_win[kSmEvals * kWinPitch];
     __shared__ unsigned s_w0[kSmEvals];
-    const int n_evals = counters[CNT_EVALS];
+    // (list mode: slot j holds evaluation idx_list[j] of the window [list_off, list_off + list_cap) of the list counted by list_counter)
+    const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kSmEvals >= n_pad) return;
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
@@ -1531,10 +1701,12 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_F32) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
+    const int n_groups = (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
+    double *x64 = reinterpret_cast<double *>(X) + (size_t)(e >> 4) * kKP * 16 + (e & 15);      // XMODE_F64: see k_features
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e], d.H, d.W) : 0xffffffffu;
+    const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;   // the evaluation this slot holds
+    if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e_src], d.H, d.W) : 0xffffffffu;
     __syncthreads();
     for (int idx = threadIdx.x; idx < kSmEvals * 15 * 16; idx += kSmWaves * 64) {
         const int col = idx & 15, seg = idx >> 4, wev = seg & (kSmEvals - 1), x = seg >> 4;       // 16 lanes = one window row
@@ -1562,7 +1734,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
                 const float ex = F.scr_extra;                            // (per quarter wave here: the group differs between them)
                 if (ex != 0.0f) { const float ff = (float)xd; sx = fmaf(ex * ff, ff, sx); }
             } else if (live && f < d.nf) {
-                xd = attribute_value_rec(src, fd[f], lower, upper, tb, (dbg) ? dbg + (size_t)e * kKP + f : nullptr);
+                xd = attribute_value_rec(src, fd[f], lower, upper, tb, (dbg) ? dbg + (size_t)e_src * kKP + f : nullptr);
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
@@ -1574,6 +1746,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
                 lo[q] = l;
                 const float xe = (float)h + (float)l;                  // the value the three passes actually multiply
                 xx = fma((double)xe, (double)xe, xx);
+            } else if (MODE == XMODE_F64) {
+                if (f < kKP) x64[(size_t)f * 16] = xd;
             } else {
                 if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
                 xx = fma((double)xf, (double)xf, xx);
@@ -1596,7 +1770,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             if (live) screen_finish(t, t2, t + t3, t4, t5, sp, band, nax);
             store_band(ax + kBandFloats * e, band);
             ax2[e] = nax;
-        } else {
+        } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
     }
@@ -1606,38 +1780,45 @@ template <int MODE>
 static void launch_features_mode(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                                  Dims d, double lower, double upper, float neg_gamma2, long max_evals, ScreenParams sp,
                                  const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals,
-                                 AttrRecord *dbg, float *ax2, hipStream_t s)
+                                 AttrRecord *dbg, float *ax2, hipStream_t s, int list_off = 0)
 {
-    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : kSvmBlockEvals;
-    if (large) {
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64) ? 64 : kSvmBlockEvals;
+    if (large && MODE != XMODE_F64) {
         // enough evaluations to fill the chip with one thread each
         long blocks = (max_evals + kBlock - 1) / kBlock * (kBlock / 256);
         hipLaunchKernelGGL(k_features_serial<MODE>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
                            lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
         return;
     }
-    if (!idx_list && sel_evals <= kSmallEvals) {
+    // small requests -- and every list of the fp64 tier, which is short unless the model is ill-conditioned: a third of the
+    // serial chain per thread (C3's ~8 000 flagged evaluations: 27 us against 56 us with the 64-evaluation workgroups)
+    if ((!idx_list && sel_evals <= kSmallEvals) || (idx_list && MODE == XMODE_F64)) {
         const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
         hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, dbg, ax2);
+                           lower, upper, neg_gamma2, sp, dbg, ax2, idx_list, list_counter, list_cap, list_off);
         return;
     }
     long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
     if (idx_list && blocks > 4096) blocks = 4096;                      // grid-stride inside the kernel
     if (idx_list || sel_evals <= 24576)
         hipLaunchKernelGGL((k_features<MODE, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2, list_off);
     else
         hipLaunchKernelGGL((k_features<MODE, 8>), dim3((unsigned)blocks), dim3(8 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
+                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2, list_off);
 }
 
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                      Dims d, double lower, double upper, float neg_gamma2, long max_evals, int xmode, ScreenParams sp,
                      const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
-                     float *ax2, hipStream_t s)
+                     float *ax2, hipStream_t s, int list_off)
 {
     if (max_evals <= 0) return;
+    if (xmode == XMODE_F64) {
+        launch_features_mode<XMODE_F64>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
+                                        list_counter, list_cap, false, sel_evals, dbg, ax2, s, list_off);
+        return;
+    }
     // (screening form: the kernels index their descriptor argument by SLOT; through the __restrict__ kernel argument the
     // wave-uniform descriptor words arrive by scalar loads -- through the pointer inside ScreenParams they would not)
     if (xmode == XMODE_SCREEN)
@@ -2289,12 +2470,10 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
 // (v_mfma_f64_16x16x4_f64, GEMM form, fp64 exp).  Its error is ~2^-44 of sum|coef|K, so only evaluations with
 // |dec| <= 2^-40 * T * sum|coef|K (practically none) still need libsvm's strict summation order (k_recheck).
 // Workgroup = 4 waves x 16 flagged evaluations; each wave keeps its 16 x 324 fp64 attributes as the A operand in 162
-// VGPRs (loaded from the image k_recheck_x writes with one thread per attribute), the fp64 SV tile
+// VGPRs (loaded from the image the feature kernels write in their XMODE_F64 form), the fp64 SV tile
 // (326 x 16: attributes, |s|^2, coef) is shared through LDS, double buffered with a register-staged prefetch.
 // ---------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-// entries of a list of `total` that fall into the window [off, off + cap)
-__device__ __forceinline__ int window_count(int total, int off, int cap) { return max(0, min(total - off, cap)); }
 constexpr int kMWaves = 4;
 constexpr int kMSplit = 8;                        // SV ranges a group of evaluations is split over (k_recheck_mfma tasks)
 static_assert(kRecheckPartRows == 2 * kMSplit + 1, "part64 layout");
@@ -2303,32 +2482,10 @@ constexpr int kMSteps = kKP / 4;                 // 81 k-steps of 4
 constexpr int kMTileDoubles = kM64Rows * 16;     // 5216 doubles = 41728 B
 constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per thread per tile (11)
 
-// fp64 attribute vectors of the flagged evaluations, one thread per (evaluation, attribute): [group of 16][324][16],
-// the register image of the fp64 MFMA A operand (64 consecutive doubles per k-step).
-__global__ __launch_bounds__(256) void k_recheck_x(const float *__restrict__ ii, const int *__restrict__ evalcell,
-                                                   const FeatDesc *__restrict__ fd, ExactParams p,
-                                                   const int *__restrict__ flag_list, int flag_cap, int list_off,
-                                                   const int *__restrict__ counters, double *__restrict__ x64, Dims d)
-{
-    // flag_list points at entry list_off of the tier's list; this launch takes the window [list_off, list_off + flag_cap)
-    const int n_flag = window_count(counters[CNT_FLAGGED], list_off, flag_cap);
-    const int n_grp = (n_flag + 63) / 64 * 4;          // whole k_recheck_mfma workgroups (64 evaluations): unused slots get zeros
-    const int H = d.H, W = d.W;
-    const rsrc_t iir = make_ii_rsrc(ii, d);
-    // grid-stride over the (group, attribute, evaluation) items: a handful of flagged evaluations (a small request) still
-    // spreads over the whole launch instead of keeping one workgroup busy for twenty rounds
-    const long n_items = (long)n_grp * 16 * kKP;
-    for (long item = (long)blockIdx.x * 256 + threadIdx.x; item < n_items; item += (long)gridDim.x * 256) {
-        const int grp = (int)(item / (16 * kKP)), it = (int)(item - (long)grp * (16 * kKP));
-        const int k = it >> 4, ev = it & 15;
-        const int slot = grp * 16 + ev;
-        double v = 0.0;
-        if (slot < n_flag && k < d.nf && !fd[k].skip)
-            v = attribute_value(SrcBuf<false>{iir, window_origin(evalcell[flag_list[slot]], H, W)}, fd[k], p.lower, p.upper, hafq::GlobalTabs());
-        x64[(size_t)grp * kKP * 16 + it] = v;
-    }
-}
-
+// The fp64 attribute image of the flagged evaluations -- [group of 16][324][16] doubles, the register image of the fp64 MFMA A
+// operand (64 consecutive doubles per k-step) -- is written by the feature kernels in their XMODE_F64 form (list mode, windows
+// staged in LDS).  Round 2 had a kernel of its own for it (one thread per (evaluation, attribute), per-lane descriptors and
+// corner loads): 19 ns per evaluation against 3 ns here.
 __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__ x64, const int *__restrict__ evalcell,
                                                       const double *__restrict__ sv64,
                                                       ExactParams p, const int *__restrict__ flag_list, int flag_cap,
@@ -2351,7 +2508,7 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
     for (int task = blockIdx.x; task < n_groups * kMSplit; task += gridDim.x) {
         const int g = task / kMSplit, h = task - g * kMSplit;
         const int t_begin = h * tiles_per_part, t_end = min(n_tiles, t_begin + tiles_per_part);
-        // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, from k_recheck_x's image ----
+        // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, from the XMODE_F64 image ----
         const int grp = g * kMWaves + wave;                          // 16 flagged evaluations
         double a[kMSteps];
         double xxp = 0.0;
@@ -2391,12 +2548,20 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
         for (int t = t_begin; t < t_end; t++) {
             const double *B = bt[0];
             if (t + 1 < t_end) tile_load(t + 1);
-            f64x4 acc = {0, 0, 0, 0};
+            // three interleaved chains (k-steps s, s+1, s+2 mod 3): a dependent fp64 MFMA does not issue back to back
+            f64x4 acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+            static_assert(kMSteps % 3 == 0, "81 k-steps in three chains");
 #pragma unroll
-            for (int s = 0; s < kMSteps; s++) {
-                const double b = B[(4 * s + (lane >> 4)) * 16 + (lane & 15)];      // B[k = 4s + (lane>>4)][j = lane&15]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
+            for (int s = 0; s < kMSteps; s += 3) {
+                const double b0 = B[(4 * s + (lane >> 4)) * 16 + (lane & 15)];      // B[k = 4s + (lane>>4)][j = lane&15]
+                const double b1 = B[(4 * (s + 1) + (lane >> 4)) * 16 + (lane & 15)];
+                const double b2 = B[(4 * (s + 2) + (lane >> 4)) * 16 + (lane & 15)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b0, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 2], b2, acc2, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = (acc[r] + acc1[r]) + acc2[r];
             const double ss = B[kKP * 16 + (lane & 15)];
             const double cf = B[(kKP + 1) * 16 + (lane & 15)];
 #pragma unroll
@@ -2469,14 +2634,18 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
 // host runs window 0 with every request and further windows only when more evaluations were flagged than one window holds.
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
                          const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
-                         double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s)
+                         double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s, AttrRecord *dbg,
+                         bool have_x64)
 {
     int groups = (window_cap + kMEvals - 1) / kMEvals;
     int blocks = groups < 2048 ? groups : 2048;
     if (blocks <= 0) return;
     flag_list += list_off;
     dec_exact += list_off;
-    hipLaunchKernelGGL(k_recheck_x, dim3(blocks * 2), dim3(256), 0, s, ii, evalcell, fd, p, flag_list, window_cap, list_off, counters, x64, d);
+    // (have_x64: a request that went straight to this tier -- its feature kernel wrote the image for the identity list)
+    if (!have_x64)
+        launch_features(ii, evalcell, counters, fd, reinterpret_cast<float *>(x64), nullptr, d, p.lower, p.upper, 0.0f, window_cap, XMODE_F64,
+                        ScreenParams{}, flag_list, CNT_FLAGGED, window_cap, false, window_cap, dbg, nullptr, s, list_off);
     const long tasks = (long)groups * kMSplit;
     hipLaunchKernelGGL(k_recheck_mfma, dim3((unsigned)(tasks < 4096 ? tasks : 4096)), dim3(256), 0, s, x64, evalcell, sv64, p,
                        flag_list, window_cap, list_off, counters, part64, d);

@@ -21,12 +21,12 @@
 
 namespace haf {
 
-// every evaluation onto the strict tier's list
-__global__ __launch_bounds__(256) void k_prob_list(int *__restrict__ counters, int *__restrict__ list, int cap)
+// every evaluation onto a tier's list (the strict tier's in the probability branch; the fp64 MFMA tier's for a tiny request)
+__global__ __launch_bounds__(256) void k_prob_list(int *__restrict__ counters, int slot, int *__restrict__ list, int cap)
 {
     const int n = min(counters[CNT_EVALS], cap);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) list[i] = i;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[CNT_FLAGGED2] = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[slot] = n;
 }
 
 __device__ __forceinline__ double sigmoid_predict(double dec, double A, double B)          // svm.cpp:1818-1826
@@ -242,9 +242,9 @@ void launch_probability(const double *dec_exact, const int *evalcell, const int 
     hipLaunchKernelGGL(k_prob_pick, dim3(d.B * d.R), dim3(1024), 0, s, evf, heights, brcount, rec, d);
 }
 
-void launch_prob_list(int *counters, int *list, int cap, hipStream_t s)
+void launch_prob_list(int *counters, int slot, int *list, int cap, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prob_list, dim3(1024), dim3(256), 0, s, counters, list, cap);
+    hipLaunchKernelGGL(k_prob_list, dim3(cap < 65536 ? 64 : 1024), dim3(256), 0, s, counters, slot, list, cap);
 }
 
 }  // namespace haf

@@ -63,7 +63,7 @@ DEC_REL_SCREEN = 2.0 ** -8
 
 # environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
-              "HAF_SCREEN_NO_CENTRE")
+              "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -176,6 +176,32 @@ def test_c1_c2_pcd2_stage_by_stage(data_dir, surrogate, orc, mode):
     compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32, show_only_best_grasp=1))
     compare_full(eng, orc, xyz, dict(n_rolls=12), dict(approach_vector=(0.2, -0.1, 1.0)))
     compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_center=(0.01, -0.02, 0.005), gripper_opening_width=2))
+    eng.close()
+
+
+@pytest.mark.parametrize("knobs", [(), ("HAF_NO_DIRECT",), ("HAF_NO_FUSED_PRE",), ("HAF_NO_DIRECT", "HAF_NO_FUSED_PRE")])
+def test_small_request_paths_agree_with_the_oracle(data_dir, surrogate, orc, monkeypatch, knobs):
+    """Round 3: a request on a grid that fits LDS runs its pre-stages in ONE launch (k_small_pre), and a request whose whole SVM
+    work is tiny goes straight to the fp64 MFMA tier.  Both shortcuts, either one, and neither (the separate kernels, the fast
+    tiers) must give the oracle's grids, labels and grasp: C1, C2, a tilted approach vector, the client's default area, a large
+    cloud on the small grid (k_bin_lds feeds the fused kernel), an empty and a one-point cloud."""
+    for k in knobs:
+        monkeypatch.setenv(k, "1")
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    eng = make_engine(data_dir, surrogate, testing=True)
+    got, _ = compare_full(eng, orc, xyz, dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))   # C2
+    assert got["eval"] == 103
+    cnt = eng.last_counts()
+    if "HAF_NO_DIRECT" in knobs:
+        assert cnt["n_rechecked"] < cnt["n_evals"]
+    else:
+        assert cnt["n_rechecked"] == cnt["n_evals"] == got["n_evals"] and cnt["n_refined"] == 0     # every evaluation through the fp64 tier
+    compare_full(eng, orc, xyz, dict(n_rolls=12), dict(approach_vector=(0.2, -0.1, 1.0), show_only_best_grasp=1))
+    compare_full(eng, orc, xyz, dict(n_rolls=12), dict())                                       # 32 x 44: not tiny any more
+    big = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    compare_full(eng, orc, big, dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)))
+    compare_full(eng, orc, np.zeros((0, 3), np.float32), dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))
+    compare_full(eng, orc, np.array([[0.0, 0.0, 0.05]], np.float32), dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))
     eng.close()
 
 

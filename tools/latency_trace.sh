@@ -2,22 +2,22 @@
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/lat
+O=$GRAFT_REPO_ROOT/gpurun_out/lat_${1:-C2}
 rm -rf $O; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/latency_breakdown.py --only C2 > $O/kt.log 2>&1
-python3 - <<'PY'
+mkdir -p $O; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/latency_breakdown.py --only ${1:-C2} > $O/kt.log 2>&1
+python3 - ${1:-C2} <<'PY'
 import csv,glob,os,sys
-fs=glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "lat/kt/**/*kernel_trace.csv"), recursive=True)
+fs=glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "lat_%s/kt/**/*kernel_trace.csv" % (sys.argv[1] if len(sys.argv) > 1 else "C2")), recursive=True)
 if not fs: sys.exit("no rocprofv3 CSV under $GRAFT_REPO_ROOT/gpurun_out: did the profiled run fail? see the .log next to it")
 f=fs[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-# last request = last occurrence of k_bin / k_bin_lds / k_fill to the end
+# last request = from the last launch of a request's FIRST kernel (k_small_pre, or k_fill / k_bkt_count / k_bin* when the separate
+# pre-stage kernels run) to the end
 names=[r["Kernel_Name"].split("(")[0].replace("void ","").replace("haf::","") for r in rows]
-last=max(i for i,n in enumerate(names) if n.startswith("k_fill") ) 
-# find start of last request: walk back to the first k_fill of the trailing group
-i=last
-while i>0 and names[i-1].startswith("k_fill"): i-=1
+firsts=("k_small_pre","k_fill","k_bkt_count")
+starts=[i for i,n in enumerate(names) if n.startswith(firsts) and (i==0 or not names[i-1].startswith(("k_fill","k_bin")))]
+i=starts[-1]
 t0=int(rows[i]["Start_Timestamp"]); prev=t0
 for r,n in zip(rows[i:],names[i:]):
     s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
