@@ -240,24 +240,34 @@ def reference_tools_baseline(o, O, rng_file, model_path, xyz, args):
                        "%d evals; features+text %.2f s, svm-scale %.2f s, svm-predict %.2f s" % (c, c, args.nsv, n, t_feat, t_scale, t_pred))
 
 
-def latency_c2(feat, rng_file, device, flags):
-    """BASELINE config C2 (pcd2.pcd, 32x32 cm area, 12 rolls, surrogate model), host-resident cloud: wall time of one
-    haf_score call including the PCIe copies -- the second half of the metric."""
+def latency_small(feat, rng_file, device, flags):
+    """BASELINE configs C2 (pcd2.pcd, 32x32 cm area, 12 rolls) and C3 (table1_mult_obj, 56x56 cm, 20 rolls of 9 degrees), surrogate
+    model, host-resident cloud: wall time of one haf_score call including the PCIe copies -- the second half of the metric."""
     from haf_grasping_amd import capi
     model = os.path.join(ROOT, "tests", "golden", "surrogate.model")
-    xyz = capi.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "pcd2.pcd"))
-    eng = capi.Engine(feat, rng_file, model, device=device, flags=flags)
-    inp = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32)
-    for _ in range(3):
-        out = eng.score(xyz, inp)
-    ts = []
-    for _ in range(20):
-        t0 = time.perf_counter()
-        out = eng.score(xyz, inp)
-        ts.append(time.perf_counter() - t0)
-    eng.close()
-    return dict(workload="C2: pcd2.pcd 5088 pts, 32x32 cm, 12 rolls, surrogate model nSV=172, host cloud (PCIe included)",
-                ms_median=1e3 * float(np.median(ts)), ms_min=1e3 * float(np.min(ts)), evals=out["n_evals"], eval=out["eval"])
+    data = os.path.join(ROOT, "tests", "golden", "data")
+
+    def one(name, pcd, inp, **cfg):
+        xyz = capi.load_pcd(os.path.join(data, pcd))
+        eng = capi.Engine(feat, rng_file, model, device=device, flags=flags, max_points=1 << 18, **cfg)
+        for _ in range(3):
+            out = eng.score(xyz, inp)
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            out = eng.score(xyz, inp)
+            ts.append(time.perf_counter() - t0)
+        eng.close()
+        return dict(workload=name % xyz.shape[0], ms_median=1e3 * float(np.median(ts)), ms_min=1e3 * float(np.min(ts)),
+                    evals=out["n_evals"], eval=out["eval"])
+
+    c2 = one("C2: pcd2.pcd %d pts, 32x32 cm, 12 rolls, surrogate model nSV=172, host cloud (PCIe included)", "pcd2.pcd",
+             capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32))
+    c3 = one("C3: table1_mult_obj %d pts, 56x56 cm, centre (0.13, 0.25, 0), 20 rolls x 9 deg, surrogate model nSV=172, host cloud (PCIe included)",
+             "table1_mult_obj_rcs_1428580506606673.pcd",
+             capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)), n_rolls=20, roll_step_deg=9)
+    c2["c3"] = c3
+    return c2
 
 
 def main():
@@ -509,7 +519,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.no_latency:
-            line["grasp_latency"] = latency_c2(feat, rng_file, local_rank,
+            line["grasp_latency"] = latency_small(feat, rng_file, local_rank,
                                                {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision])
         line["ranks"] = {"world_size": world, "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                          ("bench.py (self-spawned ranks)" if world > 1 else "single process"),

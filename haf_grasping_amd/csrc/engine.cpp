@@ -280,9 +280,10 @@ struct haf_engine {
     // pinned host staging (views into h_in / h_out; the input views are set per request)
     RollRecordDev *h_rec = nullptr;
     int *h_counters = nullptr;
-    // requests whose whole SVM work (evaluations x support vectors) is at most this go straight to the fp64 MFMA tier: its three
-    // launches then cost less than a fast tier's launches plus the rechecks behind it (C2: 3 760 x 172)
-    long direct_work = 1L << 20;
+    // requests whose whole SVM work (evaluations x support vectors) is at most this go straight to tier 2's arithmetic in one
+    // launch (k_small_direct): cheaper than a feature kernel, a fast contraction and the rechecks behind it (C2: 3 760 x 172 in
+    // 36 us against 21 + 30 + 30 us; measured the other way round at C3's 31 093 x 172: 203 us against 186)
+    long direct_work = 1L << 21;
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
     // last call
@@ -1044,8 +1045,8 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
 #endif
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
-    if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_LARGE_EVALS") ||
-        test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE"))
+    if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_GUARD2_REL") ||
+        test_env("HAF_LARGE_EVALS") || test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE") || test_env("HAF_FLAG_WINDOW"))
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     int rc = build_tables(e);
@@ -1153,12 +1154,6 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             cd.xyz = clouds[b].xyz;
             cd.stride = (int)clouds[b].stride_floats;
         } else {
-            float *dst = h_points + off * 3;
-            const float *src = clouds[b].xyz;
-            const size_t st = clouds[b].stride_floats;
-            if (clouds[b].n_points == 0) { /* nothing to stage */ }
-            else if (st == 3) memcpy(dst, src, clouds[b].n_points * 3 * sizeof(float));
-            else for (size_t i = 0; i < clouds[b].n_points; i++) { dst[i * 3] = src[i * st]; dst[i * 3 + 1] = src[i * st + 1]; dst[i * 3 + 2] = src[i * st + 2]; }
             cd.xyz = d_points + off * 3;
             cd.stride = 3;
             off += clouds[b].n_points;
@@ -1166,7 +1161,42 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     }
     hipStream_t s = e->stream;
     mark(e, 0);
-    HIPCHK(e, hipMemcpyAsync(e->d_in.p, e->h_in, pts_off + off * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    // Host clouds go through the pinned block in pieces: while the DMA engine moves one piece the host packs the next (a 1.2 MB
+    // cloud -- C3 -- costs ~100 us of host memcpy; its transfer hides behind that).  The first copy carries the two header arrays.
+    {
+        constexpr size_t kPiece = 256 * 1024;                     // bytes of packed points per copy
+        size_t staged = 0, sent = 0;                              // bytes of the points area packed / handed to the DMA engine
+        bool header_sent = false;
+        auto flush = [&](bool last) -> int {
+            if (!header_sent) {
+                HIPCHK(e, hipMemcpyAsync(e->d_in.p, e->h_in, pts_off + staged, hipMemcpyHostToDevice, s));
+                header_sent = true;
+            } else if (staged > sent) {
+                HIPCHK(e, hipMemcpyAsync(e->d_in.p + pts_off + sent, e->h_in + pts_off + sent, staged - sent, hipMemcpyHostToDevice, s));
+            }
+            sent = staged;
+            (void)last;
+            return HAF_OK;
+        };
+        for (int b = 0; b < B; b++) {
+            if (clouds[b].on_device || clouds[b].n_points == 0) continue;
+            const float *src = clouds[b].xyz;
+            const size_t st = clouds[b].stride_floats, n = clouds[b].n_points;
+            for (size_t i0 = 0; i0 < n;) {
+                const size_t room = std::max<size_t>(1, (kPiece - (staged - sent)) / 12);
+                const size_t cnt = std::min(n - i0, room);
+                float *dst = reinterpret_cast<float *>(e->h_in + pts_off + staged);
+                if (st == 3) memcpy(dst, src + i0 * 3, cnt * 12);
+                else for (size_t i = 0; i < cnt; i++) { dst[i * 3] = src[(i0 + i) * st]; dst[i * 3 + 1] = src[(i0 + i) * st + 1]; dst[i * 3 + 2] = src[(i0 + i) * st + 2]; }
+                staged += cnt * 12;
+                i0 += cnt;
+                if (staged - sent >= kPiece) { const int rc = flush(false); if (rc != HAF_OK) return rc; }
+            }
+        }
+        const int rc = flush(true);
+        if (rc != HAF_OK) return rc;
+        (void)h_points;
+    }
     // (the counters were zeroed behind the previous request's copy-out; after an error they may not have been)
     if (!e->counters_clean) HIPCHK(e, hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s));
     e->counters_clean = false;
@@ -1188,7 +1218,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     // A request whose whole SVM work is tiny goes straight to the fp64 MFMA tier (every evaluation enters its list): same
     // labels by construction -- the tier decides outside its own band and hands the rest to the strict tier -- and three
     // launches instead of a feature kernel, a contraction kernel and the rechecks behind them.
-    const bool direct = !e->prob_mode && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= e->direct_work && evals_sel <= e->flag_cap;
+    const bool direct = !e->prob_mode && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= e->direct_work;
     const bool short_request = evals_sel * (long)e->n_sv_pad <= (1L << 26) && total_n <= (1L << 20);
     // small grids: a1 (tail) + a2 + a3 + a4 in ONE launch (k_small_pre); the probability branch needs k_scan's row-major order
     bool fused_pre = false;
@@ -1220,11 +1250,10 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         mark(e, HAF_ST_FEATURES);
         const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
         if (direct) {
-            // tiny request: every evaluation is on the fp64 tier's list already (k_small_pre / k_prob_list); the feature kernel
-            // writes that tier's fp64 attribute image for all of them
-            launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, reinterpret_cast<float *>(e->d_x64.p), nullptr, d,
-                            e->range.lower, e->range.upper, 0.0f, std::min<long>(evals_cap, e->flag_cap), XMODE_F64, e->screen, nullptr, 0, 0,
-                            false, evals_sel, e->d_attr.p, nullptr, s);
+            // tiny request: exact attributes, fp64 MFMA decision and label of EVERY evaluation in one launch (k_small_direct: tier 2's
+            // arithmetic); every evaluation counts as rechecked (k_small_pre / k_prob_list have put them on that tier's list)
+            launch_small_direct(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_sv64.p, e->exact, d, std::min<long>(evals_cap, e->list_cap),
+                                e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, e->d_attr.p, s);
             mark(e, HAF_ST_SVM);
             mark(e, HAF_ST_REFINE);
         } else if (mode == MODE_SCREEN) {
@@ -1264,9 +1293,9 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
         // is still within 2^-40 of zero (practically nothing).  Window 0 of the tier-2 list goes with every request; the
         // strict tier is launched only when the counters that come back with the roll records say it has work (never so far).
-        launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, 0, e->d_counters.p,
-                            e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s,
-                            nullptr, direct);
+        if (!direct)
+            launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, 0, e->d_counters.p,
+                                e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s);
         // the counters come back with the roll records: a second window costs nothing unless it is needed
         auto vote = [&]() -> int {
             mark(e, HAF_ST_VOTE);
@@ -1289,7 +1318,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         int rc = vote();
         if (rc != HAF_OK) return rc;
         const int flagged = e->h_counters[CNT_FLAGGED];
-        if (flagged > e->flag_cap && !(mode == MODE_SCREEN && e->h_counters[CNT_FLAGGED0] > e->flag0_cap)) {
+        if (!direct && flagged > e->flag_cap && !(mode == MODE_SCREEN && e->h_counters[CNT_FLAGGED0] > e->flag0_cap)) {
             // More evaluations inside the guard band of the fast contraction than one window of the fp64 tier holds (an
             // ill-conditioned model): the reference never fails a goal on this path (server.cpp:778-796), so neither does
             // the engine -- the remaining windows of the list go through the same kernels one after the other, then the

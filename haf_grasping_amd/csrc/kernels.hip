@@ -28,6 +28,7 @@
 namespace haf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------
 // helpers
@@ -1776,6 +1777,118 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     }
 }
 
+// Tiny requests (the whole SVM work of the request is a few hundred thousand evaluation x support-vector pairs: C2 with a model of
+// a few hundred support vectors), ONE launch for a5-a8: a workgroup takes 16 evaluations exactly as k_features_small does -- a
+// quarter wave per group of 8 attributes, both text round trips in exact arithmetic -- but leaves the fp64 attributes in LDS, and
+// its eleven waves then share the SV tiles of the fp64 MFMA contraction between them (v_mfma_f64_16x16x4_f64, the B operand straight
+// from the model image in L2: a tile is used once per workgroup).  Same arithmetic as tier 2 (k_recheck_mfma / k_recheck_combine)
+// except for the order in which the partial sums of the SV tiles are added -- eleven waves instead of eight ranges, fixed -- and
+// the same hand-over to the strict tier for |dec| <= guard2 * T * S.  Replaces three launches and the 10 MB round trip of the
+// attribute image for such a request.
+constexpr int kSdMSteps = kKP / 4;                // 81 k-steps of 4
+__global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                                const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
+                                                                ExactParams p, Dims d, double *__restrict__ dec_exact,
+                                                                int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap,
+                                                                int *counters, AttrRecord *__restrict__ dbg)
+{
+    __shared__ double s_x[kKP * 16];                  // [attribute][evaluation]: the A operand of the fp64 MFMA, k-major
+    __shared__ double s_part[kSmWaves][16][2];        // per wave: sum coef*K and sum |coef|*K of its SV tiles, per evaluation
+    __shared__ double s_xx[16];
+    __shared__ float s_win[kSmEvals * kWinPitch];
+    __shared__ unsigned s_w0[kSmEvals];
+    __shared__ double s_tab[hafq::kTabDoubles];
+    const int n_evals = counters[CNT_EVALS];
+    if ((long)blockIdx.x * kSmEvals >= n_evals) return;
+    const hafq::PtrTabs tb = load_decimal_tables(s_tab);
+    const int ev = threadIdx.x & 15, slot = threadIdx.x >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * kSmEvals + ev;
+    const bool live = e < n_evals;
+    const rsrc_t iir = make_ii_rsrc(ii, d);
+    if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e], d.H, d.W) : 0xffffffffu;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kSmEvals * 15 * 16; idx += kSmWaves * 64) {
+        const int col = idx & 15, seg = idx >> 4, wev = seg & (kSmEvals - 1), x = seg >> 4;       // 16 lanes = one window row
+        const unsigned o = s_w0[wev];
+        if (col < 15)
+            s_win[wev * kWinPitch + x * 15 + col] =
+                (o != 0xffffffffu) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, (int)(o + (unsigned)(x * (d.W + 1) + col) * 4u), 0, 0)) : 0.0f;
+    }
+    __syncthreads();
+    const SrcWin src{s_win + ev * kWinPitch};
+    const int g = slot;
+    if (g < (kKP + 7) / 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int f = g * 8 + q;
+            double xd = 0.0;
+            if (live && f < d.nf) xd = attribute_value_rec(src, fd[f], p.lower, p.upper, tb, dbg ? dbg + (size_t)e * kKP + f : nullptr);
+            if (f < kKP) s_x[f * 16 + ev] = xd;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {                           // |x|^2, attributes in index order (as k_recheck_mfma's per-lane sums would not be: fixed here)
+        double xx = 0.0;
+        for (int k = 0; k < kKP; k++) xx = fma(s_x[k * 16 + threadIdx.x], s_x[k * 16 + threadIdx.x], xx);
+        s_xx[threadIdx.x] = xx;
+    }
+    __syncthreads();
+    // ---- fp64 MFMA over this wave's SV tiles: A[row = lane&15][k = 4s + (lane>>4)] from LDS, B[k][col = lane&15] from the model ----
+    const int n_tiles = p.n_sv_pad / 16;
+    double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
+    for (int t = wave; t < n_tiles; t += kSmWaves) {
+        const double *Bg = sv64 + (size_t)t * 16 + (lane & 15);
+        f64x4 acc = {0, 0, 0, 0};
+#pragma unroll 9
+        for (int s = 0; s < kSdMSteps; s++) {
+            const int k = 4 * s + (lane >> 4);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_x[k * 16 + (lane & 15)], Bg[(size_t)k * p.n_sv_pad], acc, 0, 0, 0);
+        }
+        const double ss = Bg[(size_t)kKP * p.n_sv_pad];
+        const double cf = Bg[(size_t)(kKP + 1) * p.n_sv_pad];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = (lane >> 4) + 4 * r;                               // f64 C/D layout: row = (lane>>4) + 4*reg
+            const double d2 = fma(-2.0, acc[r], s_xx[row] + ss);
+            const double kv = exp(-p.gamma * d2);
+            part[r] = fma(cf, kv, part[r]);
+            pabs[r] = fma(fabs(cf), kv, pabs[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double v = part[r], w = pabs[r];
+        v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
+        v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
+        v += __shfl_xor(v, 2, 64); w += __shfl_xor(w, 2, 64);
+        v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
+        if ((lane & 15) == 0) { s_part[wave][(lane >> 4) + 4 * r][0] = v; s_part[wave][(lane >> 4) + 4 * r][1] = w; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && live) {
+        double P = 0.0, S = 0.0;
+#pragma unroll
+        for (int w = 0; w < kSmWaves; w++) { P += s_part[w][threadIdx.x][0]; S += s_part[w][threadIdx.x][1]; }   // fixed order
+        const double dv = P - p.rho;
+        dec_exact[e] = dv;
+        labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+        const double T = p.as_max1 + p.gamma2 * s_xx[threadIdx.x];
+        if (!(fabs(dv) > p.guard2 * T * S)) {
+            const int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
+            if (s2 < flag2_cap) flag2_list[s2] = (int)e;
+        }
+    }
+}
+
+void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,
+                         long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s)
+{
+    const long nb = (max_evals + kSmEvals - 1) / kSmEvals;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(k_small_direct, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, fd, sv64, p, d, dec_exact, labels,
+                       flag2_list, flag2_cap, counters, dbg);
+}
+
 template <int MODE>
 static void launch_features_mode(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
                                  Dims d, double lower, double upper, float neg_gamma2, long max_evals, ScreenParams sp,
@@ -2473,7 +2586,6 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
 // VGPRs (loaded from the image the feature kernels write in their XMODE_F64 form), the fp64 SV tile
 // (326 x 16: attributes, |s|^2, coef) is shared through LDS, double buffered with a register-staged prefetch.
 // ---------------------------------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kMWaves = 4;
 constexpr int kMSplit = 8;                        // SV ranges a group of evaluations is split over (k_recheck_mfma tasks)
 static_assert(kRecheckPartRows == 2 * kMSplit + 1, "part64 layout");

@@ -197,7 +197,7 @@ def test_small_request_paths_agree_with_the_oracle(data_dir, surrogate, orc, mon
     else:
         assert cnt["n_rechecked"] == cnt["n_evals"] == got["n_evals"] and cnt["n_refined"] == 0     # every evaluation through the fp64 tier
     compare_full(eng, orc, xyz, dict(n_rolls=12), dict(approach_vector=(0.2, -0.1, 1.0), show_only_best_grasp=1))
-    compare_full(eng, orc, xyz, dict(n_rolls=12), dict())                                       # 32 x 44: not tiny any more
+    compare_full(eng, orc, xyz, dict(n_rolls=12), dict())                                       # the client's default 32 x 44 area
     big = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
     compare_full(eng, orc, big, dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)))
     compare_full(eng, orc, np.zeros((0, 3), np.float32), dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))
@@ -580,6 +580,7 @@ def test_screening_tier_forced_and_reported(data_dir, surrogate, orc, monkeypatc
     band of the plain variant) the labels are still the oracle's and the engine switches to the kernel variant that measures
     |w|_2 = sqrt(sum (coef K)^2), which decides most evaluations again; (3) with the band forced wide open every evaluation
     goes through the three-pass kernel in list mode and meets that kernel's bar."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")                  # (a request of this size would go straight to tier 2's arithmetic)
     xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
     inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
     f, r = _files(data_dir)
@@ -814,7 +815,8 @@ def test_attribute_pipeline_thread_per_evaluation_kernel_and_list_mode(data_dir,
             assert (_bits64(attr["scaled"][:, :323] + 0.0) == _bits64(S + 0.0)).all()
         eng.close()
     monkeypatch.delenv("HAF_LARGE_EVALS")
-    eng = make_engine(data_dir, surrogate, 0)                   # default mode, product library
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")                    # (a request of this size would otherwise go straight to tier 2's arithmetic)
+    eng = make_engine(data_dir, surrogate, 0)                   # default mode: screening pass, three-pass kernel on its list
     eng.score(xyz, capi.default_input(**in_kw))
     n_comp = 0
     for roll in range(12):
