@@ -277,16 +277,33 @@ void hafo_model_free(hafo_model *m)
 /* ------------------------------------------------------------------ */
 static void mat4_identity(float *A) { memset(A, 0, 16 * sizeof(float)); A[0] = A[5] = A[10] = A[15] = 1.0f; }
 
-/* C = A*B, fp32, inner sum left to right, no FMA (definition of record; Eigen order unpinned) */
+/* Third-party arithmetic the reference does not pin (Eigen 4x4 products, pcl::transformPointCloud, cv::integral):
+ * variant 0 is the definition of record -- what the product's kernels reproduce bit for bit.  The other variants restate the
+ * plausible alternative evaluation orders of those libraries so that tests/test_oracle.py can MEASURE how much the choice
+ * matters (how many height bins, mask cells, labels and winners change over every golden cloud x configuration).  Test
+ * infrastructure only; not thread-safe (set it, run, reset). */
+static int g_variant = 0;
+void hafo_set_variant(int flags) { g_variant = flags; }
+int hafo_get_variant(void) { return g_variant; }
+
+/* C = A*B, fp32, no FMA.  Variant 0: inner sum left to right (definition of record).  HAFO_V_EIGEN_TREE: Eigen's vectorised
+ * 4-term reduction (a0b0 + a1b1) + (a2b2 + a3b3). */
 static void mat4_mul(const float *A, const float *B, float *C)
 {
     float T[16];
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
-            float s = A[i * 4 + 0] * B[0 * 4 + j];
-            s = s + A[i * 4 + 1] * B[1 * 4 + j];
-            s = s + A[i * 4 + 2] * B[2 * 4 + j];
-            s = s + A[i * 4 + 3] * B[3 * 4 + j];
+            float s;
+            if (g_variant & HAFO_V_EIGEN_TREE) {
+                const float lo = A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j];
+                const float hi = A[i * 4 + 2] * B[2 * 4 + j] + A[i * 4 + 3] * B[3 * 4 + j];
+                s = lo + hi;
+            } else {
+                s = A[i * 4 + 0] * B[0 * 4 + j];
+                s = s + A[i * 4 + 1] * B[1 * 4 + j];
+                s = s + A[i * 4 + 2] * B[2 * 4 + j];
+                s = s + A[i * 4 + 3] * B[3 * 4 + j];
+            }
             T[i * 4 + j] = s;
         }
     memcpy(C, T, sizeof T);
@@ -335,6 +352,14 @@ void hafo_transform(const hafo_cfg *cfg, const hafo_input *in, int roll, int use
 
     /* mat_scale_x_dir * mat_rot * mat_sh_from_orig * mat_rot_x_axis * mat_rot_z_axis * mat_sh_to_orig (483 / 1334) */
     float T[16];
+    if (g_variant & HAFO_V_CHAIN_RTL) {              /* the product chain associated from the right: S (R (Tf (Rx (Rz To)))) */
+        mat4_mul(Rz, To, T);
+        mat4_mul(Rx, T, T);
+        mat4_mul(Tf, T, T);
+        mat4_mul(R, T, T);
+        mat4_mul(S, T, M);
+        return;
+    }
     mat4_mul(S, R, T);
     mat4_mul(T, Tf, T);
     mat4_mul(T, Rx, T);
@@ -354,9 +379,20 @@ void hafo_height_grid(const hafo_cfg *cfg, const float *xyz, size_t n, size_t st
     for (size_t i = 0; i < n; i++) {
         const float x = xyz[i * stride + 0], y = xyz[i * stride + 1], z = xyz[i * stride + 2];
         /* pcl::transformPointCloud (488): fp32, left to right, no FMA (definition of record) */
-        float px = M[0] * x; px = px + M[1] * y; px = px + M[2] * z; px = px + M[3];
-        float py = M[4] * x; py = py + M[5] * y; py = py + M[6] * z; py = py + M[7];
-        float pz = M[8] * x; pz = pz + M[9] * y; pz = pz + M[10] * z; pz = pz + M[11];
+        float px, py, pz;
+        if (g_variant & HAFO_V_PCL_SSE) {            /* PCL >= 1.8 SSE path: (m0 x + m1 y) + (m2 z + m3) */
+            px = (M[0] * x + M[1] * y) + (M[2] * z + M[3]);
+            py = (M[4] * x + M[5] * y) + (M[6] * z + M[7]);
+            pz = (M[8] * x + M[9] * y) + (M[10] * z + M[11]);
+        } else if (g_variant & HAFO_V_FMA) {         /* the left-to-right expression with the compiler contracting a*b + c */
+            px = fmaf(M[2], z, fmaf(M[1], y, M[0] * x)) + M[3];
+            py = fmaf(M[6], z, fmaf(M[5], y, M[4] * x)) + M[7];
+            pz = fmaf(M[10], z, fmaf(M[9], y, M[8] * x)) + M[11];
+        } else {
+            px = M[0] * x; px = px + M[1] * y; px = px + M[2] * z; px = px + M[3];
+            py = M[4] * x; py = py + M[5] * y; py = py + M[6] * z; py = py + M[7];
+            pz = M[8] * x; pz = pz + M[9] * y; pz = pz + M[10] * z; pz = pz + M[11];
+        }
         if ((px > -r_row_m) && (px < r_row_m) && (py > -r_col_m) && (py < r_col_m)) {    /* 510-511 */
             int idx_x = (int)floorf(100 * (px - (-r_row_m)));                             /* 513 */
             int idx_y = (int)floorf(100 * (py - (-r_col_m)));                             /* 514 */
@@ -374,6 +410,21 @@ void hafo_height_grid(const hafo_cfg *cfg, const float *xyz, size_t n, size_t st
 void hafo_integral(const hafo_cfg *cfg, const float *h, float *ii)
 {
     const int H = cfg->H, W = cfg->W, W1 = W + 1;
+    if (g_variant & HAFO_V_INTEGRAL_COLFIRST) {       /* running COLUMN sums, then accumulate along the row */
+        double *col = (double *)calloc((size_t)W, sizeof(double));
+        for (int c = 0; c < W1; c++) ii[c] = 0.0f;
+        for (int r = 0; r < H; r++) {
+            double acc = 0.0;
+            ii[(r + 1) * W1] = 0.0f;
+            for (int c = 0; c < W; c++) {
+                col[c] += (double)h[r * W + c];
+                acc += col[c];
+                ii[(r + 1) * W1 + c + 1] = (float)acc;
+            }
+        }
+        free(col);
+        return;
+    }
     double *prev = (double *)calloc((size_t)W1, sizeof(double));
     double *cur = (double *)calloc((size_t)W1, sizeof(double));
     for (int c = 0; c < W1; c++) ii[c] = 0.0f;

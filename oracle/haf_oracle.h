@@ -117,6 +117,16 @@ typedef struct {
 
 /* ---- stage functions (each cites the reference lines it follows) ---- */
 
+/* Alternative evaluation orders of the third-party arithmetic the reference leaves unpinned (haf_oracle.c: g_variant).  0 = the
+ * definition of record.  hafo_set_variant() is for tests/test_oracle.py only: it measures how many results change. */
+enum { HAFO_V_EIGEN_TREE = 1,         /* 4x4 products: (a0b0 + a1b1) + (a2b2 + a3b3)           server.cpp:483, 1334 */
+       HAFO_V_CHAIN_RTL = 2,          /* the six-matrix product associated from the right       server.cpp:483      */
+       HAFO_V_PCL_SSE = 4,            /* point transform (m0 x + m1 y) + (m2 z + m3)            server.cpp:488      */
+       HAFO_V_FMA = 8,                /* point transform with a*b + c contracted to fma         server.cpp:488      */
+       HAFO_V_INTEGRAL_COLFIRST = 16  /* summed-area table by running column sums               server.cpp:595      */ };
+void hafo_set_variant(int flags);
+int hafo_get_variant(void);
+
 void hafo_transform(const hafo_cfg *cfg, const hafo_input *in, int roll,
                     int use_double_atan2, float M[16]);
 void hafo_height_grid(const hafo_cfg *cfg, const float *xyz, size_t n, size_t stride_floats,

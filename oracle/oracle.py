@@ -100,11 +100,21 @@ def lib():
         L.hafo_run.restype = C.c_int
         L.hafo_run.argtypes = [C.POINTER(Cfg), C.POINTER(Features), C.POINTER(Range), C.POINTER(Model), C.c_void_p,
                                C.c_size_t, C.c_size_t, C.POINTER(Input), C.POINTER(Output), C.POINTER(Debug)]
+        L.hafo_set_variant.argtypes = [C.c_int]
+        L.hafo_get_variant.restype = C.c_int
         L.hafo_dump_feature_file.restype = C.c_long
         L.hafo_dump_feature_file.argtypes = [C.POINTER(Cfg), C.POINTER(Features), C.c_void_p, C.c_size_t, C.c_size_t,
                                              C.POINTER(Input), C.c_int, C.c_char_p]
         _LIB = L
     return _LIB
+
+
+# alternative evaluation orders of the unpinned third-party arithmetic (haf_oracle.h); 0 = the definition of record
+V_EIGEN_TREE, V_CHAIN_RTL, V_PCL_SSE, V_FMA, V_INTEGRAL_COLFIRST = 1, 2, 4, 8, 16
+
+
+def set_variant(flags):
+    lib().hafo_set_variant(int(flags))
 
 
 def ref_dir():

@@ -301,7 +301,7 @@ CONFIGS = {
     "tilt": dict(cfg=dict(n_rolls=12), inp=dict(length_x=32, length_y=44, approach=(0.2, -0.1, 1.0), gripper_width=1)),
 }
 CLOUD_CONFIGS = [
-    ("pcd2", ["C1", "C2", "C2best", "default", "tilt"]),
+    ("pcd2", ["C1", "C2", "C2best", "default", "tilt", "C4"]),
     ("pcd1", ["C2", "C4"]), ("pcd3", ["C2", "C4"]), ("pcd4", ["C4"]), ("pcd5", ["C4"]), ("pcd6", ["C4"]),
     ("pcd7", ["C4"]), ("pcd8", ["C4"]), ("pcd9", ["default"]), ("pcd10", ["default"]), ("pcd11", ["default"]),
     ("pcd12", ["default", "C2"]), ("plastic_mug2", ["default", "C2best"]),
