@@ -2660,20 +2660,12 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
         for (int t = t_begin; t < t_end; t++) {
             const double *B = bt[0];
             if (t + 1 < t_end) tile_load(t + 1);
-            // three interleaved chains (k-steps s, s+1, s+2 mod 3): a dependent fp64 MFMA does not issue back to back
-            f64x4 acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-            static_assert(kMSteps % 3 == 0, "81 k-steps in three chains");
+            f64x4 acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < kMSteps; s += 3) {
-                const double b0 = B[(4 * s + (lane >> 4)) * 16 + (lane & 15)];      // B[k = 4s + (lane>>4)][j = lane&15]
-                const double b1 = B[(4 * (s + 1) + (lane >> 4)) * 16 + (lane & 15)];
-                const double b2 = B[(4 * (s + 2) + (lane >> 4)) * 16 + (lane & 15)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b0, acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], b1, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 2], b2, acc2, 0, 0, 0);
+            for (int s = 0; s < kMSteps; s++) {
+                const double b = B[(4 * s + (lane >> 4)) * 16 + (lane & 15)];      // B[k = 4s + (lane>>4)][j = lane&15]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = (acc[r] + acc1[r]) + acc2[r];
             const double ss = B[kKP * 16 + (lane & 15)];
             const double cf = B[(kKP + 1) * 16 + (lane & 15)];
 #pragma unroll
