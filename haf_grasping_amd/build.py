@@ -5,8 +5,9 @@
                            environment switches that scale the guard bands (tests/ only)
   haf_grasp_cli            ROS-free command line front end (C++ over the C-ABI)
 
-After compiling, check_exp_hazard() disassembles the contraction kernels and fails the build when a v_exp_f32 result is
-read too soon (a measured gfx950 hazard that a compiler update could silently re-open).
+After linking (under temporary names), check_exp_hazard() disassembles the contraction kernels and fails the build when a
+v_exp_f32 result is read too soon (a measured gfx950 hazard that a compiler update could silently re-open); only a
+build that passes gets the library names up_to_date() looks for.
 """
 import os
 import re
@@ -157,11 +158,28 @@ def build(force=False, verbose=False):
     test_kernels = compile_one("testkernels.hip")                  # device code of the testing build only
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"]
     libs = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
-    for out, eng in ((LIB, objs["engine.cpp"]), (LIB_TESTING, engine_testing)):
-        cmd = link + [eng if s == "engine.cpp" else objs[s] for s in SOURCES] + ([test_kernels] if out == LIB_TESTING else []) + libs + ["-o", out]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    # The libraries are linked under temporary names and get their real ones only after the v_exp_f32 check has passed: a build
+    # that fails the check (or cannot run it: llvm-objdump missing) leaves NO libhafgrasp.so behind, so the next build() cannot
+    # mistake it for an up-to-date one.
+    staged = []
+    try:
+        for out, eng in ((LIB, objs["engine.cpp"]), (LIB_TESTING, engine_testing)):
+            tmp = out + ".unchecked"
+            cmd = link + [eng if s == "engine.cpp" else objs[s] for s in SOURCES] + ([test_kernels] if out == LIB_TESTING else []) + libs + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            staged.append((tmp, out))
+        for out in (LIB, LIB_TESTING):
+            if os.path.exists(out):
+                os.remove(out)                  # whatever happens below, a stale library must not survive a failed build
+        check_exp_hazard(staged[0][0], verbose=verbose)
+        for tmp, out in staged:
+            os.replace(tmp, out)
+    finally:
+        for tmp, _ in staged:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     # ROS-free command line front end (C++ host code over the C-ABI)
     cli = os.path.join(HERE, "haf_grasp_cli")
     cmd = [hipcc, "-O2", "-std=c++17", "-I" + os.path.join(HERE, "..", "ros_shim"), "-I" + os.path.join(HERE, "..", "include"),
@@ -170,7 +188,6 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    check_exp_hazard(LIB, verbose=verbose)
     return LIB
 
 

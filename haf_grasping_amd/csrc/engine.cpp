@@ -284,6 +284,7 @@ struct haf_engine {
     // launch (k_small_direct): cheaper than a feature kernel, a fast contraction and the rechecks behind it (C2: 3 760 x 172 in
     // 36 us against 21 + 30 + 30 us; measured the other way round at C3's 31 093 x 172: 203 us against 186)
     long direct_work = 1L << 21;
+    bool no_bucket_sort = false;    // set (for good) when a tile of the bucket-sorted binning path overflowed its candidate list
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
     // last call
@@ -1124,7 +1125,6 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         if (clouds[b].n_points && !clouds[b].xyz) return fail(e, HAF_E_ARG, "cloud with null xyz");
         if (clouds[b].stride_floats < 3) return fail(e, HAF_E_ARG, "stride_floats must be >= 3");
         if (clouds[b].n_points > (size_t)INT32_MAX) return fail(e, HAF_E_CAPACITY, "cloud too large");
-        if ((int)in[b].max_calculation_time < 0) return fail(e, HAF_E_BUDGET, "max_calculation_time expired before the first roll");
         if (!clouds[b].on_device) host_pts += clouds[b].n_points;
         max_n = std::max(max_n, (int)clouds[b].n_points);
     }
@@ -1236,7 +1236,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         bs.bkt_count = e->d_bkt.p; bs.bkt_off = e->d_bkt.p ? e->d_bkt.p + (size_t)c.max_clouds * e->bkt_ints : nullptr;
         bs.bkt_cursor = e->d_bkt.p ? e->d_bkt.p + (size_t)2 * c.max_clouds * e->bkt_ints : nullptr;
         bs.bkt_cap = e->d_bkt.p ? c.max_clouds * e->bkt_ints : 0;
-        launch_bin(d_clouds, h_clouds, max_n, total_n, d_geo, e->d_heights.p, d, r_row, r_col, bucket_ok, bs, s);
+        launch_bin(d_clouds, h_clouds, max_n, total_n, d_geo, e->d_heights.p, d, r_row, r_col, bucket_ok && !e->no_bucket_sort, bs, e->d_counters.p, s);
         mark(e, HAF_ST_INTEGRAL);
         launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, e->d_inexact.p, e->d_counters.p, d, s);
         mark(e, HAF_ST_MASK);
@@ -1361,6 +1361,13 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     if (mode == MODE_SCREEN && !e->screen_active) mode = MODE_SPLIT;
     int rc = e->prob_mode ? decide_probability() : decide(mode, false);
     if (rc != HAF_OK) return rc;
+    if (e->h_counters[CNT_ERROR] != 0 && !e->no_bucket_sort) {
+        // a tile of k_bin_tiles had more candidate buckets than its list holds (never observed; the bound is geometric): the
+        // height grids of this call may miss points.  Serve the request -- and this engine from now on -- with k_bin instead.
+        e->no_bucket_sort = true;
+        e->counters_clean = false;
+        return score_rolls_impl(e, n_clouds, clouds, in, roll_first, roll_count, records);
+    }
     const int inexact_grids = e->h_counters[CNT_INEXACT];     // (a redo of the decision stage below resets the counters)
     if (mode == MODE_SCREEN && !e->prob_mode && !direct) {
         auto undecided = [&]() { return e->h_counters[CNT_FLAGGED0]; };
@@ -1458,7 +1465,11 @@ static int finalize_impl(const haf_config &c, const haf_grasp_input *in, const h
     // loop_control + show_predicted_gps bookkeeping: server.cpp:322-326, 362-365, 953-960
     int o_row = -1, o_col = -1, o_roll = -1, o_top = -1000, done = 0;
     int64_t evals = 0;
-    for (int r = 0; r < c.n_rolls; r++) {
+    // A negative budget (337: truncated to int) stops the reference's loop before roll 0 (367-374: 0 s elapsed > budget); the goal
+    // still SUCCEEDS with the untouched overall best (322-326): eval -1000 - 20, roll -1.  (Its pose is then computed from row/col
+    // -1, reading the height grid out of bounds at 1343-1347; the engine returns zero points instead.)
+    const int n_run = ((int)in->max_calculation_time < 0) ? 0 : c.n_rolls;
+    for (int r = 0; r < n_run; r++) {
         if (in->show_only_best_grasp && o_top >= c.graspval_top) break;
         if (rec[r].vote > o_top) { o_top = rec[r].vote; o_row = rec[r].row; o_col = rec[r].col; o_roll = r; }
         evals += rec[r].n_evals;

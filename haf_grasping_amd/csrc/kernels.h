@@ -255,7 +255,7 @@ struct BinScratch {
 int bin_bucket_grid(int H, int *bucket_cells);     // buckets per side for a grid of H cells; bucket edge in cells
 // returns true when the bucket-sorted path ran (it also fills the empty cells: no separate fill launch needed)
 bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, long total_n, const RollGeo *geo, int *hkeys, Dims d,
-                float r_row, float r_col, bool bucket_ok, BinScratch bs, hipStream_t s);
+                float r_row, float r_col, bool bucket_ok, BinScratch bs, int *counters, hipStream_t s);   // counters[CNT_ERROR]: a tile's bucket list overflowed
 // small grids: a1 (tail) + a2 + a3 + a4 in one launch, one workgroup per (cloud, roll); false when the grid does not fit LDS
 bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int *hkeys, float *ii, uint8_t *mask, int *rowcount,
                       int *brcount, int8_t *labels, int *evalcell, int *counters, int *flag_list, bool direct, Dims d, float r_row,

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void k_bkt_scatter(const CloudDev *__restrict_
 constexpr int kBinTileThreads = 512;
 __global__ __launch_bounds__(kBinTileThreads) void k_bin_tiles(const CloudDev *__restrict__ clouds, const RollGeo *__restrict__ geo,
                                                    const float *__restrict__ sorted, const int *__restrict__ bkt_off,
-                                                   int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty)
+                                                   int *__restrict__ hkeys, Dims d, float r_row, float r_col, int key_empty,
+                                                   int *__restrict__ counters)
 {
     __shared__ int cells[kBinTile * kBinTile];
     __shared__ int lstart[kBktListCap], lend[kBktListCap];         // point ranges of the candidate buckets
@@ -328,7 +329,10 @@ __global__ __launch_bounds__(kBinTileThreads) void k_bin_tiles(const CloudDev *_
         }
     }
     __syncthreads();
-    const int nl = min(nlist, kBktListCap);     // (the cap is ~8x what a tile can reach; launch_bin checks the geometry it relies on)
+    // The cap is ~5x what a tile can reach (about 205 buckets for |x-scale| >= 1).  Should a geometry ever exceed it, the grid
+    // would silently miss points: say so instead -- the host redoes the request with k_bin (engine.cpp: CNT_ERROR).
+    if (threadIdx.x == 0 && nlist > kBktListCap) atomicOr(&counters[CNT_ERROR], 1);
+    const int nl = min(nlist, kBktListCap);
     const float *pts = sorted + (size_t)c.sorted_off * 3;
     // a wave per candidate bucket (a bucket of 8 x 8 cells holds ~128 points: two per lane), both loads of a trip in flight
     // before either point is processed; the ranges come from LDS, so nothing in this loop waits on a dependent global load
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(kBinTileThreads) void k_bin_tiles(const CloudDev *_
 }
 
 bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, long total_n, const RollGeo *geo, int *hkeys, Dims d,
-                float r_row, float r_col, bool bucket_ok, BinScratch bs, hipStream_t s)
+                float r_row, float r_col, bool bucket_ok, BinScratch bs, int *counters, hipStream_t s)
 {
     const int HW = d.H * d.W;
     float minus_one = -1.0f;
@@ -385,7 +389,7 @@ bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, 
         hipLaunchKernelGGL(k_bkt_scatter, grid, dim3(256), 0, s, clouds, bs.bkt_cursor, bs.sorted, d);
         const int tiles = ((d.H + kBinTile - 1) / kBinTile) * ((d.W + kBinTile - 1) / kBinTile);
         hipLaunchKernelGGL(k_bin_tiles, dim3(tiles, d.B * d.R), dim3(kBinTileThreads), 0, s, clouds, geo, bs.sorted, bs.bkt_off, hkeys, d, r_row, r_col,
-                           key_empty);
+                           key_empty, counters);
         return true;
     }
     (void)clouds_host;

@@ -246,9 +246,10 @@ int create_multi(const haf_config *cfg, const int32_t *devices, int32_t n, int32
     }
     (void)ncclGetVersion(&m->rccl_version);
     const size_t block_bytes = (size_t)m->block_records * sizeof(haf_roll_record) * (size_t)m->shards_per_rank;
+    // every communicator belongs to its rank BEFORE anything below can fail: destroy_multi (the guard) then releases all of them
+    for (int r = 0; r < n_ranks; r++) m->ranks[(size_t)r].comm = comms[(size_t)r];
     for (int r = 0; r < n_ranks; r++) {
         Rank &rk = m->ranks[(size_t)r];
-        rk.comm = comms[(size_t)r];
         bool ok = hipSetDevice(rk.device) == hipSuccess;
         ok = ok && hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipMalloc((void **)&rk.d_send, std::max<size_t>(16, block_bytes)) == hipSuccess;
@@ -280,6 +281,10 @@ int broadcast_cloud(haf_multi *m, const haf_cloud *cloud, std::vector<const floa
             rk.cloud_cap = floats;
         }
     }
+    // The broadcast runs on the ranks' private non-blocking streams: nothing orders it behind the stream that PRODUCED the cloud
+    // on devices[0].  One device-wide synchronisation there (a few microseconds against a multi-megabyte broadcast) does.
+    MHIP(m, hipSetDevice(m->ranks[0].device));
+    MHIP(m, hipDeviceSynchronize());
     MNCCL(m, ncclGroupStart());
     for (int r = 0; r < n_ranks; r++) {
         Rank &rk = m->ranks[(size_t)r];
@@ -445,25 +450,36 @@ template <class F> int guarded(std::string *err, F &&f)
 
 }  // namespace
 
+// The entry points below walk over the ranks with hipSetDevice on the CALLER's thread: put its current device back on the way
+// out, so that a C++ or torch host is not left on the last rank's GPU.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 extern "C" {
 
 int haf_create_multi(const haf_config *cfg, const int32_t *devices, int32_t n_devices, int32_t shard_mode, haf_multi **out)
 {
+    DeviceGuard keep;
     return guarded(&g_multi_create_error, [&] { return create_multi(cfg, devices, n_devices, shard_mode, out); });
 }
 
-void haf_destroy_multi(haf_multi *m) { destroy_multi(m); }
+void haf_destroy_multi(haf_multi *m) { DeviceGuard keep; destroy_multi(m); }
 
 const char *haf_multi_last_error(const haf_multi *m) { return m ? m->error.c_str() : g_multi_create_error.c_str(); }
 
 int haf_score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *in, haf_grasp_output *out)
 {
+    DeviceGuard keep;
     return guarded(m ? &m->error : nullptr, [&] { return score_sharded(m, cloud, in, out); });
 }
 
 int haf_score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, haf_grasp_output *out,
                             int32_t *best_cloud)
 {
+    DeviceGuard keep;
     return guarded(m ? &m->error : nullptr, [&] { return score_batch_sharded(m, n_clouds, clouds, in, out, best_cloud); });
 }
 

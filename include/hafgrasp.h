@@ -33,7 +33,7 @@ enum {
     HAF_E_IO = -2,         /* cannot read or parse Features.txt / range file / model file      */
     HAF_E_DEVICE = -3,     /* no usable HIP device, HIP runtime error                          */
     HAF_E_CAPACITY = -4,   /* request exceeds the capacity the engine was created with         */
-    HAF_E_BUDGET = -5,     /* max_calculation_time expired before the first roll (server.cpp:371) */
+    HAF_E_BUDGET = -5,     /* (not returned any more: a negative budget yields the reference's empty result, see haf_grasp_input) */
     HAF_E_INTERNAL = -6
 };
 
@@ -85,8 +85,10 @@ typedef struct haf_grasp_input {
     double  max_calculation_time;        /* seconds (277), truncated to int like server.cpp:337.  The reference tests it
                                             at the START of every roll with time()'s 1 s resolution (367-374); this engine
                                             starts all rolls of a request together, so every roll sees 0 s elapsed and
-                                            the budget only stops a request whose truncated value is negative
-                                            (HAF_E_BUDGET) -- it never cuts the roll set of a request that has begun      */
+                                            the budget only stops a request whose truncated value is negative: like the
+                                            reference (break before roll 0, the goal still succeeds) the call returns HAF_OK
+                                            with rolls_done = 0, best_roll = -1, eval = -1020 -- it never cuts the roll set
+                                            of a request that has begun                                                   */
     int32_t show_only_best_grasp;        /* changes the result: early exit at >= graspval_top (362-365)    */
     int32_t threshold_grasp_evaluation;  /* carried for API parity; the reference server never reads it    */
     int32_t gripper_opening_width;       /* x-scale factor (281, 433)                                      */
@@ -120,7 +122,8 @@ typedef struct haf_cloud {
     const float *xyz;        /* x,y,z fp32 triples                                                        */
     size_t       n_points;
     size_t       stride_floats; /* 3 for packed xyz, 4 for pcl::PointXYZ                                  */
-    int32_t      on_device;  /* 0: host memory (copied over PCIe inside the call); 1: HBM resident        */
+    int32_t      on_device;  /* 0: host memory (copied over PCIe inside the call); 1: HBM resident: the caller has
+                                synchronised the stream that wrote it (the engine reads it on its own stream)        */
 } haf_cloud;
 
 typedef struct haf_engine haf_engine;

@@ -369,9 +369,11 @@ def test_edge_inputs(data_dir, surrogate, orc):
     with pytest.raises(capi.HafError) as ei:
         eng.score_batch([xyz, xyz], [capi.default_input(), capi.default_input()])
     assert ei.value.code == capi.HAF_E_CAPACITY
-    with pytest.raises(capi.HafError) as ei:
-        eng.score(xyz, capi.default_input(max_calculation_time=-1.0))
-    assert ei.value.code == capi.HAF_E_BUDGET
+    # a negative budget stops the reference's loop before roll 0 and the goal still succeeds with the untouched overall best
+    # (server.cpp:322-326, 367-374, 390): eval -1000 - 20, roll -1, no roll executed
+    got = eng.score(xyz, capi.default_input(max_calculation_time=-1.0))
+    assert (got["eval"], got["best_roll"], got["best_row"], got["best_col"], got["rolls_done"]) == (-1020, -1, -1, -1, 0)
+    assert eng.score(xyz, capi.default_input(max_calculation_time=-0.5))["rolls_done"] > 0      # (int)(-0.5) == 0: not negative
     eng.close()
 
 

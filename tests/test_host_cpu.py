@@ -499,3 +499,36 @@ def test_host_paths_under_address_and_ub_sanitizers(golden_dir, tmp_path):
     assert p.returncode == 0 and "sanitizer job ok" in p.stdout and "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, \
         (p.returncode, p.stdout[-500:], p.stderr[-3000:])
     shutil.rmtree(str(scratch), ignore_errors=True)
+
+
+def test_failed_exp_hazard_check_leaves_no_library(tmp_path, monkeypatch):
+    """the v_exp_f32 distance check runs BEFORE the libraries get the names up_to_date() looks for, so a build that
+    fails it (or cannot run it) is not mistaken for a finished one by the next build() call.  Compiler calls are faked."""
+    from haf_grasping_amd import build as b
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    monkeypatch.setattr(b, "HERE", str(tmp_path))
+    monkeypatch.setattr(b, "CSRC", str(csrc))
+    monkeypatch.setattr(b, "LIB", str(tmp_path / "libhafgrasp.so"))
+    monkeypatch.setattr(b, "LIB_TESTING", str(tmp_path / "libhafgrasp_testing.so"))
+    for stale in (b.LIB, b.LIB_TESTING):
+        with open(stale, "w") as f:
+            f.write("stale")
+
+    def fake_call(cmd, **kw):
+        with open(cmd[cmd.index("-o") + 1], "w") as f:
+            f.write("built")
+    monkeypatch.setattr(b.subprocess, "check_call", fake_call)
+
+    def failing(*a, **k):
+        raise RuntimeError("build check failed: hazard")
+    monkeypatch.setattr(b, "check_exp_hazard", failing)
+    with pytest.raises(RuntimeError):
+        b.build(force=True)
+    assert not os.path.exists(b.LIB) and not os.path.exists(b.LIB_TESTING) and not b.up_to_date()
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".unchecked")]
+    with pytest.raises(RuntimeError):
+        b.build()                                   # NOT "up to date": it tries again (and fails again)
+    monkeypatch.setattr(b, "check_exp_hazard", lambda *a, **k: {})
+    b.build()
+    assert open(b.LIB).read() == "built" and open(b.LIB_TESTING).read() == "built" and b.up_to_date()

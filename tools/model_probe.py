@@ -1,5 +1,9 @@
-import ctypes as C, sys
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Timing models of the screening kernel's inner loop on this GPU (testing build): the bare MFMA loop and the tilings of
+DESIGN.md 5 (4 / 8 row blocks per wave, hand-placed AccVGPR form).  python tools/model_probe.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from haf_grasping_amd import capi
 tl = capi.testlib()
 tf = C.c_double()
