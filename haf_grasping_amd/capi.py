@@ -99,6 +99,7 @@ def _bind(path, testing):
     L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.haf_last_tiers.argtypes = [E] + [C.POINTER(C.c_int64)] * 4
     L.haf_last_prestage.argtypes = [E, C.POINTER(C.c_int64)]
+    L.haf_last_strict_host.argtypes = [E, C.POINTER(C.c_int64)]
     L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                C.c_size_t]
     L.haf_free.argtypes = [C.c_void_p]
@@ -246,6 +247,11 @@ class Engine:
         a, r, b, c = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._L.haf_last_tiers(self._h, C.byref(a), C.byref(r), C.byref(b), C.byref(c)))
         return dict(n_evals=a.value, n_refined=r.value, n_rechecked=b.value, n_strict=c.value)
+
+    def last_strict_host(self):
+        a = C.c_int64()
+        self._check(self._L.haf_last_strict_host(self._h, C.byref(a)))
+        return a.value
 
     def last_prestage(self):
         a = C.c_int64()

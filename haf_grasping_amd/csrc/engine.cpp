@@ -284,6 +284,11 @@ struct haf_engine {
     // launch (k_small_direct): cheaper than a feature kernel, a fast contraction and the rechecks behind it (C2: 3 760 x 172 in
     // 36 us against 21 + 30 + 30 us; measured the other way round at C3's 31 093 x 172: 203 us against 186)
     long direct_work = 1L << 21;
+    // strict tier: an evaluation whose libsvm-order decision value is within this of zero is decided on the HOST with glibc's exp
+    // (the device's exp may differ from it in the last bit: 2^-52 per kernel value, i.e. at most 2^-52 sum|coef| in the sum)
+    double host_exp_thr = 0.0;
+    int last_host_resolved = 0;
+    bool calibrated = false;        // the screening variant was chosen at creation (calibrate())
     bool no_bucket_sort = false;    // set (for good) when a tile of the bucket-sorted binning path overflowed its candidate list
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
@@ -817,6 +822,8 @@ int build_tables(haf_engine *e)
     }
     e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
     e->svm.sqrt_cmax = (float)(e->screen.sqrt_cmax * (1.0 + 1e-7));
+    e->host_exp_thr = std::ldexp(e->sum_abs_coef, -44);        // 256 x the largest difference a last-bit exp error can make
+    if (test_env("HAF_HOST_EXP_ALL")) e->host_exp_thr = INFINITY;   // tests: every strict-tier evaluation through the host path
     e->exact.gamma = m.gamma; e->exact.rho = m.rho;
     e->exact.lower = e->range.lower; e->exact.upper = e->range.upper;
     e->exact.n_sv = m.n_sv; e->exact.n_sv_pad = e->n_sv_pad; e->exact.kx = e->kx;
@@ -988,6 +995,89 @@ void haf_destroy(haf_engine *e)
     delete e;
 }
 
+static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
+                            int32_t roll_count, haf_roll_record *records);
+
+// Default mode: which screening variant serves this MODEL is found out here, at creation, not on the first goals of a fresh
+// action server: up to three requests on a synthetic table scene (a plane with a few dozen boxes and domes of 2-12 cm, a point
+// per grid cell) run through the same adaptive rule as every later call (plain variant -> the variant that measures |w|_2 when
+// more than a quarter of the evaluations stay undecided -> no screening pass when that still leaves more than 60 %).  On the
+// committed surrogate the scene classifies like the real clouds do (plain 94 % undecided, measuring variant 66 %: screening
+// off); a model the scene misjudges is still re-classified by the rule on its first real requests, as before.
+static int calibrate(haf_engine *e)
+{
+    const haf_config &c = e->cfg;
+    if (contraction_mode(c) != MODE_SCREEN || !e->screen_active || e->prob_mode) return HAF_OK;
+    const int G = c.grid_h;
+    const long cells = (long)G * G;
+    const long stride = std::max<long>(1, (cells + c.max_points - 1) / c.max_points);
+    std::vector<float> xyz;
+    xyz.reserve((size_t)(cells / stride + 1) * 3);
+    uint32_t lcg = 0x9E3779B9u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((lcg >> 8) & 0xFFFFFF) / 16777216.0f; };
+    struct Obj { float cx, cy, sx, sy, h, ct, st; int dome; };
+    std::vector<Obj> objs((size_t)std::max<long>(4, cells / 400));
+    const float half = 0.005f * (float)G;
+    for (size_t k = 0; k < objs.size(); k++) {
+        Obj &o = objs[k];
+        o.cx = (2.0f * rnd() - 1.0f) * half; o.cy = (2.0f * rnd() - 1.0f) * half;
+        o.sx = 0.015f + 0.045f * rnd(); o.sy = 0.015f + 0.045f * rnd();
+        o.h = 0.02f + 0.10f * rnd();
+        const float th = 3.14159265f * rnd();
+        o.ct = std::cos(th); o.st = std::sin(th);
+        o.dome = (k % 3) == 0;
+    }
+    // (objects only reach a few cells: a coarse bucket grid keeps the scene of a 512 x 512 engine cheap to build)
+    const int nbk = std::max(1, G / 16);
+    std::vector<std::vector<int>> bk((size_t)nbk * nbk);
+    for (size_t k = 0; k < objs.size(); k++) {
+        const float r = 1.5f * std::max(objs[k].sx, objs[k].sy);
+        const int i0 = std::max(0, (int)((objs[k].cx - r + half) / (2 * half) * nbk)), i1 = std::min(nbk - 1, (int)((objs[k].cx + r + half) / (2 * half) * nbk));
+        const int j0 = std::max(0, (int)((objs[k].cy - r + half) / (2 * half) * nbk)), j1 = std::min(nbk - 1, (int)((objs[k].cy + r + half) / (2 * half) * nbk));
+        for (int i = i0; i <= i1; i++) for (int j = j0; j <= j1; j++) bk[(size_t)i * nbk + j].push_back((int)k);
+    }
+    for (long cell = 0; cell < cells; cell += stride) {
+        const int i = (int)(cell / G), j = (int)(cell % G);
+        const float x = ((float)i + 0.5f) * 0.01f - half, y = ((float)j + 0.5f) * 0.01f - half;
+        float z = 0.0f;
+        for (int k : bk[(size_t)std::min(nbk - 1, i * nbk / G) * nbk + std::min(nbk - 1, j * nbk / G)]) {
+            const Obj &o = objs[(size_t)k];
+            const float u = (x - o.cx) * o.ct + (y - o.cy) * o.st, v = -(x - o.cx) * o.st + (y - o.cy) * o.ct;
+            if (o.dome) {
+                const float q = u * u / (o.sx * o.sx) + v * v / (o.sy * o.sy);
+                if (q < 1.0f) z = std::max(z, o.h * std::sqrt(std::max(0.0f, 1.0f - 0.5f * q)));
+            } else if (std::fabs(u) < o.sx && std::fabs(v) < o.sy) {
+                z = std::max(z, o.h);
+            }
+        }
+        xyz.push_back(x); xyz.push_back(y); xyz.push_back(z + 0.002f * rnd());
+    }
+    haf_cloud cl{};
+    cl.xyz = xyz.data(); cl.n_points = xyz.size() / 3; cl.stride_floats = 3; cl.on_device = 0;
+    haf_grasp_input in;
+    haf_grasp_input_default(&in);
+    in.grasp_area_length_x = (float)G; in.grasp_area_length_y = (float)G;
+    const int R = std::min(e->max_rolls, 2);
+    std::vector<haf_roll_record> rec((size_t)R);
+    const long keep_direct = e->direct_work;
+    e->direct_work = 0;                                   // the tiers themselves, also on a small grid
+    int rc = HAF_OK;
+    for (int pass = 0; pass < 3 && rc == HAF_OK; pass++) {
+        const bool sumsq0 = e->screen_sumsq, active0 = e->screen_active;
+        rc = score_rolls_impl(e, 1, &cl, &in, 0, R, rec.data());
+        if (e->screen_sumsq == sumsq0 && e->screen_active == active0) break;
+        if (!e->screen_active) break;
+    }
+    e->direct_work = keep_direct;
+    e->calibrated = true;
+    // (the calibration requests are not a "last scored batch")
+    e->last_B = e->last_R = e->last_roll_first = 0;
+    e->last_evals = e->last_flagged = e->last_flagged2 = e->last_flagged0 = e->last_inexact = e->last_host_resolved = 0;
+    e->last_screened = false;
+    e->last_inputs.clear();
+    return rc;
+}
+
 static int create_impl(const haf_config *cfg, haf_engine **out)
 {
     if (out) *out = nullptr;
@@ -1047,13 +1137,19 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
     if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_GUARD2_REL") ||
-        test_env("HAF_LARGE_EVALS") || test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE") || test_env("HAF_FLAG_WINDOW"))
+        test_env("HAF_LARGE_EVALS") || test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE") || test_env("HAF_FLAG_WINDOW") ||
+        test_env("HAF_HOST_EXP_ALL"))
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
     rc = alloc_buffers(e);
     if (rc != HAF_OK) return bail(rc);
+    // (a test that scales the screening band wants the tiers and the adaptive rule as they are, not a model classified under that band)
+    if (!test_env("HAF_NO_CALIBRATE") && !test_env("HAF_GUARD0_REL")) {
+        rc = calibrate(e);
+        if (rc != HAF_OK) return bail(rc);
+    }
     guard.e = nullptr;
     *out = e;
     return HAF_OK;
@@ -1087,6 +1183,13 @@ int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, in
     return HAF_OK;
 }
 
+int haf_last_strict_host(const haf_engine *e, int64_t *n_host)
+{
+    if (!e) return HAF_E_ARG;
+    if (n_host) *n_host = e->last_host_resolved;
+    return HAF_OK;
+}
+
 int haf_last_prestage(const haf_engine *e, int64_t *n_inexact_grids)
 {
     if (!e) return HAF_E_ARG;
@@ -1105,6 +1208,61 @@ int haf_set_stream(haf_engine *e, void *s)
 }
 
 void *haf_get_stream(haf_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// The strict tier (k_recheck) restates libsvm's summation order operation for operation, but its exp() is the device's, not
+// glibc's.  Both are within an ulp of the true value, so the two sums differ by at most 2^-52 sum|coef|; a strict-tier decision
+// value closer to zero than host_exp_thr (256 x that) is therefore evaluated once more HERE, on the host, with the C library's
+// exp -- the very function the reference's svm-predict calls (svm.cpp:325-365, 2478-2532) -- from the attributes the device
+// computed (the decimal round trips are bit-pinned to glibc, tests/).  Nothing has come this far in any run; the path exists so
+// that "the labels are libsvm's" has no residual.  Returns the number of evaluations decided here; *changed = a label moved.
+static int host_resolve_strict(haf_engine *e, const Dims &d, hipStream_t s, bool *changed)
+{
+    *changed = false;
+    e->last_host_resolved = 0;
+    const int n2 = std::min(std::min(e->h_counters[CNT_FLAGGED2], e->list_cap), e->flag_cap);     // (one window of the attribute image)
+    if (n2 <= 0 || e->prob_mode) return HAF_OK;
+    std::vector<double> dec((size_t)n2);
+    std::vector<int> ev((size_t)n2);
+    HIPCHK(e, hipMemcpyAsync(dec.data(), e->d_dec_exact2.p, (size_t)n2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(ev.data(), e->d_flag2_list.p, (size_t)n2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    std::vector<int> cand;
+    for (int i = 0; i < n2; i++) if (!(std::fabs(dec[(size_t)i]) > e->host_exp_thr)) cand.push_back(i);
+    if (cand.empty()) return HAF_OK;
+    // the fp64 attribute image of the strict tier's list ([group of 16][324][16]) through the feature kernel, then to the host
+    launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, reinterpret_cast<float *>(e->d_x64.p), nullptr, d, e->range.lower,
+                    e->range.upper, 0.0f, n2, XMODE_F64, ScreenParams{}, e->d_flag2_list.p, CNT_FLAGGED2, n2, false, n2, nullptr, nullptr, s, 0);
+    const size_t groups = ((size_t)n2 + 15) / 16;
+    std::vector<double> x64(groups * kKP * 16);
+    HIPCHK(e, hipMemcpyAsync(x64.data(), e->d_x64.p, x64.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    const SvmModel &m = e->model;
+    const int kx = e->kx;
+    for (int i : cand) {
+        const double *xg = x64.data() + (size_t)(i >> 4) * kKP * 16 + (i & 15);
+        double sum = 0.0;
+        for (int n = 0; n < m.n_sv; n++) {                       // svm.cpp:2509-2512: both classes' terms in model order
+            double d2 = 0.0;
+            for (int k = 0; k < kx; k++) {                       // svm.cpp:333-347: index order, a missing entry is 0
+                const double sv = k < m.dim ? m.sv[(size_t)n * m.dim + k] : 0.0;
+                const double dd = xg[(size_t)k * 16] - sv;
+                d2 += dd * dd;
+            }
+            sum += m.coef[(size_t)n] * std::exp(-m.gamma * d2);  // svm.cpp:364: glibc's exp
+        }
+        const double dv = sum - m.rho;                           // 2513
+        const int8_t lab = (int8_t)(dv > 0.0 ? e->gv0 : e->gv1);
+        int cell = 0;
+        int8_t old = 0;
+        HIPCHK(e, hipMemcpy(&cell, e->d_evalcell.p + ev[(size_t)i], sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(&old, e->d_labels.p + cell, 1, hipMemcpyDeviceToHost));
+        if (old != lab) *changed = true;
+        HIPCHK(e, hipMemcpy(e->d_labels.p + cell, &lab, 1, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->d_dec_exact2.p + i, &dv, sizeof(double), hipMemcpyHostToDevice));
+        e->last_host_resolved++;
+    }
+    return HAF_OK;
+}
 
 static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
                             int32_t roll_count, haf_roll_record *records)
@@ -1317,6 +1475,8 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         };
         int rc = vote();
         if (rc != HAF_OK) return rc;
+        bool strict_ran = false;
+        e->last_host_resolved = 0;
         const int flagged = e->h_counters[CNT_FLAGGED];
         if (!direct && flagged > e->flag_cap && !(mode == MODE_SCREEN && e->h_counters[CNT_FLAGGED0] > e->flag0_cap)) {
             // More evaluations inside the guard band of the fast contraction than one window of the fp64 tier holds (an
@@ -1331,11 +1491,20 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
                            e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();
             if (rc != HAF_OK) return rc;
+            strict_ran = e->h_counters[CNT_FLAGGED2] > 0;
         } else if (e->h_counters[CNT_FLAGGED2] > 0) {
             launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
                            e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();
             if (rc != HAF_OK) return rc;
+            strict_ran = true;
+        }
+        if (strict_ran) {
+            // what the strict tier left within a last-bit exp error of zero: glibc's exp on the host, then the vote once more
+            bool changed = false;
+            rc = host_resolve_strict(e, d, s, &changed);
+            if (rc != HAF_OK) return rc;
+            if (changed) { rc = vote(); if (rc != HAF_OK) return rc; }
         }
         return HAF_OK;
     };

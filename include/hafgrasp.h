@@ -235,6 +235,11 @@ int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked,
  * (they went through the three-pass kernel; 0 in the other modes), then the fp64 MFMA tier, then the strict tier. */
 int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, int64_t *n_rechecked, int64_t *n_strict);
 
+/* Strict tier of the last scored batch: evaluations whose libsvm-order decision value lay within a last-bit exp error of zero
+ * (2^-44 sum|coef|) and were therefore decided on the host with the C library's exp, the function svm-predict itself calls
+ * (svm.cpp:364).  None in any run so far. */
+int haf_last_strict_host(const haf_engine *e, int64_t *n_host);
+
 /* Pre-stages of the last scored batch: (cloud, roll) grids whose integral image had to be summed in the reference's
  * sequential fp64 order because a parallel partial sum was not exact (normally 0; the result is bit-identical either way). */
 int haf_last_prestage(const haf_engine *e, int64_t *n_inexact_grids);

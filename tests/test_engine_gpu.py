@@ -63,7 +63,8 @@ DEC_REL_SCREEN = 2.0 ** -8
 
 # environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
-              "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE")
+              "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
+              "HAF_NO_CALIBRATE")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -536,6 +537,60 @@ def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
             monkeypatch.delenv("HAF_GUARD2_REL")
 
 
+def test_model_is_classified_at_creation(data_dir, surrogate, orc, monkeypatch, tmp_path):
+    """Round 3: haf_create scores a synthetic table scene and settles the screening variant for the MODEL before
+    the first goal: the ill-conditioned surrogate is served by the three-pass kernel from its first request on (no refinement
+    list, and identical calls report identical counters); a well-conditioned random model keeps the plain screening variant."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")                  # tiers as such, on requests of reference size
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
+    eng = make_engine(data_dir, surrogate)
+    counts = []
+    for _ in range(3):
+        compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
+        counts.append(eng.last_counts())
+    assert counts[0]["n_refined"] == 0 and counts[0] == counts[1] == counts[2], counts
+    eng.close()
+    f, r = _files(data_dir)
+    path = str(tmp_path / "rand300.model")
+    models.write_random_model(path, 300, seed=2, balanced=True)
+    eng = make_engine(data_dir, path)
+    o = O.Oracle(f, r, path)
+    counts = []
+    for _ in range(2):
+        compare_full(eng, o, xyz, dict(n_rolls=12), inp)
+        counts.append(eng.last_counts())
+    assert 0 < counts[0]["n_refined"] < 0.25 * counts[0]["n_evals"] and counts[0] == counts[1], counts
+    eng.close()
+
+
+def test_strict_tier_residual_is_decided_with_the_c_librarys_exp(data_dir, surrogate, orc, monkeypatch):
+    """Round 3: the strict tier's exp() is the device's; an evaluation whose libsvm-order decision value lies within a last-bit exp
+    error of zero (2^-44 sum|coef|) is evaluated once more on the HOST with glibc's exp, the function svm-predict calls.  Nothing
+    ever comes that far, so the test forces it: every evaluation through the strict tier (HAF_GUARD_REL / HAF_GUARD2_REL wide
+    open), every one of those through the host path (HAF_HOST_EXP_ALL).  Labels, votes and grasp = the oracle's, and the
+    decision values the host wrote back are the oracle's BIT FOR BIT (same summation order, same libm)."""
+    monkeypatch.setenv("HAF_GUARD_REL", "1e30")
+    monkeypatch.setenv("HAF_GUARD2_REL", "1e30")
+    monkeypatch.setenv("HAF_HOST_EXP_ALL", "1")
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd2.pcd"))
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=32)
+    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16, n_rolls=2)
+    got, want = compare_full(eng, orc, xyz, dict(n_rolls=2), inp, check_dec=False)
+    cnt = eng.last_counts()
+    assert cnt["n_strict"] == cnt["n_evals"] == eng.last_strict_host() == want["n_evals"] > 0
+    for roll in range(2):
+        m = want["mask"][roll] == 1
+        d = eng.debug(capi.DBG_DECISION, 0, roll)
+        assert (d[m].view(np.uint64) == want["dec"][roll][m].view(np.uint64)).all()
+    eng.close()
+    monkeypatch.delenv("HAF_HOST_EXP_ALL")
+    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16, n_rolls=2)      # the normal threshold: nothing is that close to zero
+    compare_full(eng, orc, xyz, dict(n_rolls=2), inp)
+    assert eng.last_counts()["n_strict"] > 0 and eng.last_strict_host() == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("mode", [pytest.param(capi.FLAG_SPLIT_F16, id="splitf16"), pytest.param(0, id="screen")])
 def test_guard_list_overflow_degrades_to_windows(data_dir, surrogate, orc, monkeypatch, mode):
     """More guard-band evaluations than one window of the fp64 tier holds must NOT fail the goal (the reference never fails
@@ -583,6 +638,7 @@ def test_screening_tier_forced_and_reported(data_dir, surrogate, orc, monkeypatc
     |w|_2 = sqrt(sum (coef K)^2), which decides most evaluations again; (3) with the band forced wide open every evaluation
     goes through the three-pass kernel in list mode and meets that kernel's bar."""
     monkeypatch.setenv("HAF_NO_DIRECT", "1")                  # (a request of this size would go straight to tier 2's arithmetic)
+    monkeypatch.setenv("HAF_NO_CALIBRATE", "1")               # the adaptive rule itself, from the plain variant on
     xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
     inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
     f, r = _files(data_dir)
@@ -818,6 +874,7 @@ def test_attribute_pipeline_thread_per_evaluation_kernel_and_list_mode(data_dir,
         eng.close()
     monkeypatch.delenv("HAF_LARGE_EVALS")
     monkeypatch.setenv("HAF_NO_DIRECT", "1")                    # (a request of this size would otherwise go straight to tier 2's arithmetic)
+    monkeypatch.setenv("HAF_NO_CALIBRATE", "1")                 # (and the surrogate would be served without the screening pass)
     eng = make_engine(data_dir, surrogate, 0)                   # default mode: screening pass, three-pass kernel on its list
     eng.score(xyz, capi.default_input(**in_kw))
     n_comp = 0
