@@ -99,6 +99,8 @@ def _bind(path, testing):
     L.haf_last_counts.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.haf_last_tiers.argtypes = [E] + [C.POINTER(C.c_int64)] * 4
     L.haf_last_prestage.argtypes = [E, C.POINTER(C.c_int64)]
+    L.haf_multi_plan.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.haf_last_strict_host.argtypes = [E, C.POINTER(C.c_int64)]
     L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                C.c_size_t]
@@ -151,6 +153,20 @@ def lib():
     if _lib is None:
         _lib = _bind(LIB_PATH, testing=False)
     return _lib
+
+
+def multi_plan(devices, shard_mode, n_rolls):
+    """haf_multi_plan: the partition haf_create_multi would build for `devices` (no device is touched).  Raises HafError like
+    MultiEngine would.  -> dict(rank_of, slot_of, roll_first, roll_count, n_ranks)"""
+    L = lib()
+    n = len(devices)
+    dev = (C.c_int32 * max(1, n))(*devices)
+    rk, sl, rf, rc_ = [(C.c_int32 * max(1, n))() for _ in range(4)]
+    nr = C.c_int32()
+    rc = L.haf_multi_plan(dev, n, shard_mode, n_rolls, rk, sl, rf, rc_, C.byref(nr))
+    if rc != 0:
+        raise HafError(rc, L.haf_multi_last_error(None).decode())
+    return dict(rank_of=list(rk)[:n], slot_of=list(sl)[:n], roll_first=list(rf)[:n], roll_count=list(rc_)[:n], n_ranks=nr.value)
 
 
 def testlib():

@@ -85,7 +85,7 @@ static void usage()
     fprintf(stderr,
             "usage: haf_grasp_cli --features F --range R --model M [options] cloud.pcd [cloud2.pcd ...]\n"
             "  --center x y z  --search-size x y  --approach x y z  --max-time s  --show-only-best  --gripper-width w\n"
-            "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll  --hypotheses  --probability\n"
+            "  --grid N  --rolls N  --roll-step deg  --device d  --per-roll  --hypotheses  --probability  --grid-out FILE\n"
             "  --gpus N [--shard rolls|clouds] [--shards-per-gpu K]\n");
 }
 
@@ -97,6 +97,7 @@ int main(int argc, char **argv)
     haf_grasp_input_default(&in);
     double sx = 18, sy = 30;                       // launch defaults (launch/haf_grasping_all.launch:25-65)
     bool per_roll = false, hypotheses = false;
+    std::string grid_out;                          // --grid-out FILE: the per-roll grasp grid the shim's callback delivers (979-1016)
     int gpus = 0, shards_per_gpu = 1;
     std::string shard = "rolls";
     std::string features, range, model;
@@ -119,6 +120,7 @@ int main(int argc, char **argv)
         else if (a == "--device") { need(1); cfg.device = atoi(argv[++i]); }
         else if (a == "--per-roll") per_roll = true;
         else if (a == "--hypotheses") hypotheses = true;
+        else if (a == "--grid-out") { need(1); grid_out = argv[++i]; }
         else if (a == "--probability") cfg.flags |= HAF_FLAG_PROBABILITY;     // svm_with_probability (server.cpp:383, 791, 831-841)
         else if (a == "--gpus") { need(1); gpus = atoi(argv[++i]); }
         else if (a == "--shard") { need(1); shard = argv[++i]; }
@@ -158,7 +160,15 @@ int main(int argc, char **argv)
         hafshim::ResultFields res;
         haf_grasp_output out;
         std::string serr;
-        if (hafshim::run_goal(eng, cfg, goal, cloud, [&](const std::string &l) { lines.push_back(l); }, &res, &out, &serr) != HAF_OK) {
+        FILE *gf = grid_out.empty() ? nullptr : fopen(grid_out.c_str(), i == first_cloud ? "w" : "a");
+        hafshim::GridFn on_grid;
+        if (gf) on_grid = [&](int roll, const std::vector<hafshim::GridCell> &cells) {
+            for (const hafshim::GridCell &c : cells)
+                fprintf(gf, "%d %d %d %.9g %.9g %.9g %.9g\n", roll, c.row, c.col, c.x, c.y, c.z, c.value);
+        };
+        const int grc = hafshim::run_goal(eng, cfg, goal, cloud, [&](const std::string &l) { lines.push_back(l); }, &res, &out, &serr, on_grid);
+        if (gf) fclose(gf);
+        if (grc != HAF_OK) {
             fprintf(stderr, "%s: %s\n", argv[i], serr.c_str());
             rc = 1;
             haf_free(xyz);

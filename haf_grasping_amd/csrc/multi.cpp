@@ -150,6 +150,30 @@ void roll_range(int n_rolls, int n_shards, int s, int *first, int *count)
     *count = q + (s < r ? 1 : 0);
 }
 
+// The partition haf_create_multi builds, without touching a device (also behind haf_multi_plan): rank and slot of every shard
+// (ranks = distinct devices in order of first appearance), and for HAF_SHARD_ROLLS the roll range of every shard.
+int plan_shards(const int32_t *devices, int n, int mode, int n_rolls, int *rank_of, int *slot_of, int *roll_first, int *roll_count,
+                std::vector<int> *rank_dev, std::string *err)
+{
+    if (!devices || n < 1 || n > 64) { if (err) *err = "haf_create_multi: bad argument"; return HAF_E_ARG; }
+    if (mode != HAF_SHARD_ROLLS && mode != HAF_SHARD_CLOUDS) { if (err) *err = "haf_create_multi: unknown shard mode"; return HAF_E_ARG; }
+    if (mode == HAF_SHARD_ROLLS && n > n_rolls) { if (err) *err = "more shards than rolls"; return HAF_E_ARG; }
+    std::vector<int> devs, per_rank;
+    for (int s = 0; s < n; s++) {
+        if (devices[s] < 0) { if (err) *err = "negative device ordinal in devices[]"; return HAF_E_ARG; }
+        int rk = -1;
+        for (size_t r = 0; r < devs.size(); r++) if (devs[r] == devices[s]) rk = (int)r;
+        if (rk < 0) { devs.push_back(devices[s]); per_rank.push_back(0); rk = (int)devs.size() - 1; }
+        if (rank_of) rank_of[s] = rk;
+        if (slot_of) slot_of[s] = per_rank[(size_t)rk];
+        per_rank[(size_t)rk]++;
+        if (mode == HAF_SHARD_ROLLS && roll_first && roll_count) roll_range(n_rolls, n, s, &roll_first[s], &roll_count[s]);
+    }
+    for (int c : per_rank) if (c != per_rank[0]) { if (err) *err = "every device must appear the same number of times in devices[]"; return HAF_E_ARG; }
+    if (rank_dev) *rank_dev = devs;
+    return HAF_OK;
+}
+
 void run_on_all(haf_multi *m, const std::function<void(Shard &)> &f)
 {
     for (Shard &sh : m->shards) sh.worker->submit([&sh, &f] { f(sh); });
@@ -205,20 +229,23 @@ int create_multi(const haf_config *cfg, const int32_t *devices, int32_t n, int32
     m->feature_file = cfg->feature_file; m->range_file = cfg->range_file; m->model_file = cfg->model_file;
     m->cfg.feature_file = m->feature_file.c_str(); m->cfg.range_file = m->range_file.c_str(); m->cfg.model_file = m->model_file.c_str();
     m->mode = mode;
-    if (mode == HAF_SHARD_ROLLS && n > cfg->n_rolls) { m->error = "more shards than rolls"; return bail(HAF_E_ARG); }
 
     // ranks = distinct devices in order of first appearance; every rank must hold the same number of shards (equal all-gather blocks)
     m->shards.resize((size_t)n);
-    std::vector<int> per_rank;
-    for (int s = 0; s < n; s++) {
-        int rk = -1;
-        for (size_t r = 0; r < m->ranks.size(); r++) if (m->ranks[r].device == devices[s]) rk = (int)r;
-        if (rk < 0) { Rank r; r.device = devices[s]; m->ranks.push_back(r); per_rank.push_back(0); rk = (int)m->ranks.size() - 1; }
-        m->shards[(size_t)s].device = devices[s];
-        m->shards[(size_t)s].rank = rk;
-        m->shards[(size_t)s].slot = per_rank[(size_t)rk]++;
+    std::vector<int> rank_of((size_t)n), slot_of((size_t)n), rank_dev;
+    {
+        std::string perr;
+        const int prc = plan_shards(devices, n, mode, cfg->n_rolls, rank_of.data(), slot_of.data(), nullptr, nullptr, &rank_dev, &perr);
+        if (prc != HAF_OK) { m->error = perr; return bail(prc); }
     }
-    for (int c : per_rank) if (c != per_rank[0]) { m->error = "every device must appear the same number of times in devices[]"; return bail(HAF_E_ARG); }
+    std::vector<int> per_rank(rank_dev.size(), 0);
+    for (int d : rank_dev) { Rank r; r.device = d; m->ranks.push_back(r); }
+    for (int s = 0; s < n; s++) {
+        m->shards[(size_t)s].device = devices[s];
+        m->shards[(size_t)s].rank = rank_of[(size_t)s];
+        m->shards[(size_t)s].slot = slot_of[(size_t)s];
+        per_rank[(size_t)rank_of[(size_t)s]]++;
+    }
     m->shards_per_rank = per_rank[0];
     const int n_ranks = (int)m->ranks.size();
     m->block_records = (cfg->n_rolls + n - 1) / n;
@@ -481,6 +508,17 @@ int haf_score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clo
 {
     DeviceGuard keep;
     return guarded(m ? &m->error : nullptr, [&] { return score_batch_sharded(m, n_clouds, clouds, in, out, best_cloud); });
+}
+
+int haf_multi_plan(const int32_t *devices, int32_t n_devices, int32_t shard_mode, int32_t n_rolls, int32_t *rank_of, int32_t *slot_of,
+                   int32_t *roll_first, int32_t *roll_count, int32_t *n_ranks)
+{
+    std::vector<int> devs;
+    std::string err;
+    const int rc = plan_shards(devices, n_devices, shard_mode, n_rolls, rank_of, slot_of, roll_first, roll_count, &devs, &err);
+    if (rc != HAF_OK) { g_multi_create_error = err; return rc; }
+    if (n_ranks) *n_ranks = (int32_t)devs.size();
+    return HAF_OK;
 }
 
 int haf_multi_info(const haf_multi *m, int32_t *n_shards, int32_t *n_ranks, int32_t *rccl_version)

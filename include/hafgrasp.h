@@ -182,6 +182,12 @@ int haf_score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_inpu
 int haf_score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in,
                             haf_grasp_output *out, int32_t *best_cloud);
 int haf_multi_info(const haf_multi *m, int32_t *n_shards, int32_t *n_ranks, int32_t *rccl_version);
+/* The partition haf_create_multi would build for devices[], WITHOUT touching a device: per shard its RCCL rank (distinct devices in
+ * order of first appearance) and its slot on that rank, and for HAF_SHARD_ROLLS its contiguous roll range (36 rolls over 8 shards:
+ * 5,5,5,5,4,4,4,4).  Arrays of n_devices entries, any of them may be NULL.  Same argument checks, same error texts
+ * (haf_multi_last_error(NULL)). */
+int haf_multi_plan(const int32_t *devices, int32_t n_devices, int32_t shard_mode, int32_t n_rolls, int32_t *rank_of, int32_t *slot_of,
+                   int32_t *roll_first, int32_t *roll_count, int32_t *n_ranks);
 haf_engine *haf_multi_engine(haf_multi *m, int32_t shard);      /* the shard's engine (stage timings, counters, roll grids) */
 /* rank `rank`'s copy of the n_rolls gathered records of the last haf_score_sharded call (all ranks hold the same) */
 int haf_multi_last_records(const haf_multi *m, int32_t rank, haf_roll_record *records);

@@ -3,8 +3,11 @@
 // messages and ros_shim/shim_core.h, which holds the whole goal -> result logic and IS compiled and tested here:
 //   add_executable(calc_grasppoints_action_server_hip src/calc_grasppoints_action_server_hip.cpp)
 //   target_link_libraries(calc_grasppoints_action_server_hip hafgrasp ${catkin_LIBRARIES} ${PCL_LIBRARIES})
-// Node name, action name, parameters, TF handling and topics are the reference's (server.cpp:181-228, 250-329);
-// marker / rviz publishing is out of scope.
+// Node name, action name, parameters, TF handling and topics are the reference's (server.cpp:181-228, 250-329).  The per-roll
+// grasp grid (901-902, 979-1016) is forwarded as the reference's MarkerArray topic with plain cube markers (one per masked cell at
+// the reference's position, height = vote); the tf_help frame and the styling of gp_to_marker / grasp_area_to_marker (1020-1270)
+// stay out of scope (rviz).
+// tests/test_host_cpu.py compiles this translation unit (-fsyntax-only) against the minimal mock headers of tests/mock_ros/.
 #include <ros/ros.h>
 #include <ros/package.h>
 #include <actionlib/server/simple_action_server.h>
@@ -14,6 +17,7 @@
 #include <pcl_ros/transforms.h>
 #include <std_msgs/String.h>
 #include <tf/transform_listener.h>
+#include <visualization_msgs/MarkerArray.h>
 
 #include "shim_core.h"
 
@@ -21,7 +25,7 @@ class CalcGrasppointsHip
 {
     ros::NodeHandle nh_;
     actionlib::SimpleActionServer<haf_grasping::CalcGraspPointsServerAction> as_;
-    ros::Publisher pub_eval_, pub_input_pc_;
+    ros::Publisher pub_eval_, pub_input_pc_, pub_grid_;
     tf::TransformListener tf_listener_;
     haf_engine *engine_ = nullptr;
     haf_config cfg_;
@@ -29,8 +33,9 @@ class CalcGrasppointsHip
 
 public:
     explicit CalcGrasppointsHip(const std::string &name)
-        : as_(nh_, name, boost::bind(&CalcGrasppointsHip::execute, this, _1), false)
+        : as_(nh_, name, [this](const haf_grasping::CalcGraspPointsServerGoalConstPtr &goal) { this->execute(goal); }, false)
     {
+        pub_grid_ = nh_.advertise<visualization_msgs::MarkerArray>("visualization_marker_array", 1);           // server.cpp:187
         pub_eval_ = nh_.advertise<std_msgs::String>("/haf_grasping/grasp_hypothesis_with_eval", 1);          // server.cpp:185
         pub_input_pc_ = nh_.advertise<sensor_msgs::PointCloud2>("/haf_grasping/calc_gp_as_inputpcROS", 1);   // 189
         haf_config_default(&cfg_);
@@ -77,7 +82,30 @@ public:
         hafshim::ResultFields r;
         std::string err;
         auto publish = [this](const std::string &s) { std_msgs::String m; m.data = s; pub_eval_.publish(m); };   // 1419
-        if (hafshim::run_goal(engine_, cfg_, g, cloud, publish, &r, NULL, &err) != HAF_OK) {
+        // the per-roll grasp grid (901-902 -> 979-1016): one marker per masked cell, where publish_grasp_grid puts it (987-996)
+        auto on_grid = [this, &frame](int roll, const std::vector<hafshim::GridCell> &cells) {
+            visualization_msgs::MarkerArray ma;
+            int id = 1;
+            for (const hafshim::GridCell &c : cells) {
+                visualization_msgs::Marker mk;
+                mk.header.frame_id = frame;
+                mk.header.stamp = ros::Time::now();
+                mk.ns = "haf_grasp_grid";
+                mk.id = roll * 100000 + id++;
+                mk.type = visualization_msgs::Marker::CUBE;
+                mk.action = visualization_msgs::Marker::ADD;
+                mk.pose.position.x = c.x; mk.pose.position.y = c.y; mk.pose.position.z = c.z;
+                mk.pose.orientation.w = 1.0;
+                mk.scale.x = 0.002; mk.scale.y = 0.002; mk.scale.z = 0.001 * (c.value > 1 ? c.value : 1);
+                mk.color.a = 1.0; mk.color.g = c.value > 0 ? 1.0 : 0.0; mk.color.r = c.value > 0 ? 0.0 : 1.0;
+                ma.markers.push_back(mk);
+            }
+            pub_grid_.publish(ma);
+        };
+        auto preempted = [this]() { return as_.isPreemptRequested() || !ros::ok(); };                           // 350
+        const int rc = hafshim::run_goal(engine_, cfg_, g, cloud, publish, &r, NULL, &err, on_grid, preempted);
+        if (rc == hafshim::HAF_SHIM_PREEMPTED) { as_.setPreempted(); return; }                                  // 354-356
+        if (rc != HAF_OK) {
             ROS_ERROR("hafgrasp: %s", err.c_str());
             as_.setAborted();
             return;

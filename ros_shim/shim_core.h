@@ -5,13 +5,14 @@
 // ros_shim/calc_grasppoints_action_server_hip.cpp is the thin adapter that fills GoalFields from the ROS message and
 // copies ResultFields back.
 //
-// Reference lines (src/calc_grasppoints_action_server.cpp): goal parsing 258-301, roll loop 343-386, per-roll publication
-// 962-969, result fields and string 1384-1401, final call 390.
+// Reference lines (src/calc_grasppoints_action_server.cpp): goal parsing 258-301, roll loop 343-386 (preemption 350-357), per-roll
+// grasp grid 901-902 / 979-1016, per-roll publication 962-969, result fields and string 1384-1401, final call 390.
 #ifndef HAF_SHIM_CORE_H_
 #define HAF_SHIM_CORE_H_
 
 #include <hafgrasp.h>
 
+#include <cstdint>
 #include <functional>
 #include <sstream>
 #include <string>
@@ -39,6 +40,17 @@ struct ResultFields {
     double approach_vector[3] = {0, 0, 0};
     float  roll = 0;
 };
+
+// One cell of the per-roll grasp grid as publish_grasp_grid (979-1016) hands it to gp_to_marker: every cell of
+// point_inside_box_grid (the mask), its position in the base frame (987-989, 996) and graspseval[row][col] (865-880).
+struct GridCell {
+    int row, col;
+    float x, y, z;
+    float value;
+};
+typedef std::function<void(int roll, const std::vector<GridCell> &)> GridFn;
+typedef std::function<bool()> PreemptFn;             // as_.isPreemptRequested() || !ros::ok() (350)
+enum { HAF_SHIM_PREEMPTED = 1 };                      // run_goal: the goal was preempted -> setPreempted() (354-356)
 
 inline std::string base_frame(const GoalFields &g) { return g.goal_frame_id.empty() ? std::string("/base_link") : g.goal_frame_id; }   // 294-301
 
@@ -90,12 +102,17 @@ inline std::string hypothesis_string(const haf_grasp_output &o, int roll_step_de
 // are handed to `publish` in roll order for the rolls the sequential loop would have executed (early exit 362-365), then
 // the overall best (390) -- which the server publishes on the same topic (1419) -- and the result fields.
 // Returns the engine's status; on failure *err carries haf_last_error().
+// `grid` (optional) receives, for every roll the sequential loop would have executed and in roll order, the cells of that roll's
+// grasp grid (901-902): what the reference turns into rviz markers.  `preempted` (optional) is asked where the reference asks
+// (350: at the top of a roll -- here all rolls of a goal are scored in ONE call of a few hundred microseconds to milliseconds, so
+// that is before the call and again before anything is published); a preempted goal returns HAF_SHIM_PREEMPTED and publishes nothing.
 inline int run_goal(haf_engine *engine, const haf_config &cfg, const GoalFields &goal, const haf_cloud &cloud,
                     const std::function<void(const std::string &)> &publish, ResultFields *result, haf_grasp_output *raw,
-                    std::string *err)
+                    std::string *err, const GridFn &grid = GridFn(), const PreemptFn &preempted = PreemptFn())
 {
     haf_grasp_input in;
     goal_to_input(goal, &in);
+    if (preempted && preempted()) return HAF_SHIM_PREEMPTED;
     std::vector<haf_roll_record> rec((size_t)cfg.n_rolls);
     int rc = haf_score_rolls(engine, 1, &cloud, &in, 0, cfg.n_rolls, rec.data());
     haf_grasp_output out;
@@ -103,6 +120,32 @@ inline int run_goal(haf_engine *engine, const haf_config &cfg, const GoalFields 
     if (rc != HAF_OK) {
         if (err) *err = haf_last_error(engine);
         return rc;
+    }
+    if (preempted && preempted()) return HAF_SHIM_PREEMPTED;
+    if (grid) {
+        const size_t HW = (size_t)cfg.grid_h * cfg.grid_w;
+        std::vector<float> ev(HW);
+        std::vector<uint8_t> mask(HW);
+        std::vector<GridCell> cells;
+        const int gw = in.gripper_opening_width;
+        // publish_grasp_grid 987-989 (float arithmetic on the double centre, integer division HEIGHT/2/gripperwidth inside 0.01*...)
+        const float x0 = (float)(in.grasp_area_center[0] - 0.01 * cfg.grid_h / 2 / gw);
+        const float y0 = (float)(in.grasp_area_center[1] - 0.01 * cfg.grid_w / 2);
+        const float z0 = (float)(in.grasp_area_center[2] + cfg.z_shift);
+        for (int r = 0; r < out.rolls_done; r++) {
+            rc = haf_get_roll_grid(engine, 0, r, ev.data(), mask.data());
+            if (rc != HAF_OK) {
+                if (err) *err = haf_last_error(engine);
+                return rc;
+            }
+            cells.clear();
+            for (int row = 0; row < cfg.grid_h; row++)
+                for (int col = 0; col < cfg.grid_w; col++)
+                    if (mask[(size_t)row * cfg.grid_w + col])                                           // 993-995
+                        cells.push_back(GridCell{row, col, (float)(x0 + 0.01 / gw * row), (float)(y0 + 0.01 * col), z0,
+                                                 ev[(size_t)row * cfg.grid_w + col]});                  // 996
+            grid(r, cells);
+        }
     }
     for (int r = 0; r < out.rolls_done; r++) {
         haf_grasp_output ro;

@@ -93,3 +93,46 @@ def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
                        capture_output=True, text=True, timeout=240, env=env)
     assert p.returncode != 0 and "stopping the other ranks" in p.stderr and time.time() - t0 < 120
     assert p.stdout.strip() == ""                              # no JSON line from a failed run
+
+
+def test_multi_gpu_partition_without_a_device(data_dir=None):
+    """the argument and partition logic of haf_create_multi (csrc/multi.cpp) runs here, on the CPU, through
+    haf_multi_plan -- the function create_multi itself uses: 36 rolls over 8 GPUs are 5,5,5,5,4,4,4,4 contiguous ranges
+    (SURVEY.md 8e), ranks are the distinct devices in order of first appearance, several shards may share a rank as long as every
+    device appears equally often, and bad device lists are refused with the texts a caller of haf_create_multi would get."""
+    from haf_grasping_amd import capi
+    p = capi.multi_plan(list(range(8)), capi.SHARD_ROLLS, 36)
+    assert p["roll_count"] == [5, 5, 5, 5, 4, 4, 4, 4] and p["roll_first"] == [0, 5, 10, 15, 20, 24, 28, 32]
+    assert p["rank_of"] == list(range(8)) and p["slot_of"] == [0] * 8 and p["n_ranks"] == 8
+    for n_rolls, n in ((12, 5), (20, 8), (36, 7), (1, 1), (12, 12)):
+        q = capi.multi_plan(list(range(n)), capi.SHARD_ROLLS, n_rolls)
+        assert sum(q["roll_count"]) == n_rolls and max(q["roll_count"]) - min(q["roll_count"]) <= 1
+        assert q["roll_first"] == [sum(q["roll_count"][:s]) for s in range(n)] and sorted(q["roll_count"], reverse=True) == q["roll_count"]
+    p = capi.multi_plan([2, 2, 5, 5], capi.SHARD_ROLLS, 12)                    # two shards on each of two GPUs
+    assert p["rank_of"] == [0, 0, 1, 1] and p["slot_of"] == [0, 1, 0, 1] and p["n_ranks"] == 2 and p["roll_count"] == [3, 3, 3, 3]
+    p = capi.multi_plan([3, 1, 3, 1], capi.SHARD_CLOUDS, 12)                   # ranks in order of first appearance
+    assert p["rank_of"] == [0, 1, 0, 1] and p["slot_of"] == [0, 0, 1, 1] and p["n_ranks"] == 2
+    for devices, mode, n_rolls, text in (([0, 0, 1], capi.SHARD_ROLLS, 12, "same number of times"),
+                                         ([0] * 13, capi.SHARD_ROLLS, 12, "more shards than rolls"),
+                                         ([0, 1], 7, 12, "unknown shard mode"),
+                                         ([0, -1], capi.SHARD_CLOUDS, 12, "negative device"),
+                                         ([], capi.SHARD_ROLLS, 12, "bad argument")):
+        with pytest.raises(capi.HafError) as ei:
+            capi.multi_plan(devices, mode, n_rolls)
+        assert ei.value.code == capi.HAF_E_ARG and text in str(ei.value), (devices, str(ei.value))
+    assert capi.multi_plan([0] * 13, capi.SHARD_CLOUDS, 12)["n_ranks"] == 1      # (clouds: any number of shards)
+
+
+def test_create_multi_fails_loudly_without_a_device():
+    """No GPU in this container: haf_create_multi gets as far as the first engine and reports HAF_E_DEVICE with the shard and the
+    reason -- no CPU fallback, no half-built handle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from haf_grasping_amd import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = os.path.join(root, "tests", "golden", "data")
+    with pytest.raises(capi.HafError) as ei:
+        capi.MultiEngine(os.path.join(data, "Features.txt"), os.path.join(data, "range21062012_allfeatures"),
+                         os.path.join(root, "tests", "golden", "surrogate.model"), [0, 1], capi.SHARD_ROLLS)
+    assert ei.value.code == capi.HAF_E_DEVICE and "shard 0" in str(ei.value)

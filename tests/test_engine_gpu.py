@@ -505,6 +505,37 @@ def test_cli_and_server_mirror(data_dir, golden_dir, surrogate):
         assert out2.stdout.strip().splitlines()[-1].split() == tok and "2 shards on 2 RCCL ranks" in out2.stderr
 
 
+def test_shim_grid_callback_delivers_the_per_roll_grasp_grid(data_dir, surrogate, orc, tmp_path):
+    """Round 3: ros_shim/shim_core.h hands the adapter, roll by roll, what publish_grasp_grid (server.cpp:901-902,
+    979-1016) turns into markers: every cell of point_inside_box_grid with its base-frame position (987-989, 996) and
+    graspseval[row][col].  Through the CLI (--grid-out): the cells are exactly the oracle's mask, the values the oracle's vote grid,
+    the positions the reference's expression; with show_only_best the rolls behind the early exit (362-365) are not delivered."""
+    import subprocess
+    f_, r_ = _files(data_dir)
+    cli = os.path.join(os.path.dirname(capi.LIB_PATH), "haf_grasp_cli")
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "plastic_mug2.pcd"))
+    for extra, okw in (([], dict()), (["--show-only-best"], dict(show_only_best=1)),
+                       (["--center", "0.01", "-0.02", "0.005", "--gripper-width", "2"], dict(center=(0.01, -0.02, 0.005), gripper_width=2))):
+        gout = str(tmp_path / "grid.txt")
+        subprocess.run([cli, "--features", f_, "--range", r_, "--model", surrogate, "--search-size", "18", "30", "--grid-out", gout] + extra +
+                       [os.path.join(data_dir, "plastic_mug2.pcd")], check=True, capture_output=True, text=True)
+        want = orc.run(xyz, O.make_cfg(), O.make_input(length_x=32, length_y=44, **okw))
+        rows = np.loadtxt(gout, ndmin=2)
+        assert sorted(set(rows[:, 0].astype(int))) == list(range(want["rolls_done"]))
+        cx, cy, cz = okw.get("center", (0.0, 0.0, 0.0))
+        gw = okw.get("gripper_width", 1)
+        for roll in range(want["rolls_done"]):
+            rr = rows[rows[:, 0] == roll]
+            cells = np.argwhere(want["mask"][roll] == 1)
+            assert (rr[:, 1:3].astype(int) == cells).all()                                        # row-major, exactly the mask
+            assert (rr[:, 6] == want["graspseval"][roll][cells[:, 0], cells[:, 1]]).all()
+            x0 = np.float32(cx - 0.01 * 56 / 2 / gw)
+            y0 = np.float32(cy - 0.01 * 56 / 2)
+            np.testing.assert_allclose(rr[:, 3], np.float32(x0) + 0.01 / gw * cells[:, 0], atol=2e-7)
+            np.testing.assert_allclose(rr[:, 4], np.float32(y0) + 0.01 * cells[:, 1], atol=2e-7)
+            np.testing.assert_allclose(rr[:, 5], np.float32(cz + 0.15), atol=1e-7)
+
+
 def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
     """Guard tiers: fast contraction -> fp64 MFMA (GEMM form) -> libsvm's strict fp64 order.  Forcing wide bands sends
     every evaluation through tier 2, then through tier 3; labels stay identical and the decision values of tier 3 are
@@ -978,7 +1009,7 @@ def test_cloud_sharded_batch_through_the_c_abi(data_dir, golden_dir, surrogate, 
         gold = json.load(f)
     f_, r_ = _files(data_dir)
     spec = MF.CONFIGS["C4"]
-    names = ["pcd%d" % k for k in (1, 3, 4, 5, 6, 7, 8)]          # the clouds with a committed C4 golden
+    names = ["pcd%d" % k for k in range(1, 9)]                    # BASELINE config C4: pcd1..pcd8 (all eight have a committed C4 golden)
     clouds = [pcdio.load_pcd(os.path.join(data_dir, n + ".pcd")) for n in names]
     me = capi.MultiEngine(f_, r_, surrogate, devices, capi.SHARD_CLOUDS, max_clouds=8, **spec["cfg"])
     inp = capi.default_input(grasp_area_length_x=32, grasp_area_length_y=44)

@@ -532,3 +532,19 @@ def test_failed_exp_hazard_check_leaves_no_library(tmp_path, monkeypatch):
     monkeypatch.setattr(b, "check_exp_hazard", lambda *a, **k: {})
     b.build()
     assert open(b.LIB).read() == "built" and open(b.LIB_TESTING).read() == "built" and b.up_to_date()
+
+
+def test_ros_adapter_translation_unit_parses():
+    """the catkin-side adapter (ros_shim/calc_grasppoints_action_server_hip.cpp) cannot be built here (no ROS / PCL),
+    but it can be TYPE-CHECKED: g++ -fsyntax-only against the minimal declarations of tests/mock_ros/ (own code, see its README).
+    Every use of shim_core.h -- goal fields, grid callback, preemption callback, result fields -- must compile."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(root, "tests", "mock_ros"),
+           "-I", os.path.join(root, "ros_shim"), "-I", os.path.join(root, "include"),
+           os.path.join(root, "ros_shim", "calc_grasppoints_action_server_hip.cpp")]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    src = open(os.path.join(root, "ros_shim", "calc_grasppoints_action_server_hip.cpp")).read()
+    for needle in ("on_grid", "preempted", "setPreempted", "visualization_marker_array", "run_goal"):
+        assert needle in src
