@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhafgrasp.so")
 LIB_TESTING = os.path.join(HERE, "libhafgrasp_testing.so")
-SOURCES = ["kernels.hip", "screen.hip", "prob.hip", "engine.cpp", "parsers.cpp", "multi.cpp"]
+SOURCES = ["kernels.hip", "screen.hip", "prob.hip", "exact8.hip", "engine.cpp", "parsers.cpp", "multi.cpp"]
 # per-file extra flags (screen.hip: see its header)
 EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["kernels.h", "parsers.h", "decq.h", "engine_internal.h", "testkernels.hip", os.path.join("..", "..", "include", "hafgrasp.h"),

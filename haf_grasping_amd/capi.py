@@ -102,6 +102,7 @@ def _bind(path, testing):
     L.haf_multi_plan.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.haf_last_strict_host.argtypes = [E, C.POINTER(C.c_int64)]
+    L.haf_last_exact_tiers.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                C.c_size_t]
     L.haf_free.argtypes = [C.c_void_p]
@@ -263,6 +264,11 @@ class Engine:
         a, r, b, c = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._L.haf_last_tiers(self._h, C.byref(a), C.byref(r), C.byref(b), C.byref(c)))
         return dict(n_evals=a.value, n_refined=r.value, n_rechecked=b.value, n_strict=c.value)
+
+    def last_exact_tiers(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._L.haf_last_exact_tiers(self._h, C.byref(a), C.byref(b)))
+        return dict(n_integer=a.value, n_fp64=b.value)
 
     def last_strict_host(self):
         a = C.c_int64()

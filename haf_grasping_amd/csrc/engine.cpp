@@ -255,6 +255,15 @@ struct haf_engine {
     DevBuf<int> d_flag0_wgcount;                // popcounts per 256 words, for the ordered compaction
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64, d_part64;
+    // tier 2a, the exact-integer tier (exact8.hip): int8 digit images of the support vectors, its hand-over list to the fp64 MFMA
+    // tier and that tier's decision values for it (d_dec_exact then holds tier 2a's values, in the order of d_flag_list)
+    DevBuf<char> d_sv_i8;
+    DevBuf<int> d_flagi_list;
+    DevBuf<double> d_dec_exacti;
+    I8Params i8{};
+    bool i8_active = false;
+    int last_flaggedi = 0;          // evaluations that entered the fp64 MFMA tier in the last call
+    bool last_i8 = false;           // the last call ran tier 2a (then d_dec_exact holds ITS values and d_dec_exacti the fp64 tier's)
     DevBuf<short> d_ev16;
     DevBuf<float> d_margin;         // HAF_FLAG_KEEP_DEBUG, default mode: |dec^| / band of every evaluation the screening tier decided
     DevBuf<AttrRecord> d_attr;      // HAF_FLAG_KEEP_DEBUG: [max_evals][kKP] attribute records of the exact-form feature kernels
@@ -752,6 +761,46 @@ int build_tables(haf_engine *e)
         return fail(e, HAF_E_DEVICE, "hipMalloc(fp64 model)");
     HIPCHK(e, hipMemcpy(e->d_sv64.p, sv64.data(), sv64.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->d_coef64.p, coef64.data(), coef64.size() * sizeof(double), hipMemcpyHostToDevice));
+    // ---- tier 2a: support vectors as four int8 digit planes in the B-operand layout of v_mfma_i32_16x16x64_i8 (kernels.h) ----
+    e->i8_active = !(c.flags & HAF_FLAG_PROBABILITY) && !test_env("HAF_NO_I8") && e->kx <= 64 * kI8Steps;
+    if (e->i8_active) {
+        const int n_tiles16 = e->n_sv_pad / 16;
+        std::vector<char> img((size_t)n_tiles16 * kI8SvTileBytes, 0);
+        double s_max2 = 0.0;
+        for (int n = 0; n < m.n_sv && e->i8_active; n++) {
+            char *tile = img.data() + (size_t)(n / 16) * kI8SvTileBytes;
+            const int col = n % 16;
+            long long ssq = 0;
+            for (int k = 0; k < m.dim; k++) {
+                const double sc = std::nearbyint(m.sv[(size_t)n * m.dim + k] * (double)(1 << kI8Q));
+                if (!(std::fabs(sc) <= (double)kI8Max)) { e->i8_active = false; break; }      // a support vector beyond +-3.97: no tier 2a
+                int t = (int)sc;
+                ssq += (long long)t * t;
+                int dg[4];
+                dg[3] = ((t + 64) & 127) - 64; t = (t - dg[3]) >> 7;
+                dg[2] = ((t + 64) & 127) - 64; t = (t - dg[2]) >> 7;
+                dg[1] = ((t + 64) & 127) - 64; t = (t - dg[1]) >> 7;
+                dg[0] = t;
+                const int ks = k / 64, blk = (k % 64) / 16, jj = k % 16;
+                for (int j = 0; j < kI8Slices; j++) tile[(size_t)(j * kI8Steps + ks) * 1024 + (blk * 16 + col) * 16 + jj] = (char)dg[j];
+            }
+            double *cst = reinterpret_cast<double *>(tile + kI8GroupBytes);
+            cst[col] = std::ldexp((double)ssq, -2 * kI8Q);
+            cst[16 + col] = m.coef[(size_t)n];
+            s_max2 = std::max(s_max2, cst[col]);
+        }
+        if (e->i8_active) {
+            if (hipSuccess != e->d_sv_i8.alloc(img.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(int8 sv tiles)");
+            HIPCHK(e, hipMemcpy(e->d_sv_i8.p, img.data(), img.size(), hipMemcpyHostToDevice));
+            e->i8.gamma = m.gamma; e->i8.rho = m.rho;
+            e->i8.delta = 2.0 * std::sqrt((double)kKP) * std::ldexp(1.0, -(kI8Q + 1)) * (1.0 + 1e-12);
+            e->i8.s_max = std::sqrt(s_max2) * (1.0 + 1e-12);
+            e->i8.guard_scale = 1.0;
+            if (const char *g = test_env("HAF_GUARD_I8_REL")) e->i8.guard_scale = atof(g);
+            else if (test_env("HAF_GUARD2_REL")) e->i8.guard_scale = 1e30;      // a test that forces the fp64 / strict tiers means all of them
+            e->i8.n_sv_pad = e->n_sv_pad;
+        }
+    }
     e->exact.gamma2 = m.gamma * log2e;
     e->exact.as_max1 = 1.0 + m.gamma * log2e * ss_max;
     // fp64 GEMM-form tier: worst-case error ~ 324 * 2^-53 per unit of (a_x + a_s) * sum|coef|K, i.e. < 2^-44; 2^-40 leaves 16x
@@ -821,6 +870,7 @@ int build_tables(haf_engine *e)
         e->svm.as_max = (float)as_max;
     }
     e->svm.gv0 = e->gv0; e->svm.gv1 = e->gv1;
+    e->i8.gv0 = e->gv0; e->i8.gv1 = e->gv1;
     e->svm.sqrt_cmax = (float)(e->screen.sqrt_cmax * (1.0 + 1e-7));
     e->host_exp_thr = std::ldexp(e->sum_abs_coef, -44);        // 256 x the largest difference a last-bit exp error can make
     if (test_env("HAF_HOST_EXP_ALL")) e->host_exp_thr = INFINITY;   // tests: every strict-tier evaluation through the host path
@@ -896,6 +946,10 @@ int alloc_buffers(haf_engine *e)
     // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->list_cap);
+    if (e->i8_active) {
+        ok &= hipSuccess == e->d_flagi_list.alloc((size_t)e->list_cap);
+        ok &= hipSuccess == e->d_dec_exacti.alloc((size_t)e->list_cap);
+    }
     ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->list_cap);
     if ((c.flags & HAF_FLAG_KEEP_DEBUG) && mode == MODE_SCREEN) ok &= hipSuccess == e->d_margin.alloc((size_t)e->max_evals_pad);
     if (c.flags & HAF_FLAG_KEEP_DEBUG) {
@@ -986,6 +1040,7 @@ void haf_destroy(haf_engine *e)
     e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_own.release(); e->d_gridf.release(); e->d_evf.release(); e->d_ptext.release();
+    e->d_sv_i8.release(); e->d_flagi_list.release(); e->d_dec_exacti.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
@@ -1138,7 +1193,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
     if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_GUARD2_REL") ||
         test_env("HAF_LARGE_EVALS") || test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE") || test_env("HAF_FLAG_WINDOW") ||
-        test_env("HAF_HOST_EXP_ALL"))
+        test_env("HAF_HOST_EXP_ALL") || test_env("HAF_NO_I8") || test_env("HAF_GUARD_I8_REL"))
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     int rc = build_tables(e);
@@ -1180,6 +1235,14 @@ int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, in
     if (n_refined) *n_refined = e->last_flagged0;
     if (n_rechecked) *n_rechecked = e->last_flagged;
     if (n_strict) *n_strict = e->last_flagged2;
+    return HAF_OK;
+}
+
+int haf_last_exact_tiers(const haf_engine *e, int64_t *n_integer, int64_t *n_fp64)
+{
+    if (!e) return HAF_E_ARG;
+    if (n_integer) *n_integer = e->last_i8 ? e->last_flagged : 0;
+    if (n_fp64) *n_fp64 = e->last_flaggedi;
     return HAF_OK;
 }
 
@@ -1451,9 +1514,26 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         // tier 2: fp64 MFMA (GEMM form) for the guard band of the fast contraction; tier 3: libsvm's strict order for what
         // is still within 2^-40 of zero (practically nothing).  Window 0 of the tier-2 list goes with every request; the
         // strict tier is launched only when the counters that come back with the roll records say it has work (never so far).
-        if (!direct)
-            launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, 0, e->d_counters.p,
-                                e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s);
+        // tier 2a in front of it (exact8.hip): the same evaluations on EXACT integer dot products (int8 digit planes); what it
+        // cannot decide either -- |dec| inside the operands' quantisation, ~1e-7 S -- is the fp64 MFMA tier's list
+        const bool i8 = e->i8_active && !direct;
+        auto fp64_window = [&](int off) {
+            if (i8)
+                launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flagi_list.p, e->flag_cap, off, e->d_counters.p,
+                                    e->d_x64.p, e->d_part64.p, e->d_dec_exacti.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s, nullptr, false,
+                                    CNT_FLAGGEDI);
+            else
+                launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, off, e->d_counters.p,
+                                    e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s);
+        };
+        auto i8_window = [&](int off) {
+            launch_recheck_i8(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv_i8.p, e->i8, e->range.lower, e->range.upper, e->d_flag_list.p, e->flag_cap,
+                              off, e->d_counters.p, e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flagi_list.p, e->list_cap, d, s);
+        };
+        if (!direct) {
+            if (i8) i8_window(0);
+            fp64_window(0);
+        }
         // the counters come back with the roll records: a second window costs nothing unless it is needed
         auto vote = [&]() -> int {
             mark(e, HAF_ST_VOTE);
@@ -1478,15 +1558,26 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         bool strict_ran = false;
         e->last_host_resolved = 0;
         const int flagged = e->h_counters[CNT_FLAGGED];
-        if (!direct && flagged > e->flag_cap && !(mode == MODE_SCREEN && e->h_counters[CNT_FLAGGED0] > e->flag0_cap)) {
-            // More evaluations inside the guard band of the fast contraction than one window of the fp64 tier holds (an
-            // ill-conditioned model): the reference never fails a goal on this path (server.cpp:778-796), so neither does
-            // the engine -- the remaining windows of the list go through the same kernels one after the other, then the
-            // strict tier once more over its whole list (it is idempotent), then the vote again.  Slower, same labels.
-            for (int off = e->flag_cap; off < flagged; off += e->flag_cap)
-                launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flag_list.p, e->flag_cap, off,
-                                    e->d_counters.p, e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flag2_list.p,
-                                    e->list_cap, d, s);
+        const bool lists_valid = !direct && !(mode == MODE_SCREEN && e->h_counters[CNT_FLAGGED0] > e->flag0_cap);
+        const bool more_i8 = lists_valid && i8 && flagged > e->flag_cap;
+        const bool more_fp64 = lists_valid && (i8 ? e->h_counters[CNT_FLAGGEDI] > e->flag_cap : flagged > e->flag_cap);
+        if (more_i8 || more_fp64) {
+            // More evaluations inside a guard band than one window of an exact tier holds (an ill-conditioned model): the
+            // reference never fails a goal on this path (server.cpp:778-796), so neither does the engine -- the remaining
+            // windows of the lists go through the same kernels one after the other, then the strict tier over its whole list,
+            // then the vote again.  Slower, same labels.
+            int done_fp64 = e->flag_cap;                  // entries of its list the fp64 tier has seen (window 0)
+            if (more_i8) {
+                for (int off = e->flag_cap; off < flagged; off += e->flag_cap) i8_window(off);
+                // the fp64 tier's list has grown behind its first window: all of it again from the start (its results and the
+                // strict tier's list are rebuilt; both are idempotent)
+                HIPCHK(e, hipMemsetAsync(e->d_counters.p + CNT_FLAGGED2, 0, sizeof(int), s));
+                HIPCHK(e, hipMemcpyAsync(e->h_out, e->d_out.p, kCntBytes, hipMemcpyDeviceToHost, s));
+                HIPCHK(e, hipStreamSynchronize(s));
+                done_fp64 = 0;
+            }
+            const int n_fp64 = i8 ? e->h_counters[CNT_FLAGGEDI] : flagged;
+            for (int off = done_fp64; off < n_fp64; off += e->flag_cap) fp64_window(off);
             launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
                            e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();
@@ -1572,13 +1663,15 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
+    e->last_flaggedi = (e->i8_active && !direct) ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
     e->last_inexact = inexact_grids;
     e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->last_flagged0 <= e->flag0_cap;
     // zero the counters for the next request now, behind this one's copy-out: off that request's critical path
     if (hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s) == hipSuccess) e->counters_clean = true;
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
-    if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
+    if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap || e->last_flaggedi > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
+    e->last_i8 = e->i8_active && !direct;
     for (int i = 0; i < B * R; i++) {
         records[i].vote = e->h_rec[i].vote;
         records[i].row = e->h_rec[i].row;
@@ -1763,6 +1856,16 @@ static int debug_fetch_impl(haf_engine *e, int32_t what, int32_t cloud, int32_t 
             }
             std::vector<double> d64(dec.begin(), dec.end());
             for (size_t k = 0; k < nfl; k++) d64[(size_t)fl[k]] = ex[k];
+            if (e->last_i8) {                              // behind tier 2a the fp64 tier has its own list and values
+                const size_t nfi = (size_t)std::min(e->last_flaggedi, e->list_cap);
+                if (nfi) {
+                    std::vector<int> fli(nfi);
+                    std::vector<double> exi(nfi);
+                    HIPCHK(e, hipMemcpy(fli.data(), e->d_flagi_list.p, nfi * 4, hipMemcpyDeviceToHost));
+                    HIPCHK(e, hipMemcpy(exi.data(), e->d_dec_exacti.p, nfi * 8, hipMemcpyDeviceToHost));
+                    for (size_t k = 0; k < nfi; k++) d64[(size_t)fli[k]] = exi[k];
+                }
+            }
             const size_t nf2 = (size_t)std::min(e->last_flagged2, e->list_cap);
             if (nf2) {
                 std::vector<int> fl2(nf2);
@@ -2124,6 +2227,20 @@ int haf_test_mfma_model(int device, int mb, int tiles, double *tflops)
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(din); (void)hipFree(dout);
     return rc;
+}
+
+// v_mfma_i32_16x16x64_i8 on host-chosen int8 data: a [16][64], b [64][16] row-major -> c [16][16] (testkernels.hip)
+int haf_test_i8_mfma(const signed char *a, const signed char *b, int *c)
+{
+    void *da = nullptr, *db = nullptr;
+    int *dc = nullptr;
+    if (hipMalloc(&da, 1024) != hipSuccess || hipMalloc(&db, 1024) != hipSuccess || hipMalloc((void **)&dc, 1024) != hipSuccess) return HAF_E_DEVICE;
+    (void)hipMemcpy(da, a, 1024, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, 1024, hipMemcpyHostToDevice);
+    haf::launch_i8_layout_probe(da, db, dc, nullptr);
+    const hipError_t rc = hipMemcpy(c, dc, 1024, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
 }
 
 int haf_test_decq_device(const double *in, double *out, int n, int digits)

@@ -1,0 +1,200 @@
+// exact8.hip -- tier 2a of the RBF decision: the exact-integer tier (kernels.h: "tier 2a").
+//
+// The evaluations the three-pass kernel could not decide (|dec| inside ~5e-6 sum|coef|K: the fp32 accumulation of the matrix
+// core) used to go straight to the fp64 MFMA tier, which runs at 1/32 of the fp16 matrix rate and was the largest cost on
+// models whose decision values crowd around zero.  Here they first meet a contraction that has NO accumulation error at all:
+//   * attributes (k_features_small<XMODE_I8>) and support vectors (engine.cpp) as fixed-point integers with kI8Q = 23
+//     fractional bits (|value| < 15.87), each split into four balanced base-128 digits (int8, -64..63);
+//   * the sixteen digit-by-digit products of the 384-long dot product through v_mfma_i32_16x16x64_i8, one int32 accumulator per
+//     digit weight 128^(6-w), w = j + k: at most 4 x 384 x 64 x 64 < 2^23 per accumulator, so every partial sum is EXACT;
+//   * |xq - sq|^2 = |xq|^2 + |sq|^2 - 2 xq.sq from the exact integers (one fp64 rounding each), libm-grade fp64 exp, fp64 sums.
+// The only error of a kernel value is the quantisation of the operands, |(x - xq) - (s - sq)|_2 <= delta = 2 sqrt(324) 2^-24:
+//   | |x-s|^2 - |xq-sq|^2 | <= delta (2 |xq - sq| + delta) <= delta (2 (|xq| + max|sq|) + delta),
+// i.e. |dec_q - dec| <= (exp(gamma * that) - 1) * S -- about 3.5e-7 S on the bench models, 16x inside the three-pass band; what
+// is still closer to zero than that goes on to the fp64 MFMA tier (k_recheck_mfma) exactly as before.  Same task structure as
+// that tier: a workgroup = 4 waves x 16 evaluations, one of kMSplit ranges of SV tiles, partial sums added in a fixed order.
+#include "kernels.h"
+
+namespace haf {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kI8Waves = 4;
+constexpr int kI8Evals = 16 * kI8Waves;
+constexpr int kI8Split = 8;                        // SV ranges per group of evaluations (= kMSplit of the fp64 tier: same part64 layout)
+static_assert(kRecheckPartRows == 2 * kI8Split + 1, "part64 layout shared with the fp64 tier");
+constexpr int kI8TileLoads = kI8GroupBytes / (256 * 16);      // 16-byte loads per thread per tile image (6)
+static_assert(kI8TileLoads * 256 * 16 == kI8GroupBytes, "tile image = whole 16-byte loads of 256 threads");
+
+__device__ __forceinline__ int window_count8(int total, int off, int cap) { return max(0, min(total - off, cap)); }
+
+__global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ ximg, const char *__restrict__ svimg, I8Params p,
+                                                       int flag_cap, int list_off, const int *__restrict__ counters, int cslot,
+                                                       double *__restrict__ part64)
+{
+    __shared__ __attribute__((aligned(16))) char bt[kI8SvTileBytes];
+    const int n_flag = window_count8(counters[cslot], list_off, flag_cap);
+    const int n_groups = (n_flag + kI8Evals - 1) / kI8Evals;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n_tiles = p.n_sv_pad / 16;
+    const int tiles_per_part = (n_tiles + kI8Split - 1) / kI8Split;
+    const double *xnorm = part64 + (size_t)(2 * kI8Split) * flag_cap;      // |xq|^2 per slot, written by the feature kernel
+    for (int task = blockIdx.x; task < n_groups * kI8Split; task += gridDim.x) {
+        const int g = task / kI8Split, h = task - g * kI8Split;
+        const int t_begin = h * tiles_per_part, t_end = min(n_tiles, t_begin + tiles_per_part);
+        const int grp = g * kI8Waves + wave;                         // this wave's 16 slots
+        // ---- A operand: the digit image of 16 evaluations, [digit][k-step][lane][16 int8]: 1 KiB per wave load ----
+        i32x4 a[kI8Slices][kI8Steps];
+        {
+            const char *xg = ximg + (size_t)grp * kI8GroupBytes + lane * 16;
+#pragma unroll
+            for (int j = 0; j < kI8Slices; j++)
+#pragma unroll
+                for (int ks = 0; ks < kI8Steps; ks++) a[j][ks] = *reinterpret_cast<const i32x4 *>(xg + (j * kI8Steps + ks) * 1024);
+        }
+        double xx[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sl = grp * 16 + 4 * (lane >> 4) + r;            // C/D map: row = 4 (lane >> 4) + reg
+            xx[r] = (sl < n_flag) ? xnorm[sl] : 0.0;
+        }
+        // the next tile waits in registers while this one is consumed (explicit loops: through a lambda hipcc parks them in scratch)
+        uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre_c = uint4{0, 0, 0, 0};
+#define HAF_I8_TILE_LOAD(t)                                                                                   \
+        {                                                                                                         \
+            const char *src__ = svimg + (size_t)(t) * kI8SvTileBytes + (size_t)tid * 16;                          \
+            pre0 = *reinterpret_cast<const uint4 *>(src__);                                                       \
+            pre1 = *reinterpret_cast<const uint4 *>(src__ + 4096);                                                \
+            pre2 = *reinterpret_cast<const uint4 *>(src__ + 8192);                                                \
+            pre3 = *reinterpret_cast<const uint4 *>(src__ + 12288);                                               \
+            pre4 = *reinterpret_cast<const uint4 *>(src__ + 16384);                                               \
+            pre5 = *reinterpret_cast<const uint4 *>(src__ + 20480);                                               \
+            if (tid < 16) pre_c = *reinterpret_cast<const uint4 *>(src__ + kI8GroupBytes);                        \
+        }
+#define HAF_I8_TILE_STORE()                                                                                   \
+        {                                                                                                         \
+            char *dst__ = bt + (size_t)tid * 16;                                                                  \
+            *reinterpret_cast<uint4 *>(dst__) = pre0;                                                             \
+            *reinterpret_cast<uint4 *>(dst__ + 4096) = pre1;                                                      \
+            *reinterpret_cast<uint4 *>(dst__ + 8192) = pre2;                                                      \
+            *reinterpret_cast<uint4 *>(dst__ + 12288) = pre3;                                                     \
+            *reinterpret_cast<uint4 *>(dst__ + 16384) = pre4;                                                     \
+            *reinterpret_cast<uint4 *>(dst__ + 20480) = pre5;                                                     \
+            if (tid < 16) *reinterpret_cast<uint4 *>(dst__ + kI8GroupBytes) = pre_c;                              \
+        }
+        static_assert(kI8TileLoads == 6, "six 16-byte loads per thread");
+        __syncthreads();                                             // (the previous task's last tile is no longer read)
+        if (t_begin < t_end) { HAF_I8_TILE_LOAD(t_begin); HAF_I8_TILE_STORE(); }
+        __syncthreads();
+        double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
+        for (int t = t_begin; t < t_end; t++) {
+            if (t + 1 < t_end) HAF_I8_TILE_LOAD(t + 1);
+            i32x4 acc[7];
+#pragma unroll
+            for (int w = 0; w < 7; w++) acc[w] = i32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < kI8Steps; ks++) {
+                i32x4 b[kI8Slices];
+#pragma unroll
+                for (int k = 0; k < kI8Slices; k++) b[k] = *reinterpret_cast<const i32x4 *>(bt + (k * kI8Steps + ks) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < kI8Slices; j++)
+#pragma unroll
+                    for (int k = 0; k < kI8Slices; k++)
+                        acc[j + k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][ks], b[k], acc[j + k], 0, 0, 0);
+            }
+            const double *cst = reinterpret_cast<const double *>(bt + kI8GroupBytes);
+            const double ss = cst[lane & 15], cf = cst[16 + (lane & 15)];          // this lane's column: |sq|^2 and coef (0: padding)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double dot = 0.0;                                                // xq.sq: seven exact integers, weights 128^(6-w) 2^(-2 kI8Q)
+#pragma unroll
+                for (int w = 6; w >= 0; w--) dot = fma((double)acc[w][r], __builtin_ldexp(1.0, 7 * (6 - w) - 2 * kI8Q), dot);   // (constants after unrolling)
+                const double d2 = fma(-2.0, dot, xx[r] + ss);
+                const double kv = exp(-p.gamma * d2);
+                part[r] = fma(cf, kv, part[r]);
+                pabs[r] = fma(fabs(cf), kv, pabs[r]);
+            }
+            __syncthreads();                          // everyone is done reading the tile
+            if (t + 1 < t_end) HAF_I8_TILE_STORE();
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = part[r], w = pabs[r];
+            v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
+            v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
+            v += __shfl_xor(v, 2, 64); w += __shfl_xor(w, 2, 64);
+            v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
+            part[r] = v; pabs[r] = w;
+        }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int sl = grp * 16 + 4 * (lane >> 4) + r;
+                if (sl < n_flag) {
+                    part64[(size_t)(2 * h) * flag_cap + sl] = part[r];
+                    part64[(size_t)(2 * h + 1) * flag_cap + sl] = pabs[r];
+                }
+            }
+        }
+    }
+}
+
+// sum of the kI8Split partial decision values (fixed order), label, and what is still inside the quantisation band goes on to
+// the fp64 MFMA tier's list
+__global__ __launch_bounds__(256) void k_recheck_i8_combine(const double *__restrict__ part64, const int *__restrict__ evalcell, I8Params p,
+                                                            const int *__restrict__ flag_list, int flag_cap, int list_off,
+                                                            int *__restrict__ counters, int cslot, double *__restrict__ dec_exact,
+                                                            int8_t *__restrict__ labels, int *__restrict__ flagi_list, int flagi_cap)
+{
+    const int n_flag = window_count8(counters[cslot], list_off, flag_cap);
+    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
+        double P = 0.0, S = 0.0;
+#pragma unroll
+        for (int h = 0; h < kI8Split; h++) {
+            P += part64[(size_t)(2 * h) * flag_cap + sl];
+            S += part64[(size_t)(2 * h + 1) * flag_cap + sl];
+        }
+        const double dv = P - p.rho;
+        const double xq2 = part64[(size_t)(2 * kI8Split) * flag_cap + sl];
+        const int e = flag_list[sl];
+        bool decided = false;
+        if (xq2 >= 0.0) {                                            // (negative: an attribute beyond the fixed-point range)
+            // relative error of every kernel value: exp(gamma | |x-s|^2 - |xq-sq|^2 |) - 1, with |xq - sq| <= |xq| + max|sq|;
+            // e^y - 1 <= y (1 + y) for y < 1; the fp64 roundings of exp and of the sums are inside 2^-40 like the fp64 tier's
+            const double y = p.gamma * p.delta * (2.0 * (sqrt(xq2) * (1.0 + 1e-15) + p.s_max) + p.delta);
+            const double band = (y * (1.0 + y) * 1.01 + 9.1e-13) * p.guard_scale * S;
+            decided = (y < 0.5) && (fabs(dv) > band);
+        }
+        dec_exact[sl] = dv;
+        labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+        if (!decided) {
+            const int s2 = atomicAdd(&counters[CNT_FLAGGEDI], 1);
+            if (s2 < flagi_cap) flagi_list[s2] = e;
+        }
+    }
+}
+
+// One window [list_off, list_off + window_cap) of the list counted by counters[CNT_FLAGGED]: digit image (the feature kernel), the
+// int8 contraction, combine.  ximg holds kI8GroupBytes per 16 slots of a window, part64 the fp64 tier's [2 kMSplit + 1][window_cap].
+void launch_recheck_i8(const float *ii, const int *evalcell, const FeatDesc *fd, const void *sv_i8, I8Params p, double lower, double upper,
+                       const int *flag_list, int window_cap, int list_off, int *counters, void *ximg, double *part64, double *dec_exact,
+                       int8_t *labels, int *flagi_list, int flagi_cap, Dims d, hipStream_t s)
+{
+    const int groups = (window_cap + kI8Evals - 1) / kI8Evals;
+    if (groups <= 0) return;
+    flag_list += list_off;
+    dec_exact += list_off;
+    launch_features(ii, evalcell, counters, fd, reinterpret_cast<float *>(ximg), reinterpret_cast<float *>(part64 + (size_t)(2 * kI8Split) * window_cap),
+                    d, lower, upper, 0.0f, window_cap, XMODE_I8, ScreenParams{}, flag_list, CNT_FLAGGED, window_cap, false, window_cap, nullptr,
+                    nullptr, s, list_off);
+    const long tasks = (long)groups * kI8Split;
+    hipLaunchKernelGGL(k_recheck_i8, dim3((unsigned)(tasks < 8192 ? tasks : 8192)), dim3(256), 0, s, (const char *)ximg, (const char *)sv_i8, p,
+                       window_cap, list_off, counters, CNT_FLAGGED, part64);
+    const int blocks = groups < 2048 ? groups : 2048;
+    hipLaunchKernelGGL(k_recheck_i8_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, window_cap, list_off, counters,
+                       CNT_FLAGGED, dec_exact, labels, flagi_list, flagi_cap);
+}
+
+}  // namespace haf

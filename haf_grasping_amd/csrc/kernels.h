@@ -223,7 +223,35 @@ struct ExactParams {
 // counters[] slots in device memory
 enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAGGED0 = 4,
        CNT_INEXACT = 5,    // (cloud, roll) grids whose integral image needed the sequential summation order
+       CNT_FLAGGEDI = 6,   // evaluations the exact-integer tier (exact8.hip) handed on to the fp64 MFMA tier
        CNT_COUNT = 8 };
+
+// ---- tier 2a: the decision function on EXACT integer dot products (exact8.hip) ------------------------------------------
+// What limits the fp16 contractions is the fp32 accumulation inside the matrix core (~2.6e-6 relative per kernel value); what
+// makes the fp64 MFMA tier slow is the fp64 matrix rate (1/32 of fp16).  In between: attributes and support vectors as
+// fixed-point numbers with kI8Q fractional bits, |value| < 15.9, split into four balanced base-128 digits (-64..63, int8); the 16
+// digit-by-digit products of a 384-long dot product go through v_mfma_i32_16x16x64_i8 and are EXACT in int32 (<= 4 x 384 x 4096 per
+// accumulator, one accumulator per digit weight), so |xq - sq|^2 of the quantised vectors is exact and the only error of a kernel
+// value is the quantisation: |d - dq| <= 2 sqrt(324) 2^-(kI8Q+1), i.e. ~3.5e-7 relative instead of 5.6e-6.  An evaluation still
+// inside that (16x narrower) band goes on to the fp64 MFMA tier as before.
+// (The range: svm-scale does not clamp, and a SHAF attribute of -1 against a range [0, 0.30] scales to -7.64: the attributes of
+// real windows reach +-7.7, so 23 fractional bits -- +-15.87 -- it is; an evaluation or a model beyond that skips the tier.)
+constexpr int kI8Q = 23;                          // fractional bits: |value| <= 63 * (2^21 + 2^14 + 2^7 + 1) * 2^-23 = 15.87
+constexpr long kI8Max = 63L * (2097152L + 16384L + 128L + 1L);
+constexpr int kI8Slices = 4;                      // digits per value
+constexpr int kI8Steps = 6;                       // k-steps of 64 attributes: 384 >= 324
+constexpr int kI8GroupBytes = kI8Slices * kI8Steps * 1024;   // operand image of 16 evaluations (or 16 SVs): [digit][k-step][lane][16 int8]
+constexpr int kI8SvTileBytes = kI8GroupBytes + 256;          // + 16 doubles |sq_n|^2 + 16 doubles coef
+struct I8Params {
+    double gamma, rho;
+    double delta;                 // |(x - xq) - (s - sq)|_2 <= delta = 2 sqrt(324) 2^-(kI8Q+1)
+    double s_max;                 // max_n |sq_n|_2
+    double guard_scale;           // 1 (HAF_GUARD_I8_REL in the testing build)
+    int n_sv_pad, gv0, gv1, pad;
+};
+void launch_recheck_i8(const float *ii, const int *evalcell, const FeatDesc *fd, const void *sv_i8, I8Params p, double lower, double upper,
+                       const int *flag_list, int window_cap, int list_off, int *counters, void *ximg, double *part64, double *dec_exact,
+                       int8_t *labels, int *flagi_list, int flagi_cap, Dims d, hipStream_t s);
 
 // fp64 model image for the rechecks: attribute-major [kM64Rows][n_sv_pad]; rows 0..323 attributes (model order of SVs),
 // row 324 |s|^2, row 325 coef
@@ -267,7 +295,8 @@ void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, 
 void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s);
 // operand image the feature kernels write
 enum { XMODE_F32 = 0, XMODE_SPLIT = 1, XMODE_SCREEN = 2,
-       XMODE_F64 = 3 };   // the fp64 attribute image of the fp64 MFMA tier (X = double *, [group of 16][324][16]); no ax
+       XMODE_F64 = 3,     // the fp64 attribute image of the fp64 MFMA tier (X = double *, [group of 16][324][16]); no ax
+       XMODE_I8 = 4 };    // the int8 digit image of the exact-integer tier (kI8GroupBytes per 16 slots); ax = double * |xq|^2 per slot
 // idx_list == nullptr: evaluations 0..counters[CNT_EVALS]; otherwise slot j takes evaluation idx_list[j],
 // j < min(counters[list_counter], list_cap) (the screened evaluations that go on to the three-pass kernel)
 void launch_features(const float *ii, const int *evalcell, const int *counters, const FeatDesc *fd, float *X, float *ax,
@@ -296,13 +325,15 @@ void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *f
                          const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
                          double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s,
                          AttrRecord *dbg = nullptr,    // dbg: attribute records of a request that went straight to this tier
-                         bool have_x64 = false);       // the attribute image is in place already (launch_features XMODE_F64)
+                         bool have_x64 = false,        // the attribute image is in place already (launch_features XMODE_F64)
+                         int counter_slot = CNT_FLAGGED);   // the counter of flag_list (CNT_FLAGGEDI behind the exact-integer tier)
 constexpr int kRecheckPartRows = 2 * 8 + 1;       // part64: [2 * kMSplit + 1][flag_cap] doubles (partial sums + |x|^2)
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
                  int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s);
 void launch_mfma_accum_test(const void *a, const void *b, const float *c0, float *out, int trials, hipStream_t s);   // testkernels.hip (testing build)
 void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hipStream_t s);                       // testkernels.hip (testing build)
 void launch_mfma_model_test(const void *in, float *out, int mb, int blocks, int tiles, hipStream_t s);             // testkernels.hip (testing build)
+void launch_i8_layout_probe(const void *a, const void *b, int *c, hipStream_t s);                                 // testkernels.hip (testing build)
 void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s);
 void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
                        int n, hipStream_t s);

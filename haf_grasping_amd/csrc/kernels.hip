@@ -1681,7 +1681,10 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
                                                   AttrRecord *__restrict__ dbg, float *__restrict__ ax2,
                                                   const int *__restrict__ idx_list, int list_counter, int list_cap, int list_off)
 {
-    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64) ? 64 : kSvmBlockEvals;
+    // XMODE_I8 (list mode): the int8 digit image of the exact-integer tier (exact8.hip), kI8GroupBytes per 16 slots, and |xq|^2
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64 || MODE == XMODE_I8) ? 64 : kSvmBlockEvals;
+    __shared__ long long red_ll[(MODE == XMODE_I8) ? kSmSlots : 1][kSmEvals];
+    __shared__ int red_ovf[(MODE == XMODE_I8) ? kSmSlots : 1][kSmEvals];
     constexpr int kFinisher = 40;                     // the quarter wave that sums up the partial norms (one without a group of its own in the screening form)
     static_assert(kSmSlots >= 2 * kHSteps && kFinisher < kSmSlots, "slots cover the groups");
     __shared__ double red[kSmSlots][kSmEvals];
@@ -1706,7 +1709,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
+    const int n_groups = (MODE == XMODE_I8) ? kSmSlots : (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 44 / 41 / 40 / 42
     double *x64 = reinterpret_cast<double *>(X) + (size_t)(e >> 4) * kKP * 16 + (e & 15);      // XMODE_F64: see k_features
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
@@ -1728,6 +1731,9 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
     const int g = slot;
     const bool has_group = g < n_groups;
+    long long xx_ll = 0;                                   // XMODE_I8: sum of the squared fixed-point attributes of this group (exact)
+    int ovf = 0;
+    unsigned long long dig[4] = {0, 0, 0, 0};             // XMODE_I8: the four digit planes of this thread's 8 attributes
     if (has_group) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -1753,6 +1759,22 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
                 xx = fma((double)xe, (double)xe, xx);
             } else if (MODE == XMODE_F64) {
                 if (f < kKP) x64[(size_t)f * 16] = xd;
+            } else if (MODE == XMODE_I8) {
+                // fixed point with kI8Q fractional bits, round to nearest (the scaling by 2^kI8Q is exact): |x - X 2^-kI8Q| <= 2^-(kI8Q+1)
+                double sc = rint(xd * (double)(1 << kI8Q));
+                if (!(fabs(sc) <= (double)kI8Max)) { ovf = 1; sc = 0.0; }          // (also NaN) -> this evaluation skips the tier
+                const int X = (int)sc;
+                xx_ll += (long long)X * (long long)X;
+                // balanced base-128 digits, least significant first: d in [-64, 63], X = ((d0 128 + d1) 128 + d2) 128 + d3
+                int t = X;
+                const int d3 = ((t + 64) & 127) - 64; t = (t - d3) >> 7;
+                const int d2 = ((t + 64) & 127) - 64; t = (t - d2) >> 7;
+                const int d1 = ((t + 64) & 127) - 64; t = (t - d1) >> 7;
+                const int d0 = t;
+                dig[0] |= (unsigned long long)(unsigned char)d0 << (8 * q);
+                dig[1] |= (unsigned long long)(unsigned char)d1 << (8 * q);
+                dig[2] |= (unsigned long long)(unsigned char)d2 << (8 * q);
+                dig[3] |= (unsigned long long)(unsigned char)d3 << (8 * q);
             } else {
                 if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
                 xx = fma((double)xf, (double)xf, xx);
@@ -1760,7 +1782,24 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
         }
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
         if (MODE == XMODE_SCREEN) store_group_img(xtile, r, g, hi);
+        if (MODE == XMODE_I8) {
+            // A-operand image of v_mfma_i32_16x16x64_i8 (checked on hardware: testkernels.hip): lane = 16 (k % 64 / 16) + row holds
+            // bytes k % 16 = 0..15; this thread's attributes 8g..8g+7 are half of one lane's fragment: one 8-byte store per digit
+            char *img = reinterpret_cast<char *>(X) + (size_t)(e >> 4) * kI8GroupBytes;
+            const int row = (int)(e & 15);
+            auto put = [&](int grp8, int j, unsigned long long v) {
+                const int ks = grp8 >> 3, blk = (grp8 & 7) >> 1, half = grp8 & 1;
+                *reinterpret_cast<unsigned long long *>(img + (j * kI8Steps + ks) * 1024 + (blk * 16 + row) * 16 + half * 8) = v;
+            };
+#pragma unroll
+            for (int j = 0; j < kI8Slices; j++) put(g, j, dig[j]);
+            if (g >= 40) {                                 // attributes 352..383 (groups 44..47) have no slot of their own: zeros
+#pragma unroll
+                for (int j = 0; j < kI8Slices; j++) put(g + 4, j, 0ull);
+            }
+        }
     }
+    if (MODE == XMODE_I8) { red_ll[slot][ev] = xx_ll; red_ovf[slot][ev] = ovf; }
     red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
     if (MODE == XMODE_SCREEN) { red2[slot][ev] = (double)acc.sd2; red3[slot][ev] = (double)sx; red4[slot][ev] = acc.cr; red5[slot][ev] = acc.ub; }
     __syncthreads();
@@ -1775,6 +1814,13 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             if (live) screen_finish(t, t2, t + t3, t4, t5, sp, band, nax);
             store_band(ax + kBandFloats * e, band);
             ax2[e] = nax;
+        } else if (MODE == XMODE_I8) {
+            long long s2 = 0;
+            int any = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < kSmSlots; k2++) { s2 += red_ll[k2][ev]; any |= red_ovf[k2][ev]; }      // exact: < 324 * 2^54
+            // |xq|^2 in real units (one rounding: 2^-53 relative); negative = an attribute beyond the fixed-point range
+            reinterpret_cast<double *>(ax)[e] = any ? -1.0 : ldexp((double)s2, -2 * kI8Q);
         } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
@@ -1899,7 +1945,13 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
                                  const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals,
                                  AttrRecord *dbg, float *ax2, hipStream_t s, int list_off = 0)
 {
-    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64) ? 64 : kSvmBlockEvals;
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64 || MODE == XMODE_I8) ? 64 : kSvmBlockEvals;
+    if (MODE == XMODE_I8) {                                   // list mode only, always the 16-evaluation workgroups
+        const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
+        hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                           lower, upper, neg_gamma2, sp, dbg, ax2, idx_list, list_counter, list_cap, list_off);
+        return;
+    }
     if (large && MODE != XMODE_F64) {
         // enough evaluations to fill the chip with one thread each
         long blocks = (max_evals + kBlock - 1) / kBlock * (kBlock / 256);
@@ -1931,6 +1983,11 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
                      float *ax2, hipStream_t s, int list_off)
 {
     if (max_evals <= 0) return;
+    if (xmode == XMODE_I8) {
+        launch_features_mode<XMODE_I8>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
+                                       list_counter, list_cap, false, sel_evals, dbg, ax2, s, list_off);
+        return;
+    }
     if (xmode == XMODE_F64) {
         launch_features_mode<XMODE_F64>(ii, evalcell, counters, fd, X, ax, d, lower, upper, neg_gamma2, max_evals, sp, idx_list,
                                         list_counter, list_cap, false, sel_evals, dbg, ax2, s, list_off);
@@ -2605,13 +2662,14 @@ constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per 
 __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__ x64, const int *__restrict__ evalcell,
                                                       const double *__restrict__ sv64,
                                                       ExactParams p, const int *__restrict__ flag_list, int flag_cap,
-                                                      int list_off, int *__restrict__ counters, double *__restrict__ part64, Dims d)
+                                                      int list_off, int *__restrict__ counters, double *__restrict__ part64, Dims d,
+                                                      int cslot)
 {
     // ONE SV tile in LDS (41 KiB): the next tile waits in registers while this one is consumed, and both barriers of the
     // hand-over are needed with one buffer or two -- with one, three workgroups fit a CU instead of one
     __shared__ __attribute__((aligned(16))) double bt[1][kMTileDoubles];
     __shared__ double xxs[kMWaves][16];
-    const int n_flag = window_count(counters[CNT_FLAGGED], list_off, flag_cap);
+    const int n_flag = window_count(counters[cslot], list_off, flag_cap);
     const int n_groups = (n_flag + kMEvals - 1) / kMEvals;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_tiles = p.n_sv_pad / 16;
@@ -2715,9 +2773,10 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
 __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restrict__ part64, const int *__restrict__ evalcell,
                                                          ExactParams p, const int *__restrict__ flag_list, int flag_cap,
                                                          int list_off, int *__restrict__ counters, double *__restrict__ dec_exact,
-                                                         int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap)
+                                                         int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap,
+                                                         int cslot)
 {
-    const int n_flag = window_count(counters[CNT_FLAGGED], list_off, flag_cap);
+    const int n_flag = window_count(counters[cslot], list_off, flag_cap);
     for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
         double P = 0.0, S = 0.0;
 #pragma unroll
@@ -2743,7 +2802,7 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
                          const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
                          double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s, AttrRecord *dbg,
-                         bool have_x64)
+                         bool have_x64, int counter_slot)
 {
     int groups = (window_cap + kMEvals - 1) / kMEvals;
     int blocks = groups < 2048 ? groups : 2048;
@@ -2753,12 +2812,12 @@ void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *f
     // (have_x64: a request that went straight to this tier -- its feature kernel wrote the image for the identity list)
     if (!have_x64)
         launch_features(ii, evalcell, counters, fd, reinterpret_cast<float *>(x64), nullptr, d, p.lower, p.upper, 0.0f, window_cap, XMODE_F64,
-                        ScreenParams{}, flag_list, CNT_FLAGGED, window_cap, false, window_cap, dbg, nullptr, s, list_off);
+                        ScreenParams{}, flag_list, counter_slot, window_cap, false, window_cap, dbg, nullptr, s, list_off);
     const long tasks = (long)groups * kMSplit;
     hipLaunchKernelGGL(k_recheck_mfma, dim3((unsigned)(tasks < 4096 ? tasks : 4096)), dim3(256), 0, s, x64, evalcell, sv64, p,
-                       flag_list, window_cap, list_off, counters, part64, d);
+                       flag_list, window_cap, list_off, counters, part64, d, counter_slot);
     hipLaunchKernelGGL(k_recheck_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, window_cap, list_off, counters,
-                       dec_exact, labels, flag2_list, flag2_cap);
+                       dec_exact, labels, flag2_list, flag2_cap, counter_slot);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -199,4 +199,25 @@ void launch_mfma_accum_test(const void *a, const void *b, const float *c0, float
     hipLaunchKernelGGL(k_mfma_accum, dim3(trials), dim3(64), 0, s, (const _Float16 *)a, (const _Float16 *)b, c0, out);
 }
 
+// Operand layout of v_mfma_i32_16x16x64_i8 checked with exact integer data (the CDNA guide documents the bf16 maps only): lane l
+// holds A[row l&15][k = 16 (l>>4) + j] and B[k = 16 (l>>4) + j][col l&15] in byte j of its 16-byte fragment, C/D in the
+// dtype-independent map col = l&15, row = 4 (l>>4) + reg.  a: [16][64] int8 row-major, b: [64][16] row-major, c: [16][16] int32.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_i8_layout_probe(const signed char *__restrict__ a, const signed char *__restrict__ b, int *__restrict__ c)
+{
+    const int l = threadIdx.x, rc = l & 15, kb = l >> 4;
+    union { signed char q[16]; i32x4 v; } fa, fb;
+    for (int j = 0; j < 16; j++) {
+        fa.q[j] = a[rc * 64 + 16 * kb + j];
+        fb.q[j] = b[(16 * kb + j) * 16 + rc];
+    }
+    i32x4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.v, fb.v, acc, 0, 0, 0);
+    for (int r = 0; r < 4; r++) c[(4 * kb + r) * 16 + rc] = acc[r];
+}
+void launch_i8_layout_probe(const void *a, const void *b, int *c, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_i8_layout_probe, dim3(1), dim3(64), 0, s, (const signed char *)a, (const signed char *)b, c);
+}
+
 }  // namespace haf

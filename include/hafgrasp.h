@@ -241,6 +241,11 @@ int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked,
  * (they went through the three-pass kernel; 0 in the other modes), then the fp64 MFMA tier, then the strict tier. */
 int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, int64_t *n_rechecked, int64_t *n_strict);
 
+/* The exact tiers of the last scored batch (both counted in n_rechecked of haf_last_tiers): evaluations that went through the
+ * exact-integer tier (int8 digit planes on the matrix cores, no accumulation error; 0 when the model's support vectors do not
+ * fit its fixed-point range), and those still inside its quantisation band that went on to the fp64 MFMA tier. */
+int haf_last_exact_tiers(const haf_engine *e, int64_t *n_integer, int64_t *n_fp64);
+
 /* Strict tier of the last scored batch: evaluations whose libsvm-order decision value lay within a last-bit exp error of zero
  * (2^-44 sum|coef|) and were therefore decided on the host with the C library's exp, the function svm-predict itself calls
  * (svm.cpp:364).  None in any run so far. */

@@ -64,7 +64,7 @@ DEC_REL_SCREEN = 2.0 ** -8
 # environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
-              "HAF_NO_CALIBRATE")
+              "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -544,6 +544,7 @@ def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
     inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
     want = orc.run(xyz, O.make_cfg(), oracle_input(inp))
     monkeypatch.setenv("HAF_GUARD0_REL", "1e30")           # default mode: nothing is decided by the screening pass either
+    monkeypatch.setenv("HAF_NO_I8", "1")                   # the fp64 MFMA tier itself (the exact-integer tier in front of it: test_exact_integer_tier)
     for g1, g2, tol in (("1e30", None, 2.0 ** -40), ("1e30", "1e30", 1e-13)):
         monkeypatch.setenv("HAF_GUARD_REL", g1)
         if g2:
@@ -592,6 +593,56 @@ def test_model_is_classified_at_creation(data_dir, surrogate, orc, monkeypatch, 
         compare_full(eng, o, xyz, dict(n_rolls=12), inp)
         counts.append(eng.last_counts())
     assert 0 < counts[0]["n_refined"] < 0.25 * counts[0]["n_evals"] and counts[0] == counts[1], counts
+    eng.close()
+
+
+def test_exact_integer_tier(data_dir, surrogate, orc, monkeypatch, tmp_path):
+    """Round 3, tier 2a (csrc/exact8.hip): attributes and support vectors as fixed-point numbers in four int8 digit planes, the dot
+    products EXACT in int32 on the matrix cores.  (1) Every evaluation forced through it (HAF_GUARD_REL wide open): labels, votes
+    and grasp are the oracle's, its decision values are within its own band -- ~4e-7 S, sixteen times inside the three-pass
+    kernel's -- of the oracle's, and only what lies inside that band goes on to the fp64 tier; (2) with its band forced wide
+    open everything goes on, same labels; (3) a model with a support-vector component beyond the fixed-point range (|s| >= 15.87)
+    is served without the tier."""
+    monkeypatch.setenv("HAF_GUARD_REL", "1e30")
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
+    f, r = _files(data_dir)
+    path = str(tmp_path / "rand300.model")
+    models.write_random_model(path, 300, seed=4, balanced=True)
+    for model, o in ((surrogate, orc), (path, O.Oracle(f, r, path))):
+        eng = make_engine(data_dir, model, capi.FLAG_SPLIT_F16)
+        got, want = compare_full(eng, o, xyz, dict(n_rolls=12), inp, check_dec=False)
+        cnt, ex = eng.last_counts(), eng.last_exact_tiers()
+        assert cnt["n_rechecked"] == cnt["n_evals"] == ex["n_integer"] == want["n_evals"] and ex["n_fp64"] < 0.05 * cnt["n_evals"] and cnt["n_strict"] == 0
+        worst = 0.0
+        for roll in range(12):
+            m = want["mask"][roll] == 1
+            if m.any():
+                rel = np.abs(eng.debug(capi.DBG_DECISION, 0, roll)[m] - want["dec"][roll][m]) / want["sabs"][roll][m]
+                worst = max(worst, float(rel.max()))
+        assert worst < 1e-6, worst                                  # band: gamma delta 2 (|x| + |s|) ~ 4e-7; measured far below
+        STATS.setdefault("exact_integer_tier_max_rel_err", {})[os.path.basename(model)] = worst
+        eng.close()
+    monkeypatch.setenv("HAF_GUARD_I8_REL", "1e30")
+    eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16)
+    compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
+    ex = eng.last_exact_tiers()
+    assert ex["n_integer"] == ex["n_fp64"] == eng.last_counts()["n_evals"]
+    eng.close()
+    monkeypatch.delenv("HAF_GUARD_I8_REL")
+    big = str(tmp_path / "big.model")
+    with open(path) as fh:
+        lines = fh.read().splitlines()
+    k = lines.index("SV") + 1
+    tok = lines[k].split()
+    tok[5] = tok[5].split(":")[0] + ":16.5"                     # one component beyond the fixed-point range
+    lines[k] = " ".join(tok)
+    with open(big, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    eng = make_engine(data_dir, big, capi.FLAG_SPLIT_F16)
+    compare_full(eng, O.Oracle(f, r, big), xyz, dict(n_rolls=12), inp)
+    ex = eng.last_exact_tiers()
+    assert ex["n_integer"] == 0 and ex["n_fp64"] == eng.last_counts()["n_evals"]
     eng.close()
 
 
