@@ -793,6 +793,9 @@ int build_tables(haf_engine *e)
             if (hipSuccess != e->d_sv_i8.alloc(img.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(int8 sv tiles)");
             HIPCHK(e, hipMemcpy(e->d_sv_i8.p, img.data(), img.size(), hipMemcpyHostToDevice));
             e->i8.gamma = m.gamma; e->i8.rho = m.rho;
+            e->i8.gamma2 = m.gamma * log2e;
+            // 2 x.s enters d^2: 2 * 324 attributes * (2 * 128 + 1) * 64 * 64 * 2^(-2 kI8Q)
+            e->i8.drop = 2.0 * (double)kKP * 257.0 * 4096.0 * std::ldexp(1.0, -2 * kI8Q) * (1.0 + 1e-12);
             e->i8.delta = 2.0 * std::sqrt((double)kKP) * std::ldexp(1.0, -(kI8Q + 1)) * (1.0 + 1e-12);
             e->i8.s_max = std::sqrt(s_max2) * (1.0 + 1e-12);
             e->i8.guard_scale = 1.0;

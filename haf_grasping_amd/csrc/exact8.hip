@@ -5,9 +5,13 @@
 // models whose decision values crowd around zero.  Here they first meet a contraction that has NO accumulation error at all:
 //   * attributes (k_features_small<XMODE_I8>) and support vectors (engine.cpp) as fixed-point integers with kI8Q = 23
 //     fractional bits (|value| < 15.87), each split into four balanced base-128 digits (int8, -64..63);
-//   * the sixteen digit-by-digit products of the 384-long dot product through v_mfma_i32_16x16x64_i8, one int32 accumulator per
-//     digit weight 128^(6-w), w = j + k: at most 4 x 384 x 64 x 64 < 2^23 per accumulator, so every partial sum is EXACT;
-//   * |xq - sq|^2 = |xq|^2 + |sq|^2 - 2 xq.sq from the exact integers (one fp64 rounding each), libm-grade fp64 exp, fp64 sums.
+//   * the digit-by-digit products of the 384-long dot product through v_mfma_i32_16x16x64_i8, one int32 accumulator per digit
+//     weight 128^(6-w), w = j + k: at most 4 x 384 x 64 x 64 < 2^23 per accumulator, so every partial sum is EXACT.  The three
+//     products of weights 128 and 1 (w = 5, 6) are left out: together at most (2 x 128 + 1) x 64 x 64 x 2^-46 = 1.5e-8 per
+//     attribute, |error of xq.sq| <= 4.9e-6 -- a tenth of what the quantisation costs -- and part of the band (I8Params::drop);
+//   * |xq - sq|^2 = |xq|^2 + |sq|^2 - 2 xq.sq from the exact integers (the accumulators combined in int32 pairs, then three fp64
+//     operations), 2^(-gamma' d^2) by range reduction and a degree-11 polynomial (1e-14 relative), fp64 sums.  (What bounds this
+//     kernel is the SIMD's vector issue port: with libm's exp and seven conversions per element it ran at 60 % of its MFMA time.)
 // The only error of a kernel value is the quantisation of the operands, |(x - xq) - (s - sq)|_2 <= delta = 2 sqrt(324) 2^-24:
 //   | |x-s|^2 - |xq-sq|^2 | <= delta (2 |xq - sq| + delta) <= delta (2 (|xq| + max|sq|) + delta),
 // i.e. |dec_q - dec| <= (exp(gamma * that) - 1) * S -- about 3.5e-7 S on the bench models, 16x inside the three-pass band; what
@@ -27,6 +31,70 @@ constexpr int kI8TileLoads = kI8GroupBytes / (256 * 16);      // 16-byte loads p
 static_assert(kI8TileLoads * 256 * 16 == kI8GroupBytes, "tile image = whole 16-byte loads of 256 threads");
 
 __device__ __forceinline__ int window_count8(int total, int off, int cap) { return max(0, min(total - off, cap)); }
+
+// 2^y for y <= 0.5: n = rint(y), f = y - n in [-0.5, 0.5] exactly, Taylor polynomial of 2^f of degree 11 (truncation 8.8e-15
+// relative, Horner roundings ~1.5e-15), v_ldexp_f64.  No table, no branch, 15 instructions instead of libm's ~40.
+__device__ __forceinline__ double exp2_poly(double y)
+{
+    const double n = rint(y);
+    const double f = y - n;
+    double p = 4.4455382718708101e-10;
+    p = fma(p, f, 7.0549116208011209e-09);
+    p = fma(p, f, 1.0178086009239696e-07);
+    p = fma(p, f, 1.3215486790144305e-06);
+    p = fma(p, f, 1.5252733804059838e-05);
+    p = fma(p, f, 0.00015403530393381606);
+    p = fma(p, f, 0.0013333558146428441);
+    p = fma(p, f, 0.0096181291076284769);
+    p = fma(p, f, 0.055504108664821576);
+    p = fma(p, f, 0.24022650695910069);
+    p = fma(p, f, 0.69314718055994529);
+    p = fma(p, f, 1.0);
+    return ldexp(p, (int)fmax(n, -1200.0));
+}
+
+// the 13 x 6 MFMAs of one SV tile (16 SVs) against this wave's 16 evaluations
+__device__ __forceinline__ void i8_tile_mfma(const char *bt, int lane, const i32x4 (&a)[kI8Slices][kI8Steps], i32x4 (&acc)[5])
+{
+#pragma unroll
+    for (int w = 0; w < 5; w++) acc[w] = i32x4{0, 0, 0, 0};
+    // B fragments one k-step ahead of their MFMAs (the LDS round trip of a k-step's four reads hides behind the previous step's 13 MFMAs)
+    i32x4 b[kI8Slices], bn[kI8Slices];
+#pragma unroll
+    for (int k = 0; k < kI8Slices; k++) b[k] = *reinterpret_cast<const i32x4 *>(bt + (k * kI8Steps) * 1024 + lane * 16);
+#pragma unroll
+    for (int ks = 0; ks < kI8Steps; ks++) {
+        if (ks + 1 < kI8Steps) {
+#pragma unroll
+            for (int k = 0; k < kI8Slices; k++) bn[k] = *reinterpret_cast<const i32x4 *>(bt + (k * kI8Steps + ks + 1) * 1024 + lane * 16);
+        }
+        // the 13 digit pairs (j, k), j + k <= 4, in an order that brings the same accumulator back every third instruction at the
+        // earliest (also across the k-steps): a dependent MFMA does not issue back to back
+#define HAF_I8_MFMA(j, k) acc[(j) + (k)] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][ks], b[k], acc[(j) + (k)], 0, 0, 0)
+        HAF_I8_MFMA(0, 3); HAF_I8_MFMA(1, 3); HAF_I8_MFMA(0, 2); HAF_I8_MFMA(1, 2); HAF_I8_MFMA(0, 1); HAF_I8_MFMA(2, 2); HAF_I8_MFMA(2, 1);
+        HAF_I8_MFMA(1, 1); HAF_I8_MFMA(0, 0); HAF_I8_MFMA(3, 0); HAF_I8_MFMA(3, 1); HAF_I8_MFMA(2, 0); HAF_I8_MFMA(1, 0);
+#undef HAF_I8_MFMA
+#pragma unroll
+        for (int k = 0; k < kI8Slices; k++) b[k] = bn[k];
+    }
+}
+
+// kernel values and class sums of one finished tile: this lane's column (SV) against its four rows (evaluations)
+__device__ __forceinline__ void i8_tile_epilogue(const i32x4 (&acc)[5], const double (&xx)[4], double ss, double cf, double gamma2,
+                                                 double (&part)[4], double (&pabs)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        // xq.sq 2^(2 kI8Q) = acc0 128^6 + (acc1 128 + acc2) 128^4 + (acc3 128 + acc4) 128^2: the pairs in int32 (< 2^30), then
+        // two fp64 fmas on exact integers (< 2^63: one rounding of 2^-53 relative at most)
+        const int u1 = (acc[1][r] << 7) + acc[2][r], u2 = (acc[3][r] << 7) + acc[4][r];
+        const double dq = fma(fma((double)acc[0][r], 16384.0, (double)u1), 16384.0, (double)u2);
+        const double d2 = fma(-2.0 * __builtin_ldexp(1.0, 14 - 2 * kI8Q), dq, xx[r] + ss);
+        const double kv = exp2_poly(-gamma2 * d2);
+        part[r] = fma(cf, kv, part[r]);
+        pabs[r] = fma(fabs(cf), kv, pabs[r]);
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ ximg, const char *__restrict__ svimg, I8Params p,
                                                        int flag_cap, int list_off, const int *__restrict__ counters, int cslot,
@@ -87,38 +155,42 @@ __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ 
         if (t_begin < t_end) { HAF_I8_TILE_LOAD(t_begin); HAF_I8_TILE_STORE(); }
         __syncthreads();
         double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
-        for (int t = t_begin; t < t_end; t++) {
+        // Software pipeline over the tiles: the fp64 epilogue of tile t-1 (its accumulators and its column constants wait in
+        // registers) is issued BETWEEN the MFMAs of tile t -- one MFMA, two vector instructions, 78 times -- instead of behind
+        // them: the wave keeps the matrix pipe fed while its own vector work runs (MFMA busy 58 % -> see DESIGN.md 5).
+        const double *cst = reinterpret_cast<const double *>(bt + kI8GroupBytes);
+        i32x4 acc_prev[5], acc_cur[5];
+        double ss_prev = 0.0, cf_prev = 0.0;
+        if (t_begin < t_end) {                                         // first tile: nothing to overlap with
+            if (t_begin + 1 < t_end) HAF_I8_TILE_LOAD(t_begin + 1);
+            i8_tile_mfma(bt, lane, a, acc_prev);
+            ss_prev = cst[lane & 15]; cf_prev = cst[16 + (lane & 15)];  // this lane's column: |sq|^2 and coef (0: padding)
+            __syncthreads();                                          // everyone is done reading the tile
+            if (t_begin + 1 < t_end) HAF_I8_TILE_STORE();
+            __syncthreads();
+        }
+        for (int t = t_begin + 1; t < t_end; t++) {
             if (t + 1 < t_end) HAF_I8_TILE_LOAD(t + 1);
-            i32x4 acc[7];
-#pragma unroll
-            for (int w = 0; w < 7; w++) acc[w] = i32x4{0, 0, 0, 0};
+            i8_tile_mfma(bt, lane, a, acc_cur);
+            i8_tile_epilogue(acc_prev, xx, ss_prev, cf_prev, p.gamma2, part, pabs);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // the first k-step's B fragments
 #pragma unroll
             for (int ks = 0; ks < kI8Steps; ks++) {
-                i32x4 b[kI8Slices];
+                if (ks + 1 < kI8Steps) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the next k-step's B fragments (LDS reads)
 #pragma unroll
-                for (int k = 0; k < kI8Slices; k++) b[k] = *reinterpret_cast<const i32x4 *>(bt + (k * kI8Steps + ks) * 1024 + lane * 16);
-#pragma unroll
-                for (int j = 0; j < kI8Slices; j++)
-#pragma unroll
-                    for (int k = 0; k < kI8Slices; k++)
-                        acc[j + k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[j][ks], b[k], acc[j + k], 0, 0, 0);
+                for (int q = 0; q < 13; q++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // two VALU instructions of the previous tile's epilogue
+                }
             }
-            const double *cst = reinterpret_cast<const double *>(bt + kI8GroupBytes);
-            const double ss = cst[lane & 15], cf = cst[16 + (lane & 15)];          // this lane's column: |sq|^2 and coef (0: padding)
+            ss_prev = cst[lane & 15]; cf_prev = cst[16 + (lane & 15)];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double dot = 0.0;                                                // xq.sq: seven exact integers, weights 128^(6-w) 2^(-2 kI8Q)
-#pragma unroll
-                for (int w = 6; w >= 0; w--) dot = fma((double)acc[w][r], __builtin_ldexp(1.0, 7 * (6 - w) - 2 * kI8Q), dot);   // (constants after unrolling)
-                const double d2 = fma(-2.0, dot, xx[r] + ss);
-                const double kv = exp(-p.gamma * d2);
-                part[r] = fma(cf, kv, part[r]);
-                pabs[r] = fma(fabs(cf), kv, pabs[r]);
-            }
+            for (int w = 0; w < 5; w++) acc_prev[w] = acc_cur[w];
             __syncthreads();                          // everyone is done reading the tile
             if (t + 1 < t_end) HAF_I8_TILE_STORE();
             __syncthreads();
         }
+        if (t_begin < t_end) i8_tile_epilogue(acc_prev, xx, ss_prev, cf_prev, p.gamma2, part, pabs);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             double v = part[r], w = pabs[r];
@@ -163,7 +235,8 @@ __global__ __launch_bounds__(256) void k_recheck_i8_combine(const double *__rest
         if (xq2 >= 0.0) {                                            // (negative: an attribute beyond the fixed-point range)
             // relative error of every kernel value: exp(gamma | |x-s|^2 - |xq-sq|^2 |) - 1, with |xq - sq| <= |xq| + max|sq|;
             // e^y - 1 <= y (1 + y) for y < 1; the fp64 roundings of exp and of the sums are inside 2^-40 like the fp64 tier's
-            const double y = p.gamma * p.delta * (2.0 * (sqrt(xq2) * (1.0 + 1e-15) + p.s_max) + p.delta);
+            // (+ drop: the digit products of weights 128 and 1 the contraction leaves out, as an error of |xq - sq|^2)
+            const double y = p.gamma * (p.delta * (2.0 * (sqrt(xq2) * (1.0 + 1e-15) + p.s_max) + p.delta) + p.drop);
             const double band = (y * (1.0 + y) * 1.01 + 9.1e-13) * p.guard_scale * S;
             decided = (y < 0.5) && (fabs(dv) > band);
         }

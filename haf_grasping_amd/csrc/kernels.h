@@ -244,6 +244,8 @@ constexpr int kI8GroupBytes = kI8Slices * kI8Steps * 1024;   // operand image of
 constexpr int kI8SvTileBytes = kI8GroupBytes + 256;          // + 16 doubles |sq_n|^2 + 16 doubles coef
 struct I8Params {
     double gamma, rho;
+    double gamma2;                // gamma * log2(e)
+    double drop;                  // | |xq - sq|^2 computed - exact | from the digit products the contraction leaves out (weights 128, 1)
     double delta;                 // |(x - xq) - (s - sq)|_2 <= delta = 2 sqrt(324) 2^-(kI8Q+1)
     double s_max;                 // max_n |sq_n|_2
     double guard_scale;           // 1 (HAF_GUARD_I8_REL in the testing build)

@@ -1408,6 +1408,44 @@ __device__ __forceinline__ void store_band(float *dst, const float *band)
     reinterpret_cast<float4 *>(dst)[1] = float4{band[4], band[5], band[6], band[7]};
 }
 
+// ---- XMODE_I8: the int8 digit image of the exact-integer tier (exact8.hip; kernels.h "tier 2a") ----
+constexpr int kI8SmallList = 16384;                    // lists up to this length: k_features_small, beyond: k_features<.., 16>
+// fixed point with kI8Q fractional bits, round to nearest (the scaling by 2^kI8Q is exact): |x - X 2^-kI8Q| <= 2^-(kI8Q+1); balanced
+// base-128 digits, d in [-64, 63], X = ((d0 128 + d1) 128 + d2) 128 + d3; attribute q of this thread's group goes to byte q of the
+// four digit planes.  xx: sum of X^2 (exact in int64: < 324 * 2^54); ovf: an attribute beyond the fixed-point range (or NaN).
+__device__ __forceinline__ void i8_digits(double xd, int q, unsigned long long (&dig)[4], long long &xx, int &ovf)
+{
+    double sc = rint(xd * (double)(1 << kI8Q));
+    if (!(fabs(sc) <= (double)kI8Max)) { ovf = 1; sc = 0.0; }
+    const int X = (int)sc;
+    xx += (long long)X * (long long)X;
+    int t = X;
+    const int d3 = ((t + 64) & 127) - 64; t = (t - d3) >> 7;
+    const int d2 = ((t + 64) & 127) - 64; t = (t - d2) >> 7;
+    const int d1 = ((t + 64) & 127) - 64; t = (t - d1) >> 7;
+    const int d0 = t;
+    dig[0] |= (unsigned long long)(unsigned char)d0 << (8 * q);
+    dig[1] |= (unsigned long long)(unsigned char)d1 << (8 * q);
+    dig[2] |= (unsigned long long)(unsigned char)d2 << (8 * q);
+    dig[3] |= (unsigned long long)(unsigned char)d3 << (8 * q);
+}
+// A-operand image of v_mfma_i32_16x16x64_i8 (checked on hardware: testkernels.hip): lane = 16 (k % 64 / 16) + row holds bytes
+// k % 16 = 0..15; the attributes 8g..8g+7 of slot e are half of one lane's fragment: one 8-byte store per digit plane.  The groups
+// 44..47 (attributes 352..383: padding of the sixth k-step) have no thread of their own: the threads of groups 40..43 zero them.
+__device__ __forceinline__ void i8_store(float *X, long e, int g, const unsigned long long (&dig)[4])
+{
+    char *img = reinterpret_cast<char *>(X) + (size_t)(e >> 4) * kI8GroupBytes;
+    const int row = (int)(e & 15);
+#pragma unroll
+    for (int j = 0; j < kI8Slices; j++) {
+        *reinterpret_cast<unsigned long long *>(img + (j * kI8Steps + (g >> 3)) * 1024 + (((g & 7) >> 1) * 16 + row) * 16 + (g & 1) * 8) = dig[j];
+        if (g >= 40) {
+            const int g2 = g + 4;
+            *reinterpret_cast<unsigned long long *>(img + (j * kI8Steps + (g2 >> 3)) * 1024 + (((g2 & 7) >> 1) * 16 + row) * 16 + (g2 & 1) * 8) = 0ull;
+        }
+    }
+}
+
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
 // workgroups for C5).  Small requests use k_features below.
 template <int MODE>
@@ -1553,7 +1591,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
 {
     // XMODE_F64: the fp64 attribute image of the fp64 MFMA tier (k_recheck_mfma), [group of 16 slots][324][16] doubles, for a
     // window [list_off, list_off + list_cap) of the tier's list (idx_list already points at entry list_off)
-    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64) ? 64 : kSvmBlockEvals;
+    constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64 || MODE == XMODE_I8) ? 64 : kSvmBlockEvals;
+    __shared__ long long red_ll[(MODE == XMODE_I8) ? kFeatWaves : 1][kFeatEvals];
+    __shared__ int red_ovf[(MODE == XMODE_I8) ? kFeatWaves : 1][kFeatEvals];
     constexpr int kFeatFinisher = 0;                          // the wave that sums up the partial norms
     __shared__ double red[kFeatWaves][kFeatEvals];
     __shared__ float s_win[kFeatEvals * kWinPitch];
@@ -1562,6 +1602,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     __shared__ double red3[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     __shared__ float red4[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals], red5[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
+    if (MODE == XMODE_I8 && n_evals <= kI8SmallList) return;           // short lists are k_features_small's (see there)
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
@@ -1579,7 +1620,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 41 / 40 / 42
+    const int n_groups = (MODE == XMODE_I8) ? 44 : (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 44 / 41 / 40 / 42
     double *x64 = reinterpret_cast<double *>(X) + (size_t)(e >> 4) * kKP * 16 + (e & 15);
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
@@ -1603,9 +1644,12 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     double xx = 0.0;
     ScreenSums acc{0.0f, 0.0f, 0.0f, 0.0f};                            // screening form: fp32 partial sums of this wave's groups
     float sx = 0.0f;
+    long long xx_ll = 0;                                               // XMODE_I8 (see i8_digits)
+    int ovf = 0;
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
         double udv[8];
+        unsigned long long dig[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int f = g * 8 + q;
@@ -1629,6 +1673,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                 xx = fma((double)xe, (double)xe, xx);
             } else if (MODE == XMODE_F64) {
                 if (f < kKP) x64[(size_t)f * 16] = xd;                  // unused slots and attributes beyond the feature file: zeros
+            } else if (MODE == XMODE_I8) {
+                i8_digits(xd, q, dig, xx_ll, ovf);
             } else {
                 if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
                 xx = fma((double)xf, (double)xf, xx);
@@ -1639,7 +1685,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             screen_extra_norm(sp, g, udv, sx);
             store_group_img(xtile, r, g, hi);
         }
+        if (MODE == XMODE_I8) i8_store(X, e, g, dig);
     }
+    if (MODE == XMODE_I8) { red_ll[gl][ev] = xx_ll; red_ovf[gl][ev] = ovf; }
     red[gl][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
     if (MODE == XMODE_SCREEN) { red2[gl][ev] = (double)acc.sd2; red3[gl][ev] = (double)sx; red4[gl][ev] = acc.cr; red5[gl][ev] = acc.ub; }
     __syncthreads();
@@ -1654,6 +1702,12 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             if (live) screen_finish(t, t2, t + t3, t4, t5, sp, band, nax);
             store_band(ax + kBandFloats * e, band);
             ax2[e] = nax;
+        } else if (MODE == XMODE_I8) {
+            long long s2 = 0;
+            int any = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < kFeatWaves; k2++) { s2 += red_ll[k2][ev]; any |= red_ovf[k2][ev]; }      // exact: < 324 * 2^54
+            reinterpret_cast<double *>(ax)[e] = any ? -1.0 : ldexp((double)s2, -2 * kI8Q);
         } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
@@ -1695,6 +1749,10 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __shared__ unsigned s_w0[kSmEvals];
     // (list mode: slot j holds evaluation idx_list[j] of the window [list_off, list_off + list_cap) of the list counted by list_counter)
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
+    // XMODE_I8: lists are of unknown length at launch; both feature kernels are launched and the list's length decides on the
+    // device which of them works -- this one (a third of the serial chain per thread: latency) up to kI8SmallList entries, the
+    // 64-evaluation workgroups of k_features (half the time per evaluation at 100 k entries: 2.9 against 5.5 ns) beyond
+    if (MODE == XMODE_I8 && n_evals > kI8SmallList) return;
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kSmEvals >= n_pad) return;
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
@@ -1760,21 +1818,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             } else if (MODE == XMODE_F64) {
                 if (f < kKP) x64[(size_t)f * 16] = xd;
             } else if (MODE == XMODE_I8) {
-                // fixed point with kI8Q fractional bits, round to nearest (the scaling by 2^kI8Q is exact): |x - X 2^-kI8Q| <= 2^-(kI8Q+1)
-                double sc = rint(xd * (double)(1 << kI8Q));
-                if (!(fabs(sc) <= (double)kI8Max)) { ovf = 1; sc = 0.0; }          // (also NaN) -> this evaluation skips the tier
-                const int X = (int)sc;
-                xx_ll += (long long)X * (long long)X;
-                // balanced base-128 digits, least significant first: d in [-64, 63], X = ((d0 128 + d1) 128 + d2) 128 + d3
-                int t = X;
-                const int d3 = ((t + 64) & 127) - 64; t = (t - d3) >> 7;
-                const int d2 = ((t + 64) & 127) - 64; t = (t - d2) >> 7;
-                const int d1 = ((t + 64) & 127) - 64; t = (t - d1) >> 7;
-                const int d0 = t;
-                dig[0] |= (unsigned long long)(unsigned char)d0 << (8 * q);
-                dig[1] |= (unsigned long long)(unsigned char)d1 << (8 * q);
-                dig[2] |= (unsigned long long)(unsigned char)d2 << (8 * q);
-                dig[3] |= (unsigned long long)(unsigned char)d3 << (8 * q);
+                i8_digits(xd, q, dig, xx_ll, ovf);
             } else {
                 if (f < kDP) xcol[f * kTile] = xf;                     // rows >= nf (padding up to the tile image) are zero
                 xx = fma((double)xf, (double)xf, xx);
@@ -1782,22 +1826,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
         }
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
         if (MODE == XMODE_SCREEN) store_group_img(xtile, r, g, hi);
-        if (MODE == XMODE_I8) {
-            // A-operand image of v_mfma_i32_16x16x64_i8 (checked on hardware: testkernels.hip): lane = 16 (k % 64 / 16) + row holds
-            // bytes k % 16 = 0..15; this thread's attributes 8g..8g+7 are half of one lane's fragment: one 8-byte store per digit
-            char *img = reinterpret_cast<char *>(X) + (size_t)(e >> 4) * kI8GroupBytes;
-            const int row = (int)(e & 15);
-            auto put = [&](int grp8, int j, unsigned long long v) {
-                const int ks = grp8 >> 3, blk = (grp8 & 7) >> 1, half = grp8 & 1;
-                *reinterpret_cast<unsigned long long *>(img + (j * kI8Steps + ks) * 1024 + (blk * 16 + row) * 16 + half * 8) = v;
-            };
-#pragma unroll
-            for (int j = 0; j < kI8Slices; j++) put(g, j, dig[j]);
-            if (g >= 40) {                                 // attributes 352..383 (groups 44..47) have no slot of their own: zeros
-#pragma unroll
-                for (int j = 0; j < kI8Slices; j++) put(g + 4, j, 0ull);
-            }
-        }
+        if (MODE == XMODE_I8) i8_store(X, e, g, dig);
     }
     if (MODE == XMODE_I8) { red_ll[slot][ev] = xx_ll; red_ovf[slot][ev] = ovf; }
     red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
@@ -1946,10 +1975,17 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
                                  AttrRecord *dbg, float *ax2, hipStream_t s, int list_off = 0)
 {
     constexpr int kBlock = (MODE == XMODE_SCREEN) ? kS0BlockEvals : (MODE == XMODE_F64 || MODE == XMODE_I8) ? 64 : kSvmBlockEvals;
-    if (MODE == XMODE_I8) {                                   // list mode only, always the 16-evaluation workgroups
-        const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
+    if (MODE == XMODE_I8) {                                   // list mode only; the list's length decides on the device which kernel works
+        const long cap_small = std::min<long>(max_evals, kI8SmallList);
+        const long nb = ((cap_small + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
         hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
                            lower, upper, neg_gamma2, sp, dbg, ax2, idx_list, list_counter, list_cap, list_off);
+        if (max_evals > kI8SmallList) {
+            long blocks = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kFeatEvals);
+            if (blocks > 4096) blocks = 4096;                 // grid-stride inside the kernel
+            hipLaunchKernelGGL((k_features<MODE, 16>), dim3((unsigned)blocks), dim3(16 * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                               lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2, list_off);
+        }
         return;
     }
     if (large && MODE != XMODE_F64) {
