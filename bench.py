@@ -331,7 +331,7 @@ def main():
             return rec, out
         for _ in range(warmup):
             step()
-        svm_ms, stage_acc, evals, rechecked, strict, refined = [], {}, 0, 0, 0, 0
+        svm_ms, stage_acc, evals, rechecked, strict, refined, n_i8, n_fp64 = [], {}, 0, 0, 0, 0, 0, 0
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -341,6 +341,9 @@ def main():
             rechecked += c["n_rechecked"]
             strict += c["n_strict"]
             refined += c["n_refined"]
+            ex = eng.last_exact_tiers()
+            n_i8 += ex["n_integer"]
+            n_fp64 += ex["n_fp64"]
             st = eng.stage_ms()
             svm_ms.append(st["svm"])
             for k, v in st.items():
@@ -348,7 +351,7 @@ def main():
         fence()
         return dict(elapsed=time.perf_counter() - t0, evals=evals, steps=steps, svm_s=float(np.mean(svm_ms)) * 1e-3,
                     stage_ms={k: v / steps for k, v in stage_acc.items()}, rechecked=rechecked / steps,
-                    strict=strict / steps, refined=refined / steps, out=out)
+                    strict=strict / steps, refined=refined / steps, exact_integer=n_i8 / steps, fp64=n_fp64 / steps, out=out)
 
     def positive_share(model_file):
         """share of the evaluations libsvm labels with label[0] (untimed; a debug engine that keeps the label grids)"""
@@ -438,8 +441,8 @@ def main():
                       "per_seed": [{"seed": q["seed"], "value": q["total_evals"] / q["elapsed"],
                                     "ms_per_step": 1e3 * q["elapsed"] / args.steps,
                                     "refined_share": q["res"]["refined"] / max(1.0, q["res"]["evals"] / q["res"]["steps"]),
-                                    "three_pass_tier": q["res"]["refined"], "fp64_mfma_tier": q["res"]["rechecked"],
-                                    "strict_order_tier": q["res"]["strict"],
+                                    "three_pass_tier": q["res"]["refined"], "exact_integer_tier": q["res"]["exact_integer"],
+                                    "fp64_mfma_tier": q["res"]["fp64"], "strict_order_tier": q["res"]["strict"],
                                     "kernel_ms": q["res"]["svm_s"] * 1e3, "refine_ms": q["res"]["stage_ms"].get("refine"),
                                     "recheck_ms": q["res"]["stage_ms"].get("recheck"),
                                     "positive_label_share": (positive_share(q["model"]) if (world == 1 and not args.no_label_stats) else None),
@@ -455,8 +458,10 @@ def main():
                                                      "integral image, mask/scan/compact, vote) with 4-5 us gaps: 1.5 % of the step"})(
                 res["stage_ms"]["bin"] + res["stage_ms"]["integral"] + res["stage_ms"]["mask"] + res["stage_ms"]["vote"],
                 12.0 * args.rolls * (G * G + xyz.shape[0])),
-            "rechecked_per_step": {"three_pass_tier": res["refined"], "fp64_mfma_tier": res["rechecked"],
-                                   "strict_order_tier": res["strict"]},
+            "rechecked_per_step": {"three_pass_tier": res["refined"], "exact_integer_tier": res["exact_integer"],
+                                   "fp64_mfma_tier": res["fp64"], "strict_order_tier": res["strict"],
+                                   "note": "evaluations per step that ENTER each tier behind the screening pass: three-pass fp16 kernel (PRECISE "
+                                           "form), exact-integer tier (int8 digit planes, csrc/exact8.hip), fp64 MFMA tier, libsvm-order tier"},
             "best": {"eval": res["out"]["eval"], "row": res["out"]["best_row"], "col": res["out"]["best_col"],
                      "roll": res["out"]["best_roll"]},
         }

@@ -2163,9 +2163,9 @@ int haf_test_mfma_accum(const uint16_t *a, const uint16_t *b, const float *c0, f
 }
 
 // bare v_mfma_f32_16x16x32_f16 loop on `device` for about `iters` * 0.55 us: executed TFLOP/s by HIP events (bench.py context)
-int haf_test_mfma_rate(int device, int iters, double *tflops)
+int haf_test_mfma_rate(int device, int iters, double *tflops)      // iters < 0: v_mfma_i32_16x16x64_i8 (TOP/s), else v_mfma_f32_16x16x32_f16
 {
-    if (!tflops || iters < 1) return HAF_E_ARG;
+    if (!tflops || iters == 0) return HAF_E_ARG;
     if (hipSetDevice(device) != hipSuccess) return HAF_E_DEVICE;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HAF_E_DEVICE;
@@ -2181,12 +2181,12 @@ int haf_test_mfma_rate(int device, int iters, double *tflops)
     if (hipMalloc(&din, h.size() * 2) == hipSuccess && hipMalloc((void **)&dout, (size_t)blocks * 256 * 4) == hipSuccess &&
         hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
         hipEventCreate(&e1) == hipSuccess) {
-        haf::launch_mfma_rate_test(din, dout, blocks, 64, nullptr);                      // warm the code path
+        haf::launch_mfma_rate_test(din, dout, blocks, iters < 0 ? -64 : 64, nullptr);    // warm the code path
         (void)hipEventRecord(e0, nullptr);
         haf::launch_mfma_rate_test(din, dout, blocks, iters, nullptr);
         (void)hipEventRecord(e1, nullptr);
         if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f) {
-            *tflops = (double)blocks * 4.0 * iters * 32.0 * 16384.0 / (ms * 1e-3) / 1e12;
+            *tflops = (double)blocks * 4.0 * std::abs(iters) * 32.0 * (iters < 0 ? 32768.0 : 16384.0) / (ms * 1e-3) / 1e12;
             rc = HAF_OK;
         }
     }

@@ -57,9 +57,34 @@ __global__ __launch_bounds__(256, 2) void k_mfma_rate(const half8 *__restrict__ 
     out[tid] = s;
 }
 
+// the same loop with v_mfma_i32_16x16x64_i8 (the exact-integer tier's instruction): op = blocks * 4 waves * iters * 32 * 32768
+typedef int ri32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void k_mfma_rate_i8(const half8 *__restrict__ in, float *__restrict__ out, int iters)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    ri32x4 a[8], b[8];
+    for (int i = 0; i < 8; i++) {
+        a[i] = __builtin_bit_cast(ri32x4, in[(tid * 16 + i) & 65535]);
+        b[i] = __builtin_bit_cast(ri32x4, in[(tid * 16 + 8 + i) & 65535]);
+    }
+    ri32x4 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = ri32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[(i * 4 + j) & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[(i + j) & 7], acc[(i * 4 + j) & 7], 0, 0, 0);
+    }
+    int s = 0;
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) s += acc[i][j];
+    out[tid] = (float)s;
+}
+
 void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mfma_rate, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, iters);
+    if (iters < 0) hipLaunchKernelGGL(k_mfma_rate_i8, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, -iters);      // (negative: the int8 form)
+    else hipLaunchKernelGGL(k_mfma_rate, dim3(blocks), dim3(256), 0, s, (const half8 *)in, out, iters);
 }
 
 // Feasibility model of the screening kernel's inner loop for MB row blocks of 16 evaluations per wave (4 = the shipped tiling at

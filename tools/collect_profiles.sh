@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-P=profiles/${ROUND:-r02}_bench_c5_nsv4096
+P=profiles/${ROUND:-r03}_bench_c5_nsv4096
 newest() { ls -t $1 | head -1; }
 cp $F/bench_default.json ${P}_default.json
 for m in "" _f16x3 _f32; do

@@ -4,7 +4,9 @@
     python tools/pmc_summary.py --fetch A_counter_collection.csv --write B_counter_collection.csv \
         [--fetch-f32 C.csv --write-f32 D.csv] [--fetch-f16x3 E.csv --write-f16x3 F.csv] --grid 512 --rolls 36 --nsv 4096 -o profiles/pmc_traffic.json
 
-Per kernel the value is the AVERAGE over that kernel's launches in the pass (KiB, as the counter reports it).
+Per kernel the value is the AVERAGE over that kernel's FULL-SIZE launches in the pass (KiB, as the counter reports it): since round 3
+haf_create scores a small synthetic request once (calibrate(), engine.cpp), so every kernel has one launch of a fraction of the
+size in each process -- launches below half of the kernel's largest value are left out of the average (and counted in `small`).
 hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts wide coalesced reads at half their size
 (MI355X_MICROARCH.md, HBM / rocprofv3 section); writes are reported as they are.
 """
@@ -23,7 +25,7 @@ def short(name):
 
 
 def averages(path, counter):
-    acc = defaultdict(lambda: [0.0, 0])
+    vals = defaultdict(list)
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
@@ -31,9 +33,12 @@ def averages(path, counter):
             k = short(row["Kernel_Name"])
             if not k.startswith("k_"):
                 continue
-            acc[k][0] += float(row["Counter_Value"])
-            acc[k][1] += 1
-    return {k: (s / n, n) for k, (s, n) in acc.items()}
+            vals[k].append(float(row["Counter_Value"]))
+    out = {}
+    for k, v in vals.items():
+        full = [x for x in v if x >= 0.5 * max(v)] or v
+        out[k] = (sum(full) / len(full), len(full))
+    return out
 
 
 def fold(fetch_csv, write_csv, run):
