@@ -564,10 +564,11 @@ int build_tables(haf_engine *e)
         const int n_slots = (int)rep.size();
         if (n_slots > kS0K) e->screen_active = false;   // more distinct attributes than the ten k-steps hold: three-pass kernel for everything
         {
-            // screening attribute u' = (q4 - scr_sub) * scr_mul, scr_sub = fmin - c*lower/scr_mul (kernels.hip: screen_attribute).
+            // screening attribute u' = fma(q4, scr_mul, scr_add), scr_add = c*lower - fmin*scr_mul (kernels.hip: screen_attribute).
             // Against c*x' in exact arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's
-            // range) and the rounding of scr_sub, both amplified by scr_mul when q4 and scr_sub cancel, and by the roundings of
-            // scr_mul, the subtraction and the product; the norm over the attributes is eta_abs.
+            // range) amplified by scr_mul, by the rounding of scr_mul times |q4 - fmin|, by the rounding of scr_add (formed in long
+            // double: half an ulp of |c*lower| + |fmin*scr_mul| at most) and by the one rounding of the fma; the norm over the
+            // attributes is eta_abs.
             std::vector<ScrDesc> sd((size_t)kS0K);
             memset(sd.data(), 0, sd.size() * sizeof(ScrDesc));
             std::vector<ScrDesc3> sd3((size_t)kS0K);
@@ -582,9 +583,9 @@ int build_tables(haf_engine *e)
                 FeatDesc &d = fd2[(size_t)f];
                 if (d.skip) continue;
                 d.scr_mul = sp.c * (e->range.upper - e->range.lower) * d.inv_range;
-                d.scr_sub = d.scr_mul != 0.0 ? d.fmin - sp.c * e->range.lower / d.scr_mul : 0.0;
+                d.scr_add = d.scr_mul != 0.0 ? (double)((long double)sp.c * (long double)e->range.lower - (long double)d.fmin * (long double)d.scr_mul) : 0.0;
                 // x2: svm-scale's own fp64 roundings of the same expression
-                const double ef = 2.0 * (std::fabs(d.scr_mul) * 4.5e-16 * (1e4 + std::fabs(d.fmin) + std::fabs(d.scr_sub)) +
+                const double ef = 2.0 * (std::fabs(d.scr_mul) * 1.0e-15 * (1e4 + 2.0 * std::fabs(d.fmin)) +
                                          4.5e-16 * std::fabs(sp.c * e->range.lower));
                 ea2 += ef * ef;
             }
@@ -600,7 +601,7 @@ int build_tables(haf_engine *e)
                         sdesc.w[k] = d.w[k];
                         for (int j = 0; j < 4; j++) sdesc.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
-                    sdesc.scr_mul = d.scr_mul; sdesc.scr_sub = d.scr_sub;
+                    sdesc.scr_mul = d.scr_mul; sdesc.scr_add = d.scr_add;
                     sdesc.extra = (float)extra[(size_t)sl];
                     ScrDesc3 &s3 = sd3[(size_t)sl];
                     for (int k = 0; k < 3; k++) {
@@ -608,7 +609,7 @@ int build_tables(haf_engine *e)
                         for (int j = 0; j < 4; j++) s3.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
                     s3.shaf = d.shaf;
-                    s3.scr_mul = d.scr_mul; s3.scr_sub = d.scr_sub;
+                    s3.scr_mul = d.scr_mul; s3.scr_add = d.scr_add;
                     s3.extra = (float)extra[(size_t)sl];
                     fds[(size_t)sl] = d;
                     fds[(size_t)sl].scr_extra = (float)extra[(size_t)sl];
@@ -713,13 +714,17 @@ int build_tables(haf_engine *e)
                 }
             }
             sp.sigma_dk = sigma_upper_bound(DW.data(), m.n_sv, kS0K) * (1.0 + 1e-9);
-            std::vector<ScrCorr> sc((size_t)kS0K);
+            static_assert(sizeof(ScrCorr2) == 2 * sizeof(ScrCorr) && kS0K % 2 == 0, "pair form behind the per-slot form, one buffer");
+            std::vector<ScrCorr> sc((size_t)kS0K * 2);
+            ScrCorr2 *sc2 = reinterpret_cast<ScrCorr2 *>(sc.data() + kS0K);
             sp.g_norm = sp.hd_norm = 0.0;
             for (int sl = 0; sl < kS0K; sl++) {
                 sc[(size_t)sl].g = (float)G[(size_t)sl];
                 sc[(size_t)sl].hd = (float)Hd[(size_t)sl];
                 sc[(size_t)sl].ub = (float)ub[(size_t)sl];
                 sc[(size_t)sl].pad = 0.0f;
+                ScrCorr2 &p2 = sc2[sl >> 1];
+                p2.g[sl & 1] = sc[(size_t)sl].g; p2.hd[sl & 1] = sc[(size_t)sl].hd; p2.ub[sl & 1] = sc[(size_t)sl].ub; p2.pad[sl & 1] = 0.0f;
                 sp.g_norm += G[(size_t)sl] * G[(size_t)sl];
                 sp.hd_norm += Hd[(size_t)sl] * Hd[(size_t)sl];
             }
@@ -733,6 +738,7 @@ int build_tables(haf_engine *e)
             if (hipSuccess != e->d_corr.alloc(sc.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening corrections)");
             HIPCHK(e, hipMemcpy(e->d_corr.p, sc.data(), sc.size() * sizeof(ScrCorr), hipMemcpyHostToDevice));
             sp.corr = e->d_corr.p;
+            sp.corr2 = reinterpret_cast<const ScrCorr2 *>(e->d_corr.p + kS0K);
         }
         // the bounds feed a rigorous band: round them up past their own fp64 rounding
         sp.v_max *= 1.0 + 1e-12; sp.dv_max *= 1.0 + 1e-12; sp.das_max = sp.das_max * (1.0 + 1e-12) + 1e-300;

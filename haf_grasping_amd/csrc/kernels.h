@@ -109,6 +109,7 @@ struct ScreenParams {
     double ubar2;                 // |ubar|^2
     double g_norm, hd_norm;       // |G|_2, |Hd|_2 (the fp32 roundings of the correction and of u' against u are bounded through them)
     const struct ScrCorr *corr;   // kS0K per-slot constants {G, Hd, ubar} (device)
+    const struct ScrCorr2 *corr2; // the same constants per PAIR of slots (packed-fp32 form of the sums: k_features_serial)
     const struct ScrDesc *sd;     // kS0K compact descriptors (device), one per SLOT, for the two-region groups
     const struct ScrDesc3 *sd3;   // kS0K general descriptors (device), one per slot
     const struct FeatDesc *fd_slot;   // kS0K feature descriptors (device): the representative attribute of every slot
@@ -122,19 +123,20 @@ struct ScrDesc {
                                   // the LDS band of a wave (kBandPitch floats per row, kernels.hip: screen_quad)
     float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
     double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
-    double scr_sub;               // fmin - c * lower / scr_mul                   (0 likewise):  u' = (q4 - scr_sub) * scr_mul
+    double scr_add;               // c * lower - fmin * scr_mul                   (0 likewise):  u' = fma(q4, scr_mul, scr_add)
     float  extra;                 // attributes sharing this slot beyond the first (0 almost everywhere): |u|^2 counts u'^2 that often more
     float  pad;
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
 // per-slot constants of the centred band (ScreenParams): one 16-byte scalar load
 struct ScrCorr { float g, hd, ub, pad; };
+struct ScrCorr2 { float g[2], hd[2], ub[2], pad[2]; };   // slots 2p, 2p+1
 // The same for any feature (three regions, HAF or SHAF rule): the groups that are not in ScreenParams::fast_groups
 struct ScrDesc3 {
     int    off[12];               // band BYTE offsets of the corners of regions 0..2
     float  w[3];
     int    shaf;                  // fv.cpp:187-191 instead of the weighted sum
-    double scr_mul, scr_sub;
+    double scr_mul, scr_add;
     float  extra;                 // as in ScrDesc
     float  pad[3];
 };
@@ -180,7 +182,7 @@ struct FeatDesc {
     int   pad;
     double fmin, fmax;
     double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
-    double scr_mul, scr_sub;      // screening pass (ScrDesc below): u' = (q4 - scr_sub) * scr_mul
+    double scr_mul, scr_add;      // screening pass (ScrDesc below): u' = fma(q4, scr_mul, scr_add)
     float  scr_extra;             // fd_slot entries only: attributes sharing the slot beyond the first
     float  pad2;
 };

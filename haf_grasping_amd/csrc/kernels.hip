@@ -1092,8 +1092,8 @@ __device__ __forceinline__ double attribute_value_rec(const Src &src, const Feat
 }
 
 // Attribute for the SCREENING pass only, already multiplied by c (kernels.h: ScreenParams): the "%.4g" round trip through the
-// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (u' = (q4 - scr_sub) *
-// scr_mul: a subtraction and a product, each with one scalar operand), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
+// table-driven decq4_float_scr, svm-scale's formula in plain fp64 with the constants folded on the host (u' = fma(q4,
+// scr_mul, scr_add): one instruction with two scalar operands), and NO "%g" round trip.  With x the value svm-predict would parse and u = c x, the result u' satisfies
 // |u' - u| <= 5e-6 |u'| (six significant decimal digits: half a unit of the sixth digit is <= 5e-6 relative) plus, in norm over
 // the attributes, ScreenParams::eta_abs (engine.cpp: the fp64 roundings of both evaluations of the formula, the exact-zero
 // omission and the min/max shortcuts).  screen_finish() carries that difference through the guard band; evaluations the
@@ -1104,7 +1104,7 @@ template <class Src>
 __device__ __forceinline__ double screen_attribute(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st)
 {
     const float v = feature_value(src, f);
-    return (hafq::decq4_float_scr(v, st) - f.scr_sub) * f.scr_mul;
+    return fma(hafq::decq4_float_scr(v, st), f.scr_mul, f.scr_add);
 }
 
 // ---- the fast form of the screening feature pass ------------------------------------------------------------------
@@ -1153,12 +1153,12 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         const float r0 = __fmul_rn(sd[q].w[0], __fadd_rn(__fsub_rn(__fsub_rn(c[q][0], c[q][1]), c[q][2]), c[q][3]));
         const float r1 = __fmul_rn(sd[q].w[1], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4], c[q][5]), c[q][6]), c[q][7]));
         const float v = __fadd_rn(r0, r1);      // 0.0f + r0 first (fv.cpp:164) only turns a -0 into +0: same decimal, same u'
-        ud[q] = (hafq::decq4_float_scr(v, st) - sd[q].scr_sub) * sd[q].scr_mul;
+        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
     }
 }
 
 // Two attribute slots of any other group, from the band: three regions each, the HAF sum or the SHAF rule (feature_value).
-// A slot of a dropped or absent attribute has scr_mul = scr_sub = 0: its u' is 0 (NaN if its feature value left the decimal
+// A slot of a dropped or absent attribute has scr_mul = scr_add = 0: its u' is 0 (NaN if its feature value left the decimal
 // path's range, which only costs that evaluation the screening pass).
 typedef const ScrDesc3 __attribute__((address_space(4))) *ScrDesc3K;
 __device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (ScrDesc3K)(unsigned long long)p; }
@@ -1199,7 +1199,7 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
         } else {
             v = __fadd_rn(__fadd_rn(r[0], r[1]), r[2]);
         }
-        ud[q] = (hafq::decq4_float_scr(v, st) - sd[q].scr_sub) * sd[q].scr_mul;
+        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
     }
 }
 
@@ -1286,6 +1286,37 @@ __device__ __forceinline__ _Float16 screen_operand(double ud, ScreenSums &a, con
 }
 typedef const ScrCorr __attribute__((address_space(4))) *ScrCorrK;
 __device__ __forceinline__ ScrCorrK constant_ptr(const ScrCorr *p) { return (ScrCorrK)(unsigned long long)p; }
+
+// The same for two slots at once, every sum in packed fp32 (v_pk_fma_f32: two lanes of a sum per instruction, added up in
+// screen_sums()): 9 vector instructions per pair -- one packed RN conversion to fp16, two conversions back, a packed subtraction,
+// five packed fmas -- where the scalar form costs 17.  The sums only feed the band, whose fp32-accumulation term (kF32Acc) counts
+// roundings per summand, not their order.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+struct ScreenSums2 { f32x2 su2, sd2, cr, ub; };
+typedef const ScrCorr2 __attribute__((address_space(4))) *ScrCorr2K;
+__device__ __forceinline__ ScrCorr2K constant_ptr(const ScrCorr2 *p) { return (ScrCorr2K)(unsigned long long)p; }
+__device__ __forceinline__ half2v screen_operand2(double u0, double u1, ScreenSums2 &a, ScrCorr2K k)
+{
+    const f32x2 f = {(float)u0, (float)u1};
+    half2v h = __builtin_convertvector(f, half2v);   // RN (v_cvt_pk_f16_f32)
+#ifdef HAF_FLUSH_F16_SUBNORMALS
+    if (fabsf((float)h[0]) < kF16MinNormal) h[0] = (_Float16)0.0f;
+    if (fabsf((float)h[1]) < kF16MinNormal) h[1] = (_Float16)0.0f;
+#endif
+    const f32x2 du = __builtin_convertvector(h, f32x2) - f;
+    const f32x2 g = {k->g[0], k->g[1]}, hd = {k->hd[0], k->hd[1]}, ub = {k->ub[0], k->ub[1]};
+    a.su2 = __builtin_elementwise_fma(f, f, a.su2);
+    a.sd2 = __builtin_elementwise_fma(du, du, a.sd2);
+    a.cr = __builtin_elementwise_fma(du, g, a.cr);
+    a.cr = __builtin_elementwise_fma(f, hd, a.cr);
+    a.ub = __builtin_elementwise_fma(f, ub, a.ub);
+    return h;
+}
+__device__ __forceinline__ ScreenSums screen_sums(const ScreenSums2 &a)
+{
+    return ScreenSums{a.su2[0] + a.su2[1], a.sd2[0] + a.sd2[1], a.cr[0] + a.cr[1], a.ub[0] + a.ub[1]};
+}
 
 // attributes that share a slot beyond the first count once more in |u|^2 (the common factor), not in the operand: sx gets
 // extra * u'^2 for the slots of group g that have any (wave-uniform; three slots of the reference's feature file)
@@ -1515,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     AttrRecord *rec = (MODE != XMODE_SCREEN && dbg) ? dbg + (size_t)e_src * kKP : nullptr;   // KEEP_DEBUG only
     double xx = 0.0;
     if (MODE == XMODE_SCREEN) {
-        ScreenSums acc{0.0f, 0.0f, 0.0f, 0.0f};
+        ScreenSums2 acc2{};
         float sx = 0.0f;
         for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
             double ud[8];
@@ -1534,10 +1565,14 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             }
             half8 hi;
 #pragma unroll
-            for (int q = 0; q < 8; q++) hi[q] = screen_operand(ud[q], acc, constant_ptr(sp.corr)[g * 8 + q]);
+            for (int q = 0; q < 8; q += 2) {
+                const half2v h = screen_operand2(ud[q], ud[q + 1], acc2, constant_ptr(sp.corr2) + g * 4 + (q >> 1));
+                hi[q] = h[0]; hi[q + 1] = h[1];
+            }
             screen_extra_norm(sp, g, ud, sx);
             store_group_img(xtile, r, g, hi);
         }
+        const ScreenSums acc = screen_sums(acc2);
         float band[kBandFloats], nax;
         screen_finish((double)acc.su2, (double)acc.sd2, (double)acc.su2 + (double)sx, (double)acc.cr, (double)acc.ub, sp, band, nax);
         store_band(ax + kBandFloats * e, band);
