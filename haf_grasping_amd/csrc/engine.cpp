@@ -279,7 +279,7 @@ struct haf_engine {
     DevBuf<FeatDesc> d_fd, d_fd_slot;
     DevBuf<ScrDesc> d_sd;
     DevBuf<ScrCorr> d_corr;         // per-slot constants of the centred screening band
-    DevBuf<float> d_part1;
+    DevBuf<double> d_part1;
     long part1_stride = 0;
     // requests with at least this many evaluation slots take the thread-per-evaluation feature kernel: its floor is one thread's
     // chain of 324 attributes (~0.2 ms), the cooperative kernel costs ~1.3 us per 1000 evaluations (crossover measured at ~3e5)
@@ -773,13 +773,21 @@ int build_tables(haf_engine *e)
         const int n_tiles16 = e->n_sv_pad / 16;
         std::vector<char> img((size_t)n_tiles16 * kI8SvTileBytes, 0);
         double s_max2 = 0.0;
+        // q_s: as many fractional bits as the largest SV component leaves room for in four digits (the attributes keep kI8Q: svm-scale
+        // does not clamp, kernels.h); the quantisation of the SVs is then a small part of delta
+        double sv_abs_max = 0.0;
+        for (int n = 0; n < m.n_sv; n++)
+            for (int k = 0; k < m.dim; k++) sv_abs_max = std::max(sv_abs_max, std::fabs(m.sv[(size_t)n * m.dim + k]));
+        int qs = kI8Q;
+        while (qs < 30 && (sv_abs_max * std::ldexp(1.0, qs + 1) + 1.0) <= (double)kI8Max) qs++;
+        if (!(sv_abs_max < 1e30)) e->i8_active = false;
         for (int n = 0; n < m.n_sv && e->i8_active; n++) {
             char *tile = img.data() + (size_t)(n / 16) * kI8SvTileBytes;
             const int col = n % 16;
             long long ssq = 0;
             for (int k = 0; k < m.dim; k++) {
-                const double sc = std::nearbyint(m.sv[(size_t)n * m.dim + k] * (double)(1 << kI8Q));
-                if (!(std::fabs(sc) <= (double)kI8Max)) { e->i8_active = false; break; }      // a support vector beyond +-3.97: no tier 2a
+                const double sc = std::nearbyint(std::ldexp(m.sv[(size_t)n * m.dim + k], qs));
+                if (!(std::fabs(sc) <= (double)kI8Max)) { e->i8_active = false; break; }      // a support vector beyond +-15.87: no tier 2a
                 int t = (int)sc;
                 ssq += (long long)t * t;
                 int dg[4];
@@ -791,7 +799,7 @@ int build_tables(haf_engine *e)
                 for (int j = 0; j < kI8Slices; j++) tile[(size_t)(j * kI8Steps + ks) * 1024 + (blk * 16 + col) * 16 + jj] = (char)dg[j];
             }
             double *cst = reinterpret_cast<double *>(tile + kI8GroupBytes);
-            cst[col] = std::ldexp((double)ssq, -2 * kI8Q);
+            cst[col] = std::ldexp((double)ssq, -2 * qs);
             cst[16 + col] = m.coef[(size_t)n];
             s_max2 = std::max(s_max2, cst[col]);
         }
@@ -800,9 +808,10 @@ int build_tables(haf_engine *e)
             HIPCHK(e, hipMemcpy(e->d_sv_i8.p, img.data(), img.size(), hipMemcpyHostToDevice));
             e->i8.gamma = m.gamma; e->i8.rho = m.rho;
             e->i8.gamma2 = m.gamma * log2e;
-            // 2 x.s enters d^2: 2 * 324 attributes * (2 * 128 + 1) * 64 * 64 * 2^(-2 kI8Q)
-            e->i8.drop = 2.0 * (double)kKP * 257.0 * 4096.0 * std::ldexp(1.0, -2 * kI8Q) * (1.0 + 1e-12);
-            e->i8.delta = 2.0 * std::sqrt((double)kKP) * std::ldexp(1.0, -(kI8Q + 1)) * (1.0 + 1e-12);
+            // 2 x.s enters d^2: 2 * 324 attributes * (2 * 128 + 1) * 64 * 64 * 2^-(kI8Q + q_s)
+            e->i8.drop = 2.0 * (double)kKP * 257.0 * 4096.0 * std::ldexp(1.0, -(kI8Q + qs)) * (1.0 + 1e-12);
+            e->i8.delta = std::sqrt((double)kKP) * (std::ldexp(1.0, -(kI8Q + 1)) + std::ldexp(1.0, -(qs + 1))) * (1.0 + 1e-12);
+            e->i8.dq_scale = -2.0 * std::ldexp(1.0, 14 - kI8Q - qs);
             e->i8.s_max = std::sqrt(s_max2) * (1.0 + 1e-12);
             e->i8.guard_scale = 1.0;
             if (const char *g = test_env("HAF_GUARD_I8_REL")) e->i8.guard_scale = atof(g);
@@ -837,8 +846,7 @@ int build_tables(haf_engine *e)
     // Both constants are WORST-CASE fp32 error bounds per unit of sum|coef|K:
     //   guard_dot: the 324-term fp32 fma chain of x.s, bounded through Cauchy-Schwarz (324 * 2^-24 * ln2 in K), the fp32
     //              rounding of the attributes (2 * 2^-24; 2^-22 for the fp16 hi+lo split) and the roundings of the argument;
-    //   guard_acc: the sequential fp32 sum of coef*K over the SV tiles plus the 5-step lane reduction ((tiles + 8) * 2^-24),
-    //              v_exp_f32 and the coefficient product (3 * 2^-23).
+    //   guard_acc: the fp32 part of the sum of coef*K (below), v_exp_f32 and the coefficient product (3 * 2^-23).
     // tests/diag_guard.py measures the actual error with the band disabled: 20-30x smaller.  HAF_GUARD_REL scales the band.
     double guard_scale = 1.0;
     if (const char *g = test_env("HAF_GUARD_REL")) guard_scale = atof(g);
@@ -855,11 +863,11 @@ int build_tables(haf_engine *e)
     const bool split_mode = !(e->cfg.flags & HAF_FLAG_FP32_MFMA);
     const double acc_adds = split_mode ? (16.0 + e->n_sv_tiles / 8.0 + 2.0 + 4.0) : (e->n_sv_tiles + 5.0);
     e->svm.guard_acc = (float)(guard_scale * ((acc_adds + 6.0) * u));
-    // list mode of the three-pass kernel with the SV tiles cut into kHListParts ranges (launch_svm_h): the outer sum of a range
-    // is that much shorter, and k_svm_h_combine adds the ranges in fp64 (one rounding back to fp32)
-    const bool parts_on = e->n_sv_tiles >= 4 * kHListParts;
-    const double acc_adds_l = 16.0 + std::ceil((double)e->n_sv_tiles / kHListParts) / 8.0 + 2.0 + 4.0 + 1.0;
-    e->svm.guard_acc_l = parts_on ? (float)(guard_scale * ((acc_adds_l + 6.0) * u)) : e->svm.guard_acc;
+    // PRECISE form of the three-pass kernel (the list mode behind the screening pass): the fp32 chain is the two fmas of one tile,
+    // and from there on everything is fp64 -- fold, lane reduction, class sums, the ranges of the list mode (k_svm_h_combine) --
+    // whose roundings (2^-53 each, a few hundred of them) are far inside the 0.1 u added for them; one rounding back to fp32 at the
+    // end, +6 as above.  (sum|coef|K itself is measured with the same relative error, a few 1e-6: the factor behind the bracket.)
+    e->svm.guard_acc_l = (float)(guard_scale * ((2.0 + 1.0 + 0.1 + 6.0) * u) * (1.0 + 1e-5));
     // screening pass: one sequential fp32 sum per lane over two column blocks per tile, the 4-step lane reduction, the
     // class split, v_exp_f32 and the coefficient product; the band is ~3e-4, so nothing is gained by a two-level sum.
     // HAF_GUARD0_REL scales the whole screening band (this term and the per-evaluation one) for experiments.

@@ -3,18 +3,19 @@
 // The evaluations the three-pass kernel could not decide (|dec| inside ~5e-6 sum|coef|K: the fp32 accumulation of the matrix
 // core) used to go straight to the fp64 MFMA tier, which runs at 1/32 of the fp16 matrix rate and was the largest cost on
 // models whose decision values crowd around zero.  Here they first meet a contraction that has NO accumulation error at all:
-//   * attributes (k_features_small<XMODE_I8>) and support vectors (engine.cpp) as fixed-point integers with kI8Q = 23
-//     fractional bits (|value| < 15.87), each split into four balanced base-128 digits (int8, -64..63);
+//   * attributes (k_features_small<XMODE_I8>) and support vectors (engine.cpp) as fixed-point integers -- kI8Q = 23 fractional
+//     bits for the attributes (|value| < 15.87), q_s for the support vectors: as many as the model's largest component leaves room
+//     for (26 for SVs inside +-1.98) -- each split into four balanced base-128 digits (int8, -64..63);
 //   * the digit-by-digit products of the 384-long dot product through v_mfma_i32_16x16x64_i8, one int32 accumulator per digit
 //     weight 128^(6-w), w = j + k: at most 4 x 384 x 64 x 64 < 2^23 per accumulator, so every partial sum is EXACT.  The three
-//     products of weights 128 and 1 (w = 5, 6) are left out: together at most (2 x 128 + 1) x 64 x 64 x 2^-46 = 1.5e-8 per
+//     products of weights 128 and 1 (w = 5, 6) are left out: together at most (2 x 128 + 1) x 64 x 64 x 2^-(23 + q_s) <= 1.5e-8 per
 //     attribute, |error of xq.sq| <= 4.9e-6 -- a tenth of what the quantisation costs -- and part of the band (I8Params::drop);
 //   * |xq - sq|^2 = |xq|^2 + |sq|^2 - 2 xq.sq from the exact integers (the accumulators combined in int32 pairs, then three fp64
 //     operations), 2^(-gamma' d^2) by range reduction and a degree-11 polynomial (1e-14 relative), fp64 sums.  (What bounds this
 //     kernel is the SIMD's vector issue port: with libm's exp and seven conversions per element it ran at 60 % of its MFMA time.)
-// The only error of a kernel value is the quantisation of the operands, |(x - xq) - (s - sq)|_2 <= delta = 2 sqrt(324) 2^-24:
+// The only error of a kernel value is the quantisation of the operands, |(x - xq) - (s - sq)|_2 <= delta = sqrt(324) (2^-24 + 2^-(q_s+1)):
 //   | |x-s|^2 - |xq-sq|^2 | <= delta (2 |xq - sq| + delta) <= delta (2 (|xq| + max|sq|) + delta),
-// i.e. |dec_q - dec| <= (exp(gamma * that) - 1) * S -- about 3.5e-7 S on the bench models, 16x inside the three-pass band; what
+// i.e. |dec_q - dec| <= (exp(gamma * that) - 1) * S -- about 2e-7 S on the bench models (q_s = 26), 20x inside the three-pass band; what
 // is still closer to zero than that goes on to the fp64 MFMA tier (k_recheck_mfma) exactly as before.  Same task structure as
 // that tier: a workgroup = 4 waves x 16 evaluations, one of kMSplit ranges of SV tiles, partial sums added in a fixed order.
 #include "kernels.h"
@@ -80,16 +81,16 @@ __device__ __forceinline__ void i8_tile_mfma(const char *bt, int lane, const i32
 }
 
 // kernel values and class sums of one finished tile: this lane's column (SV) against its four rows (evaluations)
-__device__ __forceinline__ void i8_tile_epilogue(const i32x4 (&acc)[5], const double (&xx)[4], double ss, double cf, double gamma2,
+__device__ __forceinline__ void i8_tile_epilogue(const i32x4 (&acc)[5], const double (&xx)[4], double ss, double cf, double gamma2, double dq_scale,
                                                  double (&part)[4], double (&pabs)[4])
 {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        // xq.sq 2^(2 kI8Q) = acc0 128^6 + (acc1 128 + acc2) 128^4 + (acc3 128 + acc4) 128^2: the pairs in int32 (< 2^30), then
+        // xq.sq 2^(kI8Q + q_s) = acc0 128^6 + (acc1 128 + acc2) 128^4 + (acc3 128 + acc4) 128^2: the pairs in int32 (< 2^30), then
         // two fp64 fmas on exact integers (< 2^63: one rounding of 2^-53 relative at most)
         const int u1 = (acc[1][r] << 7) + acc[2][r], u2 = (acc[3][r] << 7) + acc[4][r];
         const double dq = fma(fma((double)acc[0][r], 16384.0, (double)u1), 16384.0, (double)u2);
-        const double d2 = fma(-2.0 * __builtin_ldexp(1.0, 14 - 2 * kI8Q), dq, xx[r] + ss);
+        const double d2 = fma(dq_scale, dq, xx[r] + ss);
         const double kv = exp2_poly(-gamma2 * d2);
         part[r] = fma(cf, kv, part[r]);
         pabs[r] = fma(fabs(cf), kv, pabs[r]);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ 
         for (int t = t_begin + 1; t < t_end; t++) {
             if (t + 1 < t_end) HAF_I8_TILE_LOAD(t + 1);
             i8_tile_mfma(bt, lane, a, acc_cur);
-            i8_tile_epilogue(acc_prev, xx, ss_prev, cf_prev, p.gamma2, part, pabs);
+            i8_tile_epilogue(acc_prev, xx, ss_prev, cf_prev, p.gamma2, p.dq_scale, part, pabs);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // the first k-step's B fragments
 #pragma unroll
             for (int ks = 0; ks < kI8Steps; ks++) {
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ 
             if (t + 1 < t_end) HAF_I8_TILE_STORE();
             __syncthreads();
         }
-        if (t_begin < t_end) i8_tile_epilogue(acc_prev, xx, ss_prev, cf_prev, p.gamma2, part, pabs);
+        if (t_begin < t_end) i8_tile_epilogue(acc_prev, xx, ss_prev, cf_prev, p.gamma2, p.dq_scale, part, pabs);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             double v = part[r], w = pabs[r];

@@ -231,14 +231,15 @@ enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAG
 // ---- tier 2a: the decision function on EXACT integer dot products (exact8.hip) ------------------------------------------
 // What limits the fp16 contractions is the fp32 accumulation inside the matrix core (~2.6e-6 relative per kernel value); what
 // makes the fp64 MFMA tier slow is the fp64 matrix rate (1/32 of fp16).  In between: attributes and support vectors as
-// fixed-point numbers with kI8Q fractional bits, |value| < 15.9, split into four balanced base-128 digits (-64..63, int8); the 16
+// fixed-point numbers (kI8Q fractional bits for the attributes, |value| < 15.9; q_s <= 30 for the SVs, as many as the model's largest
+// component allows), split into four balanced base-128 digits (-64..63, int8); the 16
 // digit-by-digit products of a 384-long dot product go through v_mfma_i32_16x16x64_i8 and are EXACT in int32 (<= 4 x 384 x 4096 per
 // accumulator, one accumulator per digit weight), so |xq - sq|^2 of the quantised vectors is exact and the only error of a kernel
-// value is the quantisation: |d - dq| <= 2 sqrt(324) 2^-(kI8Q+1), i.e. ~3.5e-7 relative instead of 5.6e-6.  An evaluation still
+// value is the quantisation: |d - dq| <= sqrt(324) (2^-(kI8Q+1) + 2^-(q_s+1)), i.e. ~2e-7 relative instead of 5.6e-6.  An evaluation still
 // inside that (16x narrower) band goes on to the fp64 MFMA tier as before.
 // (The range: svm-scale does not clamp, and a SHAF attribute of -1 against a range [0, 0.30] scales to -7.64: the attributes of
 // real windows reach +-7.7, so 23 fractional bits -- +-15.87 -- it is; an evaluation or a model beyond that skips the tier.)
-constexpr int kI8Q = 23;                          // fractional bits: |value| <= 63 * (2^21 + 2^14 + 2^7 + 1) * 2^-23 = 15.87
+constexpr int kI8Q = 23;                          // fractional bits of the attributes: |value| <= 63 * (2^21 + 2^14 + 2^7 + 1) * 2^-23 = 15.87
 constexpr long kI8Max = 63L * (2097152L + 16384L + 128L + 1L);
 constexpr int kI8Slices = 4;                      // digits per value
 constexpr int kI8Steps = 6;                       // k-steps of 64 attributes: 384 >= 324
@@ -248,7 +249,8 @@ struct I8Params {
     double gamma, rho;
     double gamma2;                // gamma * log2(e)
     double drop;                  // | |xq - sq|^2 computed - exact | from the digit products the contraction leaves out (weights 128, 1)
-    double delta;                 // |(x - xq) - (s - sq)|_2 <= delta = 2 sqrt(324) 2^-(kI8Q+1)
+    double delta;                 // |(x - xq) - (s - sq)|_2 <= delta = sqrt(324) (2^-(kI8Q+1) + 2^-(q_s+1))
+    double dq_scale;              // -2 * 2^(14 - kI8Q - q_s): the integer dot product (in units of 128^2) as a term of |xq - sq|^2
     double s_max;                 // max_n |sq_n|_2
     double guard_scale;           // 1 (HAF_GUARD_I8_REL in the testing build)
     int n_sv_pad, gv0, gv1, pad;
@@ -317,7 +319,7 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
                 long max_evals, hipStream_t s);
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
-                  long max_evals, const int *idx_list, int list_counter, int list_cap, float *part_out, long part_stride,
+                  long max_evals, const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride,
                   hipStream_t s);
 // tiny requests: exact attributes + fp64 MFMA decision + label in one launch (tier 2's arithmetic for every evaluation)
 void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "decq.h"
 #include <string.h>
+#include <type_traits>
 
 namespace haf {
 
@@ -2264,10 +2265,10 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                                                               int *__restrict__ flag_list, int flag_cap,
                                                               int *__restrict__ counters_rw, Dims d,
                                                               const int *__restrict__ idx_list, int list_counter, int list_cap,
-                                                              float *__restrict__ part_out, long part_stride)
+                                                              double *__restrict__ part_out, long part_stride)
 {
-    // the ONLY LDS object: 3 SV tile images + per wave one row of a_x and one row of positive-group sums
-    __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 2 * 8 * kTile * 4];
+    // the ONLY LDS object: 3 SV tile images + per wave one row of a_x (fp32) and one row of positive-group sums (fp64)
+    __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 3 * 8 * kTile * 4];
     // list mode (behind the screening pass): slot j of X / ax holds evaluation idx_list[j]
     const int n_evals = idx_list ? min(counters[list_counter], list_cap) : counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kSvmBlockEvals;
@@ -2281,7 +2282,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     const int t0 = part_out ? (int)((long)d.n_sv_tiles * blockIdx.y / gridDim.y) : 0;
     const int nt = part_out ? (int)((long)d.n_sv_tiles * (blockIdx.y + 1) / gridDim.y) : d.n_sv_tiles;
     float *axs = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + wave * kTile;
-    float *pos = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + 8 * kTile + wave * kTile;
+    double *pos = reinterpret_cast<double *>(lds + kHBuffers * kHSvTileBytes + 8 * kTile * 4) + wave * kTile;
 
     if (t0 < nt) stage_sv_tile_h(svt + (size_t)t0 * kHSvTileBytes, lds0, wave, lane);                          // first tile
     if (t0 + 1 < nt) stage_sv_tile_h(svt + (size_t)(t0 + 1) * kHSvTileBytes, lds0 + kHSvTileBytes, wave, lane);   // second
@@ -2304,14 +2305,20 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             alt[m] = *reinterpret_cast<const half4 *>(xt + kHMatBytes + kHTailOff + m * 512 + lane * 8);
         }
     }
-    if (lane < kTile) { axs[lane] = ax[tile32 * kTile + lane]; pos[lane] = 0.0f; }
-    // rows 16m + 4(lane>>4) + r, summed over this lane's columns.  Two levels: `lo` takes the products of up to 8 tiles,
-    // then folds into `part`, so the fp32 error of the coefficient sum grows with tiles/8 + 8 instead of tiles
-    float part[2][4], lo[2][4];
+    if (lane < kTile) { axs[lane] = ax[tile32 * kTile + lane]; pos[lane] = 0.0; }
+    // rows 16m + 4(lane>>4) + r, summed over this lane's columns.  Two levels: `lo` (fp32) takes the products of kFold tiles -- a
+    // chain of 2 kFold fmas -- and is then added to `part`.  PRECISE: kFold = 1 (16 conversions and adds next to ~200 vector
+    // instructions of the tile) and `part` is fp64 like everything behind it (lane reduction, class sums, the ranges of the list
+    // mode): a term of the coefficient sum passes through two fp32 roundings and no more.  Bulk form: kFold = 8, fp32 throughout
+    // (its registers are spoken for), so the error grows with tiles/8 + 8 instead of tiles.
+    constexpr int kFold = PRECISE ? 1 : 8;
+    typedef typename std::conditional<PRECISE, double, float>::type part_t;
+    part_t part[2][4];
+    float lo[2][4];
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) { part[m][r] = 0.0f; lo[m][r] = 0.0f; }
+        for (int r = 0; r < 4; r++) { part[m][r] = (part_t)0; lo[m][r] = 0.0f; }
     // pin the compiler-issued loads before any further (asm, uncounted) DMA is queued behind them (see k_svm_rbf)
 #pragma unroll
     for (int s = 0; s < kHFull; s++)
@@ -2347,13 +2354,13 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float v = part[m][r] + lo[m][r];
+                    part_t v = part[m][r] + (part_t)lo[m][r];
                     v += __shfl_xor(v, 8, 64);
                     v += __shfl_xor(v, 4, 64);
                     v += __shfl_xor(v, 2, 64);
                     v += __shfl_xor(v, 1, 64);
                     if ((lane & 15) == 0) pos[16 * m + 4 * (lane >> 4) + r] = v;
-                    part[m][r] = 0.0f;
+                    part[m][r] = (part_t)0;
                     lo[m][r] = 0.0f;
                 }
         }
@@ -2512,11 +2519,11 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) lo[m][r] = fmaf(cfn[n], acc[m][n][r], lo[m][r]);
-        if ((t & 7) == 7) {
+        if (kFold == 1 || (t & (kFold - 1)) == kFold - 1) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) { part[m][r] += lo[m][r]; lo[m][r] = 0.0f; }
+                for (int r = 0; r < 4; r++) { part[m][r] += (part_t)lo[m][r]; lo[m][r] = 0.0f; }
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
         if (more) {
@@ -2533,7 +2540,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            float v = part[m][r] + lo[m][r];
+            part_t v = part[m][r] + (part_t)lo[m][r];
             v += __shfl_xor(v, 8, 64);
             v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 2, 64);
@@ -2550,19 +2557,20 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                 const long es = tile32 * kTile + row;
                 if (es < n_evals) {
                     const int e = idx_list ? idx_list[es] : (int)es;
-                    const float P = has_neg ? pos[row] : part[m][r];
-                    const float N = has_neg ? part[m][r] : 0.0f;
+                    const part_t P = has_neg ? (part_t)pos[row] : part[m][r];         // (bulk form: pos[] holds an fp32 value)
+                    const part_t N = has_neg ? part[m][r] : (part_t)0;
                     if (part_out) {
                         part_out[(2 * blockIdx.y) * part_stride + es] = P;
                         part_out[(2 * blockIdx.y + 1) * part_stride + es] = N;
                         continue;
                     }
-                    const float dv = (P + N) - p.rho;
-                    const float sabs = P - N;                       // sum |coef| K
+                    const float dv = (float)((P + N) - (part_t)p.rho);   // (PRECISE: one rounding)
+                    const float sabs = (float)(P - N);                   // sum |coef| K
                     dec[e] = dv;
                     labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
                     const float gdot = PRECISE ? p.guard_dot_p : p.guard_dot;
-                    if (!(fabsf(dv) > (p.guard_acc + gdot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
+                    const float gacc = PRECISE ? p.guard_acc_l : p.guard_acc;
+                    if (!(fabsf(dv) > (gacc + gdot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
                         int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                         if (slot < flag_cap) flag_list[slot] = e;
                     }
@@ -2573,7 +2581,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
 
 // list mode: sums the class sums of the kHListParts tile ranges in a fixed order and finishes the evaluation exactly as the
 // kernel's own epilogue does
-__global__ __launch_bounds__(256) void k_svm_h_combine(const float *__restrict__ part_out, long part_stride, int parts,
+__global__ __launch_bounds__(256) void k_svm_h_combine(const double *__restrict__ part_out, long part_stride, int parts,
                                                        const float *__restrict__ ax, const int *__restrict__ evalcell,
                                                        const int *__restrict__ counters, SvmParams p, float *__restrict__ dec,
                                                        int8_t *__restrict__ labels, int *__restrict__ flag_list, int flag_cap,
@@ -2582,10 +2590,10 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const float *__restrict__
 {
     const int n_evals = min(counters[list_counter], list_cap);
     for (long es = (long)blockIdx.x * 256 + threadIdx.x; es < n_evals; es += (long)gridDim.x * 256) {
-        double P = 0.0, N = 0.0;                        // the ranges are added in fp64: no rounding of their own
+        double P = 0.0, N = 0.0;                        // the ranges are added in fp64 like the sums inside them
         for (int y = 0; y < parts; y++) {
-            P += (double)part_out[(2 * y) * part_stride + es];
-            N += (double)part_out[(2 * y + 1) * part_stride + es];
+            P += part_out[(2 * y) * part_stride + es];
+            N += part_out[(2 * y + 1) * part_stride + es];
         }
         const int e = idx_list[es];
         const float dv = (float)((P + N) - (double)p.rho);
@@ -2601,13 +2609,13 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const float *__restrict__
 
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters, SvmParams p,
                   float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
-                  const int *idx_list, int list_counter, int list_cap, float *part_out, long part_stride, hipStream_t s)
+                  const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride, hipStream_t s)
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
     if (idx_list) {
         const int parts = (part_out && d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;     // engine.cpp: guard_acc_l follows this rule
-        float *po = parts > 1 ? part_out : nullptr;
+        double *po = parts > 1 ? part_out : nullptr;
         hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
                            (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
                            list_counter, list_cap, po, part_stride);
@@ -2617,7 +2625,7 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
     } else {
         hipLaunchKernelGGL(k_svm_rbf_h<false>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
                            evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap,
-                           (float *)nullptr, 0L);
+                           (double *)nullptr, 0L);
     }
 }
 
