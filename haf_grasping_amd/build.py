@@ -147,7 +147,8 @@ def build(force=False, verbose=False):
 
     def compile_one(src, suffix="", defs=()):
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
-        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + list(defs) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # HAF_EXPERIMENT_FLAGS: extra compiler flags for ablation builds (tools/ablate_h.sh); never set for a build that is kept
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + os.environ.get("HAF_EXPERIMENT_FLAGS", "").split() + list(defs) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

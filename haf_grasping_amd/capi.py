@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAF_LIB", os.path.join(HERE, "libhafgrasp.so"))   # HAF_LIB: A/B another build of the same ABI
 # the TESTING build (-DHAF_TESTING): same kernels, plus the haf_test_* hooks and the environment switches that scale the
 # guard bands.  Only tests/ load it (testlib(), Engine(..., testing=True)); the product library has neither.
-TESTLIB_PATH = os.path.join(HERE, "libhafgrasp_testing.so")
+TESTLIB_PATH = os.environ.get("HAF_TESTLIB", os.path.join(HERE, "libhafgrasp_testing.so"))   # HAF_TESTLIB: likewise (tools/ablate_h.sh)
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16, FLAG_PROBABILITY = 1, 2, 4, 8, 16

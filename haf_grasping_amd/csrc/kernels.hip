@@ -25,6 +25,9 @@
 #include "decq.h"
 #include <string.h>
 #include <type_traits>
+#ifndef HAF_ABL
+#define HAF_ABL 0     // timing experiments on k_svm_rbf_h<true> (tools/ablate_h.sh): never defined in a build that is kept
+#endif
 
 namespace haf {
 
@@ -2251,6 +2254,22 @@ __device__ __forceinline__ int stage_sv_tile_h(const char *__restrict__ gtile, u
     return issued;
 }
 
+// four fp32 additions as two packed instructions (same IEEE results; the element-wise loop compiles to four v_add_f32)
+__device__ __forceinline__ f32x4 h_add4(f32x4 a, f32x4 b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = f2{a[0], a[1]} + f2{b[0], b[1]}, hi = f2{a[2], a[3]} + f2{b[2], b[3]};
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 h_add4s(f32x4 a, float s) { return h_add4(a, f32x4{s, s, s, s}); }
+__device__ __forceinline__ f32x4 h_fma4s(float s, f32x4 v, f32x4 c)        // fma(s, v[i], c[i]): two v_pk_fma_f32
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 ss = {s, s};
+    const f2 lo = __builtin_elementwise_fma(ss, f2{v[0], v[1]}, f2{c[0], c[1]}), hi = __builtin_elementwise_fma(ss, f2{v[2], v[3]}, f2{c[2], c[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // PRECISE (the list mode behind the screening pass, where speed does not matter): the dominant pass xh.sh goes ONE k-step
 // at a time into a fresh accumulator that is added to the running sum by the VALU, and the two small passes form their
 // own MFMA chain first.  Whatever order the matrix core adds the 32 products of an instruction in, the error is then at
@@ -2337,14 +2356,16 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
 
     const int my_pieces = (kHSvPieces - wave + 7) / 8;              // DMA instructions this wave issues per tile (6 or 5)
     float axr[2][4];                                                // a_x of this lane's 8 rows (LDS reads cannot be hoisted
-#pragma unroll                                                      //  over the asm DMA by the compiler, so do it by hand)
-    for (int m = 0; m < 2; m++)
+    if (!PRECISE) {                                                 //  over the asm DMA by the compiler, so do it by hand)
 #pragma unroll
-        for (int r = 0; r < 4; r++) axr[m][r] = axs[16 * m + 4 * (lane >> 4) + r];
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) axr[m][r] = axs[16 * m + 4 * (lane >> 4) + r];
+    }
     for (int t = t0; t < nt; t++) {
         const char *cur = lds + ((t - t0) % kHBuffers) * kHSvTileBytes;
         const bool more = t + 2 < nt;
-        if (more)
+        if (more && !(PRECISE && HAF_ABL == 4))
             stage_sv_tile_h(svt + (size_t)(t + 2) * kHSvTileBytes, lds0 + ((t - t0 + 2) % kHBuffers) * kHSvTileBytes, wave, lane);
         if (t == d.sv_tile_neg) {
             // The tile images hold the non-negative coefficients first: what has been summed so far is
@@ -2373,86 +2394,87 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int n = 0; n < 2; n++) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const char *bl = cur + lane * 16;
         if (PRECISE) {
-            // sweep 1: xl.sh, then xh.sl, magnitudes 2^-11 of the main pass: a plain MFMA chain (its roundings are negligible).
-            // One B fragment live and one in flight (read a step ahead); consecutive steps alternate the column block, so an
-            // accumulator is needed again only four MFMAs later.
-            {
-                half8 bnx = *reinterpret_cast<const half8 *>(bl);
+            // The B fragments of the whole tile as ONE sequence of 60 reads -- hi image (sweep 1a: xl.sh), lo image (sweep 1b: xh.sl),
+            // hi image again (sweep 2: xh.sh) -- through a ring of three registers, each read TWO steps (four MFMAs of this wave,
+            // and as many of the SIMD's other wave) ahead of its use.  One step ahead (round 2) left every step waiting for its
+            // fragment: at two waves per SIMD the LDS round trip is longer than the other wave's two MFMAs, the waves spent 43 % of
+            // their cycles in s_waitcnt and the matrix pipe was busy half the time (profiles/README.md, round 3).
+            half8 fb[3];
+#define HAF_H_FRAG(g) (((g) >= 20 && (g) < 40) ? bl + kHMatBytes + ((g) - 20) * 1024 : bl + ((g) % 20) * 1024)
+            fb[0] = *reinterpret_cast<const half8 *>(HAF_H_FRAG(0));
+            fb[1] = *reinterpret_cast<const half8 *>(HAF_H_FRAG(1));
+            // sweep 1: xl.sh, then xh.sl, magnitudes 2^-11 of the main pass: a plain MFMA chain (its roundings are negligible);
+            // consecutive steps alternate the column block, so an accumulator is needed again only four MFMAs later.
+            half4 bht[2], bqt[2];
 #pragma unroll
-                for (int s = 0; s < kHFull; s++)
+            for (int g = (HAF_ABL == 3 ? 38 : 0); g < 40; g++) {
+                const int sstep = (g % 20) >> 1, n = g & 1;
+                fb[(g + 2) % 3] = *reinterpret_cast<const half8 *>(HAF_H_FRAG(g + 2));     // (g = 38, 39: the first two of sweep 2)
+                if (g == 36) {
 #pragma unroll
-                    for (int n = 0; n < 2; n++) {
-                        const half8 b = bnx;
-                        if (s * 2 + n + 1 < kHFull * 2) bnx = *reinterpret_cast<const half8 *>(bl + (s * 2 + n + 1) * 1024);
-                        else bnx = *reinterpret_cast<const half8 *>(bl + kHMatBytes);                 // first fragment of the lo image
+                    for (int nn = 0; nn < 2; nn++) bht[nn] = *reinterpret_cast<const half4 *>(cur + kHTailOff + nn * 512 + lane * 8);
+                }
+                if (g == 37) {
 #pragma unroll
-                        for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s][m], b, acc[m][n], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);           // one step's fragments live at a time: no spills
-                    }
+                    for (int nn = 0; nn < 2; nn++) bqt[nn] = *reinterpret_cast<const half4 *>(cur + kHMatBytes + kHTailOff + nn * 512 + lane * 8);
+                }
+                const half8 b = fb[g % 3];
 #pragma unroll
-                for (int s = 0; s < kHFull; s++)
-#pragma unroll
-                    for (int n = 0; n < 2; n++) {
-                        const half8 b = bnx;
-                        if (s * 2 + n + 1 < kHFull * 2) bnx = *reinterpret_cast<const half8 *>(bl + kHMatBytes + (s * 2 + n + 1) * 1024);
-#pragma unroll
-                        for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], b, acc[m][n], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                for (int m = 0; m < 2; m++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g < 20 ? al[sstep][m] : ah[sstep][m], b, acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                   // one step's fragments live at a time: no spills
             }
 #pragma unroll
             for (int n = 0; n < 2; n++) {
-                const half4 bht = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
-                const half4 bqt = *reinterpret_cast<const half4 *>(cur + kHMatBytes + kHTailOff + n * 512 + lane * 8);
 #pragma unroll
-                for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(alt[m], bht[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt, acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; m++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bqt[n], acc[m][n], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             // sweep 2: xh.sh, each k-step into a fresh accumulator, summed by the VALU -- one step behind: the adds of a step
             // are issued after the MFMAs of the next one, so the matrix pipe does not idle under the result latency
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             f32x4 tp[2] = {zero, zero};
-            half8 bnx = *reinterpret_cast<const half8 *>(bl);         // B fragments are read one step ahead as well
 #pragma unroll
-            for (int s = 0; s < kHFull; s++)
+            for (int g = 40; g < 60; g++) {
+                const int sstep = (g - 40) >> 1, n = g & 1;
+                if (g + 2 < 60) fb[(g + 2) % 3] = *reinterpret_cast<const half8 *>(HAF_H_FRAG(g + 2));
+                if (g == 57) {
 #pragma unroll
-                for (int n = 0; n < 2; n++) {
-                    const half8 bhv = bnx;
-                    if (s * 2 + n + 1 < kHFull * 2) bnx = *reinterpret_cast<const half8 *>(bl + (s * 2 + n + 1) * 1024);
-                    f32x4 t4[2];
+                    for (int nn = 0; nn < 2; nn++) bht[nn] = *reinterpret_cast<const half4 *>(cur + kHTailOff + nn * 512 + lane * 8);
+                }
+                const half8 bhv = fb[g % 3];
+                f32x4 t4[2];
+                const int pn = n ^ 1;                                  // the previous step had the other column block
+                // MFMA, the adds of the previous step's FIRST result in its shadow, MFMA, the adds of the second: pinned, because
+                // left alone hipcc puts a step's adds right behind the MFMAs that produce their operands and fills the gap with
+                // s_nop 5 (measured: the adds of this sweep cost 29 % of the kernel)
 #pragma unroll
-                    for (int m = 0; m < 2; m++) t4[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s][m], bhv, zero, 0, 0, 0);
-                    if (s + n > 0) {
-                        const int pn = n ^ 1;                          // the previous (s, n) pair had the other column block
-#pragma unroll
-                        for (int m = 0; m < 2; m++)
-#pragma unroll
-                            for (int r = 0; r < 4; r++) acc[m][pn][r] = acc[m][pn][r] + tp[m][r];
-                    }
-                    tp[0] = t4[0];
-                    tp[1] = t4[1];
+                for (int m = 0; m < 2; m++) {
+                    t4[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sstep][m], bhv, zero, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g > 40 && HAF_ABL != 1) acc[m][pn] = h_add4(acc[m][pn], tp[m]);    // (packed: two v_pk_add_f32)
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                tp[0] = t4[0];
+                tp[1] = t4[1];
+            }
+#undef HAF_H_FRAG
 #pragma unroll
             for (int n = 0; n < 2; n++) {
-                const half4 bht = *reinterpret_cast<const half4 *>(cur + kHTailOff + n * 512 + lane * 8);
                 f32x4 t4[2];
 #pragma unroll
-                for (int m = 0; m < 2; m++) t4[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bht, zero, 0, 0, 0);
+                for (int m = 0; m < 2; m++) t4[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(aht[m], bht[n], zero, 0, 0, 0);
                 const int pn = n ^ 1;                                  // (kHFull - 1, 1) before tail 0, tail 0 before tail 1
 #pragma unroll
-                for (int m = 0; m < 2; m++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) acc[m][pn][r] = acc[m][pn][r] + tp[m][r];
+                for (int m = 0; m < 2; m++) acc[m][pn] = h_add4(acc[m][pn], tp[m]);
                 tp[0] = t4[0];
                 tp[1] = t4[1];
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[m][1][r] = acc[m][1][r] + tp[m][r];      // tail 1
+            for (int m = 0; m < 2; m++) acc[m][1] = h_add4(acc[m][1], tp[m]);            // tail 1
         } else {
         half8 bh[2][2], bq[2][2];                                    // [ring][column block n]
 #pragma unroll
@@ -2497,10 +2519,36 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
         }
         }
         const float *tail = reinterpret_cast<const float *>(cur + 2 * kHMatBytes);
-        float cfn[2];
         // HAZARD (measured on gfx950, two waves per SIMD; screen.hip has the details): a VALU instruction that reads a
         // v_exp_f32 result within a few instructions of the v_exp_f32 can read the register before it is written.  All
         // sixteen exps are issued first and pinned there; the coefficient fmas follow.
+        if (PRECISE) {
+            // the arithmetic around the sixteen exps in packed fp32 (same results): 24 vector instructions instead of 48; a_x comes
+            // back from LDS (its eight registers go to the fragment ring during the sweeps); `lo` starts from zero in every tile
+            f32x4 ax4[2], l4[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) ax4[m] = *reinterpret_cast<const f32x4 *>(axs + 16 * m + 4 * (lane >> 4));
+            float cfn[2];
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const float as_ = tail[16 * n + (lane & 15)];        // -g2*|s_j|^2
+                cfn[n] = tail[kTile + 16 * n + (lane & 15)];         // coef_j (0 for padding SVs)
+#pragma unroll
+                for (int m = 0; m < 2; m++) {                        // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
+                    const f32x4 arg = h_fma4s(p.two_gamma2, acc[m][n], h_add4s(ax4[m], as_));
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[m][n][r] = (HAF_ABL == 2) ? arg[r] : __builtin_amdgcn_exp2f(arg[r]);
+                }
+            }
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#pragma unroll
+            for (int m = 0; m < 2; m++) l4[m] = h_fma4s(cfn[1], acc[m][1], h_fma4s(cfn[0], acc[m][0], f32x4{0.0f, 0.0f, 0.0f, 0.0f}));
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) part[m][r] += (part_t)l4[m][r];
+        } else {
+        float cfn[2];
 #pragma unroll
         for (int n = 0; n < 2; n++) {
             const float as_ = tail[16 * n + (lane & 15)];            // -g2*|s_j|^2
@@ -2519,11 +2567,12 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) lo[m][r] = fmaf(cfn[n], acc[m][n][r], lo[m][r]);
-        if (kFold == 1 || (t & (kFold - 1)) == kFold - 1) {
+        if ((t & (kFold - 1)) == kFold - 1) {
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) { part[m][r] += (part_t)lo[m][r]; lo[m][r] = 0.0f; }
+        }
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
         if (more) {
