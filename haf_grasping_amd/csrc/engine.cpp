@@ -298,6 +298,8 @@ struct haf_engine {
     double host_exp_thr = 0.0;
     int last_host_resolved = 0;
     bool calibrated = false;        // the screening variant was chosen at creation (calibrate())
+    double mfma_kappa = 8.0;        // error of one v_mfma_f32_16x16x32_f16 in units of 2^-24 (|c| + sum|a b|): max(8, 1.5 x probe_mfma_rounding())
+    double mfma_kappa_measured = 0.0;
     bool no_bucket_sort = false;    // set (for good) when a tile of the bucket-sorted binning path overflowed its candidate list
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
@@ -534,6 +536,7 @@ int build_tables(haf_engine *e)
         // ---- screening pass: K slots, operand images, and the model-wide bounds of the per-evaluation guard band ----
         ScreenParams &sp = e->screen;
         sp.c = std::sqrt(2.0 * m.gamma * log2e);
+        sp.acc_rel = (kS0K / 32) * e->mfma_kappa * std::ldexp(1.0, -24);      // ten accumulating instructions, kappa u each (kernels.h)
         std::vector<FeatDesc> fd2((size_t)e->nf);
         HIPCHK(e, hipMemcpy(fd2.data(), e->d_fd.p, fd2.size() * sizeof(FeatDesc), hipMemcpyDeviceToHost));
         // Slots (kernels.h): attributes that are the same function of the window (same active regions, weights and rule) with
@@ -852,10 +855,11 @@ int build_tables(haf_engine *e)
     if (const char *g = test_env("HAF_GUARD_REL")) guard_scale = atof(g);
     const double u = std::ldexp(1.0, -24);
     e->svm.guard_dot = (float)(guard_scale * (0.6932 * 324.0 * u + 8.0 * u));
-    // PRECISE form of the three-pass kernel (k_svm_rbf_h<true>): 31 roundings per instruction of the main pass whatever
-    // the matrix core's internal order, 11 VALU adds, one for the small-pass chain (whose own roundings are 2^-10 of
-    // that): 43 instead of 324
-    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * 44.0 * u + 8.0 * u));
+    // PRECISE form of the three-pass kernel (k_svm_rbf_h<true>): every instruction of the main pass starts from zero and is off by
+    // at most kappa u of its sum|products| (mfma_kappa: measured at creation, with its margin), 11 VALU adds join the instructions'
+    // results (one rounding each, of at most the whole sum|x_i s_i|), one more for the small-pass chain (whose own roundings are
+    // 2^-10 of that): kappa + 12 instead of 324
+    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * (e->mfma_kappa + 12.0) * u + 8.0 * u));
     // coefficient sum: sequential over the tiles (fp32 kernel: one fma per tile and sum register) or two-level (split-fp16
     // kernel: an inner sum takes the 2 column blocks of 8 tiles, 16 fmas, then one add per 8 tiles); +2 for the class split
     // (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product.  All terms of a class sum have
@@ -1206,6 +1210,27 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         if (keeps == 0) { e->error = "this device flushes fp16 subnormal MFMA operands: rebuild with -DHAF_FLUSH_F16_SUBNORMALS"; return bail(HAF_E_DEVICE); }
     }
 #endif
+    if (contraction_mode(e->cfg) != MODE_F32) {
+        // the guard bands of the fp16 tiers carry the rounding of the matrix core as a MEASURED constant (screen.hip:
+        // probe_mfma_rounding): once per device and process
+        static std::mutex kappa_mutex;
+        static double kappa_of[64];                   // 0: not yet
+        double meas;
+        {
+            std::lock_guard<std::mutex> lock(kappa_mutex);
+            const int slot = cfg->device & 63;
+            if (cfg->device >= 64 || kappa_of[slot] == 0.0) {
+                meas = probe_mfma_rounding(e->stream);
+                if (cfg->device < 64 && meas > 0.0) kappa_of[slot] = meas;
+            } else {
+                meas = kappa_of[slot];
+            }
+        }
+        if (!(meas > 0.0)) { e->error = "matrix-core rounding probe failed to run"; return bail(HAF_E_DEVICE); }
+        e->mfma_kappa_measured = meas;
+        e->mfma_kappa = std::max(8.0, 1.5 * meas);
+        if (!(e->mfma_kappa < 64.0)) { e->error = "this device's fp16 MFMA rounds far worse than the guard bands allow for (probe_mfma_rounding)"; return bail(HAF_E_DEVICE); }
+    }
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
     if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_GUARD2_REL") ||
@@ -2257,6 +2282,31 @@ int haf_test_i8_mfma(const signed char *a, const signed char *b, int *c)
     haf::launch_i8_layout_probe(da, db, dc, nullptr);
     const hipError_t rc = hipMemcpy(c, dc, 1024, hipMemcpyDeviceToHost);
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
+
+// the engine's matrix-core rounding constant: what the probe measured and what the bands use
+int haf_test_mfma_kappa(haf_engine *e, double *measured, double *used)
+{
+    if (!e) return HAF_E_ARG;
+    *measured = e->mfma_kappa_measured; *used = e->mfma_kappa;
+    return HAF_OK;
+}
+
+// v_mfma_f32_16x16x32_f16 on host-chosen data (testkernels.hip: k_f16_mfma_probe)
+int haf_test_f16_mfma(const unsigned short *a, const unsigned short *b, const float *c, float *d, int trials, int chain)
+{
+    void *da = nullptr, *db = nullptr;
+    float *dc = nullptr, *dd = nullptr;
+    const size_t na = (size_t)trials * 1024, nc = (size_t)trials * 1024;
+    if (hipMalloc(&da, na) != hipSuccess || hipMalloc(&db, na) != hipSuccess || hipMalloc((void **)&dc, nc) != hipSuccess ||
+        hipMalloc((void **)&dd, nc) != hipSuccess) return HAF_E_DEVICE;
+    (void)hipMemcpy(da, a, na, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, na, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dc, c, nc, hipMemcpyHostToDevice);
+    haf::launch_f16_mfma_probe(da, db, dc, dd, trials, chain, nullptr);
+    const hipError_t rc = hipMemcpy(d, dd, nc, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd);
     return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
 }
 

@@ -107,6 +107,8 @@ struct ScreenParams {
     double sigma_dk;              // upper bound of the largest singular value of diag(c kappa) W^   (inf: centred form switched off)
     double ck_max;                // max_n |c_n kappa_n|
     double ubar2;                 // |ubar|^2
+    double acc_rel;               // fp32 accumulation inside the matrix core over the ten instructions of a chain, per unit of |t_n| + |u||w^_n|:
+                                  // 10 kappa 2^-24 with kappa from probe_mfma_rounding() (engine.cpp)
     double g_norm, hd_norm;       // |G|_2, |Hd|_2 (the fp32 roundings of the correction and of u' against u are bounded through them)
     const struct ScrCorr *corr;   // kS0K per-slot constants {G, Hd, ubar} (device)
     const struct ScrCorr2 *corr2; // the same constants per PAIR of slots (packed-fp32 form of the sums: k_features_serial)
@@ -310,6 +312,7 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
                      const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
                      float *ax2, hipStream_t s,    // ax2: screening form only, -|u|^2/2 per evaluation
                      int list_off = 0);            // list mode: idx_list points at entry list_off of the list counted by list_counter
+double probe_mfma_rounding(hipStream_t s);  // largest error of one v_mfma_f32_16x16x32_f16 in units of 2^-24 (|c| + sum|a b|) over adversarial inputs; < 0: HIP error
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
@@ -340,6 +343,7 @@ void launch_mfma_accum_test(const void *a, const void *b, const float *c0, float
 void launch_mfma_rate_test(const void *in, float *out, int blocks, int iters, hipStream_t s);                       // testkernels.hip (testing build)
 void launch_mfma_model_test(const void *in, float *out, int mb, int blocks, int tiles, hipStream_t s);             // testkernels.hip (testing build)
 void launch_i8_layout_probe(const void *a, const void *b, int *c, hipStream_t s);                                 // testkernels.hip (testing build)
+void launch_f16_mfma_probe(const void *a, const void *b, const float *c, float *d, int trials, int chain, hipStream_t s);   // testkernels.hip (testing build)
 void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s);
 void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
                        int n, hipStream_t s);

@@ -1352,8 +1352,8 @@ __device__ __forceinline__ void screen_extra_norm(const ScreenParams &sp, int g,
 // (b) grows with sqrt(S) only and is ~7x tighter on a 4096-SV model; the kernel takes the smaller of the two.
 // |u^-u| <= |u^-u'| + eta and |u| <= |u'| + eta (norms; |u^-u'| and |u'| are accumulated exactly in fp64).
 // Second order: |2^e - 1 - ln2 e| <= 0.6 (ln2 e)^2 for |e| < 0.05.  The bracket is bounded per unit of S: norm split exactly
-// (das_max), matrix-core accumulation generously (11 accumulating instructions, a few ulp of the largest partial sum each:
-// 2^-18 of |u||v^| + a_x + a_s).  The kernel measures S^ = 2^D sum|c_n| K_n 2^e_n: the true S is at most S^ * 2^(|D| + max|e_n|),
+// (das_max), matrix-core accumulation generously (ten accumulating instructions, kappa u of |c| + sum|products| each:
+// ScreenParams::acc_rel).  The kernel measures S^ = 2^D sum|c_n| K_n 2^e_n: the true S is at most S^ * 2^(|D| + max|e_n|),
 // folded into the outputs.  Output {gA, gB, gC, cm} (kernels.h), scaled by sp.scale:
 //   |dec^ - dec| <= [min(gA |w|_2^, gC S^) + (guard_acc0' + gB) S^ + cm (|dec^| + |rho|)] * 1.002,
 //   |w|_2^ = sqrt(max|c_n| S^) or, in the kernel's SUMSQ variant, the measured sqrt(sum_n (c_n K_n)^2)
@@ -1391,9 +1391,10 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2
     const double un = un1 + eta, dn = dn1 + eta;                                // |u|, |u^ - u|
     const double ln2 = 0.69314718056;
     const double d_max = dn * sp.v_max + (un + dn) * sp.dv_max;
-    // fp32 accumulation inside the matrix core: ten accumulating instructions per element, a few ulp of the largest partial sum
-    // each, bounded generously by 2^-18 of |t_n| + |u||w^_n| (the chain starts at t_n)
-    const double acc = 3.814697265625e-06 * (un * sp.v_max + sp.as_max);
+    // fp32 accumulation inside the matrix core: ten accumulating instructions per element, each off by at most kappa u of its
+    // |c| + sum|products| <= |t_n| + |u||w^_n| (the chain starts at t_n; kappa: the measured property of screen.hip's
+    // probe_mfma_rounding() with its margin, 8 on the devices seen so far: sp.acc_rel = 80 u)
+    const double acc = sp.acc_rel * (un * sp.v_max + sp.as_max);
     // D = | log2 of (the factor the kernel applies / 2^(-|u|^2/2)) |: a_x from the fp32 sums and u' instead of u, its cast to
     // fp32, v_exp_f32 and the two products (3 * 2^-23 relative = 5.2e-7 in the exponent)
     const double D = (kF32Acc + 6.0e-8) * a_x + un_t * eta_t + 0.5 * eta_t * eta_t + 6.0e-7;

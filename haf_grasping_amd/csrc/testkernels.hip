@@ -240,6 +240,34 @@ __global__ __launch_bounds__(64) void k_i8_layout_probe(const signed char *__res
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.v, fb.v, acc, 0, 0, 0);
     for (int r = 0; r < 4; r++) c[(4 * kb + r) * 16 + rc] = acc[r];
 }
+// v_mfma_f32_16x16x32_f16 on host-chosen data, one wave per trial: a [16][32] fp16, b [32][16] fp16, c [16][16] fp32 (row-major)
+// -> d [16][16] fp32; chain > 1 feeds the result back as C that many times with the same A and B.  (tools/mfma_rounding_probe.py:
+// how does the matrix core round its 33-term sums?)
+__global__ __launch_bounds__(64) void k_f16_mfma_probe(const _Float16 *__restrict__ a, const _Float16 *__restrict__ b, const float *__restrict__ c,
+                                                        float *__restrict__ d, int chain)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int t = blockIdx.x, l = threadIdx.x, rc = l & 15, kb = l >> 4;
+    a += (size_t)t * 512; b += (size_t)t * 512; c += (size_t)t * 256; d += (size_t)t * 256;
+    h8 fa, fb;
+    for (int j = 0; j < 8; j++) {
+        fa[j] = a[rc * 32 + 8 * kb + j];
+        fb[j] = b[(8 * kb + j) * 16 + rc];
+    }
+    f4 acc;
+    for (int r = 0; r < 4; r++) acc[r] = c[(4 * kb + r) * 16 + rc];
+    for (int i = 0; i < chain; i++) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+        asm volatile("" : "+v"(acc));
+    }
+    for (int r = 0; r < 4; r++) d[(4 * kb + r) * 16 + rc] = acc[r];
+}
+void launch_f16_mfma_probe(const void *a, const void *b, const float *c, float *d, int trials, int chain, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_f16_mfma_probe, dim3((unsigned)trials), dim3(64), 0, s, (const _Float16 *)a, (const _Float16 *)b, c, d, chain);
+}
+
 void launch_i8_layout_probe(const void *a, const void *b, int *c, hipStream_t s)
 {
     hipLaunchKernelGGL(k_i8_layout_probe, dim3(1), dim3(64), 0, s, (const signed char *)a, (const signed char *)b, c);

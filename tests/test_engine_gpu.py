@@ -1199,14 +1199,26 @@ def test_bucket_sorted_binning_of_large_grids(data_dir, surrogate, orc, in_kw):
     eng.close()
 
 
-def test_matrix_core_accumulation_stays_inside_the_band_assumption():
-    """The one assumption about undocumented hardware behaviour in the screening band: a chain of ten
-    v_mfma_f32_16x16x32_f16 that starts from C deviates from the exact C + sum a_k b_k by at most 2^-18 (|C| + sum |a_k b_k|).
-    The products are exact in fp32; how the matrix core adds them is not documented.  Evidence, not proof: the chain of
-    k_svm_screen (same builtin, same operand layout, same start-value mechanism) on 2 048 trials x 256 outputs of operands
-    made to hurt -- magnitudes over the whole fp16 range the operands can take, signs arranged for near-total cancellation,
-    start values like t_n -- against an fp64 evaluation.  The worst observed error is reported as a fraction of the budget."""
+def test_matrix_core_accumulation_stays_inside_the_band_assumption(data_dir, surrogate):
+    """The one assumption about undocumented hardware behaviour in the bands of the fp16 tiers: ONE
+    v_mfma_f32_16x16x32_f16 deviates from the exact c + sum a_k b_k by at most kappa 2^-24 (|c| + sum |a_k b_k|), so a chain of ten
+    that starts from C by at most 10 kappa 2^-24 (|C| + sum |a_k b_k|).  The products are exact in fp32; how the matrix core adds
+    them is not documented.  Round 3: kappa is MEASURED at haf_create on the device the engine runs on (screen.hip:
+    probe_mfma_rounding, adversarial families) and used with a margin, kappa = max(8, 1.5 x measured).  Evidence, not proof:
+    (1) what the engine measured here (5.3 on the devices seen so far) and what it uses; (2) the chain of k_svm_screen (same
+    builtin, same operand layout, same start-value mechanism) on 2 048 trials x 256 outputs of operands made to hurt --
+    magnitudes over the whole fp16 range the operands can take, signs arranged for near-total cancellation, start values like
+    t_n -- against an fp64 evaluation.  The worst observed error is reported as a fraction of the budget."""
     L = capi.testlib()
+    import ctypes as C
+    eng = make_engine(data_dir, surrogate, 0, testing=True)
+    meas, used = C.c_double(0), C.c_double(0)
+    L.haf_test_mfma_kappa.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.haf_test_mfma_kappa(eng._h, C.byref(meas), C.byref(used)) == 0
+    eng.close()
+    assert 0.5 <= meas.value <= 8.0 and used.value == max(8.0, 1.5 * meas.value), (meas.value, used.value)
+    budget = 10.0 * used.value * 2.0 ** -24
+    STATS["mfma_rounding_kappa"] = {"measured": meas.value, "used": used.value}
     rng = np.random.RandomState(77)
     trials = 2048
     a = np.zeros((trials, 16, 320), np.float16)
@@ -1231,9 +1243,9 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption():
     a64, b64 = a.astype(np.float64), b.astype(np.float64)
     exact = np.einsum("trk,tkc->trc", a64, b64) + c0[:, None, :].astype(np.float64)
     scale = np.einsum("trk,tkc->trc", np.abs(a64), np.abs(b64)) + np.abs(c0[:, None, :].astype(np.float64))
-    ratio = np.abs(out.astype(np.float64) - exact) / (2.0 ** -18 * scale)
+    ratio = np.abs(out.astype(np.float64) - exact) / (budget * scale)
     assert np.isfinite(out).all() and ratio.max() <= 1.0, float(ratio.max())
-    STATS["mfma_accumulation_error_as_fraction_of_the_2^-18_budget"] = {"max": float(ratio.max()),
+    STATS["mfma_accumulation_error_as_fraction_of_the_10_kappa_u_budget"] = {"max": float(ratio.max()),
                                                                           "by_kind": [float(ratio[k::4].max()) for k in range(4)]}
 
 
