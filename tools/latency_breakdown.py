@@ -29,6 +29,7 @@ def bench(name, clouds, inputs, **cfg):
             for k, v in eng.stage_ms().items():
                 acc[k] = acc.get(k, 0) + v / 30
     ev = sum(o["n_evals"] for o in out)
+    print("   tiers:", eng.last_counts(), eng.last_exact_tiers(), "screened" if eng.last_counts().get("n_refined", 0) or False else "")
     print("%-28s wall median %.3f ms  min %.3f ms  evals %d  (%.2e evals/s)  gpu stages: %s  sum %.3f" %
           (name, 1e3 * np.median(ts), 1e3 * min(ts), ev, ev / np.median(ts),
            " ".join("%s=%.3f" % (k, v) for k, v in acc.items()), sum(acc.values())))
