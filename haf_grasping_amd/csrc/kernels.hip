@@ -1393,7 +1393,7 @@ __device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2
     const double d_max = dn * sp.v_max + (un + dn) * sp.dv_max;
     // fp32 accumulation inside the matrix core: ten accumulating instructions per element, each off by at most kappa u of its
     // |c| + sum|products| <= |t_n| + |u||w^_n| (the chain starts at t_n; kappa: the measured property of screen.hip's
-    // probe_mfma_rounding() with its margin, 8 on the devices seen so far: sp.acc_rel = 80 u)
+    // probe_mfma_rounding() with its margin, 8.2 on the devices seen so far: sp.acc_rel = 82 u)
     const double acc = sp.acc_rel * (un * sp.v_max + sp.as_max);
     // D = | log2 of (the factor the kernel applies / 2^(-|u|^2/2)) |: a_x from the fp32 sums and u' instead of u, its cast to
     // fp32, v_exp_f32 and the two products (3 * 2^-23 relative = 5.2e-7 in the exponent)

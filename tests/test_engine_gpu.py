@@ -1205,7 +1205,7 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption(data_dir, sur
     that starts from C by at most 10 kappa 2^-24 (|C| + sum |a_k b_k|).  The products are exact in fp32; how the matrix core adds
     them is not documented.  Round 3: kappa is MEASURED at haf_create on the device the engine runs on (screen.hip:
     probe_mfma_rounding, adversarial families) and used with a margin, kappa = max(8, 1.5 x measured).  Evidence, not proof:
-    (1) what the engine measured here (5.3 on the devices seen so far) and what it uses; (2) the chain of k_svm_screen (same
+    (1) what the engine measured here (5.5 on the devices seen so far) and what it uses; (2) the chain of k_svm_screen (same
     builtin, same operand layout, same start-value mechanism) on 2 048 trials x 256 outputs of operands made to hurt --
     magnitudes over the whole fp16 range the operands can take, signs arranged for near-total cancellation, start values like
     t_n -- against an fp64 evaluation.  The worst observed error is reported as a fraction of the budget."""
