@@ -238,7 +238,7 @@ enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAG
 // digit-by-digit products of a 384-long dot product go through v_mfma_i32_16x16x64_i8 and are EXACT in int32 (<= 4 x 384 x 4096 per
 // accumulator, one accumulator per digit weight), so |xq - sq|^2 of the quantised vectors is exact and the only error of a kernel
 // value is the quantisation: |d - dq| <= sqrt(324) (2^-(kI8Q+1) + 2^-(q_s+1)), i.e. ~2e-7 relative instead of 5.6e-6.  An evaluation still
-// inside that (16x narrower) band goes on to the fp64 MFMA tier as before.
+// inside that (9x narrower) band goes on to the fp64 MFMA tier as before.
 // (The range: svm-scale does not clamp, and a SHAF attribute of -1 against a range [0, 0.30] scales to -7.64: the attributes of
 // real windows reach +-7.7, so 23 fractional bits -- +-15.87 -- it is; an evaluation or a model beyond that skips the tier.)
 constexpr int kI8Q = 23;                          // fractional bits of the attributes: |value| <= 63 * (2^21 + 2^14 + 2^7 + 1) * 2^-23 = 15.87

@@ -599,7 +599,7 @@ def test_model_is_classified_at_creation(data_dir, surrogate, orc, monkeypatch, 
 def test_exact_integer_tier(data_dir, surrogate, orc, monkeypatch, tmp_path):
     """Round 3, tier 2a (csrc/exact8.hip): attributes and support vectors as fixed-point numbers in four int8 digit planes, the dot
     products EXACT in int32 on the matrix cores.  (1) Every evaluation forced through it (HAF_GUARD_REL wide open): labels, votes
-    and grasp are the oracle's, its decision values are within its own band -- ~4e-7 S, sixteen times inside the three-pass
+    and grasp are the oracle's, its decision values are within its own band -- ~2e-7 S, nine times inside the three-pass
     kernel's -- of the oracle's, and only what lies inside that band goes on to the fp64 tier; (2) with its band forced wide
     open everything goes on, same labels; (3) a model with a support-vector component beyond the fixed-point range (|s| >= 15.87)
     is served without the tier."""

@@ -1,5 +1,11 @@
-import sys, ctypes as C
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Operand layout of v_mfma_i32_16x16x64_i8, checked with exact integer data on the GPU box (testing build: haf_test_i8_mfma):
+python tools/i8_layout_probe.py"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from haf_grasping_amd import capi
 tl = capi.testlib()
