@@ -470,15 +470,17 @@ int probe_f16_subnormal_mfma(hipStream_t s)
 // reaches 5.3 u (u = 2^-24) when two large products cancel over thirty small ones: the terms are aligned to the largest exponent
 // and truncated with a few guard bits.  The guard bands of the fp16 tiers take  |error| <= kappa u scale  per instruction with
 // kappa = max(8, 1.5 x the largest ratio this probe sees) -- on the device and in the process the engine is created in, over the
-// same adversarial families (seeded, 64 trials each: 114 688 sums), so a matrix core that rounds worse than the one the
+// same adversarial families (seeded, 64 trials each: 114 688 sums, and as many of the 16-wide shape of the three-pass kernel's K
+// tail on the first sixteen products of the same data), so a matrix core that rounds worse than the one the
 // constants were chosen on widens the bands by itself.  A measured property with a margin, not a theorem: DESIGN.md 2 says so.
 __global__ __launch_bounds__(64) void k_probe_mfma_rounding(const _Float16 *__restrict__ a, const _Float16 *__restrict__ b,
-                                                            const float *__restrict__ c, float *__restrict__ d)
+                                                            const float *__restrict__ c, float *__restrict__ d, float *__restrict__ d16)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int t = blockIdx.x, l = threadIdx.x, rc = l & 15, kb = l >> 4;
-    a += (size_t)t * 512; b += (size_t)t * 512; c += (size_t)t * 256; d += (size_t)t * 256;
+    a += (size_t)t * 512; b += (size_t)t * 512; c += (size_t)t * 256; d += (size_t)t * 256; d16 += (size_t)t * 256;
     h8 fa, fb;
     for (int j = 0; j < 8; j++) {                    // A[row][k] row-major, B[k][col] row-major
         fa[j] = a[rc * 32 + 8 * kb + j];
@@ -486,8 +488,17 @@ __global__ __launch_bounds__(64) void k_probe_mfma_rounding(const _Float16 *__re
     }
     f4 acc;
     for (int r = 0; r < 4; r++) acc[r] = c[(4 * kb + r) * 16 + rc];
+    const f4 c0 = acc;
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
     for (int r = 0; r < 4; r++) d[(4 * kb + r) * 16 + rc] = acc[r];
+    // the 16-wide shape of the three-pass kernel's K tail on the first sixteen products of the same data: lane holds k = 4 kb + j
+    h4 ga, gb;
+    for (int j = 0; j < 4; j++) {
+        ga[j] = a[rc * 32 + 4 * kb + j];
+        gb[j] = b[(4 * kb + j) * 16 + rc];
+    }
+    const f4 t16 = __builtin_amdgcn_mfma_f32_16x16x16f16(ga, gb, c0, 0, 0, 0);
+    for (int r = 0; r < 4; r++) d16[(4 * kb + r) * 16 + rc] = t16[r];
 }
 
 // returns the largest |d - exact| / (u (|c| + sum|a_k b_k|)) over the families, or a negative number when HIP fails
@@ -495,7 +506,7 @@ double probe_mfma_rounding(hipStream_t s)
 {
     constexpr int kFam = 7, kTrials = 64, T = kFam * kTrials;
     std::vector<_Float16> A((size_t)T * 512), B((size_t)T * 512);
-    std::vector<float> Cm((size_t)T * 256), D((size_t)T * 256);
+    std::vector<float> Cm((size_t)T * 256), D((size_t)T * 256), D16((size_t)T * 256);
     unsigned long long st = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) * (1.0 / 9007199254740992.0); };   // [0, 1)
     auto sgn = [&]() { return rnd() < 0.5 ? -1.0 : 1.0; };
@@ -528,17 +539,19 @@ double probe_mfma_rounding(hipStream_t s)
             }
         }
     _Float16 *da = nullptr, *db = nullptr;
-    float *dc = nullptr, *dd = nullptr;
+    float *dc = nullptr, *dd = nullptr, *dd16 = nullptr;
     bool ok = hipMalloc((void **)&da, A.size() * 2) == hipSuccess && hipMalloc((void **)&db, B.size() * 2) == hipSuccess &&
-              hipMalloc((void **)&dc, Cm.size() * 4) == hipSuccess && hipMalloc((void **)&dd, D.size() * 4) == hipSuccess;
+              hipMalloc((void **)&dc, Cm.size() * 4) == hipSuccess && hipMalloc((void **)&dd, D.size() * 4) == hipSuccess &&
+              hipMalloc((void **)&dd16, D16.size() * 4) == hipSuccess;
     ok = ok && hipMemcpyAsync(da, A.data(), A.size() * 2, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(db, B.data(), B.size() * 2, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(dc, Cm.data(), Cm.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_probe_mfma_rounding, dim3(T), dim3(64), 0, s, da, db, dc, dd);
-        ok = hipMemcpyAsync(D.data(), dd, D.size() * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        hipLaunchKernelGGL(k_probe_mfma_rounding, dim3(T), dim3(64), 0, s, da, db, dc, dd, dd16);
+        ok = hipMemcpyAsync(D.data(), dd, D.size() * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(D16.data(), dd16, D16.size() * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dd); (void)hipFree(dd16);
     if (!ok) return -1.0;
     // the exact sums: products of two fp16 numbers are exact in fp64; 33 of them in long double (64 significant bits) are exact to
     // 2^-58 of the scale, far below the 2^-24 being measured
@@ -552,6 +565,11 @@ double probe_mfma_rounding(hipStream_t s)
                     const double pr = (double)(float)A[(size_t)t * 512 + i * 32 + k] * (double)(float)B[(size_t)t * 512 + k * 16 + j];
                     sum += (long double)pr;
                     scale += std::fabs(pr);
+                    if (k == 15) {                                                    // the 16-wide shape: the first sixteen products
+                        const double e16 = std::fabs((double)((long double)D16[(size_t)t * 256 + i * 16 + j] - sum));
+                        if (!(e16 == e16)) return 1e30;
+                        if (scale > 0.0) worst = std::max(worst, e16 / (5.9604644775390625e-08 * scale));
+                    }
                 }
                 const double err = std::fabs((double)((long double)D[(size_t)t * 256 + i * 16 + j] - sum));
                 if (!(err == err)) return 1e30;                                       // NaN: never trusted

@@ -1121,8 +1121,14 @@ def test_bench_configuration_against_the_oracle_where_screening_was_closest(data
         close += [(roll, int(ii[k]), int(jj[k]), float(mg[ii[k], jj[k]])) for k in order]
         hi, hj = np.nonzero(ok & (mg == 0))
         if len(hi):
-            order = np.argsort(np.abs(dec[hi, hj]))[:10]
-            handed += [(roll, int(hi[k]), int(hj[k]), 0.0) for k in order]
+            by_abs = np.argsort(np.abs(dec[hi, hj]))
+            # the ten closest to zero (decided by the exact tiers), and five each around the 12th, 16th and 25th percentile of |dec|
+            # among the handed-on cells: where the three-pass tier's band ends (it passes on ~15 %), its closest calls
+            order = list(by_abs[:10])
+            for q in (0.12, 0.16, 0.25):
+                k0 = int(q * len(by_abs))
+                order += list(by_abs[k0:k0 + 5])
+            handed += [(roll, int(hi[k]), int(hj[k]), 0.0) for k in dict.fromkeys(order)]
         pick = rng.choice(len(ii), 8, replace=False)
         rnd += [(roll, int(ii[k]), int(jj[k]), float(mg[ii[k], jj[k]])) for k in pick]
     assert n_decided == cnt["n_evals"] - cnt["n_refined"]
