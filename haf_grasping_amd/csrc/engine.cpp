@@ -299,7 +299,8 @@ struct haf_engine {
     int last_host_resolved = 0;
     bool calibrated = false;        // the screening variant was chosen at creation (calibrate())
     double mfma_kappa = 8.0;        // error of one v_mfma_f32_16x16x32_f16 in units of 2^-24 (|c| + sum|a b|): max(8, 1.5 x probe_mfma_rounding())
-    double mfma_kappa_measured = 0.0;
+    double mfma_kappa16 = 8.0;      // the same for v_mfma_f32_16x16x16f16 (the K tail of the three-pass kernel)
+    double mfma_kappa_measured = 0.0, mfma_kappa16_measured = 0.0;
     bool no_bucket_sort = false;    // set (for good) when a tile of the bucket-sorted binning path overflowed its candidate list
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
@@ -858,8 +859,8 @@ int build_tables(haf_engine *e)
     // PRECISE form of the three-pass kernel (k_svm_rbf_h<true>): every instruction of the main pass starts from zero and is off by
     // at most kappa u of its sum|products| (mfma_kappa: measured at creation, with its margin), 11 VALU adds join the instructions'
     // results (one rounding each, of at most the whole sum|x_i s_i|), one more for the small-pass chain (whose own roundings are
-    // 2^-10 of that): kappa + 12 instead of 324
-    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * (e->mfma_kappa + 12.0) * u + 8.0 * u));
+    // 2^-10 of that): kappa + 12 instead of 324 (kappa: the larger of the two shapes' -- the K tail is a 16-wide instruction)
+    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * (std::max(e->mfma_kappa, e->mfma_kappa16) + 12.0) * u + 8.0 * u));
     // coefficient sum: sequential over the tiles (fp32 kernel: one fma per tile and sum register) or two-level (split-fp16
     // kernel: an inner sum takes the 2 column blocks of 8 tiles, 16 fmas, then one add per 8 tiles); +2 for the class split
     // (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product.  All terms of a class sum have
@@ -1214,22 +1215,25 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         // the guard bands of the fp16 tiers carry the rounding of the matrix core as a MEASURED constant (screen.hip:
         // probe_mfma_rounding): once per device and process
         static std::mutex kappa_mutex;
-        static double kappa_of[64];                   // 0: not yet
-        double meas;
+        static double kappa_of[64], kappa16_of[64];   // 0: not yet
+        double meas, meas16 = 0.0;
         {
             std::lock_guard<std::mutex> lock(kappa_mutex);
             const int slot = cfg->device & 63;
             if (cfg->device >= 64 || kappa_of[slot] == 0.0) {
-                meas = probe_mfma_rounding(e->stream);
-                if (cfg->device < 64 && meas > 0.0) kappa_of[slot] = meas;
+                meas = probe_mfma_rounding(e->stream, &meas16);
+                if (cfg->device < 64 && meas > 0.0) { kappa_of[slot] = meas; kappa16_of[slot] = meas16; }
             } else {
                 meas = kappa_of[slot];
+                meas16 = kappa16_of[slot];
             }
         }
-        if (!(meas > 0.0)) { e->error = "matrix-core rounding probe failed to run"; return bail(HAF_E_DEVICE); }
+        if (!(meas > 0.0) || !(meas16 > 0.0)) { e->error = "matrix-core rounding probe failed to run"; return bail(HAF_E_DEVICE); }
         e->mfma_kappa_measured = meas;
+        e->mfma_kappa16_measured = meas16;
         e->mfma_kappa = std::max(8.0, 1.5 * meas);
-        if (!(e->mfma_kappa < 64.0)) { e->error = "this device's fp16 MFMA rounds far worse than the guard bands allow for (probe_mfma_rounding)"; return bail(HAF_E_DEVICE); }
+        e->mfma_kappa16 = std::max(8.0, 1.5 * meas16);
+        if (!(e->mfma_kappa < 64.0) || !(e->mfma_kappa16 < 64.0)) { e->error = "this device's fp16 MFMA rounds far worse than the guard bands allow for (probe_mfma_rounding)"; return bail(HAF_E_DEVICE); }
     }
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
@@ -2286,10 +2290,11 @@ int haf_test_i8_mfma(const signed char *a, const signed char *b, int *c)
 }
 
 // the engine's matrix-core rounding constant: what the probe measured and what the bands use
-int haf_test_mfma_kappa(haf_engine *e, double *measured, double *used)
+int haf_test_mfma_kappa(haf_engine *e, double *measured, double *used)      // [0]: 16x16x32, [1]: 16x16x16
 {
     if (!e) return HAF_E_ARG;
-    *measured = e->mfma_kappa_measured; *used = e->mfma_kappa;
+    measured[0] = e->mfma_kappa_measured; used[0] = e->mfma_kappa;
+    measured[1] = e->mfma_kappa16_measured; used[1] = e->mfma_kappa16;
     return HAF_OK;
 }
 

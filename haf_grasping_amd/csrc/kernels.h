@@ -312,7 +312,7 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
                      const int *idx_list, int list_counter, int list_cap, bool large, long sel_evals, AttrRecord *dbg,
                      float *ax2, hipStream_t s,    // ax2: screening form only, -|u|^2/2 per evaluation
                      int list_off = 0);            // list mode: idx_list points at entry list_off of the list counted by list_counter
-double probe_mfma_rounding(hipStream_t s);  // largest error of one v_mfma_f32_16x16x32_f16 in units of 2^-24 (|c| + sum|a b|) over adversarial inputs; < 0: HIP error
+double probe_mfma_rounding(hipStream_t s, double *worst16);  // largest error of one v_mfma_f32_16x16x32_f16 (*worst16: 16x16x16f16) in units of 2^-24 (|c| + sum|a b|) over adversarial inputs; < 0: HIP error
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,

@@ -501,8 +501,9 @@ __global__ __launch_bounds__(64) void k_probe_mfma_rounding(const _Float16 *__re
     for (int r = 0; r < 4; r++) d16[(4 * kb + r) * 16 + rc] = t16[r];
 }
 
-// returns the largest |d - exact| / (u (|c| + sum|a_k b_k|)) over the families, or a negative number when HIP fails
-double probe_mfma_rounding(hipStream_t s)
+// returns the largest |d - exact| / (u (|c| + sum|a_k b_k|)) over the families for the 32-wide shape (the screening kernel's only one)
+// and, in *worst16, for the 16-wide shape; a negative number when HIP fails
+double probe_mfma_rounding(hipStream_t s, double *worst16)
 {
     constexpr int kFam = 7, kTrials = 64, T = kFam * kTrials;
     std::vector<_Float16> A((size_t)T * 512), B((size_t)T * 512);
@@ -555,7 +556,7 @@ double probe_mfma_rounding(hipStream_t s)
     if (!ok) return -1.0;
     // the exact sums: products of two fp16 numbers are exact in fp64; 33 of them in long double (64 significant bits) are exact to
     // 2^-58 of the scale, far below the 2^-24 being measured
-    double worst = 0.0;
+    double worst = 0.0, w16 = 0.0;
     for (int t = 0; t < T; t++)
         for (int i = 0; i < 16; i++)
             for (int j = 0; j < 16; j++) {
@@ -568,13 +569,14 @@ double probe_mfma_rounding(hipStream_t s)
                     if (k == 15) {                                                    // the 16-wide shape: the first sixteen products
                         const double e16 = std::fabs((double)((long double)D16[(size_t)t * 256 + i * 16 + j] - sum));
                         if (!(e16 == e16)) return 1e30;
-                        if (scale > 0.0) worst = std::max(worst, e16 / (5.9604644775390625e-08 * scale));
+                        if (scale > 0.0) w16 = std::max(w16, e16 / (5.9604644775390625e-08 * scale));
                     }
                 }
                 const double err = std::fabs((double)((long double)D[(size_t)t * 256 + i * 16 + j] - sum));
                 if (!(err == err)) return 1e30;                                       // NaN: never trusted
                 if (scale > 0.0) worst = std::max(worst, err / (5.9604644775390625e-08 * scale));
             }
+    *worst16 = w16;
     return worst;
 }
 

@@ -1218,13 +1218,14 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption(data_dir, sur
     L = capi.testlib()
     import ctypes as C
     eng = make_engine(data_dir, surrogate, 0, testing=True)
-    meas, used = C.c_double(0), C.c_double(0)
+    meas, used = (C.c_double * 2)(), (C.c_double * 2)()          # [0]: 16x16x32 (the screening kernel's shape), [1]: 16x16x16 (K tail of tier 1)
     L.haf_test_mfma_kappa.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    assert L.haf_test_mfma_kappa(eng._h, C.byref(meas), C.byref(used)) == 0
+    assert L.haf_test_mfma_kappa(eng._h, meas, used) == 0
     eng.close()
-    assert 0.5 <= meas.value <= 8.0 and used.value == max(8.0, 1.5 * meas.value), (meas.value, used.value)
-    budget = 10.0 * used.value * 2.0 ** -24
-    STATS["mfma_rounding_kappa"] = {"measured": meas.value, "used": used.value}
+    for k in range(2):
+        assert 0.5 <= meas[k] <= 8.0 and used[k] == max(8.0, 1.5 * meas[k]), (k, meas[k], used[k])
+    budget = 10.0 * used[0] * 2.0 ** -24
+    STATS["mfma_rounding_kappa"] = {"measured_32": meas[0], "used_32": used[0], "measured_16": meas[1], "used_16": used[1]}
     rng = np.random.RandomState(77)
     trials = 2048
     a = np.zeros((trials, 16, 320), np.float16)
