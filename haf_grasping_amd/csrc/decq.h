@@ -323,6 +323,10 @@ HAF_HD double decq4_float_scr(float v, const ScrTabs &st)
     const float a = __builtin_bit_cast(float, bits & 0x7fffffffu);
     const float thr = __builtin_bit_cast(float, (unsigned)ent);
     const int s = (int)(ent >> 32) - ((a >= thr) ? 1 : 0);
+#if defined(HAF_ABL) && HAF_ABL == 5                   // timing experiment: an 8-byte pair entry (two floats) instead of 16 bytes
+    const float *pf = reinterpret_cast<const float *>(st.w + kScrExpEntries + s);
+    return rint((double)v * (double)pf[0]) * (double)pf[1];
+#endif
     const double *pr = reinterpret_cast<const double *>(st.w + kScrExpEntries) + 2 * s;
     return rint((double)v * pr[0]) * pr[1];          // round-half-even is symmetric: the sign (of a zero too) rides along
 }
