@@ -267,6 +267,21 @@ def latency_small(feat, rng_file, device, flags):
              "table1_mult_obj_rcs_1428580506606673.pcd",
              capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)), n_rolls=20, roll_step_deg=9)
     c2["c3"] = c3
+    # C4: the eight pcd files as ONE batched call (haf_score_batch), 20 rolls of 9 degrees each: what a server that collects goals pays per cloud
+    clouds = [capi.load_pcd(os.path.join(data, "pcd%d.pcd" % i)) for i in range(1, 9)]
+    inputs = [capi.default_input() for _ in clouds]
+    eng = capi.Engine(feat, rng_file, model, device=device, flags=flags, max_clouds=len(clouds), max_points=1 << 18, n_rolls=20, roll_step_deg=9)
+    for _ in range(3):
+        outs = eng.score_batch(clouds, inputs)
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        outs = eng.score_batch(clouds, inputs)
+        ts.append(time.perf_counter() - t0)
+    eng.close()
+    c2["c4"] = dict(workload="C4: pcd1..pcd8 (%d pts) in one batched call, 32x44 cm, 20 rolls x 9 deg, surrogate model nSV=172, host clouds (PCIe included)"
+                    % sum(c.shape[0] for c in clouds), ms_median=1e3 * float(np.median(ts)), ms_min=1e3 * float(np.min(ts)),
+                    ms_per_cloud=1e3 * float(np.median(ts)) / len(clouds), evals=int(sum(o["n_evals"] for o in outs)), evals_best=[int(o["eval"]) for o in outs])
     return c2
 
 

@@ -13,7 +13,7 @@ for s in d["seeds"]["per_seed"]:
                                                              s.get("fp64_mfma_tier", 0), s["kernel_ms"], s["refine_ms"], s["recheck_ms"]))
 print("worst/median", round(d["seeds"]["worst_over_median_ms"], 3))
 g = d["grasp_latency"]
-print("C2 %.3f ms  C3 %.3f ms" % (g["ms_median"], g["c3"]["ms_median"]))
+print("C2 %.3f ms  C3 %.3f ms" % (g["ms_median"], g["c3"]["ms_median"]) + ("  C4 %.3f ms (%.3f per cloud)" % (g["c4"]["ms_median"], g["c4"]["ms_per_cloud"]) if "c4" in g else ""))
 h = d["hard_model"]
 print("hard_model %.3e (%.2f ms, refined %.2f %%)" % (h["value"], h["ms_per_step"], 100 * h["refined_share"]))
 for k in ("f16x3_mode", "f32_mode"):
