@@ -1487,6 +1487,13 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     // launches instead of a feature kernel, a contraction kernel and the rechecks behind them.
     const bool direct = !e->prob_mode && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= e->direct_work;
     const bool short_request = evals_sel * (long)e->n_sv_pad <= (1L << 26) && total_n <= (1L << 20);
+    // A small engine with a small model behind one of the fast contractions: what that contraction flags goes through the SAME one-launch
+    // kernel in list mode (exact attributes + fp64 MFMA decision, tier 2's arithmetic) instead of tier 2a's three launches and tier 2's
+    // three -- at a few thousand evaluations x a few hundred SVs the six launches and two more attribute kernels cost more than the
+    // exact work (C3: 81 -> 30 us; the kernel costs ~9 ns per listed evaluation at 192 SVs, so it wins up to ~8 000 of them: a request
+    // of up to 2^25 evaluation x SV pairs, of which a trained model flags around a tenth).  Decided from the request's search areas and
+    // the model's size, so identical calls take identical paths.
+    const bool small_exact = !direct && !e->prob_mode && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= 16 * e->direct_work;
     // small grids: a1 (tail) + a2 + a3 + a4 in ONE launch (k_small_pre); the probability branch needs k_scan's row-major order
     bool fused_pre = false;
     mark(e, HAF_ST_BIN);
@@ -1562,9 +1569,12 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         // strict tier is launched only when the counters that come back with the roll records say it has work (never so far).
         // tier 2a in front of it (exact8.hip): the same evaluations on EXACT integer dot products (int8 digit planes); what it
         // cannot decide either -- |dec| inside the operands' quantisation, ~1e-7 S -- is the fp64 MFMA tier's list
-        const bool i8 = e->i8_active && !direct;
+        const bool i8 = e->i8_active && !direct && !small_exact;
         auto fp64_window = [&](int off) {
-            if (i8)
+            if (small_exact)
+                launch_small_direct(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_sv64.p, e->exact, d, e->flag_cap, e->d_dec_exact.p,
+                                    e->d_labels.p, e->d_flag2_list.p, e->list_cap, nullptr, s, e->d_flag_list.p, CNT_FLAGGED, off);
+            else if (i8)
                 launch_recheck_mfma(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->exact, e->d_flagi_list.p, e->flag_cap, off, e->d_counters.p,
                                     e->d_x64.p, e->d_part64.p, e->d_dec_exacti.p, e->d_labels.p, e->d_flag2_list.p, e->list_cap, d, s, nullptr, false,
                                     CNT_FLAGGEDI);
@@ -1709,7 +1719,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
-    e->last_flaggedi = (e->i8_active && !direct) ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
+    e->last_flaggedi = (e->i8_active && !direct && !small_exact) ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
     e->last_inexact = inexact_grids;
     e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->last_flagged0 <= e->flag0_cap;
     // zero the counters for the next request now, behind this one's copy-out: off that request's critical path
@@ -1717,7 +1727,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
     if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap || e->last_flaggedi > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
-    e->last_i8 = e->i8_active && !direct;
+    e->last_i8 = e->i8_active && !direct && !small_exact;
     for (int i = 0; i < B * R; i++) {
         records[i].vote = e->h_rec[i].vote;
         records[i].row = e->h_rec[i].row;

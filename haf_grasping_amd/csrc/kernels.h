@@ -326,7 +326,8 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
                   hipStream_t s);
 // tiny requests: exact attributes + fp64 MFMA decision + label in one launch (tier 2's arithmetic for every evaluation)
 void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,
-                         long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s);
+                         long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s,
+                         const int *idx_list = nullptr, int list_counter = 0, int list_off = 0);   // list mode: window [list_off, list_off + max_evals) of idx_list
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);

@@ -1909,22 +1909,27 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
                                                                 const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
                                                                 ExactParams p, Dims d, double *__restrict__ dec_exact,
                                                                 int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap,
-                                                                int *counters, AttrRecord *__restrict__ dbg)
+                                                                int *counters, AttrRecord *__restrict__ dbg,
+                                                                const int *__restrict__ idx_list, int list_counter, int list_cap, int list_off)
 {
+    // (list mode, idx_list != nullptr: the window [list_off, list_off + list_cap) of a tier's list instead of every evaluation --
+    // the exact stage of a SMALL request behind the three-pass kernel in one launch; slot j holds evaluation idx_list[j], its
+    // decision value goes to dec_exact[j]; idx_list and dec_exact already point at entry list_off)
     __shared__ double s_x[kKP * 16];                  // [attribute][evaluation]: the A operand of the fp64 MFMA, k-major
     __shared__ double s_part[kSmWaves][16][2];        // per wave: sum coef*K and sum |coef|*K of its SV tiles, per evaluation
     __shared__ double s_xx[16];
     __shared__ float s_win[kSmEvals * kWinPitch];
     __shared__ unsigned s_w0[kSmEvals];
     __shared__ double s_tab[hafq::kTabDoubles];
-    const int n_evals = counters[CNT_EVALS];
+    const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     if ((long)blockIdx.x * kSmEvals >= n_evals) return;
     const hafq::PtrTabs tb = load_decimal_tables(s_tab);
     const int ev = threadIdx.x & 15, slot = threadIdx.x >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long e = (long)blockIdx.x * kSmEvals + ev;
     const bool live = e < n_evals;
+    const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;    // the evaluation this slot holds
     const rsrc_t iir = make_ii_rsrc(ii, d);
-    if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e], d.H, d.W) : 0xffffffffu;
+    if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e_src], d.H, d.W) : 0xffffffffu;
     __syncthreads();
     for (int idx = threadIdx.x; idx < kSmEvals * 15 * 16; idx += kSmWaves * 64) {
         const int col = idx & 15, seg = idx >> 4, wev = seg & (kSmEvals - 1), x = seg >> 4;       // 16 lanes = one window row
@@ -1941,7 +1946,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
         for (int q = 0; q < 8; q++) {
             const int f = g * 8 + q;
             double xd = 0.0;
-            if (live && f < d.nf) xd = attribute_value_rec(src, fd[f], p.lower, p.upper, tb, dbg ? dbg + (size_t)e * kKP + f : nullptr);
+            if (live && f < d.nf) xd = attribute_value_rec(src, fd[f], p.lower, p.upper, tb, dbg ? dbg + (size_t)e_src * kKP + f : nullptr);
             if (f < kKP) s_x[f * 16 + ev] = xd;
         }
     }
@@ -1990,22 +1995,24 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
         for (int w = 0; w < kSmWaves; w++) { P += s_part[w][threadIdx.x][0]; S += s_part[w][threadIdx.x][1]; }   // fixed order
         const double dv = P - p.rho;
         dec_exact[e] = dv;
-        labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+        labels[evalcell[e_src]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
         const double T = p.as_max1 + p.gamma2 * s_xx[threadIdx.x];
         if (!(fabs(dv) > p.guard2 * T * S)) {
             const int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
-            if (s2 < flag2_cap) flag2_list[s2] = (int)e;
+            if (s2 < flag2_cap) flag2_list[s2] = e_src;
         }
     }
 }
 
 void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,
-                         long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s)
+                         long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s,
+                         const int *idx_list, int list_counter, int list_off)
 {
     const long nb = (max_evals + kSmEvals - 1) / kSmEvals;
     if (nb <= 0) return;
+    if (idx_list) { idx_list += list_off; dec_exact += list_off; }
     hipLaunchKernelGGL(k_small_direct, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, fd, sv64, p, d, dec_exact, labels,
-                       flag2_list, flag2_cap, counters, dbg);
+                       flag2_list, flag2_cap, counters, dbg, idx_list, list_counter, (int)max_evals, list_off);
 }
 
 template <int MODE>

@@ -183,7 +183,8 @@ def test_c1_c2_pcd2_stage_by_stage(data_dir, surrogate, orc, mode):
 @pytest.mark.parametrize("knobs", [(), ("HAF_NO_DIRECT",), ("HAF_NO_FUSED_PRE",), ("HAF_NO_DIRECT", "HAF_NO_FUSED_PRE")])
 def test_small_request_paths_agree_with_the_oracle(data_dir, surrogate, orc, monkeypatch, knobs):
     """Round 3: a request on a grid that fits LDS runs its pre-stages in ONE launch (k_small_pre), and a request whose whole SVM
-    work is tiny goes straight to the fp64 MFMA tier.  Both shortcuts, either one, and neither (the separate kernels, the fast
+    work is tiny goes straight to the fp64 MFMA tier (a somewhat larger one sends what its three-pass kernel flags through the same
+    kernel in list mode).  Both shortcuts, either one, and neither (the separate kernels, the fast
     tiers) must give the oracle's grids, labels and grasp: C1, C2, a tilted approach vector, the client's default area, a large
     cloud on the small grid (k_bin_lds feeds the fused kernel), an empty and a one-point cloud."""
     for k in knobs:
@@ -201,6 +202,14 @@ def test_small_request_paths_agree_with_the_oracle(data_dir, surrogate, orc, mon
     compare_full(eng, orc, xyz, dict(n_rolls=12), dict())                                       # the client's default 32 x 44 area
     big = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
     compare_full(eng, orc, big, dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)))
+    # the exact stage of such a request (too large for the direct path, small enough that launches count): what the three-pass
+    # kernel flags goes through ONE launch of the direct kernel in list mode -- or, with that switched off, tier 2a and the fp64 tier
+    cnt, ex = eng.last_counts(), eng.last_exact_tiers()
+    assert 0 < cnt["n_rechecked"] < cnt["n_evals"]
+    if "HAF_NO_DIRECT" in knobs:
+        assert ex["n_integer"] == cnt["n_rechecked"] and ex["n_fp64"] < ex["n_integer"]
+    else:
+        assert ex["n_integer"] == 0 and ex["n_fp64"] == cnt["n_rechecked"]
     compare_full(eng, orc, np.zeros((0, 3), np.float32), dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))
     compare_full(eng, orc, np.array([[0.0, 0.0, 0.05]], np.float32), dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=32))
     eng.close()
