@@ -855,14 +855,15 @@ def test_screening_pass_alone_is_accurate_and_stable(data_dir, surrogate, orc, m
     eng.close()
 
 
-@pytest.mark.parametrize("nsv,modes", [(512, (capi.FLAG_SPLIT_F16, 0, capi.FLAG_FP32_MFMA)), (4096, (capi.FLAG_SPLIT_F16, 0))])
-def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path, nsv, modes):
+@pytest.mark.parametrize("nsv,modes,seed", [(512, (capi.FLAG_SPLIT_F16, 0, capi.FLAG_FP32_MFMA), 7), (4096, (capi.FLAG_SPLIT_F16, 0), 7),
+                                            (4096, (capi.FLAG_SPLIT_F16, 0), 11)])
+def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path, nsv, modes, seed):
     """All three contraction modes claim libsvm's labels (each tier decides only outside a rigorous error band).  At BASELINE
     config C5 (7.9 M evaluations) the label grids of the screening mode, the three-pass mode and the fp32 mode must be
     identical cell for cell, for a model whose decision values crowd around zero -- a hole in a band would show up here as
     a handful of differing cells out of millions."""
     path = str(tmp_path / ("rand%d.model" % nsv))
-    models.write_random_model(path, nsv, seed=7, balanced=True)
+    models.write_random_model(path, nsv, seed=seed, balanced=True)        # (seed 11: the hardest of bench.py's five)
     xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
     inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
     ref_labels, ref_rec, counts = None, None, {}
@@ -879,7 +880,7 @@ def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path,
             assert int((labels != ref_labels).sum()) == 0, (mode, int((labels != ref_labels).sum()))
             assert (rec == ref_rec).all(), mode
     assert 0 < counts[0]["n_refined"] < 0.2 * counts[0]["n_evals"]          # the screening pass was really in charge
-    STATS["c5_nsv%d_tiers" % nsv] = {str(k): v for k, v in counts.items()}
+    STATS["c5_nsv%d_seed%d_tiers" % (nsv, seed)] = {str(k): v for k, v in counts.items()}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
