@@ -881,8 +881,10 @@ int build_tables(haf_engine *e)
     // (plain variant: two levels -- a term passes through at most 16 fmas of the lower level, one fold, and the folds of its
     // sweep, <= tiles/8 + 1; then the final fma and add, the 4-step lane reduction, the class split, exp2 + product, the two
     // products with the common factor.  SUMSQ variant: one level, 2 fmas per tile.)
-    e->svm.guard_acc0 = (float)(guard0_scale * ((16.0 + 1.0 + (e->n_sv_tiles / 8.0 + 1.0) + 2.0 + 4.0 + 2.0 + 6.0 + 2.0) * u));
-    e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * e->n_sv_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
+    // (a sweep covers the tiles of ONE class -- the kernel restarts its sums at the class boundary -- so "tiles" is the larger class's)
+    const double sweep_tiles = (double)std::max(e->sv_tile_neg, e->n_sv_tiles - e->sv_tile_neg);
+    e->svm.guard_acc0 = (float)(guard0_scale * ((16.0 + 1.0 + (sweep_tiles / 8.0 + 1.0) + 2.0 + 4.0 + 2.0 + 6.0 + 2.0) * u));
+    e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * sweep_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
