@@ -1795,6 +1795,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     if (MODE == XMODE_I8 && n_evals > kI8SmallList) return;
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kSmEvals >= n_pad) return;
+    // (list mode is launched for the list's CAPACITY -- at C5 123 k workgroups for a list of a few hundred entries, 90 us of empty
+    // workgroups -- so its grid is capped and the workgroups stride over the blocks of 16 evaluations)
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
     __shared__ unsigned long long s_scr[MODE == XMODE_SCREEN ? hafq::kScrTabWords : 1];
     hafq::PtrTabs tb{};
@@ -1802,7 +1804,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
     else tb = load_decimal_tables(s_tab);
     const int ev = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const long e = (long)blockIdx.x * kSmEvals + ev;
+    for (long blk = blockIdx.x; blk * kSmEvals < n_pad; blk += gridDim.x) {
+    const long e = blk * kSmEvals + ev;
     const long tile = e >> 5;
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
@@ -1893,6 +1896,8 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
         } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
         }
+    }
+    __syncthreads();                                                   // the next block reuses s_w0, s_win and the reduction arrays
     }
 }
 
@@ -2045,7 +2050,8 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
     // small requests -- and every list of the fp64 tier, which is short unless the model is ill-conditioned: a third of the
     // serial chain per thread (C3's ~8 000 flagged evaluations: 27 us against 56 us with the 64-evaluation workgroups)
     if ((!idx_list && sel_evals <= kSmallEvals) || (idx_list && MODE == XMODE_F64)) {
-        const long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
+        long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
+        if (idx_list && nb > 2048) nb = 2048;                          // grid-stride inside the kernel
         hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
                            lower, upper, neg_gamma2, sp, dbg, ax2, idx_list, list_counter, list_cap, list_off);
         return;
