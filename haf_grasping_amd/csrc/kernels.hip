@@ -2797,6 +2797,19 @@ constexpr int kMSteps = kKP / 4;                 // 81 k-steps of 4
 constexpr int kMTileDoubles = kM64Rows * 16;     // 5216 doubles = 41728 B
 constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per thread per tile (11)
 
+// How many ranges of SV tiles a group of 64 evaluations is split over, and the row pitch of part64: kMSplit ranges and one row per
+// list slot of the window -- or, when the list fills at most a quarter of the window (the rule at C5: a few thousand entries of a
+// window of two million), FOUR times as many ranges on a quarter of the pitch (65 rows x flag_cap / 4 fit the 17 x flag_cap doubles
+// of the buffer): a task's chain of dependent MFMAs and tile hand-overs is a quarter as long and four times as many CUs have one,
+// which is what a short list needs (C5, 1 574 entries: 118 -> ~40 us).  Both kernels of the tier derive the same numbers from the
+// same counter, so the partial sums are added in a fixed order for a given list length.
+__device__ __forceinline__ void recheck_split(int n_flag, int flag_cap, int n_tiles, int &splits, size_t &pitch)
+{
+    const bool fine = (long)n_flag * 4 <= (long)flag_cap && n_tiles >= 16 * kMSplit && flag_cap >= 4;
+    splits = fine ? 4 * kMSplit : kMSplit;
+    pitch = fine ? (size_t)(flag_cap / 4) : (size_t)flag_cap;
+}
+
 // The fp64 attribute image of the flagged evaluations -- [group of 16][324][16] doubles, the register image of the fp64 MFMA A
 // operand (64 consecutive doubles per k-step) -- is written by the feature kernels in their XMODE_F64 form (list mode, windows
 // staged in LDS).  Round 2 had a kernel of its own for it (one thread per (evaluation, attribute), per-lane descriptors and
@@ -2820,9 +2833,12 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
     // a task = (group of 64 evaluations, one of kMSplit ranges of SV tiles): a few thousand flagged evaluations would
     // otherwise occupy a fraction of the CUs for the full length of the model; k_recheck_combine adds the partial sums in
     // a fixed order
-    const int tiles_per_part = (n_tiles + kMSplit - 1) / kMSplit;
-    for (int task = blockIdx.x; task < n_groups * kMSplit; task += gridDim.x) {
-        const int g = task / kMSplit, h = task - g * kMSplit;
+    int splits;
+    size_t pitch;
+    recheck_split(n_flag, flag_cap, n_tiles, splits, pitch);
+    const int tiles_per_part = (n_tiles + splits - 1) / splits;
+    for (int task = blockIdx.x; task < n_groups * splits; task += gridDim.x) {
+        const int g = task / splits, h = task - g * splits;
         const int t_begin = h * tiles_per_part, t_end = min(n_tiles, t_begin + tiles_per_part);
         // ---- A operand: lane holds x[eval lane&15][k = 4s + (lane>>4)], s = 0..80, from the XMODE_F64 image ----
         const int grp = g * kMWaves + wave;                          // 16 flagged evaluations
@@ -2900,9 +2916,9 @@ __global__ __launch_bounds__(256) void k_recheck_mfma(const double *__restrict__
                 const int row = (lane >> 4) + 4 * r;
                 const int sl = g * kMEvals + wave * 16 + row;
                 if (sl < n_flag) {
-                    part64[(size_t)(2 * h) * flag_cap + sl] = part[r];
-                    part64[(size_t)(2 * h + 1) * flag_cap + sl] = pabs[r];
-                    if (h == 0) part64[(size_t)(2 * kMSplit) * flag_cap + sl] = xxs[wave][row];
+                    part64[(size_t)(2 * h) * pitch + sl] = part[r];
+                    part64[(size_t)(2 * h + 1) * pitch + sl] = pabs[r];
+                    if (h == 0) part64[(size_t)(2 * splits) * pitch + sl] = xxs[wave][row];
                 }
             }
         }
@@ -2919,18 +2935,20 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
                                                          int cslot)
 {
     const int n_flag = window_count(counters[cslot], list_off, flag_cap);
+    int splits;
+    size_t pitch;
+    recheck_split(n_flag, flag_cap, p.n_sv_pad / 16, splits, pitch);
     for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
         double P = 0.0, S = 0.0;
-#pragma unroll
-        for (int h = 0; h < kMSplit; h++) {
-            P += part64[(size_t)(2 * h) * flag_cap + sl];
-            S += part64[(size_t)(2 * h + 1) * flag_cap + sl];
+        for (int h = 0; h < splits; h++) {
+            P += part64[(size_t)(2 * h) * pitch + sl];
+            S += part64[(size_t)(2 * h + 1) * pitch + sl];
         }
         const double dv = P - p.rho;
         dec_exact[sl] = dv;
         const int e = flag_list[sl];
         labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
-        const double T = p.as_max1 + p.gamma2 * part64[(size_t)(2 * kMSplit) * flag_cap + sl];
+        const double T = p.as_max1 + p.gamma2 * part64[(size_t)(2 * splits) * pitch + sl];
         if (!(fabs(dv) > p.guard2 * T * S)) {
             int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
             if (s2 < flag2_cap) flag2_list[s2] = e;
@@ -2955,7 +2973,7 @@ void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *f
     if (!have_x64)
         launch_features(ii, evalcell, counters, fd, reinterpret_cast<float *>(x64), nullptr, d, p.lower, p.upper, 0.0f, window_cap, XMODE_F64,
                         ScreenParams{}, flag_list, counter_slot, window_cap, false, window_cap, dbg, nullptr, s, list_off);
-    const long tasks = (long)groups * kMSplit;
+    const long tasks = (long)groups * 4 * kMSplit;                      // (the kernel strides over the tasks the list really has)
     hipLaunchKernelGGL(k_recheck_mfma, dim3((unsigned)(tasks < 4096 ? tasks : 4096)), dim3(256), 0, s, x64, evalcell, sv64, p,
                        flag_list, window_cap, list_off, counters, part64, d, counter_slot);
     hipLaunchKernelGGL(k_recheck_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, window_cap, list_off, counters,
