@@ -2801,11 +2801,13 @@ constexpr int kMLoads = (kMTileDoubles / 2 + 255) / 256;   // 16-byte loads per 
 // list slot of the window -- or, when the list fills at most a quarter of the window (the rule at C5: a few thousand entries of a
 // window of two million), FOUR times as many ranges on a quarter of the pitch (65 rows x flag_cap / 4 fit the 17 x flag_cap doubles
 // of the buffer): a task's chain of dependent MFMAs and tile hand-overs is a quarter as long and four times as many CUs have one,
-// which is what a short list needs (C5, 1 574 entries: 118 -> ~40 us).  Both kernels of the tier derive the same numbers from the
+// which is what a short list needs (C5, 383 entries: 108 -> 35 us).  Both kernels of the tier derive the same numbers from the
 // same counter, so the partial sums are added in a fixed order for a given list length.
 __device__ __forceinline__ void recheck_split(int n_flag, int flag_cap, int n_tiles, int &splits, size_t &pitch)
 {
-    const bool fine = (long)n_flag * 4 <= (long)flag_cap && n_tiles >= 16 * kMSplit && flag_cap >= 4;
+    // (only while the coarse split leaves half of the CUs without a task: from ~1 500 entries on the tier is bound by the fp64 matrix
+    // rate -- 1 574 entries x 4096 SVs are 54 us at its peak -- and finer tasks only reload the A operands: 118 -> 131 us measured)
+    const bool fine = (long)n_flag * 4 <= (long)flag_cap && n_tiles >= 16 * kMSplit && flag_cap >= 4 && n_flag <= 1024;
     splits = fine ? 4 * kMSplit : kMSplit;
     pitch = fine ? (size_t)(flag_cap / 4) : (size_t)flag_cap;
 }
