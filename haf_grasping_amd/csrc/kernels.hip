@@ -1763,7 +1763,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
 // the descriptors come by vector loads (four addresses per wave) and the HAF / SHAF branch may diverge in the one group
 // where both occur.  Same arithmetic, same operand images.
 constexpr int kSmEvals = 16;
-constexpr int kSmWaves = 11;
+constexpr int kSmWaves = 12;
 constexpr int kSmSlots = kSmWaves * 4;                 // quarter waves: >= 42 attribute groups
 constexpr long kSmallEvals = 12288;                    // requests of up to this many evaluations (host estimate) take k_features_small
 
@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __shared__ long long red_ll[(MODE == XMODE_I8) ? kSmSlots : 1][kSmEvals];
     __shared__ int red_ovf[(MODE == XMODE_I8) ? kSmSlots : 1][kSmEvals];
     constexpr int kFinisher = 40;                     // the quarter wave that sums up the partial norms (one without a group of its own in the screening form)
-    static_assert(kSmSlots >= 2 * kHSteps && kFinisher < kSmSlots, "slots cover the groups");
+    static_assert(kSmSlots >= 44 && kSmSlots >= 2 * kHSteps && kFinisher < kSmSlots, "slots cover the groups");
     __shared__ double red[kSmSlots][kSmEvals];
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
     __shared__ double red3[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
@@ -1810,7 +1810,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     const int r = (int)(e & 31);
     float *xcol = X + (size_t)tile * kTileFloats + (e & 31);
     char *xtile = reinterpret_cast<char *>(X) + (size_t)tile * (MODE == XMODE_SCREEN ? kS0MatBytes : kHXTileBytes);
-    const int n_groups = (MODE == XMODE_I8) ? kSmSlots : (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 44 / 41 / 40 / 42
+    const int n_groups = (MODE == XMODE_I8) ? 44 : (MODE == XMODE_F32 || MODE == XMODE_F64) ? (kKP + 7) / 8 : (MODE == XMODE_SCREEN) ? kS0Groups : 2 * kHSteps;   // 44 (i8_store zeroes 44..47 itself) / 41 / 40 / 42
     double *x64 = reinterpret_cast<double *>(X) + (size_t)(e >> 4) * kKP * 16 + (e & 15);      // XMODE_F64: see k_features
     const bool live = e < n_evals;
     const rsrc_t iir = make_ii_rsrc(ii, d);
