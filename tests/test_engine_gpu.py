@@ -263,6 +263,30 @@ def test_table_cloud_live_against_oracle(data_dir, surrogate, orc, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, capi.FLAG_SPLIT_F16])
+def test_identical_calls_give_identical_decision_values(data_dir, surrogate, mode):
+    """The same request six times through one engine (C3: a model the three-pass kernel serves, 6 short SV tiles -- the regime where
+    the LDS-DMA ring of that kernel really waits for its data): every decision value, label and tier counter identical from call
+    to call.  A timing experiment of round 3 (a build whose ONLY difference was the code of other kernels) showed ~4 000 decision
+    values of this request moving by up to 1e-5 S between calls -- inside the band, so no label changed and no parity test saw
+    it; that build was dropped, this test makes the next one like it fail."""
+    xyz = capi.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    eng = make_engine(data_dir, surrogate, mode, n_rolls=20, roll_step_deg=9, max_points=1 << 18)
+    inp = capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0))
+    ref = None
+    for call in range(6):
+        eng.score(xyz, inp)
+        dec = np.stack([eng.debug(capi.DBG_DECISION, 0, r) for r in range(20)])
+        lab = np.stack([eng.debug(capi.DBG_LABELS, 0, r) for r in range(20)])
+        cur = (np.nan_to_num(dec, nan=-1e300), lab, eng.last_counts(), eng.last_exact_tiers())
+        if ref is None:
+            ref = cur
+            continue
+        assert int((cur[0] != ref[0]).sum()) == 0, (call, int((cur[0] != ref[0]).sum()), float(np.abs(cur[0] - ref[0]).max()))
+        assert (cur[1] == ref[1]).all() and cur[2] == ref[2] and cur[3] == ref[3], (call, cur[2], ref[2])
+    eng.close()
+
+
 def test_batch_of_eight_equals_single_and_shards_compose(data_dir, surrogate):
     """C4: pcd1..8 in one batch call == eight single calls; roll shards + haf_finalize == the unsharded call."""
     names = ["pcd%d" % i for i in range(1, 9)]
