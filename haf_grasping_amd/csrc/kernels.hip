@@ -2589,7 +2589,10 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
         }
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
-        if (more) {
+        // (bulk form: ALL of this wave's pieces, those of tile t+2 included -- they have had this tile's whole time to land.  With the
+        // counted wait the bulk form once turned nondeterministic inside its band on a short model, in a build that differed only in
+        // the code of other kernels, and deterministic again with this wait: DESIGN.md 2, "An open observation".)
+        if (more && PRECISE) {
             if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         } else {
