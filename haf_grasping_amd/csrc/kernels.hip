@@ -2589,15 +2589,13 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
         }
         }
         // tile t+1 must have landed before anyone reads it; the pieces of tile t+2 (just issued) may stay in flight
-        // (bulk form: ALL of this wave's pieces, those of tile t+2 included -- they have had this tile's whole time to land.  With the
-        // counted wait the bulk form once turned nondeterministic inside its band on a short model, in a build that differed only in
-        // the code of other kernels, and deterministic again with this wait: DESIGN.md 2, "An open observation".)
-        if (more && PRECISE) {
-            if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // ALL of this wave's pieces, those of tile t+2 included (they have had this tile's whole time to land), not a counted
+        // vmcnt(pieces of t+2): with the counted wait the bulk form turned nondeterministic inside its band -- a few evaluations per
+        // workgroup off by one lo-image fragment's worth, i.e. a late piece of tile t+1 read before it had landed -- in a build that
+        // differed only in the code of other kernels, and was deterministic again with this wait ("Counted waits on
+        // LDS-DMA do not hold": the likely reading is that LDS-DMA loads do not complete in issue order, so counting them proves nothing).
+        (void)my_pieces;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                              // no LDS read of the next tile may move above the barrier
     }

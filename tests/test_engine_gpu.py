@@ -269,7 +269,7 @@ def test_identical_calls_give_identical_decision_values(data_dir, surrogate, mod
     the LDS-DMA ring of that kernel really waits for its data): every decision value, label and tier counter identical from call
     to call.  A timing experiment of round 3 (a build whose ONLY difference was the code of other kernels) showed ~4 000 decision
     values of this request moving by up to 1e-5 S between calls -- inside the band, so no label changed and no parity test saw
-    it; that build was dropped, this test makes the next one like it fail."""
+    it; the ring kernels now wait for all of their DMA pieces, and this test makes the next build like that one fail."""
     xyz = capi.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
     eng = make_engine(data_dir, surrogate, mode, n_rolls=20, roll_step_deg=9, max_points=1 << 18)
     inp = capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0))
