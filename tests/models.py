@@ -96,3 +96,51 @@ def write_probability_model(dst, src, probA, probB):
     with open(dst, "w") as f:
         f.write(head + "probA %s\nprobB %s\nnr_sv" % (probA, probB) + body)
     return dst
+
+
+def pack_trained_model(model_path, npz_path):
+    """Lossless, compact form of a libsvm-3.12 text model (svm_save_model, svm.cpp:2599-2691) for a committed fixture: the
+    header text, the coefficients as doubles ("%.16g" tokens; a token that a double does not print back to is kept as
+    text) and the sparse SV values -- which libsvm prints "%.8g" from doubles that svm-scale wrote with six significant
+    digits -- as float32 + "%.6g" when every token survives that, else as float64 + "%.8g".  unpack_trained_model()
+    rewrites the file byte for byte (the caller checks)."""
+    with open(model_path) as f:
+        text = f.read()
+    head, body = text.split("SV\n", 1)
+    coef, coef_txt, indptr, indices, toks = [], {}, [0], [], []
+    for r, line in enumerate(body.splitlines()):
+        t = line.split()
+        c = float(t[0])
+        if "%.16g" % c != t[0]:
+            coef_txt[r] = t[0]
+        coef.append(c)
+        for p in t[1:]:
+            k, v = p.split(":")
+            indices.append(int(k))
+            toks.append(v)
+        indptr.append(len(indices))
+    v64 = np.array([float(v) for v in toks], np.float64)
+    v32 = v64.astype(np.float32)
+    as32 = all("%.6g" % float(a) == tok for a, tok in zip(v32, toks))
+    if not as32:
+        assert all("%.8g" % a == tok for a, tok in zip(v64, toks))
+    np.savez_compressed(npz_path, head=np.array(head), coef=np.array(coef, np.float64),
+                        coef_txt_rows=np.array(sorted(coef_txt), np.int64), coef_txt=np.array([coef_txt[r] for r in sorted(coef_txt)]),
+                        indptr=np.array(indptr, np.int64), indices=np.array(indices, np.int16), vals=v32 if as32 else v64)
+    keys = dict(line.split(" ", 1) for line in head.strip().splitlines())
+    return dict(total_sv=int(keys["total_sv"]), nr_sv=[int(t) for t in keys["nr_sv"].split()], values_as="float32" if as32 else "float64")
+
+
+def unpack_trained_model(npz_path, model_path):
+    """Writes the libsvm text model packed by pack_trained_model()."""
+    z = np.load(npz_path)
+    vals, fmt = z["vals"], ("%d:%.6g " if z["vals"].dtype == np.float32 else "%d:%.8g ")
+    over = dict(zip(z["coef_txt_rows"].tolist(), z["coef_txt"].tolist()))
+    indptr, indices, coef = z["indptr"], z["indices"], z["coef"]
+    with open(model_path, "w") as f:
+        f.write(str(z["head"]) + "SV\n")
+        for r in range(len(coef)):
+            a, b = indptr[r], indptr[r + 1]
+            f.write((over[r] if r in over else "%.16g" % coef[r]) + " " +
+                    "".join(fmt % (k, float(v)) for k, v in zip(indices[a:b].tolist(), vals[a:b].tolist())) + "\n")
+    return model_path
