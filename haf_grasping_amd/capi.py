@@ -145,6 +145,7 @@ def _bind(path, testing):
         L.haf_test_finalize.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
         L.haf_test_roll_pose.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.c_int,
                                          C.POINTER(GraspOutput), C.POINTER(C.c_int32)]
+        L.haf_test_screen_state.argtypes = [E, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     return L
 
 
@@ -350,6 +351,13 @@ class Engine:
         a = np.zeros(shape, dt)
         self._check(self._L.haf_debug_fetch(self._h, what, cloud, roll, a.ctypes.data, a.nbytes))
         return a
+
+    def screen_state(self):
+        """TESTING build: which form of the screening pass serves the model (0 plain, 1 sumsq, 2 centred-remainder with exp, 3 with the
+        polynomial), whether the pass is on, and the undecided share of every form on the calibration scene (-1: not tried)."""
+        v, a, sh = C.c_int(), C.c_int(), (C.c_double * 4)()
+        self._check(self._L.haf_test_screen_state(self._h, C.byref(v), C.byref(a), sh))
+        return dict(variant=v.value, active=bool(a.value), shares=list(sh))
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._L.haf_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

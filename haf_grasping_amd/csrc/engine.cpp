@@ -220,10 +220,18 @@ struct haf_engine {
     int flag0_cap = 0;      // screening pass: evaluations that go on to the three-pass kernel
     bool screen_active = true;   // default mode only: cleared (for good) once more than 60 % of a call's evaluations fell inside
                                  // the screening band even with the measured |w|_2 -- for such a model the single pass is wasted work
-    bool screen_sumsq = false;   // set (for good) once more than 25 % of a call's evaluations fell inside the band of the plain
-                                 // variant: from then on the kernel variant that measures |w|_2 = sqrt(sum (coef K)^2) runs
-                                 // (ill-conditioned models: large coefficients whose kernel values are small)
+    // which form of the screening pass serves this model (kernels.h: SCREEN_*): chosen at creation (calibrate()) and re-chosen
+    // by the adaptive rule when a call leaves too much undecided.  PLAIN: |w|_2 through its bound; SUMSQ: |w|_2 measured
+    // (ill-conditioned models: large coefficients whose kernel values are small); CR_EXP / CR_POLY: the centred-remainder
+    // form (round 4: trained models with a large C, whose decisions are 1e-5..1e-8 of sum|coef|K)
+    int screen_variant = SCREEN_PLAIN;
+    bool cr_available = false;   // the centred-remainder tables exist (screen_cr, d_svt0_cr, ...)
+    bool variant_forced = false; // testing build: HAF_SCREEN_VARIANT pins the variant (no adaptive rule)
+    bool variant_settled = false;   // every form has been seen (at calibration or on requests) and the engine has chosen: no more switching
+    double variant_share[SCREEN_VARIANTS] = {-1.0, -1.0, -1.0, -1.0};   // undecided share of each variant on the calibration scene (-1: not tried)
     ScreenParams screen{};
+    ScreenParams screen_cr{};    // the centred-remainder form's constants and descriptor tables
+    CrParams crp{};
     size_t cells_cap = 0;   // B*R*H*W
 
     // ONE input block per request: [CloudDev x B][RollGeo x B*R][host clouds' points], packed at call time so that a single
@@ -249,6 +257,11 @@ struct haf_engine {
     DevBuf<float> d_X, d_ax, d_dec, d_svt;
     DevBuf<char> d_svt_h;            // split-fp16 SV tile images
     DevBuf<char> d_svt0;             // screening-pass SV tile images
+    DevBuf<char> d_svt0_cr;          // the same for the centred-remainder form: fp16(w_n - mu), t_n = 0, coefficient b_n
+    DevBuf<FeatDesc> d_fd_slot_cr;
+    DevBuf<ScrDesc> d_sd_cr;
+    DevBuf<ScrDesc3> d_sd3_cr;
+    DevBuf<ScrCorr> d_corr_cr;
     DevBuf<float> d_X1, d_ax1, d_gband;   // three-pass operand images / a_x of the screened-out rest; per-evaluation guard band
     DevBuf<int> d_flag0_list;
     DevBuf<unsigned long long> d_flag0_words;   // one bit per evaluation: undecided by the screening pass
@@ -321,6 +334,12 @@ namespace {
             return HAF_E_DEVICE;                                                                          \
         }                                                                                                 \
     } while (0)
+
+// Cost model of the screening pass's forms, in units of the plain kernel's time per evaluation (measured at C5, nSV 4096: plain 14.1 ms,
+// SUMSQ 15.8, CR_EXP 15.5, CR_POLY 16.3); an undecided evaluation costs ~8.5 screened ones in the three-pass tier and the exact tiers
+// behind it (seed 11 of the bench generator: 5.8 ms for 378 k evaluations against 14.1 ms for 7.9 M)
+constexpr double kVariantCost[SCREEN_VARIANTS] = {1.0, 1.12, 1.10, 1.16};
+constexpr double kUndecidedCost = 8.5;
 
 constexpr size_t kCntBytes = (CNT_COUNT * sizeof(int) + 15) / 16 * 16;      // the counters' share of the output block (d_out)
 
@@ -567,6 +586,10 @@ int build_tables(haf_engine *e)
         }
         const int n_slots = (int)rep.size();
         if (n_slots > kS0K) e->screen_active = false;   // more distinct attributes than the ten k-steps hold: three-pass kernel for everything
+        std::vector<ScrDesc> sd_keep;
+        std::vector<ScrDesc3> sd3_keep;
+        std::vector<FeatDesc> fds_keep;
+        double ea2_keep = 0.0;
         {
             // screening attribute u' = fma(q4, scr_mul, scr_add), scr_add = c*lower - fmin*scr_mul (kernels.hip: screen_attribute).
             // Against c*x' in exact arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's
@@ -625,6 +648,7 @@ int build_tables(haf_engine *e)
             // a degenerate target range or bounds beyond the decimal path's error budget: serve the model without screening
             if (!(e->range.upper > e->range.lower) || std::fabs(e->range.lower) > 1e3 || std::fabs(e->range.upper) > 1e3) e->screen_active = false;
             sp.eta_abs = std::max(std::sqrt(ea2) * 1.01, 1e-12 * 18.0 * sp.c);
+            sd_keep = sd; sd3_keep = sd3; fds_keep = fds; ea2_keep = ea2;
             HIPCHK(e, hipMemcpy(e->d_fd.p, fd2.data(), fd2.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
             if (hipSuccess != e->d_sd.alloc(sd.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
             HIPCHK(e, hipMemcpy(e->d_sd.p, sd.data(), sd.size() * sizeof(ScrDesc), hipMemcpyHostToDevice));
@@ -750,6 +774,141 @@ int build_tables(haf_engine *e)
         if (!(sp.v_max < 60000.0)) return fail(e, HAF_E_ARG, "support vectors too large for the fp16 screening pass; use HAF_FLAG_SPLIT_F16");
         if (hipSuccess != e->d_svt0.alloc(img.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening sv tiles)");
         HIPCHK(e, hipMemcpy(e->d_svt0.p, img.data(), img.size(), hipMemcpyHostToDevice));
+
+        // ---- the centred-remainder form (kernels.h: ScreenParams::cr) ----
+        // Centre mu: the |c_n| 2^(t_n)-weighted mean of the support vectors, per slot (attributes that share a slot share a centre: their
+        // operands are one number).  Any centre gives the same decision function; this one puts the data near the origin, where
+        // psi(z) = 2^z - 1 - z ln2 is small.
+        if (e->screen_active && !test_env("HAF_NO_CR")) {
+            ScreenParams &cp = e->screen_cr;
+            cp = sp;
+            cp.cr = 1;
+            cp.cr_poly = 0;
+            const double ln2 = 0.6931471805599453;
+            std::vector<double> mu((size_t)kS0K, 0.0), mult((size_t)kS0K, 0.0);
+            {
+                double wsum = 0.0;
+                std::vector<double> acc((size_t)kS0K, 0.0);
+                for (int n = 0; n < m.n_sv; n++) {
+                    const double wgt = std::fabs(m.coef[(size_t)n]) * std::exp2(tns[(size_t)n]);
+                    wsum += wgt;
+                    for (int sl = 0; sl < S; sl++) acc[(size_t)sl] += wgt * W[(size_t)n * kS0K + sl];
+                }
+                for (int sl = 0; sl < S; sl++) mult[(size_t)sl] = 1.0 + (double)extra[(size_t)sl];
+                // W holds the SUM of a slot's attributes: the centre of one attribute is the mean over them
+                if (wsum > 0.0) for (int sl = 0; sl < S; sl++) mu[(size_t)sl] = acc[(size_t)sl] / (wsum * mult[(size_t)sl]);
+                if (test_env("HAF_CR_NO_CENTRE")) std::fill(mu.begin(), mu.end(), 0.0);
+            }
+            cp.cr_mu_norm = cp.cr_mu_norm_t = 0.0;
+            for (int sl = 0; sl < S; sl++) { cp.cr_mu_norm += mu[(size_t)sl] * mu[(size_t)sl]; cp.cr_mu_norm_t += mult[(size_t)sl] * mu[(size_t)sl] * mu[(size_t)sl]; }
+            cp.cr_mu_norm = std::sqrt(cp.cr_mu_norm) * (1.0 + 1e-12); cp.cr_mu_norm_t = std::sqrt(cp.cr_mu_norm_t) * (1.0 + 1e-12);
+            // descriptors: the same features, scr_add - mu (formed in long double: its rounding joins eta_abs)
+            std::vector<ScrDesc> sdc = sd_keep;
+            std::vector<ScrDesc3> sd3c = sd3_keep;
+            std::vector<FeatDesc> fdsc = fds_keep;
+            double ea2c = ea2_keep;
+            for (int sl = 0; sl < S; sl++) {
+                const FeatDesc &d0 = fds_keep[(size_t)sl];
+                const double add = d0.scr_mul != 0.0 ? (double)((long double)sp.c * (long double)e->range.lower - (long double)d0.fmin * (long double)d0.scr_mul -
+                                                               (long double)mu[(size_t)sl]) : 0.0;
+                if (d0.scr_mul == 0.0) mu[(size_t)sl] = 0.0;          // a slot whose attribute svm-scale drops stays 0
+                sdc[(size_t)sl].scr_add = add; sd3c[(size_t)sl].scr_add = add; fdsc[(size_t)sl].scr_add = add;
+                const double ef = 4.5e-16 * std::fabs(mu[(size_t)sl]);
+                ea2c += ef * ef;
+            }
+            cp.eta_abs = std::max(std::sqrt(ea2c) * 1.01, 1e-12 * 18.0 * sp.c);
+            // centred support vectors: Q (fp64), Q^ = fp16(Q), b_n = c_n 2^(-|q_n|^2/2) with |q_n|^2 over ALL attributes of the model
+            std::vector<double> Q((size_t)m.n_sv * kS0K, 0.0), Qh((size_t)m.n_sv * kS0K, 0.0), b((size_t)m.n_sv, 0.0);
+            std::vector<char> imgc((size_t)e->n_sv_tiles * kS0SvTileBytes, 0);
+            long double B0 = 0.0L;
+            std::vector<long double> gl((size_t)kS0K, 0.0L);
+            cp.cr_Ca = cp.cr_Cq1 = cp.cr_Cqq = cp.cr_Babs = cp.cr_qmax = cp.cr_dqmax = 0.0;
+            for (int n = 0; n < m.n_sv; n++) {
+                double qq = 0.0;
+                for (int k = 0; k < m.dim; k++) {
+                    const int sl = (k < kKP) ? slot_of_attr[(size_t)k] : -1;
+                    const double v = m.sv[(size_t)n * m.dim + k] * sp.c - ((sl >= 0 && sl < S) ? mu[(size_t)sl] : 0.0);
+                    qq += v * v;
+                }
+                const double bn = m.coef[(size_t)n] * std::exp2(-0.5 * qq);
+                b[(size_t)n] = bn;
+                B0 += (long double)bn;
+                const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
+                char *tile = imgc.data() + (size_t)t * kS0SvTileBytes;
+                double q2 = 0.0, h2 = 0.0, d2 = 0.0;
+                for (int sl = 0; sl < S; sl++) {
+                    const double q = W[(size_t)n * kS0K + sl] - mult[(size_t)sl] * mu[(size_t)sl];
+                    _Float16 h = (_Float16)(float)q;
+                    if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+                    memcpy(tile + h_image_offset(j, sl), &h, 2);
+                    const double hd = (double)(float)h;
+                    Q[(size_t)n * kS0K + sl] = q; Qh[(size_t)n * kS0K + sl] = hd;
+                    q2 += q * q; h2 += hd * hd; d2 += (hd - q) * (hd - q);
+                    gl[(size_t)sl] += (long double)bn * (long double)q;
+                }
+                reinterpret_cast<float *>(tile + kS0MatBytes)[j] = 0.0f;                       // the chains start from 0
+                reinterpret_cast<float *>(tile + kS0MatBytes)[kTile + j] = (float)bn;
+                const double qn = std::sqrt(q2), qhn = std::sqrt(h2), dqn = std::sqrt(d2), ab = std::fabs(bn);
+                cp.cr_Ca += ab * qhn * qn; cp.cr_Cq1 += ab * qhn; cp.cr_Cqq += ab * h2; cp.cr_Babs += ab;
+                cp.cr_qmax = std::max(cp.cr_qmax, qhn); cp.cr_dqmax = std::max(cp.cr_dqmax, dqn);
+            }
+            // N = Q'BQ^ and M = Q'B(Q^ - Q) (320 x 320, SIGNED: the classes cancel), the unsigned second-order matrices through
+            // sigma(diag(sqrt|b|) .)^2; g = sum b_n q_n
+            {
+                const int K = kS0K;
+                std::vector<double> Nm((size_t)K * K, 0.0), Mm((size_t)K * K, 0.0), Rh((size_t)m.n_sv * K), Rd((size_t)m.n_sv * K);
+                for (int n = 0; n < m.n_sv; n++) {
+                    const double *q = Q.data() + (size_t)n * K, *h = Qh.data() + (size_t)n * K;
+                    const double sb = std::sqrt(std::fabs(b[(size_t)n]));
+                    for (int l = 0; l < K; l++) { Rh[(size_t)n * K + l] = sb * h[l]; Rd[(size_t)n * K + l] = sb * (h[l] - q[l]); }
+                    for (int k = 0; k < K; k++) {
+                        const double a = b[(size_t)n] * q[k];
+                        if (a == 0.0) continue;
+                        double *nr = Nm.data() + (size_t)k * K, *mr = Mm.data() + (size_t)k * K;
+                        for (int l = 0; l < K; l++) { nr[l] += a * h[l]; mr[l] += a * (h[l] - q[l]); }
+                    }
+                }
+                for (int k = 0; k < K; k++)
+                    for (int l = 0; l < k; l++) { const double sy = 0.5 * (Mm[(size_t)k * K + l] + Mm[(size_t)l * K + k]); Mm[(size_t)k * K + l] = Mm[(size_t)l * K + k] = sy; }
+                // (the 1e-9 of sigma_upper_bound and the 1e-6 here cover the fp64 roundings of the accumulations above)
+                cp.cr_nN = sigma_upper_bound(Nm.data(), K, K) * (1.0 + 1e-6);
+                cp.cr_nM = sigma_upper_bound(Mm.data(), K, K) * (1.0 + 1e-6);
+                const double sh = sigma_upper_bound(Rh.data(), m.n_sv, K), sdq = sigma_upper_bound(Rd.data(), m.n_sv, K);
+                cp.cr_nHabs = sh * sh * (1.0 + 1e-6);
+                cp.cr_nDabs = sdq * sdq * (1.0 + 1e-6);
+            }
+            double gn = 0.0;
+            std::vector<ScrCorr> scc((size_t)kS0K * 2);
+            ScrCorr2 *sc2 = reinterpret_cast<ScrCorr2 *>(scc.data() + kS0K);
+            for (int sl = 0; sl < kS0K; sl++) {
+                const double gs = (double)gl[(size_t)sl];
+                gn += gs * gs;
+                scc[(size_t)sl].g = 0.0f; scc[(size_t)sl].hd = (float)(ln2 * gs); scc[(size_t)sl].ub = 0.0f; scc[(size_t)sl].pad = 0.0f;
+                ScrCorr2 &p2 = sc2[sl >> 1];
+                p2.g[sl & 1] = 0.0f; p2.hd[sl & 1] = scc[(size_t)sl].hd; p2.ub[sl & 1] = 0.0f; p2.pad[sl & 1] = 0.0f;
+            }
+            cp.cr_gnorm = std::sqrt(gn) * (1.0 + 1e-6);
+            for (double *x : {&cp.cr_Ca, &cp.cr_Cq1, &cp.cr_Cqq, &cp.cr_Babs, &cp.cr_qmax, &cp.cr_dqmax}) *x *= 1.0 + 1e-9;
+            e->crp.B0 = (double)B0;
+            e->crp.rho = m.rho;
+            const bool finite = std::isfinite(cp.cr_nN) && std::isfinite(cp.cr_nM) && std::isfinite(cp.cr_nHabs) && std::isfinite(cp.cr_Babs) &&
+                                std::isfinite(e->crp.B0) && cp.cr_Babs < 1e30 && cp.cr_qmax < 60000.0;
+            if (finite) {
+                bool ok = hipSuccess == e->d_svt0_cr.alloc(imgc.size()) && hipSuccess == e->d_sd_cr.alloc(sdc.size()) &&
+                          hipSuccess == e->d_sd3_cr.alloc(sd3c.size()) && hipSuccess == e->d_fd_slot_cr.alloc(fdsc.size()) &&
+                          hipSuccess == e->d_corr_cr.alloc(scc.size());
+                if (!ok) return fail(e, HAF_E_DEVICE, "hipMalloc(centred-remainder tables)");
+                HIPCHK(e, hipMemcpy(e->d_svt0_cr.p, imgc.data(), imgc.size(), hipMemcpyHostToDevice));
+                HIPCHK(e, hipMemcpy(e->d_sd_cr.p, sdc.data(), sdc.size() * sizeof(ScrDesc), hipMemcpyHostToDevice));
+                HIPCHK(e, hipMemcpy(e->d_sd3_cr.p, sd3c.data(), sd3c.size() * sizeof(ScrDesc3), hipMemcpyHostToDevice));
+                HIPCHK(e, hipMemcpy(e->d_fd_slot_cr.p, fdsc.data(), fdsc.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
+                HIPCHK(e, hipMemcpy(e->d_corr_cr.p, scc.data(), scc.size() * sizeof(ScrCorr), hipMemcpyHostToDevice));
+                cp.sd = e->d_sd_cr.p; cp.sd3 = e->d_sd3_cr.p; cp.fd_slot = e->d_fd_slot_cr.p;
+                cp.corr = e->d_corr_cr.p;
+                cp.corr2 = reinterpret_cast<const ScrCorr2 *>(e->d_corr_cr.p + kS0K);
+                e->cr_available = true;
+            }
+        }
     }
 
     // fp64 image for both recheck tiers, SVs in MODEL order: rows 0..323 attributes, row 324 |s|^2, row 325 coef
@@ -886,6 +1045,7 @@ int build_tables(haf_engine *e)
     e->svm.guard_acc0 = (float)(guard0_scale * ((16.0 + 1.0 + (sweep_tiles / 8.0 + 1.0) + 2.0 + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * sweep_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
+    e->screen_cr.scale = 1.001 * guard0_scale;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
         double as_max = 0;
@@ -1067,6 +1227,7 @@ void haf_destroy(haf_engine *e)
     e->d_sv_i8.release(); e->d_flagi_list.release(); e->d_dec_exacti.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
+    e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1140,18 +1301,48 @@ static int calibrate(haf_engine *e)
     std::vector<haf_roll_record> rec((size_t)R);
     const long keep_direct = e->direct_work;
     e->direct_work = 0;                                   // the tiers themselves, also on a small grid
+    // Every form the engine has is tried on the scene (pinned, so that the adaptive rule does not interfere), cheapest kernel first;
+    // a form that leaves next to nothing undecided ends the search.  The choice minimises kernel cost + what the undecided
+    // evaluations cost behind it, in units of the plain kernel's time per evaluation (SUMSQ and CR_EXP: three VALU instructions
+    // behind the exp instead of one, measured 1.085; CR_POLY: six and no exp, ~1.2; an undecided evaluation costs ~8.5 screened
+    // ones in the three-pass tier and the exact tiers behind it: seed 11 of the bench generator).
     int rc = HAF_OK;
-    for (int pass = 0; pass < 3 && rc == HAF_OK; pass++) {
-        const bool sumsq0 = e->screen_sumsq, active0 = e->screen_active;
+    const bool forced0 = e->variant_forced;
+    const int variant0 = e->screen_variant;
+    if (!forced0) {
+        static const int order[SCREEN_VARIANTS] = {SCREEN_PLAIN, SCREEN_CR_EXP, SCREEN_SUMSQ, SCREEN_CR_POLY};   // cheapest kernel first
+        double best_cost = 1e30;
+        int best = -1;
+        e->variant_forced = true;
+        for (int oi = 0; oi < SCREEN_VARIANTS && rc == HAF_OK; oi++) {
+            const int v = order[oi];
+            if (v >= SCREEN_CR_EXP && !e->cr_available) continue;
+            e->screen_variant = v;
+            e->screen_active = true;
+            rc = score_rolls_impl(e, 1, &cl, &in, 0, R, rec.data());
+            if (rc != HAF_OK) break;
+            const double ne = (double)std::max(1, e->last_evals);
+            const double share = e->last_screened ? (double)e->last_flagged0 / ne : 1.0;
+            e->variant_share[v] = share;
+            const double cost = kVariantCost[v] + kUndecidedCost * share;
+            if (cost < best_cost) { best_cost = cost; best = v; }
+            if (share < 0.001) break;                    // nothing a later form could win back
+        }
+        e->variant_forced = false;
+        if (rc == HAF_OK) {
+            e->screen_variant = best >= 0 ? best : variant0;
+            e->screen_active = best >= 0 && e->variant_share[best] <= 0.6;
+        }
+    } else {
         rc = score_rolls_impl(e, 1, &cl, &in, 0, R, rec.data());
-        if (e->screen_sumsq == sumsq0 && e->screen_active == active0) break;
-        if (!e->screen_active) break;
     }
     e->direct_work = keep_direct;
     e->calibrated = true;
     // (the calibration requests are not a "last scored batch")
     e->last_B = e->last_R = e->last_roll_first = 0;
     e->last_evals = e->last_flagged = e->last_flagged2 = e->last_flagged0 = e->last_inexact = e->last_host_resolved = 0;
+    e->last_flaggedi = 0;
+    e->last_i8 = false;
     e->last_screened = false;
     e->last_inputs.clear();
     return rc;
@@ -1244,8 +1435,10 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         test_env("HAF_HOST_EXP_ALL") || test_env("HAF_NO_I8") || test_env("HAF_GUARD_I8_REL"))
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
+    if (const char *v = test_env("HAF_SCREEN_VARIANT")) { e->screen_variant = std::max(0, std::min(SCREEN_VARIANTS - 1, atoi(v))); e->variant_forced = true; e->direct_work = 0; }
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
+    if (e->screen_variant >= SCREEN_CR_EXP && !e->cr_available) e->screen_variant = SCREEN_PLAIN;   // (a pinned form the model has no tables for)
     rc = alloc_buffers(e);
     if (rc != HAF_OK) return bail(rc);
     // (a test that scales the screening band wants the tiers and the adaptive rule as they are, not a model classified under that band)
@@ -1534,12 +1727,17 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             mark(e, HAF_ST_REFINE);
         } else if (mode == MODE_SCREEN) {
             // tier 0: single-pass fp16 screening of every evaluation; tier 1: the three-pass kernel on what it could not decide
+            // (the centred-remainder variants have their own operand images: translated attributes, centred support vectors)
+            const bool cr = e->screen_variant == SCREEN_CR_EXP || e->screen_variant == SCREEN_CR_POLY;
+            ScreenParams sp_now = cr ? e->screen_cr : e->screen;
+            sp_now.cr_poly = e->screen_variant == SCREEN_CR_POLY;
             if (!reuse_operands)
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
-                                e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, e->screen, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
+                                e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, sp_now, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
             mark(e, HAF_ST_SVM);
-            launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                              e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p, e->screen_sumsq, s);
+            launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, cr ? e->d_svt0_cr.p : e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                              e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,
+                              e->screen_variant, e->crp, s);
             mark(e, HAF_ST_REFINE);
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
@@ -1690,26 +1888,54 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     if (mode == MODE_SCREEN && !e->prob_mode && !direct) {
         auto undecided = [&]() { return e->h_counters[CNT_FLAGGED0]; };
         const int ne = e->h_counters[CNT_EVALS];
-        if (undecided() > e->flag0_cap && !e->screen_sumsq) {
-            // More undecided evaluations than the refinement list holds: this pass's labels are incomplete.  First remedy: the
-            // kernel variant that measures |w|_2 (same operand images, so only the decision stage is redone), and stay with it.
-            e->screen_sumsq = true;
+        // the next form of the screening pass to try when the one in use leaves too much undecided: PLAIN -> SUMSQ (the same operand
+        // images: only the decision stage is redone) -> CR_EXP -> CR_POLY (their own images) -> none
+        auto next_variant = [&](int v) {
+            if (v == SCREEN_PLAIN) return (int)SCREEN_SUMSQ;
+            if (v == SCREEN_SUMSQ && e->cr_available) return (int)SCREEN_CR_EXP;
+            if (v == SCREEN_CR_EXP) return (int)SCREEN_CR_POLY;
+            return -1;
+        };
+        // More undecided evaluations than the refinement list holds: this pass's labels are incomplete.  Remedy: the next form, and
+        // stay with it; when none is left (or the variant is pinned by a test), the three-pass kernel for every evaluation of
+        // this call (same labels by construction) -- and, unless pinned, no screening pass for this model from now on.
+        while (undecided() > e->flag0_cap && !e->variant_forced && next_variant(e->screen_variant) >= 0) {
+            const bool reuse = e->screen_variant == SCREEN_PLAIN;
+            e->screen_variant = next_variant(e->screen_variant);
             HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
-            rc = decide(MODE_SCREEN, true);
+            rc = decide(MODE_SCREEN, reuse);
             if (rc != HAF_OK) return rc;
         }
         if (undecided() > e->flag0_cap) {
-            // Still too many: redo the decision stage with the three-pass kernel for every evaluation (same labels by
-            // construction) and serve this model without the screening pass from now on.
-            e->screen_active = false;
+            if (!e->variant_forced) e->screen_active = false;
             mode = MODE_SPLIT;
             HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
             rc = decide(MODE_SPLIT, false);
             if (rc != HAF_OK) return rc;
-        } else if (ne >= 256 && !e->screen_sumsq && (double)undecided() > 0.25 * (double)ne) {
-            e->screen_sumsq = true;                      // from the next call on
-        } else if (ne >= 256 && e->screen_sumsq && (double)undecided() > 0.6 * (double)ne) {
-            e->screen_active = false;
+        } else if (ne >= 256 && !e->variant_forced && !e->variant_settled) {
+            // Adaptive rule on real requests (an engine that was not calibrated, or whose calibration scene misjudged the model): a form
+            // that leaves more than a quarter undecided makes room for the next untried one; when all have been seen the engine
+            // settles on the one with the lowest cost -- or on none, if even that one leaves more than 60 %.
+            const double share = (double)undecided() / (double)ne;
+            e->variant_share[e->screen_variant] = share;
+            if (share > 0.25) {
+                int nv = next_variant(e->screen_variant);
+                while (nv >= 0 && e->variant_share[nv] >= 0.0) nv = next_variant(nv);       // (already seen: at calibration or on a request)
+                if (nv >= 0) {
+                    e->screen_variant = nv;
+                } else {
+                    int best = e->screen_variant;
+                    double best_cost = 1e30;
+                    for (int v = 0; v < SCREEN_VARIANTS; v++) {
+                        if (e->variant_share[v] < 0.0) continue;
+                        const double cost = kVariantCost[v] + kUndecidedCost * e->variant_share[v];
+                        if (cost < best_cost) { best_cost = cost; best = v; }
+                    }
+                    e->screen_variant = best;
+                    e->variant_settled = true;
+                    if (e->variant_share[best] > 0.6) e->screen_active = false;
+                }
+            }
         }
     }
 
@@ -2299,6 +2525,16 @@ int haf_test_i8_mfma(const signed char *a, const signed char *b, int *c)
     const hipError_t rc = hipMemcpy(c, dc, 1024, hipMemcpyDeviceToHost);
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
     return rc == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
+
+// which form of the screening pass serves the model, whether the pass is on, and the undecided shares calibrate() saw per form
+int haf_test_screen_state(haf_engine *e, int *variant, int *active, double *shares /* [4] */)
+{
+    if (!e) return HAF_E_ARG;
+    if (variant) *variant = e->screen_variant;
+    if (active) *active = e->screen_active ? 1 : 0;
+    if (shares) for (int i = 0; i < SCREEN_VARIANTS; i++) shares[i] = e->variant_share[i];
+    return HAF_OK;
 }
 
 // the engine's matrix-core rounding constant: what the probe measured and what the bands use

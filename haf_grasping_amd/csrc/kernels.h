@@ -117,7 +117,30 @@ struct ScreenParams {
     const struct FeatDesc *fd_slot;   // kS0K feature descriptors (device): the representative attribute of every slot
     unsigned long long fast_groups;   // bit g: every slot of group g is a plain HAF feature of at most two regions
     unsigned long long extra_groups;  // bit g: some slot of group g is shared by more than one attribute (ScrDesc::extra != 0)
+    // ---- centred-remainder form (round 4; cr != 0: this instance serves k_svm_screen<SCREEN_CR_EXP / SCREEN_CR_POLY>) ----
+    // The kernel is translation invariant: with a centre mu (slot space, the |c| kappa-weighted centroid of the support vectors),
+    // p = u - mu, q_n = w_n - mu, b_n = c_n 2^(-|q_n|^2/2), A = 2^(-|p|^2/2), z_n = p.q_n, psi(z) = 2^z - 1 - z ln2 >= 0:
+    //     dec + rho = A [ B0 + L + sum_n b_n psi(z_n) ],   B0 = sum b_n,  L = ln2 p.g,  g = sum b_n q_n   (model constants, fp64 at load).
+    // B0 and L are exact per evaluation; only the remainder goes through the fp16 matrix core, and everything its roundings are
+    // relative to is S_psi = sum|b_n| psi(z_n) -- for a trained model with a large C 1e4 times smaller than S = sum|c_n| K_n.  The
+    // translation is folded into the descriptors' scr_add (the feature kernels are the same code), L rides in the `cr` sum
+    // (corr.hd = ln2 g, corr.g = corr.ub = 0).  Band (screen_finish_cr): psi(z) = (ln2 z)^2/2 + psi3(z); the quadratic part's
+    // first-order error is p'N dp + p'M p with the SIGNED matrices N = Q'BQ^, M = Q'B(Q^ - Q) -- the two classes cancel in them --
+    // bounded through their spectral norms; psi3' = ln2 psi >= 0 costs ln2 eps_max S_psi.
+    int    cr;                    // 0: the plain / SUMSQ forms above
+    int    cr_poly;               // the band is written for the polynomial epilogue (SCREEN_CR_POLY): truncation instead of the v_exp_f32 term
+    double cr_nN, cr_nM;          // |N|_2, |sym M|_2
+    double cr_nHabs, cr_nDabs;    // |Q^' |B| Q^|_2, |dQ' |B| dQ|_2   (second order)
+    double cr_Ca, cr_Cq1, cr_Cqq; // sum|b||q^||q|, sum|b||q^|, sum|b||q^|^2   (accumulation inside the matrix core; sum|b|2^z through sum|b||z|)
+    double cr_Babs;               // sum|b_n|
+    double cr_qmax, cr_dqmax;     // max_n |q^_n|, max_n |q^_n - q_n|
+    double cr_gnorm;              // |g|_2
+    double cr_mu_norm, cr_mu_norm_t;   // |mu| in slot space / over all attributes: |u'| <= |p'| + |mu| (the missing "%g" round trip is relative to u')
 };
+// constants of the centred-remainder form that the contraction kernel's tail needs (fp64: B0 + L cancels against rho)
+struct CrParams { double B0, rho; };
+// variants of k_svm_screen (screen.hip)
+enum { SCREEN_PLAIN = 0, SCREEN_SUMSQ = 1, SCREEN_CR_EXP = 2, SCREEN_CR_POLY = 3, SCREEN_VARIANTS = 4 };
 // Compact descriptor of one attribute slot for the screening feature pass: 64 bytes, one s_load_dwordx16.  A slot without a
 // feature (beyond the feature file, norm slots) is all zero and evaluates to exactly 0.
 struct ScrDesc {
@@ -316,7 +339,7 @@ double probe_mfma_rounding(hipStream_t s, double *worst16);  // largest error of
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
-                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, bool sumsq, hipStream_t s);
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s);
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);

@@ -1371,9 +1371,68 @@ __device__ __forceinline__ double sqrt_upper(double x)
 // 2^z - 1 <= ln2 z + 0.26 z^2 for 0 <= z < 0.05 (y = z ln2: e^y - 1 <= y + y^2/2 e^y)
 __device__ __forceinline__ double exp2m1_upper(double z) { return 0.69314718056 * z + 0.26 * z * z; }
 
+// The band of the CENTRED-REMAINDER form (kernels.h: ScreenParams::cr; derivation in DESIGN.md 2).  The feature kernels are the same
+// code: p' = u' - mu through the descriptors' scr_add, su2 / sd2 / sx2 are the norms of p', p^ - p' and p' over all attributes,
+// lsum = sum fl32(p'_s) fl32(ln2 g_s) = L in fp32.  With p the TRUE centred operand, dp = p^ - p, dq_n = q^_n - q_n, a_n the rounding of the
+// matrix core's fp32 accumulation (|a_n| <= acc_rel |p^||q^_n|), eps_n = dp.q^_n + p.dq_n + a_n the error of z_n:
+//   R^ - R = sum b_n (psi(z_n + eps_n) - psi(z_n)),  psi(z) = (ln2 z)^2/2 + psi3(z),  psi3' = ln2 psi >= 0
+//   quadratic part:  ln2^2 [p'N dp + p'M p + sum b_n z_n a_n] + ln2^2/2 sum b_n eps_n^2
+//                    |.| <= ln2^2 (|N||p||dp| + |M_s||p|^2 + acc_rel |p^||p| C_a) + 1.5 ln2^2 (|H_abs||dp|^2 + |D_abs||p|^2 + acc_rel^2|p^|^2 C_qq)
+//   the rest:        |sum b_n (psi3(z^_n) - psi3(z_n))| <= ln2 eps_max sum|b_n| psi(xi_n),  psi(xi) <= psi(z^) + ln2 (2^zmax - 1) eps_max
+// Output {L, c_abs, k_psi, cm}: the contraction kernel forms dec^ = A^ (B0 + L + R^) - rho and trusts it when
+//   |dec^| > [A^ (c_abs + (guard_acc0' + k_psi) S_psi^) + cm (|dec^| + |rho|)] * 1.002 + guard_abs,   S_psi^ = sum|b_n| psi^(z^_n) as measured.
+__device__ __forceinline__ void screen_finish_cr(double su2, double sd2, double sx2, double lsum, const ScreenParams &sp, float *band, float &nax)
+{
+    constexpr double kF32Acc = 326.0 * 5.9604644775390625e-08 * 1.01;
+    const double ln2 = 0.69314718056;
+    const double a_x = 0.5 * sx2;
+    nax = (float)(-a_x);
+    const double un_t = sqrt_upper(sx2 * (1.0 + kF32Acc));                                     // |p'| over all attributes
+    const double eta_t = kScreenEtaRel * (un_t + sp.cr_mu_norm_t) + sp.eta_abs;                // |p' - p| = |u' - u| <= 5e-6 |u'| + ..., |u'| <= |p'| + |mu|
+    const double un1 = sqrt_upper(su2 * (1.0 + kF32Acc));                                      // |p'| in slot space
+    const double dn1 = sqrt_upper(sd2 * (1.0 + kF32Acc)) + 5.97e-8 * un1 + 1e-17;              // |p^ - p'|
+    const double eta = kScreenEtaRel * (un1 + sp.cr_mu_norm) + sp.eta_abs;
+    const double un = un1 + eta, dn = dn1 + eta, ph = un1 + dn1;                               // |p|, |p^ - p|, |p^|
+    const double D = (kF32Acc + 6.0e-8) * a_x + un_t * eta_t + 0.5 * eta_t * eta_t + 6.0e-7;   // error of the common factor's exponent (screen_finish)
+    const double eps = dn * sp.cr_qmax + un * sp.cr_dqmax + sp.acc_rel * ph * sp.cr_qmax;      // sup_n |eps_n|
+    const double zmax = ph * sp.cr_qmax + eps;                                                 // sup_n of |z^_n| and |z_n|
+    const double zf = floor(zmax);
+    const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();   // >= 2^zmax (chord of the convex 2^x)
+    const double quad1 = ln2 * ln2 * (sp.cr_nN * un * dn + sp.cr_nM * un * un + sp.acc_rel * ph * un * sp.cr_Ca);
+    const double quad2 = 1.5 * ln2 * ln2 * (sp.cr_nHabs * dn * dn + sp.cr_nDabs * un * un + sp.acc_rel * sp.acc_rel * ph * ph * sp.cr_Cqq);
+    const double cub2 = ln2 * ln2 * (p2 - 1.0) * eps * eps * sp.cr_Babs * 1.01;
+    // L: fl32 of p' and of ln2 g, 320 fp32 fmas (|sum of the terms' magnitudes| <= |p'||g|), p' against p
+    const double cL = ln2 * sp.cr_gnorm * (eta + 330.0 * 5.97e-8 * un1) * 1.01 + 1.2e-7 * fabs(lsum);
+    double c_abs = quad1 + quad2 + cub2 + cL;
+    double k_psi = ln2 * eps * 1.01;
+    if (sp.cr_poly) {
+        // psi(t) = t^2 (1/2 + t/6 + t^2/24 + t^3/120), t = z ln2: the dropped tail is at most 4.1 t^4/360 of psi for |t| <= 1; eight
+        // fp32 roundings per element of the Horner form and the two products
+        const double t = ln2 * zmax;
+        k_psi += 4.1 * t * t * t * t / 360.0 + 8.0 * 5.97e-8;
+        if (!(t <= 1.0)) k_psi = (double)__builtin_inff();
+    } else {
+        // 2^z by v_exp_f32 (an ulp of 2^z: taken as 2^-22), the constant ln2 in fp32: relative to sum|b_n| 2^z_n <= S_psi + B_abs + ln2 sum|b_n||z_n|
+        const double uexp = 2.4e-7;
+        k_psi += uexp;
+        c_abs += uexp * (sp.cr_Babs + ln2 * ph * sp.cr_Cq1) * 1.01;
+    }
+    const double infl = 1.0 + exp2m1_upper(D);
+    band[0] = (float)lsum;
+    band[1] = (float)(c_abs * infl * sp.scale * (1.0 + 1e-6));
+    band[2] = (float)(k_psi * infl * sp.scale * (1.0 + 1e-6));
+    band[3] = (float)(exp2m1_upper(D) * sp.scale);
+    band[4] = 0.0f; band[5] = 0.0f; band[6] = 0.0f; band[7] = 0.0f;
+    if (!(D < 0.05) || !(a_x < 30.0) || !(zmax < 60.0)) band[1] = __builtin_inff();
+}
+
 __device__ __forceinline__ void screen_finish(double su2, double sd2, double sx2, double cr, double ubd, const ScreenParams &sp, float *band,
                                               float &nax)
 {
+    if (sp.cr) {                                         // wave-uniform: the centred-remainder form has its own band
+        screen_finish_cr(su2, sd2, sx2, cr, sp, band, nax);
+        return;
+    }
     // su2 = sum over the SLOTS of fl32(u')^2 and sd2 = sum over the slots of (u^ - fl32(u'))^2: the two norms of the operand the
     // contraction sees (kernels.h: attributes that share a slot are one operand).  sx2 = su2 + the squares of the attributes
     // beyond the first of every slot = |u'|^2 over ALL attributes, which is what the common factor 2^(-|u|^2/2) needs.

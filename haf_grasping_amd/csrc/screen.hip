@@ -90,11 +90,19 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // wait for an LDS round trip.  (Across tiles that is not possible: the next tile is only known to have landed behind the
 // barrier.)  Two steps ahead measured the same (round 1) and costs four VGPRs, which now hold a second level of the
 // coefficient sum.
-template <int FIRST, int COUNT, bool SUMSQ>
+// CR_EXP / CR_POLY (round 4, kernels.h: the centred-remainder form): the chains start from 0, the accumulator is z = p^.q^_n and the
+// epilogue accumulates b_n psi(z), psi(z) = 2^z - 1 - z ln2 -- by v_exp_f32, a subtraction and an fma (CR_EXP: three VALU
+// instructions behind the exp, like SUMSQ), or with no transcendental at all as z^2 (a2 + a3 z + a4 z^2 + a5 z^3), a_k = ln2^k / k!
+// (CR_POLY: six VALU instructions per element, for models whose z stay small and whose sum|b| is so large that an ulp of 2^z is
+// too much: relative accuracy instead of absolute).
+constexpr float kLn2f = 0.693147180559945f;
+constexpr float kPsiA2 = 0.240226506959101f, kPsiA3 = 0.0555041086648216f, kPsiA4 = 0.00961812910762848f, kPsiA5 = 0.00133335581464284f;
+template <int FIRST, int COUNT, int VAR>
 __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, const half8 (&a)[kHFull][4], f32x4 (&acc)[4],
                                              const f32x4 (&old)[4], float t, float cf_old, float (&sum)[4][4], float (&sq)[4][4],
                                              const TileDma &dma, unsigned lane16, half8 &b, half8 &b1)
 {
+    constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CRE = VAR == SCREEN_CR_EXP, CRP = VAR == SCREEN_CR_POLY, PLAIN = VAR == SCREEN_PLAIN;
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
     const f32x4 t4 = {t, t, t, t};                                   // rows differ, the column (this lane's SV) is the same
@@ -113,18 +121,37 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
         const bool ex = s >= 1 && s < 9, fm = s >= 2;
         const int e0 = 2 * (s - 1), e1 = e0 + 1, f0 = 2 * (s - 2), f1 = f0 + 1;
         float q0 = 0.0f, q1 = 0.0f;
+        float pt0 = 0.0f, ph0 = 0.0f, pt1 = 0.0f, ph1 = 0.0f;       // CR_POLY: z^2 and the Horner value of this step's pair
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][0], b, s == 0 ? t4 : acc[0], 0, 0, 0);
         HAF_SB();
         if (COUNT > 0 && s == 0) { dma_piece(dma.g[FIRST], dma.l[FIRST], lane16); HAF_SB(); }
-        if (ex) { q0 = __builtin_amdgcn_exp2f(old[e0 >> 2][e0 & 3]); HAF_SB(); }
+        if (ex && !CRP) { q0 = __builtin_amdgcn_exp2f(old[e0 >> 2][e0 & 3]); HAF_SB(); }
+        if (ex && CRP) {                                             // the polynomial form works on this step's own pair: no exp to wait for
+            const float z = old[e0 >> 2][e0 & 3];
+            pt0 = z * z;
+            HAF_SB();
+            ph0 = fmaf(z, kPsiA5, kPsiA4);
+            HAF_SB();
+            ph0 = fmaf(ph0, z, kPsiA3);
+            HAF_SB();
+        }
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, s == 0 ? t4 : acc[1], 0, 0, 0);
         HAF_SB();
         if (COUNT > 1 && s == 0) { dma_piece(dma.g[FIRST + 1], dma.l[FIRST + 1], lane16); HAF_SB(); }
-        if (ex) { q1 = __builtin_amdgcn_exp2f(old[e1 >> 2][e1 & 3]); HAF_SB(); }
+        if (ex && !CRP) { q1 = __builtin_amdgcn_exp2f(old[e1 >> 2][e1 & 3]); HAF_SB(); }
+        if (ex && CRP) {
+            const float z = old[e1 >> 2][e1 & 3];
+            pt1 = z * z;
+            HAF_SB();
+            ph1 = fmaf(z, kPsiA5, kPsiA4);
+            HAF_SB();
+            ph1 = fmaf(ph1, z, kPsiA3);
+            HAF_SB();
+        }
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, s == 0 ? t4 : acc[2], 0, 0, 0);
         HAF_SB();
         if (COUNT > 2 && s == 0) { dma_piece(dma.g[FIRST + 2], dma.l[FIRST + 2], lane16); HAF_SB(); }
-        if (fm && !SUMSQ) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
+        if (fm && PLAIN) { sum[f0 >> 2][f0 & 3] = fmaf(cf_old, k0, sum[f0 >> 2][f0 & 3]); HAF_SB(); }
         if (fm && SUMSQ) {
             const float ck = cf_old * k0;
             HAF_SB();
@@ -133,15 +160,47 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             sq[f0 >> 2][f0 & 3] = fmaf(ck, ck, sq[f0 >> 2][f0 & 3]);
             HAF_SB();
         }
+        if (fm && CRE) {                                             // b psi(z) = b ((2^z - 1) - z ln2)
+            const float em1 = k0 - 1.0f;
+            HAF_SB();
+            const float ps = fmaf(old[f0 >> 2][f0 & 3], -kLn2f, em1);
+            HAF_SB();
+            sum[f0 >> 2][f0 & 3] = fmaf(cf_old, ps, sum[f0 >> 2][f0 & 3]);
+            HAF_SB();
+        }
+        if (ex && CRP) {
+            ph0 = fmaf(ph0, old[e0 >> 2][e0 & 3], kPsiA2);
+            HAF_SB();
+            const float w = cf_old * pt0;
+            HAF_SB();
+            sum[e0 >> 2][e0 & 3] = fmaf(w, ph0, sum[e0 >> 2][e0 & 3]);
+            HAF_SB();
+        }
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, s == 0 ? t4 : acc[3], 0, 0, 0);
         HAF_SB();
-        if (fm && !SUMSQ) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
+        if (fm && PLAIN) { sum[f1 >> 2][f1 & 3] = fmaf(cf_old, k1, sum[f1 >> 2][f1 & 3]); HAF_SB(); }
         if (fm && SUMSQ) {
             const float ck = cf_old * k1;
             HAF_SB();
             sum[f1 >> 2][f1 & 3] += ck;
             HAF_SB();
             sq[f1 >> 2][f1 & 3] = fmaf(ck, ck, sq[f1 >> 2][f1 & 3]);
+            HAF_SB();
+        }
+        if (fm && CRE) {
+            const float em1 = k1 - 1.0f;
+            HAF_SB();
+            const float ps = fmaf(old[f1 >> 2][f1 & 3], -kLn2f, em1);
+            HAF_SB();
+            sum[f1 >> 2][f1 & 3] = fmaf(cf_old, ps, sum[f1 >> 2][f1 & 3]);
+            HAF_SB();
+        }
+        if (ex && CRP) {
+            ph1 = fmaf(ph1, old[e1 >> 2][e1 & 3], kPsiA2);
+            HAF_SB();
+            const float w = cf_old * pt1;
+            HAF_SB();
+            sum[e1 >> 2][e1 & 3] = fmaf(w, ph1, sum[e1 >> 2][e1 & 3]);
             HAF_SB();
         }
         k0 = q0;
@@ -153,7 +212,7 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
 
-template <bool SUMSQ>
+template <int VAR>
 __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
                                                                const float *__restrict__ nax,
                                                                const char *__restrict__ svt0,
@@ -161,8 +220,9 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
                                                                const int *__restrict__ counters, SvmParams p,
                                                                float *__restrict__ dec, int8_t *__restrict__ labels,
                                                                unsigned long long *__restrict__ flag0_words, Dims d,
-                                                               float *__restrict__ margin)
+                                                               float *__restrict__ margin, CrParams crp)
 {
+    constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CRE = VAR == SCREEN_CR_EXP, CRP = VAR == SCREEN_CR_POLY, CR = CRE || CRP;
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
     __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
     const int n_evals = counters[CNT_EVALS];
@@ -248,8 +308,8 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
             const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];   // and its coefficient (0 for padding SVs)
             // block 0 | epilogue of the previous tile's block 1, then block 1 | epilogue of block 0
             half8 bf0, bf1;                                          // B fragments in flight, handed from block 0 to block 1
-            screen_block<0, 3, SUMSQ>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, sq, dma, lane16, bf0, bf1);
-            screen_block<3, 2, SUMSQ>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, sq, dma, lane16, bf0, bf1);
+            screen_block<0, 3, VAR>(cur, 0, lane, a, acc0, acc1, t0, cf_prev, sum, sq, dma, lane16, bf0, bf1);
+            screen_block<3, 2, VAR>(cur, 1, lane, a, acc1, acc0, t1, cf0, sum, sq, dma, lane16, bf0, bf1);
             cf_prev = cf1;
             if (!SUMSQ && ++fold == 8) {                             // wave-uniform, outside the MFMA stream
                 fold = 0;
@@ -269,17 +329,30 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         // epilogue of the sweep's last block, then the sum over the 16 column lanes
         float *dst = ph ? fin : pos;
         // (all sixteen v_exp_f32 first, their consumers behind wait states that hang on the data: see the hazard note)
+        f32x4 zz[4];                                                 // CR_EXP: the arguments, still needed behind the exps
 #pragma unroll
-        for (int m = 0; m < 4; m++)
+        for (int m = 0; m < 4; m++) zz[m] = acc1[m];
+        if (!CRP) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc1[m][r] = __builtin_amdgcn_exp2f(acc1[m][r]);
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
-        __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc1[m][r] = __builtin_amdgcn_exp2f(acc1[m][r]);
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float ck = cf_prev * acc1[m][r];
+                float ck;
+                if (CRE) {
+                    ck = cf_prev * fmaf(zz[m][r], -kLn2f, acc1[m][r] - 1.0f);
+                } else if (CRP) {
+                    const float z = zz[m][r];
+                    ck = (cf_prev * (z * z)) * fmaf(fmaf(fmaf(z, kPsiA5, kPsiA4), z, kPsiA3), z, kPsiA2);
+                } else {
+                    ck = cf_prev * acc1[m][r];
+                }
                 float v = ck + sum[m][r];
                 if (!SUMSQ) v += part[m][r];
                 if (SUMSQ) sq[m][r] = fmaf(ck, ck, sq[m][r]);
@@ -317,6 +390,18 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         const float4 g2 = *reinterpret_cast<const float4 *>(gband + kBandFloats * e + 4);
         const float Ps = pos[lane], Ns = fin[lane];
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
+        float val, err;
+        if (CR) {
+            // centred-remainder form: dec^ = A^ (B0 + L + R^) - rho in fp64 (B0 + L cancels against rho), R^ = the two class sums of
+            // b psi(z^), S_psi^ = their difference; band {L, c_abs, k_psi, cm} from screen_finish_cr (kernels.hip)
+            const double T = (crp.B0 + (double)g.x) + ((double)Ps + (double)Ns);
+            const double dvd = (double)sc * T - crp.rho;
+            val = (float)dvd;
+            const float spsi = Ps - Ns;                             // sum |b| psi, raw (before the common factor)
+            // fp32 class sums: two-level, as in the plain variant (guard_acc0); the casts of this tail: 3 u of the terms
+            const float raw = g.y + (p.guard_acc0 * 1.04f + g.z) * spsi + 1.8e-7f * (fabsf(g.x) + fabsf(Ps) + fabsf(Ns));
+            err = (raw * sc * 1.002f + (g.w + 2.4e-7f) * (fabsf(val) + fabsf((float)crp.rho))) * 1.002f + p.guard_abs;
+        } else {
         const float P = Ps * sc, N = Ns * sc;
         const float dv = (P + N) - p.rho;
         const float sabs = P - N;                                   // sum |coef| K
@@ -335,7 +420,9 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         const float dvc = dv - corr;
         const float err2 = (g2.y * sc + sterm + (g.w + 2.4e-7f) * (fabsf(dvc) + fabsf(corr) + fabsf(p.rho))) * 1.002f + p.guard_abs;
         const bool centred = err2 < err1;                           // decide from the estimate with the narrower band
-        const float val = centred ? dvc : dv, err = centred ? err2 : err1;
+        val = centred ? dvc : dv;
+        err = centred ? err2 : err1;
+        }
         dec[e] = val;
         labels[evalcell[e]] = (int8_t)(val > 0.0f ? p.gv0 : p.gv1);
         flagged = !(fabsf(val) > err);                              // also catches NaN
@@ -583,16 +670,20 @@ double probe_mfma_rounding(hipStream_t s, double *worst16)
 
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
-                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, bool sumsq, hipStream_t s)
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
-    if (sumsq)
-        hipLaunchKernelGGL(k_svm_screen<true>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,
-                           (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin);
-    else
-        hipLaunchKernelGGL(k_svm_screen<false>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,
-                           (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin);
+#define HAF_SCREEN_LAUNCH(V)                                                                                                      \
+    hipLaunchKernelGGL(k_svm_screen<V>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,          \
+                       (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr)
+    switch (variant) {
+        case SCREEN_SUMSQ: HAF_SCREEN_LAUNCH(SCREEN_SUMSQ); break;
+        case SCREEN_CR_EXP: HAF_SCREEN_LAUNCH(SCREEN_CR_EXP); break;
+        case SCREEN_CR_POLY: HAF_SCREEN_LAUNCH(SCREEN_CR_POLY); break;
+        default: HAF_SCREEN_LAUNCH(SCREEN_PLAIN); break;
+    }
+#undef HAF_SCREEN_LAUNCH
     // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
     hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters);

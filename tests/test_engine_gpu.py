@@ -64,7 +64,7 @@ DEC_REL_SCREEN = 2.0 ** -8
 # environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
-              "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL")
+              "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -603,18 +603,24 @@ def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
 
 
 def test_model_is_classified_at_creation(data_dir, surrogate, orc, monkeypatch, tmp_path):
-    """Round 3: haf_create scores a synthetic table scene and settles the screening variant for the MODEL before
-    the first goal: the ill-conditioned surrogate is served by the three-pass kernel from its first request on (no refinement
-    list, and identical calls report identical counters); a well-conditioned random model keeps the plain screening variant."""
+    """Round 3: haf_create scores a synthetic table scene and settles the form of the screening pass for the MODEL
+    before the first goal, so identical calls report identical counters from the first one on.  Round 4: the ill-conditioned
+    surrogate -- which the plain and the SUMSQ form leave 90 % and 70 % undecided -- is served by the centred-remainder form
+    (SCREEN_CR_EXP: under a third undecided on this cloud, 2 % on the calibration scene); a well-conditioned random model keeps a form
+    that leaves a few per cent."""
     monkeypatch.setenv("HAF_NO_DIRECT", "1")                  # tiers as such, on requests of reference size
     xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
     inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
     eng = make_engine(data_dir, surrogate)
+    st = eng.screen_state()
+    assert st["active"] and st["variant"] == 2 and st["shares"][0] > 0.6 and 0 <= st["shares"][2] < 0.1, st
     counts = []
     for _ in range(3):
         compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
         counts.append(eng.last_counts())
-    assert counts[0]["n_refined"] == 0 and counts[0] == counts[1] == counts[2], counts
+    assert 0 < counts[0]["n_refined"] < 0.4 * counts[0]["n_evals"] and counts[0] == counts[1] == counts[2], counts
+    st2 = eng.screen_state()
+    assert (st2["variant"], st2["active"]) == (st["variant"], st["active"])
     eng.close()
     f, r = _files(data_dir)
     path = str(tmp_path / "rand300.model")
@@ -627,6 +633,52 @@ def test_model_is_classified_at_creation(data_dir, surrogate, orc, monkeypatch, 
         counts.append(eng.last_counts())
     assert 0 < counts[0]["n_refined"] < 0.25 * counts[0]["n_evals"] and counts[0] == counts[1], counts
     eng.close()
+
+
+@pytest.fixture(scope="module")
+def trained_model(tmp_path_factory):
+    """The repo's large genuine libsvm-3.12 model (tests/golden/trained.model.npz: 8964 SVs, C 2048, gamma 2^-13, trained by the
+    reference svm-train on 24000 harvested rows, tools/make_trained_model.py), unpacked to its text file."""
+    path = str(tmp_path_factory.mktemp("trained") / "trained.model")
+    models.unpack_trained_model(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained.model.npz"), path)
+    return path
+
+
+def test_every_form_of_the_screening_pass_gives_the_oracles_labels(data_dir, surrogate, orc, trained_model, monkeypatch, tmp_path):
+    """Round 4: the screening pass has four forms (kernels.h SCREEN_*: plain, SUMSQ, and the centred-remainder form with the exp or
+    the polynomial epilogue).  Each of them pinned (HAF_SCREEN_VARIANT), on three models -- the 172-SV surrogate, a seeded random
+    model and the 8964-SV trained model, whose decisions are 1e-7 of sum|coef|K -- every stage and every label must be the
+    oracle's; what a form cannot decide goes on (n_refined), and a form that overflows the refinement list falls back to the
+    three-pass kernel for that call.  The form calibrate() picks by itself must be the one with the fewest undecided evaluations
+    among those it tried, and for the trained model that is the polynomial form with under a fifth undecided on a real cloud (the
+    other three: everything)."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    f, r = _files(data_dir)
+    rnd = str(tmp_path / "rand600.model")
+    models.write_random_model(rnd, 600, seed=7, balanced=True)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
+    refined = {}
+    for name, model, o in (("surrogate", surrogate, orc), ("random", rnd, O.Oracle(f, r, rnd)), ("trained", trained_model, O.Oracle(f, r, trained_model))):
+        for v in (0, 1, 2, 3):
+            monkeypatch.setenv("HAF_SCREEN_VARIANT", str(v))
+            eng = make_engine(data_dir, model)
+            assert eng.screen_state()["variant"] == v
+            got, want = compare_full(eng, o, xyz, dict(n_rolls=12), inp, check_dec=False)
+            refined[(name, v)] = eng.last_counts()["n_refined"] / float(want["n_evals"])
+            eng.close()
+        monkeypatch.delenv("HAF_SCREEN_VARIANT")
+        eng = make_engine(data_dir, model)
+        st = eng.screen_state()
+        tried = [s_ for s_ in st["shares"] if s_ >= 0]
+        assert st["active"] and st["shares"][st["variant"]] <= min(tried) + 0.01, st
+        compare_full(eng, o, xyz, dict(n_rolls=12), inp, check_dec=False)
+        refined[(name, "auto")] = (st["variant"], eng.last_counts()["n_refined"] / float(want["n_evals"]))
+        eng.close()
+    STATS["screening_forms_refined_share"] = {"%s/%s" % k: v for k, v in refined.items()}
+    assert refined[("surrogate", 2)] < 0.4 < refined[("surrogate", 0)]
+    assert refined[("trained", "auto")][0] == 3 and refined[("trained", 3)] < 0.2 and min(refined[("trained", v)] for v in (0, 1, 2)) > 0.95
+    assert refined[("random", 2)] <= refined[("random", 0)] + 0.01
 
 
 def test_exact_integer_tier(data_dir, surrogate, orc, monkeypatch, tmp_path):
@@ -773,14 +825,19 @@ def test_screening_tier_forced_and_reported(data_dir, surrogate, orc, monkeypatc
     compare_full(eng, orc, xyz, dict(n_rolls=12), inp)          # the engine has switched to the variant that measures |w|_2
     cnt2 = eng.last_counts()
     # It helps, but not enough for a model of 172 SVs: the fp16 rounding of the operands alone bounds the error by
-    # |u^-u| sigma(W^) |w|_2 ~ 0.5 for this model, and most of its decision values are smaller than that.  Only the bound
-    # is large (the measured error is 20x smaller), but the labels are promised, not likely: the engine serves the model
-    # with the three-pass kernel from the third call on.  (Replicated to 4128 SVs the same model is decided to 96 % by
-    # the measuring variant: bench.py's hard_model line.)
+    # |u^-u| sigma(W^) |w|_2 ~ 0.5 for this model, and most of its decision values are smaller than that.  Round 3 served the
+    # model with the three-pass kernel from the third call on; since round 4 the third call runs the centred-remainder form
+    # (SCREEN_CR_EXP), whose band is relative to sum|b| psi(z) instead of sum|coef| K: under a third undecided, and the engine stays there.
     assert 0 < cnt2["n_refined"] < cnt["n_refined"], (cnt, cnt2)
     STATS["screen_refined_share_surrogate_sumsq"] = cnt2["n_refined"] / max(1, cnt2["n_evals"])
     compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
-    assert eng.last_counts()["n_refined"] == 0                # screening switched off for this model
+    cnt3 = eng.last_counts()
+    assert 0 < cnt3["n_refined"] < 0.4 * cnt3["n_evals"] and cnt3["n_refined"] < cnt2["n_refined"], (cnt2, cnt3)
+    STATS["screen_refined_share_surrogate_cr_exp"] = cnt3["n_refined"] / max(1, cnt3["n_evals"])
+    st = eng.screen_state()
+    assert st["active"] and st["variant"] == 2, st
+    compare_full(eng, orc, xyz, dict(n_rolls=12), inp)
+    assert eng.last_counts() == cnt3 and eng.screen_state()["variant"] == 2
     eng.close()
     monkeypatch.setenv("HAF_GUARD0_REL", "1e30")
     eng = make_engine(data_dir, surrogate)
