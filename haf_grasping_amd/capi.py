@@ -103,6 +103,7 @@ def _bind(path, testing):
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.haf_last_strict_host.argtypes = [E, C.POINTER(C.c_int64)]
     L.haf_last_exact_tiers.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.haf_screen_form.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                C.c_size_t]
     L.haf_free.argtypes = [C.c_void_p]
@@ -351,6 +352,14 @@ class Engine:
         a = np.zeros(shape, dt)
         self._check(self._L.haf_debug_fetch(self._h, what, cloud, roll, a.ctypes.data, a.nbytes))
         return a
+
+    SCREEN_FORMS = ("plain", "sumsq", "centred-remainder/exp", "centred-remainder/poly")
+
+    def screen_form(self):
+        """haf_screen_form: the form of the screening kernel that serves the model, or "off" (three-pass kernel for everything)."""
+        f, a = C.c_int32(), C.c_int32()
+        self._check(self._L.haf_screen_form(self._h, C.byref(f), C.byref(a)))
+        return self.SCREEN_FORMS[f.value] if a.value else "off"
 
     def screen_state(self):
         """TESTING build: which form of the screening pass serves the model (0 plain, 1 sumsq, 2 centred-remainder with exp, 3 with the

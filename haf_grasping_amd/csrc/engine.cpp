@@ -1460,6 +1460,15 @@ int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_
     return HAF_OK;
 }
 
+int haf_screen_form(const haf_engine *e, int32_t *form, int32_t *active)
+{
+    if (!e) return HAF_E_ARG;
+    const bool on = contraction_mode(e->cfg) == MODE_SCREEN && e->screen_active && !e->prob_mode;
+    if (form) *form = e->screen_variant;
+    if (active) *active = on ? 1 : 0;
+    return HAF_OK;
+}
+
 int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked, int64_t *n_strict)
 {
     if (!e) return HAF_E_ARG;

@@ -258,6 +258,12 @@ int haf_last_prestage(const haf_engine *e, int64_t *n_inexact_grids);
 /* Model facts for reporting: support vectors, attribute dimension, feature rows (incl. phantom rows). */
 int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_features);
 
+/* Which form of the single-pass screening kernel serves this model in the default mode (chosen at haf_create on a synthetic scene,
+ * re-chosen when a request leaves too much undecided): 0 plain, 1 with the measured |w|_2, 2 / 3 the centred-remainder form with the
+ * exp / the polynomial epilogue (models with a large C, whose decisions are 1e-5..1e-8 of sum|coef|K); *active = 0 when no form can
+ * decide enough and every evaluation takes the three-pass kernel.  Labels are identical in every case; for reporting only. */
+int haf_screen_form(const haf_engine *e, int32_t *form, int32_t *active);
+
 /* PCD v0.7 reader (ascii / binary / binary_compressed; pcl::io::loadPCDFile in client.cpp:141).
  * Returns a malloc'ed packed xyz array (free with haf_free) and the point count. */
 int  haf_pcd_load(const char *path, float **xyz, size_t *n_points, char *err, size_t err_cap);

@@ -18,6 +18,8 @@ Outputs (all data, no code):
                           the reference svm-predict -b 1 output lines for the g23 rows.
   g6_end_to_end.json      per-roll (row, col, val), overall best and GraspOutput of the ORACLE for every cloud x
                           configuration: regression goldens for the GPU engine.
+  g6_trained.json         the same for the large trained model (trained.model.npz, made by tools/make_trained_model.py) on six
+                          cloud x configuration cases (`g6t`; not part of the default set: the model must exist first).
 """
 import ctypes as C
 import json
@@ -179,6 +181,29 @@ def make_g23(model):
         print("g23", name, roll, n, "rows; +1:", int((labels > 0).sum()))
 
 
+def make_g3t(model):
+    """g3_trained.npz: for the rows of the four g23 fixtures (the doubles the REAL svm-scale printed and svm-predict parses), the fp64
+    decision values of the REAL svm_predict_values (libsvm_ref.so) and the labels of the REAL svm-predict with the large trained
+    model: pins the oracle's RBF decision on an 8964-SV model whose decisions are ~1e-7 of sum|coef|K."""
+    decs, labs, names = [], [], []
+    for name in ["g23_pcd2_r0", "g23_pcd2_r5", "g23_pcd3_r2", "g23_plastic_mug2_r7"]:
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        fpath = os.path.join(TMP, name + ".scaled.txt")
+        with open(fpath, "w") as f:
+            for row in g["scaled"]:
+                f.write("0 " + " ".join("%d:%r" % (k + 1, float(v)) for k, v in enumerate(row) if v != 0.0) + "\n")   # repr: strtod gives the double back
+        run([os.path.join(REF, "svm-predict"), fpath, model, fpath + ".out"], stdout=subprocess.DEVNULL)
+        labels = np.loadtxt(fpath + ".out").reshape(-1)
+        dec, lab2 = ref_decisions(model, fpath)
+        assert (labels == lab2).all() and len(dec) == len(g["scaled"])
+        decs.append(dec)
+        labs.append(labels.astype(np.int8))
+        names.append(name)
+        print("g3t", name, len(dec), "rows; +1:", int((labels > 0).sum()), "min |dec| %.3g" % np.abs(dec).min())
+    np.savez_compressed(os.path.join(HERE, "g3_trained.npz"), **{n + "_dec": d for n, d in zip(names, decs)},
+                        **{n + "_labels": l for n, l in zip(names, labs)})
+
+
 def make_g5():
     src = "/root/reference/libsvm-3.12/heart_scale"
     dst = os.path.join(HERE, "heart_scale")
@@ -311,10 +336,14 @@ CLOUD_CONFIGS = [
 ]
 
 
-def make_g6(model):
+TRAINED_CLOUD_CONFIGS = [("pcd2", ["C2", "C2best"]), ("pcd12", ["default"]), ("plastic_mug2", ["default"]),
+                         ("table1_mult_obj_rcs_1428580506606673", ["C3c"]), ("table3_mult_obj_rcs_1428581033679923", ["C3"])]
+
+
+def make_g6(model, cloud_configs=None, out_name="g6_end_to_end.json"):
     orc = O.Oracle(FEATURES, RANGE, model)
     res = {}
-    for name, cfgs in CLOUD_CONFIGS:
+    for name, cfgs in (cloud_configs or CLOUD_CONFIGS):
         xyz = pcdio.load_pcd(os.path.join(DATA, name + ".pcd"))
         for cname in cfgs:
             spec = CONFIGS[cname]
@@ -329,7 +358,7 @@ def make_g6(model):
                             masked=[int(v) for v in r["mask"].reshape(cfg.n_rolls, -1).sum(1)],
                             positives=[int(v) for v in (r["labels"] > 0).reshape(cfg.n_rolls, -1).sum(1)])
             print("g6", key, res[key]["eval"], res[key]["row"], res[key]["col"], res[key]["roll_idx"], r["n_evals"])
-    with open(os.path.join(HERE, "g6_end_to_end.json"), "w") as f:
+    with open(os.path.join(HERE, out_name), "w") as f:
         json.dump(res, f, indent=0, sort_keys=True)
 
 
@@ -347,6 +376,20 @@ if __name__ == "__main__":
         make_g5()
     if "g6" in what:
         make_g6(model)
+    if "g6t" in what:
+        # the same goldens for the large trained model (tools/make_trained_model.py -> trained.model.npz): ORACLE results, like g6
+        import models
+        tpath = os.path.join(TMP, "trained.model")
+        os.makedirs(TMP, exist_ok=True)
+        models.unpack_trained_model(os.path.join(HERE, "trained.model.npz"), tpath)
+        make_g6(tpath, TRAINED_CLOUD_CONFIGS, "g6_trained.json")
+    if "g3t" in what:
+        import models
+        tpath = os.path.join(TMP, "trained.model")
+        os.makedirs(TMP, exist_ok=True)
+        if not os.path.exists(tpath):
+            models.unpack_trained_model(os.path.join(HERE, "trained.model.npz"), tpath)
+        make_g3t(tpath)
     if "g5p" in what:
         make_g5p()
     if "g23p" in what:

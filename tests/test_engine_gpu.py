@@ -215,11 +215,21 @@ def test_small_request_paths_agree_with_the_oracle(data_dir, surrogate, orc, mon
     eng.close()
 
 
+def test_trained_model_against_committed_goldens(data_dir, golden_dir, trained_model):
+    """Round 4: the 8964-SV trained model (tests/golden/trained.model.npz) on six cloud x configuration cases of
+    tests/golden/g6_trained.json (oracle results): argmax-identical cell / roll, same eval, per-roll winners, in the default mode."""
+    _against_goldens(data_dir, golden_dir, trained_model, 0, "g6_trained.json")
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_all_clouds_against_committed_goldens(data_dir, golden_dir, surrogate, mode):
     """Every data/*.pcd x configuration of tests/golden/g6_end_to_end.json: argmax-identical cell/roll, same eval."""
+    _against_goldens(data_dir, golden_dir, surrogate, mode, "g6_end_to_end.json")
+
+
+def _against_goldens(data_dir, golden_dir, surrogate, mode, gold_name):
     import make_fixtures as mf
-    with open(os.path.join(golden_dir, "g6_end_to_end.json")) as f:
+    with open(os.path.join(golden_dir, gold_name)) as f:
         gold = json.load(f)
     engines = {}
     for key, g in sorted(gold.items()):
@@ -936,32 +946,59 @@ def test_screening_pass_alone_is_accurate_and_stable(data_dir, surrogate, orc, m
     eng.close()
 
 
-@pytest.mark.parametrize("nsv,modes,seed", [(512, (capi.FLAG_SPLIT_F16, 0, capi.FLAG_FP32_MFMA), 7), (4096, (capi.FLAG_SPLIT_F16, 0), 7),
-                                            (4096, (capi.FLAG_SPLIT_F16, 0), 11)])
-def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path, nsv, modes, seed):
+def _bench_model(tmp_path, spec, trained_path):
+    """(model file, screening form to pin or None) of a bench-size model: ("rand", nsv, seed) the generator of bench.py's headline,
+    ("hard", form): the libsvm-trained surrogate x 24 jittered copies (bench.py's hard_model), ("trained", form): the 8964-SV model."""
+    if spec[0] == "rand":
+        path = str(tmp_path / ("rand%d_%d.model" % (spec[1], spec[2])))
+        models.write_random_model(path, spec[1], seed=spec[2], balanced=True)
+        return path, None
+    if spec[0] == "hard":
+        path = str(tmp_path / "hard.model")
+        models.write_replicated_model(path, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "surrogate.model"), copies=24,
+                                      jitter=0.01, seed=5)
+        return path, spec[1]
+    return trained_path, spec[1]
+
+
+@pytest.mark.parametrize("spec,modes", [(("rand", 512, 7), (capi.FLAG_SPLIT_F16, 0, capi.FLAG_FP32_MFMA)), (("rand", 4096, 7), (capi.FLAG_SPLIT_F16, 0)),
+                                        (("rand", 4096, 11), (capi.FLAG_SPLIT_F16, 0)), (("hard", 1), (capi.FLAG_SPLIT_F16, 0)),
+                                        (("hard", None), (capi.FLAG_SPLIT_F16, 0)), (("trained", None), (capi.FLAG_SPLIT_F16, 0))],
+                         ids=["rand512-7", "rand4096-7", "rand4096-11", "hard-sumsq", "hard-auto", "trained-auto"])
+def test_contraction_modes_agree_on_every_label_at_full_size(data_dir, tmp_path, trained_model, monkeypatch, spec, modes):
     """All three contraction modes claim libsvm's labels (each tier decides only outside a rigorous error band).  At BASELINE
     config C5 (7.9 M evaluations) the label grids of the screening mode, the three-pass mode and the fp32 mode must be
     identical cell for cell, for a model whose decision values crowd around zero -- a hole in a band would show up here as
-    a handful of differing cells out of millions."""
-    path = str(tmp_path / ("rand%d.model" % nsv))
-    models.write_random_model(path, nsv, seed=seed, balanced=True)        # (seed 11: the hardest of bench.py's five)
+    a handful of differing cells out of millions.  Round 4: the same for bench.py's hard_model
+    through k_svm_screen<SUMSQ> (pinned) and through the form the engine picks by itself, and for the trained 8964-SV model
+    (centred-remainder form; its three-pass reference run decides next to nothing in fp32 and walks the exact tiers window by window)."""
+    path, form = _bench_model(tmp_path, spec, trained_model)
     xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
     inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
-    ref_labels, ref_rec, counts = None, None, {}
+    ref_labels, ref_rec, counts, forms = None, None, {}, {}
     for mode in modes:
+        if form is not None and mode == 0:
+            monkeypatch.setenv("HAF_SCREEN_VARIANT", str(form))
         eng = make_engine(data_dir, path, mode, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+        monkeypatch.delenv("HAF_SCREEN_VARIANT", raising=False)
         rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
         counts[mode] = eng.last_counts()
+        forms[mode] = eng.screen_form()
         labels = np.stack([eng.debug(capi.DBG_LABELS, 0, roll) for roll in range(36)])
         eng.close()
         if ref_labels is None:
             ref_labels, ref_rec = labels, rec
-            assert (labels == 1).sum() > 100000 and (labels == -1).sum() > 100000
+            if spec[0] == "rand":
+                assert (labels == 1).sum() > 100000 and (labels == -1).sum() > 100000
         else:
             assert int((labels != ref_labels).sum()) == 0, (mode, int((labels != ref_labels).sum()))
             assert (rec == ref_rec).all(), mode
     assert 0 < counts[0]["n_refined"] < 0.2 * counts[0]["n_evals"]          # the screening pass was really in charge
-    STATS["c5_nsv%d_seed%d_tiers" % (nsv, seed)] = {str(k): v for k, v in counts.items()}
+    if form is not None:
+        assert forms[0] == capi.Engine.SCREEN_FORMS[form]
+    if spec[0] == "trained":
+        assert forms[0] == "centred-remainder/poly" and counts[0]["n_refined"] < 0.02 * counts[0]["n_evals"]
+    STATS["c5_%s_tiers" % "_".join(str(t) for t in spec)] = {"forms": {str(k): v for k, v in forms.items()}, "counts": {str(k): v for k, v in counts.items()}}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1174,22 +1211,26 @@ def test_multi_rejects_bad_requests(data_dir, surrogate):
     me.close()
 
 
-@pytest.mark.parametrize("seed", [1234, 11])
-def test_bench_configuration_against_the_oracle_where_screening_was_closest(data_dir, tmp_path, seed):
+@pytest.mark.parametrize("spec", [("rand", 4096, 1234), ("rand", 4096, 11), ("hard", 1), ("hard", None), ("trained", None)],
+                         ids=["rand4096-1234", "rand4096-11", "hard-sumsq", "hard-auto", "trained-auto"])
+def test_bench_configuration_against_the_oracle_where_screening_was_closest(data_dir, tmp_path, trained_model, monkeypatch, spec):
     """The bench's own workload -- C5 (512 x 512, 36 rolls of 5 degrees, 524 288 points), seeded random model nSV = 4096
     (seeds 1234 -- round 2's headline, one-signed -- and 11 -- the hardest of bench.py's five: 37 % positive labels, decision
     values crowding around zero), default mode -- against the oracle's feature / scale / decision chain
     (hafo_feature_values, hafo_q4, hafo_scale_row, hafo_decision: libsvm's fp64 order) on >= 2 000 cells chosen where a
     band hole would show first: the cells the screening tier decided with |dec^| / band closest to 1 (HAF_DBG_SCREEN_MARGIN),
     plus the cells it handed on with the smallest |dec|, plus random ones.  Label identical; decision value inside the
-    tier's own band (which the margin makes checkable: |dec^ - dec| < |dec^| / margin)."""
-    nsv = 4096
-    path = str(tmp_path / "rand4096.model")
-    models.write_random_model(path, nsv, D=323, seed=seed, balanced=True)
+    tier's own band (which the margin makes checkable: |dec^ - dec| < |dec^| / margin).  Round 4: the same for bench.py's hard_model
+    through k_svm_screen<SUMSQ> (svm.cpp:2509-2519 on 7.9 M evaluations) and through the form the engine picks,
+    and for the trained 8964-SV model through the centred-remainder form."""
+    path, form = _bench_model(tmp_path, spec, trained_model)
     f, r = _files(data_dir)
     o = O.Oracle(f, r, path)
     xyz = models.synthetic_cloud(grid=512, k=2, seed=0)
+    if form is not None:
+        monkeypatch.setenv("HAF_SCREEN_VARIANT", str(form))
     eng = make_engine(data_dir, path, 0, grid_h=512, grid_w=512, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+    monkeypatch.delenv("HAF_SCREEN_VARIANT", raising=False)
     assert not eng.cfg.flags & (capi.FLAG_SPLIT_F16 | capi.FLAG_FP32_MFMA)
     inp = capi.default_input(grasp_area_length_x=512, grasp_area_length_y=512)
     rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
@@ -1233,6 +1274,7 @@ def test_bench_configuration_against_the_oracle_where_screening_was_closest(data
     for s in sample:
         by_roll.setdefault(s[0], []).append(s)
     worst = 0.0
+    sv2 = (m["sv"] * m["sv"]).sum(1)
     for roll, items in by_roll.items():
         ii = eng.debug(capi.DBG_INTEGRAL, 0, roll)
         lab = eng.debug(capi.DBG_LABELS, 0, roll)
@@ -1246,11 +1288,12 @@ def test_bench_configuration_against_the_oracle_where_screening_was_closest(data
             if mgv > 0:                                        # decided by the screening tier: its value, inside its band
                 assert abs(dec[i, j] - d) < abs(dec[i, j]) / mgv, (roll, i, j, d, dec[i, j], mgv)
                 worst = max(worst, abs(dec[i, j] - d) * mgv / abs(dec[i, j]))
-            else:                                              # handed on: an exact tier's value
-                assert abs(dec[i, j] - d) <= 6e-3, (roll, i, j, d, dec[i, j])     # three-pass tier: 2^-20 * S, S <= 4096
-    STATS["bench_config_oracle_check_seed%d" % seed] = {"cells": len(sample), "closest_margin": close[0][3],
+            else:                                              # handed on: the value of the tier that decided it
+                S = float(np.abs(m["coef"]) @ np.exp(-m["gamma"] * (sv2 - 2.0 * (m["sv"] @ xs) + xs @ xs)))
+                assert abs(dec[i, j] - d) <= 1.5e-6 * S + 1e-9, (roll, i, j, d, dec[i, j], S)     # three-pass tier: 2^-20 S + 1e-6, the exact tiers far inside
+    STATS["bench_config_oracle_check_%s" % "_".join(str(t) for t in spec)] = {"cells": len(sample), "closest_margin": close[0][3],
                                                         "worst_error_as_fraction_of_band": worst,
-                                                        "exact_tiers": eng.last_exact_tiers(), "tiers": cnt}
+                                                        "exact_tiers": eng.last_exact_tiers(), "tiers": cnt, "form": eng.screen_form()}
     eng.close()
 
 

@@ -73,6 +73,42 @@ def test_scale_and_predict_match_reference_tools(orc, golden_dir, name):
         assert lab == labels[r]
 
 
+@pytest.fixture(scope="module")
+def trained_path(golden_dir, tmp_path_factory):
+    import models
+    path = str(tmp_path_factory.mktemp("trained") / "trained.model")
+    models.unpack_trained_model(os.path.join(golden_dir, "trained.model.npz"), path)
+    return path
+
+
+def test_trained_model_fixture_is_what_the_reference_trained(golden_dir, trained_path):
+    """tests/golden/trained.model.npz unpacks to the very text the reference svm-train wrote (sha256 in trained_model.json), and the
+    oracle's parser reads what svm_load_model would: 8964 SVs, label order -1 1, C-SVC balance sum(coef) = 0 to solver tolerance."""
+    import hashlib
+    import json
+    with open(os.path.join(golden_dir, "trained_model.json")) as f:
+        meta = json.load(f)
+    with open(trained_path, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == meta["sha256"]
+    m = O.Oracle(os.path.join(golden_dir, "data", "Features.txt"), os.path.join(golden_dir, "data", "range21062012_allfeatures"),
+                 trained_path).model_arrays()
+    assert m["l"] == meta["total_sv"] == 8964 and list(m["nSV"]) == meta["nr_sv"] and m["label"] == (-1, 1) and m["D"] == 323
+    assert m["gamma"] == float("%g" % meta["gamma"]) and np.abs(m["coef"]).max() == meta["C"] and abs(m["coef"].sum()) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["g23_pcd2_r0", "g23_pcd2_r5", "g23_pcd3_r2", "g23_plastic_mug2_r7"])
+def test_trained_model_decisions_match_reference_library(golden_dir, data_dir, trained_path, name):
+    """g3_trained.npz: the oracle's RBF decision with the 8964-SV trained model against the REAL svm_predict_values / svm-predict on
+    the rows the real svm-scale printed -- decisions that are 1e-7 of sum|coef|K, so a different summation order would show."""
+    o = O.Oracle(os.path.join(data_dir, "Features.txt"), os.path.join(data_dir, "range21062012_allfeatures"), trained_path)
+    m = o.model_arrays()
+    g, t = np.load(os.path.join(golden_dir, name + ".npz")), np.load(os.path.join(golden_dir, "g3_trained.npz"))
+    dec, labels = t[name + "_dec"], t[name + "_labels"]
+    mine = o.decision(np.ascontiguousarray(g["scaled"][:, :m["D"]]))
+    assert (mine == dec).all() or np.abs(mine - dec).max() <= 1e-15 * 1.8e7       # (bit for bit in this build; the scale is sum|coef|K)
+    assert (np.where(mine > 0, m["label"][0], m["label"][1]) == labels).all()
+
+
 def test_heart_scale_known_answer(golden_dir):
     """G5: libsvm KAT: 190 SVs, 259/270 correct, decision values from the reference library."""
     g = np.load(os.path.join(golden_dir, "g5_heart.npz"))
