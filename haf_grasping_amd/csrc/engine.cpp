@@ -232,6 +232,12 @@ struct haf_engine {
     ScreenParams screen{};
     ScreenParams screen_cr{};    // the centred-remainder form's constants and descriptor tables
     CrParams crp{};
+    // tier 1 (three-pass list kernel) in the centred-remainder form, behind SCREEN_CR_POLY: its own SV images (s - m), the centre /
+    // linear-term table of the exact-form feature kernel, L per list slot
+    bool t1_cr_available = false;
+    CrT1Params crt1{};
+    DevBuf<char> d_svt_h_cr;
+    DevBuf<double> d_t1_tab, d_t1_L;
     size_t cells_cap = 0;   // B*R*H*W
 
     // ONE input block per request: [CloudDev x B][RollGeo x B*R][host clouds' points], packed at call time so that a single
@@ -268,6 +274,7 @@ struct haf_engine {
     DevBuf<int> d_flag0_wgcount;                // popcounts per 256 words, for the ordered compaction
     DevBuf<int8_t> d_labels;
     DevBuf<double> d_dec_exact, d_dec_exact2, d_sv64, d_coef64, d_x64, d_part64;
+    DevBuf<double> d_strict_terms;   // strict tier, spread form: kStrictSlots x n_sv_pad products coef K (launch_recheck_known)
     // tier 2a, the exact-integer tier (exact8.hip): int8 digit images of the support vectors, its hand-over list to the fp64 MFMA
     // tier and that tier's decision values for it (d_dec_exact then holds tier 2a's values, in the order of d_flag_list)
     DevBuf<char> d_sv_i8;
@@ -340,6 +347,8 @@ namespace {
 // behind it (seed 11 of the bench generator: 5.8 ms for 378 k evaluations against 14.1 ms for 7.9 M)
 constexpr double kVariantCost[SCREEN_VARIANTS] = {1.0, 1.12, 1.10, 1.16};
 constexpr double kUndecidedCost = 8.5;
+
+constexpr int kStrictSlots = 64;     // evaluations per pass of the strict tier's spread form (a few per request reach it at most)
 
 constexpr size_t kCntBytes = (CNT_COUNT * sizeof(int) + 15) / 16 * 16;      // the counters' share of the output block (d_out)
 
@@ -907,6 +916,65 @@ int build_tables(haf_engine *e)
                 cp.corr = e->d_corr_cr.p;
                 cp.corr2 = reinterpret_cast<const ScrCorr2 *>(e->d_corr_cr.p + kS0K);
                 e->cr_available = true;
+                // ---- tier 1 in the same form (kernels.h: CrT1Params): hi/lo fp16 images of fl32(s - m) in raw attribute units, the
+                // centre and the linear term's constants per attribute for the exact-form feature kernel ----
+                if (!test_env("HAF_NO_CR_T1")) {
+                    std::vector<double> tab((size_t)2 * kKP, 0.0);
+                    std::vector<long double> Gr((size_t)kKP, 0.0L);
+                    for (int k = 0; k < m.dim && k < kKP; k++) {
+                        const int sl = slot_of_attr[(size_t)k];
+                        tab[(size_t)k] = (sl >= 0 && sl < S) ? mu[(size_t)sl] / sp.c : 0.0;
+                    }
+                    std::vector<char> imgh((size_t)e->n_sv_tiles * kHSvTileBytes, 0);
+                    double qmax1 = 0.0, dqmax1 = 0.0, Ca1 = 0.0, Cqq1 = 0.0, Dabs1 = 0.0;
+                    for (int n = 0; n < m.n_sv; n++) {
+                        const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
+                        char *tile = imgh.data() + (size_t)t * kHSvTileBytes;
+                        double q2 = 0.0, h2 = 0.0, d2 = 0.0;
+                        for (int k = 0; k < m.dim; k++) {
+                            const double sc = m.sv[(size_t)n * m.dim + k] - (k < kKP ? tab[(size_t)k] : 0.0);     // s - m, raw units
+                            const float sf = (float)sc;
+                            const _Float16 h = (_Float16)sf;
+                            const _Float16 l = (_Float16)(sf - (float)h);
+                            const size_t off = (size_t)h_image_offset(j, k);
+                            memcpy(tile + off, &h, 2);
+                            memcpy(tile + kHMatBytes + off, &l, 2);
+                            const double se = (double)(float)h + (double)(float)l;
+                            q2 += sc * sc; h2 += se * se; d2 += (se - sc) * (se - sc);
+                            if (k < kKP) Gr[(size_t)k] += (long double)b[(size_t)n] * (long double)sc;
+                        }
+                        float *tail = reinterpret_cast<float *>(tile + 2 * kHMatBytes);
+                        tail[j] = 0.0f;
+                        tail[kTile + j] = (float)b[(size_t)n];
+                        const double qn = sp.c * std::sqrt(q2), qhn = sp.c * std::sqrt(h2), dqn = sp.c * std::sqrt(d2), ab = std::fabs(b[(size_t)n]);
+                        qmax1 = std::max(qmax1, qhn); dqmax1 = std::max(dqmax1, dqn);
+                        Ca1 += ab * qhn * qn; Cqq1 += ab * h2 * sp.c * sp.c; Dabs1 += ab * dqn * dqn;
+                    }
+                    for (int k = 0; k < kKP; k++) tab[(size_t)kKP + k] = ln2 * 2.0 * m.gamma * log2e * (double)Gr[(size_t)k];
+                    CrT1Params &t1 = e->crt1;
+                    t1.B0 = e->crp.B0; t1.rho = m.rho; t1.c = sp.c;
+                    // Q~ against Q^: the signed matrices move by at most sigma(sqrt|b| Q) sigma(sqrt|b| (Q~ - Q^)); slot sums of two
+                    // attributes at most double a rounding error's norm (the 2 in front of sqrt(Dabs1)); Frobenius for the spectral norm
+                    const double sH = std::sqrt(cp.cr_nHabs), sD = std::sqrt(cp.cr_nDabs), sD1 = 2.0 * std::sqrt(Dabs1);
+                    t1.nN = (cp.cr_nN + (sH + sD) * (sD + sD1)) * (1.0 + 1e-9);
+                    t1.nM = (sH + sD) * sD1 * (1.0 + 1e-9) + 1e-300;
+                    t1.nHabs = (sH + sD + sD1) * (sH + sD + sD1) * (1.0 + 1e-9);
+                    t1.nDabs = sD1 * sD1 * (1.0 + 1e-9) + 1e-300;
+                    // (Ca, Cqq, qmax, dqmax bound sums over ATTRIBUTES -- the three passes multiply attribute by attribute -- so the
+                    // attribute-space norms computed above are the right ones as they are)
+                    t1.Ca = Ca1 * (1.0 + 1e-9); t1.Cqq = Cqq1 * (1.0 + 1e-9); t1.Babs = cp.cr_Babs;
+                    t1.qmax = qmax1 * (1.0 + 1e-9); t1.dqmax = dqmax1 * (1.0 + 1e-9) + 1e-300;
+                    t1.acc_rel = (std::max(e->mfma_kappa, e->mfma_kappa16) + 14.0) * std::ldexp(1.0, -24);
+                    t1.dp_rel = (std::ldexp(1.0, -22) + std::ldexp(1.0, -24)) * 1.01;
+                    t1.dp_abs = sp.c * std::sqrt((double)kKP) * std::ldexp(1.0, -25) * 1.01;
+                    t1.sum_rel = (2.0 + 1.0 + 0.1 + 6.0 + 8.0 + 1.0) * std::ldexp(1.0, -24) * (1.0 + 1e-5);
+                    t1.scale = 1.001;
+                    if (hipSuccess != e->d_svt_h_cr.alloc(imgh.size()) || hipSuccess != e->d_t1_tab.alloc(tab.size()))
+                        return fail(e, HAF_E_DEVICE, "hipMalloc(centred-remainder tier-1 tables)");
+                    HIPCHK(e, hipMemcpy(e->d_svt_h_cr.p, imgh.data(), imgh.size(), hipMemcpyHostToDevice));
+                    HIPCHK(e, hipMemcpy(e->d_t1_tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+                    e->t1_cr_available = std::isfinite(t1.nN) && std::isfinite(t1.nHabs) && std::isfinite(t1.Ca);
+                }
             }
         }
     }
@@ -1046,6 +1114,9 @@ int build_tables(haf_engine *e)
     e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * sweep_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
     e->screen_cr.scale = 1.001 * guard0_scale;
+    e->crt1.scale = 1.001 * guard_scale;
+    e->crt1.guard_abs = e->svm.guard_abs;
+    e->crt1.gv0 = e->gv0; e->crt1.gv1 = e->gv1;
     e->svm.guard_abs = (float)(std::fabs(m.rho) * 1.2e-7 + 1e-30);
     {
         double as_max = 0;
@@ -1115,6 +1186,7 @@ int alloc_buffers(haf_engine *e)
         ok &= hipSuccess == e->d_ax1.alloc(slots);
         e->part1_stride = (long)slots;
         ok &= hipSuccess == e->d_part1.alloc(slots * 2 * kHListParts);      // class sums per SV tile range (k_svm_h_combine)
+        if (e->t1_cr_available) ok &= hipSuccess == e->d_t1_L.alloc(slots);
         ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad * kBandFloats);
         ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
         ok &= hipSuccess == e->d_flag0_words.alloc((size_t)e->max_evals_pad / 64);
@@ -1135,6 +1207,7 @@ int alloc_buffers(haf_engine *e)
         ok &= hipSuccess == e->d_dec_exacti.alloc((size_t)e->list_cap);
     }
     ok &= hipSuccess == e->d_dec_exact2.alloc((size_t)e->list_cap);
+    if (!e->prob_mode) ok &= hipSuccess == e->d_strict_terms.alloc((size_t)kStrictSlots * e->n_sv_pad);
     if ((c.flags & HAF_FLAG_KEEP_DEBUG) && mode == MODE_SCREEN) ok &= hipSuccess == e->d_margin.alloc((size_t)e->max_evals_pad);
     if (c.flags & HAF_FLAG_KEEP_DEBUG) {
         // attribute records of the exact-form feature kernels (haf_debug_fetch_attr): 7.6 KB per evaluation, so only for
@@ -1221,12 +1294,13 @@ void haf_destroy(haf_engine *e)
     e->d_in.release(); e->d_out.release(); e->d_sorted.release(); e->d_bkt.release(); e->d_heights.release(); e->d_rowsum.release(); e->d_inexact.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
-    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
+    e->d_dec.release(); e->d_svt.release(); e->d_svt_h.release(); e->d_labels.release(); e->d_dec_exact.release(); e->d_strict_terms.release(); e->d_part64.release(); e->d_dec_exact2.release(); e->d_flag2_list.release(); e->d_x64.release(); e->d_sv64.release();
     e->d_svt0.release(); e->d_X1.release(); e->d_ax1.release(); e->d_gband.release(); e->d_flag0_list.release(); e->d_flag0_words.release(); e->d_flag0_wgcount.release();
     e->d_own.release(); e->d_gridf.release(); e->d_evf.release(); e->d_ptext.release();
     e->d_sv_i8.release(); e->d_flagi_list.release(); e->d_dec_exacti.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
+    e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release();
     e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
@@ -1724,6 +1798,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         if (direct) launch_prob_list(e->d_counters.p, CNT_FLAGGED, e->d_flag_list.p, e->list_cap, s);
     }
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
+    bool i8_used = false;                                    // the exact-integer tier ran in the last decide()
     auto decide = [&](int mode, bool reuse_operands) -> int {
         mark(e, HAF_ST_FEATURES);
         const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
@@ -1751,12 +1826,17 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
             // workgroups beyond the list's end exit at once)
+            // behind the polynomial centred-remainder form (a model whose decisions are 1e-7 of sum|coef|K) tier 1 runs in that form too:
+            // the plain three-pass kernel's band is relative to sum|coef|K and could decide nothing there
+            const bool t1cr = e->screen_variant == SCREEN_CR_POLY && e->t1_cr_available;
+            ScreenParams sp_t1 = e->screen;
+            if (t1cr) { sp_t1.cr_t1_tab = e->d_t1_tab.p; sp_t1.cr_t1_L = e->d_t1_L.p; }
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, e->screen, e->d_flag0_list.p, CNT_FLAGGED0,
+                            e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, sp_t1, e->d_flag0_list.p, CNT_FLAGGED0,
                             e->flag0_cap, false, list_cap, e->d_attr.p, nullptr, s);
-            launch_svm_h(e->d_X1.p, e->d_ax1.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+            launch_svm_h(e->d_X1.p, e->d_ax1.p, t1cr ? e->d_svt_h_cr.p : e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
-                         e->d_part1.p, e->part1_stride, s);
+                         e->d_part1.p, e->part1_stride, s, t1cr ? &e->crt1 : nullptr, t1cr ? e->d_t1_L.p : nullptr);
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, nullptr, s);
@@ -1778,7 +1858,11 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         // strict tier is launched only when the counters that come back with the roll records say it has work (never so far).
         // tier 2a in front of it (exact8.hip): the same evaluations on EXACT integer dot products (int8 digit planes); what it
         // cannot decide either -- |dec| inside the operands' quantisation, ~1e-7 S -- is the fp64 MFMA tier's list
-        const bool i8 = e->i8_active && !direct && !small_exact;
+        // (behind the centred-remainder form of tier 1 the exact-integer tier has nothing to add: its band is the quantisation of the
+        // operands relative to sum|coef|K -- 8e-9 S for the trained model, 0.14 -- and tier 1's is relative to S_psi, 0.02: measured,
+        // it decided 8 of 9984 evaluations in 4.6 ms.  What tier 1 leaves goes straight to the fp64 MFMA tier)
+        const bool i8 = e->i8_active && !direct && !small_exact && !(mode == MODE_SCREEN && e->screen_variant == SCREEN_CR_POLY && e->t1_cr_available);
+        i8_used = i8;
         auto fp64_window = [&](int off) {
             if (small_exact)
                 launch_small_direct(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_sv64.p, e->exact, d, e->flag_cap, e->d_dec_exact.p,
@@ -1849,8 +1933,9 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             if (rc != HAF_OK) return rc;
             strict_ran = e->h_counters[CNT_FLAGGED2] > 0;
         } else if (e->h_counters[CNT_FLAGGED2] > 0) {
-            launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
-                           e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+            // (the host knows the list's length here: the spread form of the tier, kernels.hip)
+            launch_recheck_known(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p,
+                                 std::min(e->h_counters[CNT_FLAGGED2], e->list_cap), e->d_strict_terms.p, kStrictSlots, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();
             if (rc != HAF_OK) return rc;
             strict_ran = true;
@@ -1956,7 +2041,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
-    e->last_flaggedi = (e->i8_active && !direct && !small_exact) ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
+    e->last_flaggedi = i8_used ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
     e->last_inexact = inexact_grids;
     e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->last_flagged0 <= e->flag0_cap;
     // zero the counters for the next request now, behind this one's copy-out: off that request's critical path
@@ -1964,7 +2049,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_inputs.assign(in, in + B);
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
     if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap || e->last_flaggedi > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
-    e->last_i8 = e->i8_active && !direct && !small_exact;
+    e->last_i8 = i8_used;
     for (int i = 0; i < B * R; i++) {
         records[i].vote = e->h_rec[i].vote;
         records[i].row = e->h_rec[i].row;

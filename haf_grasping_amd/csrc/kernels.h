@@ -136,6 +136,23 @@ struct ScreenParams {
     double cr_qmax, cr_dqmax;     // max_n |q^_n|, max_n |q^_n - q_n|
     double cr_gnorm;              // |g|_2
     double cr_mu_norm, cr_mu_norm_t;   // |mu| in slot space / over all attributes: |u'| <= |p'| + |mu| (the missing "%g" round trip is relative to u')
+    // tier 1 in the centred-remainder form (the three-pass list kernel behind SCREEN_CR_POLY, kernels.hip): the exact-form feature
+    // kernel subtracts the centre (raw attribute units) before the hi/lo split and sums L = sum (x_f - m_f) gl_f in fp64
+    const double *cr_t1_tab;      // device: [kKP] centre m_f, then [kKP] gl_f = ln2 * 2 gamma' * sum_n b_n (s_nf - m_f);  nullptr: plain form
+    double *cr_t1_L;              // device: L per list slot
+};
+// constants of tier 1's centred-remainder band (k_svm_h_combine_cr): the same bound as screen_finish_cr with the operands'
+// errors those of the hi+lo split (2^-22 relative) and the accumulation that of the PRECISE three-pass form ((kappa + 14) u)
+struct CrT1Params {
+    double B0, rho;
+    double c;                     // sqrt(2 gamma log2 e): |p| = c |x - m|
+    double nN, nM, nHabs, nDabs, Ca, Cqq, Babs, qmax, dqmax;   // as ScreenParams::cr_*, with Q~ = hi + lo of fl32(s - m) in place of Q^
+    double acc_rel;               // (kappa + 14) 2^-24
+    double dp_rel, dp_abs;        // |p~ - p| <= dp_rel |p| + dp_abs (fp32 rounding of x - m, fp16 hi + lo, flushed lo subnormals)
+    double sum_rel;               // fp32 part of the coefficient sum + the polynomial's roundings, relative to S_psi
+    double scale;                 // 1.001 x HAF_GUARD_REL
+    float guard_abs;
+    int gv0, gv1, pad;
 };
 // constants of the centred-remainder form that the contraction kernel's tail needs (fp64: B0 + L cancels against rho)
 struct CrParams { double B0, rho; };
@@ -346,7 +363,8 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                   long max_evals, const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride,
-                  hipStream_t s);
+                  hipStream_t s,
+                  const CrT1Params *cr = nullptr, const double *Lbuf = nullptr);   // list mode only: the centred-remainder form (svt_h = its images)
 // tiny requests: exact attributes + fp64 MFMA decision + label in one launch (tier 2's arithmetic for every evaluation)
 void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,
                          long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s,
@@ -354,6 +372,11 @@ void launch_small_direct(const float *ii, const int *evalcell, int *counters, co
 void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
+// the same tier for a list whose length the host knows: spread over (evaluation groups x SV chunks), terms = scratch of
+// terms_slots x n_sv_pad doubles (kernels.hip)
+void launch_recheck_known(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
+                          ExactParams p, const int *flag_list, int n_flag, double *terms, int terms_slots,
+                          double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
                          const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
                          double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s,

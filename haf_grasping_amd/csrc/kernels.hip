@@ -1700,6 +1700,10 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     __shared__ double red2[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     __shared__ double red3[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
     __shared__ float red4[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals], red5[(MODE == XMODE_SCREEN) ? kFeatWaves : 1][kFeatEvals];
+    // XMODE_SPLIT in the centred-remainder form (tier 1 behind SCREEN_CR_POLY, ScreenParams::cr_t1_tab): the centre is subtracted from
+    // the exact attribute (fp64) before the hi/lo split and L = sum (x_f - m_f) gl_f is summed in fp64
+    __shared__ double red_l[(MODE == XMODE_SPLIT) ? kFeatWaves : 1][kFeatEvals];
+    const double *t1_tab = (MODE == XMODE_SPLIT) ? sp.cr_t1_tab : nullptr;
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     if (MODE == XMODE_I8 && n_evals <= kI8SmallList) return;           // short lists are k_features_small's (see there)
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
@@ -1745,6 +1749,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     float sx = 0.0f;
     long long xx_ll = 0;                                               // XMODE_I8 (see i8_digits)
     int ovf = 0;
+    double lsum = 0.0;
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
         double udv[8];
@@ -1758,6 +1763,10 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                 if (live && !F.skip) xd = screen_attribute(src, F, st);  // u' = c x', not x'
             } else if (live && f < d.nf) {
                 xd = attribute_value_rec(src, fd[f], lower, upper, tb, rec ? rec + f : nullptr);
+                if (MODE == XMODE_SPLIT && t1_tab && f < kKP) {          // (wave-uniform f: the two constants come by scalar loads)
+                    xd -= t1_tab[f];
+                    lsum = fma(xd, t1_tab[kKP + f], lsum);
+                }
             }
             udv[q] = xd;
             const float xf = (float)xd;
@@ -1787,6 +1796,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
         if (MODE == XMODE_I8) i8_store(X, e, g, dig);
     }
     if (MODE == XMODE_I8) { red_ll[gl][ev] = xx_ll; red_ovf[gl][ev] = ovf; }
+    if (MODE == XMODE_SPLIT) red_l[gl][ev] = lsum;
     red[gl][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
     if (MODE == XMODE_SCREEN) { red2[gl][ev] = (double)acc.sd2; red3[gl][ev] = (double)sx; red4[gl][ev] = acc.cr; red5[gl][ev] = acc.ub; }
     __syncthreads();
@@ -1809,6 +1819,12 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
             reinterpret_cast<double *>(ax)[e] = any ? -1.0 : ldexp((double)s2, -2 * kI8Q);
         } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+            if (MODE == XMODE_SPLIT && t1_tab) {
+                double l = 0.0;
+#pragma unroll
+                for (int k = 0; k < kFeatWaves; k++) l += red_l[k][ev];   // fixed order
+                sp.cr_t1_L[e] = l;
+            }
         }
     }
     __syncthreads();                                                   // red / red2 are reused by the next block
@@ -2348,7 +2364,12 @@ __device__ __forceinline__ f32x4 h_fma4s(float s, f32x4 v, f32x4 c)        // fm
 // own MFMA chain first.  Whatever order the matrix core adds the 32 products of an instruction in, the error is then at
 // most 31 u T_s per instruction (T_s = the step's sum of |products|) + one rounding per VALU add: 43 u sum|x_i s_i| in all
 // instead of one rounding per product of a 3 x 336-term chain, and the guard band shrinks with it (guard_dot_p).
-template <bool PRECISE>
+// CRP (PRECISE list mode only; round 4): the centred-remainder form of tier 1 behind SCREEN_CR_POLY.  X and the SV tiles hold x - m
+// and s - m, the tile tail holds b_n = c_n 2^(-gamma'|s_n - m|^2) where the plain form has the coefficient (and 0 where it has
+// -gamma'|s|^2), the epilogue accumulates b psi(z), z = 2 gamma' (x - m).(s - m), psi(z) = z^2 (a2 + a3 z + a4 z^2 + a5 z^3) -- no
+// transcendental, relative accuracy -- and k_svm_h_combine_cr forms dec = 2^(a_x) (B0 + L + P + N) - rho with its band.
+constexpr float kPsiA2h = 0.240226506959101f, kPsiA3h = 0.0555041086648216f, kPsiA4h = 0.00961812910762848f, kPsiA5h = 0.00133335581464284f;
+template <bool PRECISE, bool CRP = false>
 __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__restrict__ X, const float *__restrict__ ax,
                                                               const char *__restrict__ svt,
                                                               const int *__restrict__ evalcell,
@@ -2608,12 +2629,20 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                 cfn[n] = tail[kTile + 16 * n + (lane & 15)];         // coef_j (0 for padding SVs)
 #pragma unroll
                 for (int m = 0; m < 2; m++) {                        // 16x16 C/D layout: col = lane&15, row = 16m + 4(lane>>4) + reg
+                    if (CRP) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float z = p.two_gamma2 * acc[m][n][r];
+                            acc[m][n][r] = (z * z) * fmaf(fmaf(fmaf(z, kPsiA5h, kPsiA4h), z, kPsiA3h), z, kPsiA2h);
+                        }
+                        continue;
+                    }
                     const f32x4 arg = h_fma4s(p.two_gamma2, acc[m][n], h_add4s(ax4[m], as_));
 #pragma unroll
                     for (int r = 0; r < 4; r++) acc[m][n][r] = (HAF_ABL == 2) ? arg[r] : __builtin_amdgcn_exp2f(arg[r]);
                 }
             }
-            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            if (!CRP) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #pragma unroll
             for (int m = 0; m < 2; m++) l4[m] = h_fma4s(cfn[1], acc[m][1], h_fma4s(cfn[0], acc[m][0], f32x4{0.0f, 0.0f, 0.0f, 0.0f}));
 #pragma unroll
@@ -2730,12 +2759,76 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const double *__restrict_
     }
 }
 
+// centred-remainder form of the list mode (k_svm_rbf_h<true, true>): P, N are the class sums of b psi(z); dec = A (B0 + L + P + N) - rho in
+// fp64, A = 2^(a_x) with a_x = -gamma'|x~ - m|^2 of the operand the passes multiplied.  Band: screen_finish_cr's bound with the
+// operands' errors those of the hi + lo split and the accumulation that of the PRECISE form (CrT1Params).
+__global__ __launch_bounds__(256) void k_svm_h_combine_cr(const double *__restrict__ part_out, long part_stride, int parts,
+                                                          const float *__restrict__ ax, const double *__restrict__ Lbuf,
+                                                          const int *__restrict__ evalcell, const int *__restrict__ counters, CrT1Params c,
+                                                          float *__restrict__ dec, int8_t *__restrict__ labels,
+                                                          int *__restrict__ flag_list, int flag_cap, int *__restrict__ counters_rw,
+                                                          const int *__restrict__ idx_list, int list_counter, int list_cap)
+{
+    const int n_evals = min(counters[list_counter], list_cap);
+    const double ln2 = 0.69314718056, u24 = 5.9604644775390625e-08;
+    for (long es = (long)blockIdx.x * 256 + threadIdx.x; es < n_evals; es += (long)gridDim.x * 256) {
+        double P = 0.0, N = 0.0;
+        for (int y = 0; y < parts; y++) {
+            P += part_out[(2 * y) * part_stride + es];
+            N += part_out[(2 * y + 1) * part_stride + es];
+        }
+        const int e = idx_list[es];
+        const double a_x = -(double)ax[es];                             // gamma'|x~ - m|^2 (fp32: u a_x in the exponent)
+        const double A = exp2(-a_x);
+        const double L = Lbuf[es];
+        const double dvd = A * ((c.B0 + L) + (P + N)) - c.rho;
+        const float dv = (float)dvd;
+        const double spsi = P - N;
+        // |p~| = c |x~ - m| = sqrt(2 a_x); p~ against the true p: fp32 rounding of x - m, the fp16 hi + lo split, flushed lo subnormals
+        const double ph = sqrt_upper(2.0 * a_x * (1.0 + 2.0 * u24)) + 1e-30;
+        const double dn = c.dp_rel * ph + c.dp_abs, un = ph + dn;
+        const double eps = dn * c.qmax + un * c.dqmax + c.acc_rel * ph * c.qmax + 2.0 * u24 * ph * c.qmax;   // (+ the fp32 product with 2 gamma')
+        const double zmax = ph * c.qmax + eps;
+        const double zf = floor(zmax);
+        const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();
+        const double quad1 = ln2 * ln2 * (c.nN * un * dn + c.nM * un * un + (c.acc_rel + 2.0 * u24) * ph * un * c.Ca);
+        const double quad2 = 1.5 * ln2 * ln2 * (c.nHabs * dn * dn + c.nDabs * un * un + c.acc_rel * c.acc_rel * ph * ph * c.Cqq);
+        const double cub2 = ln2 * ln2 * (p2 - 1.0) * eps * eps * c.Babs * 1.01;
+        const double t = ln2 * zmax;
+        double k_psi = ln2 * eps * 1.01 + c.sum_rel + 4.1 * t * t * t * t / 360.0;
+        if (!(t <= 1.0)) k_psi = (double)__builtin_inff();
+        // the common factor: a_x in fp32, x~ against x in |x - m|^2 (2 |p||dp| + |dp|^2 in the exponent, log2 units: x 1/2), exp2 in fp64
+        const double D = u24 * a_x + un * dn + 0.5 * dn * dn + 1e-12;
+        const double cm = exp2m1_upper(D);
+        // L: an fp64 sum of exact terms (the attributes are the exact ones): 2^-50 of the terms' magnitudes at most
+        const double cL = 1e-15 * (fabs(L) + 1.0);
+        const double err = ((A * (quad1 + quad2 + cub2 + cL + k_psi * spsi) * (1.0 + cm) + cm * (fabs(dvd) + fabs(c.rho))) * c.scale + 2.4e-7 * fabs(dvd)) * 1.002 +
+                           (double)c.guard_abs;
+        dec[e] = dv;
+        labels[evalcell[e]] = (int8_t)(dv > 0.0f ? c.gv0 : c.gv1);
+        if (!(fabs(dvd) > err) || !(D < 0.05)) {
+            int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
+            if (slot < flag_cap) flag_list[slot] = e;
+        }
+    }
+}
+
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters, SvmParams p,
                   float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
-                  const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride, hipStream_t s)
+                  const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride, hipStream_t s,
+                  const CrT1Params *cr, const double *Lbuf)
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
+    if (idx_list && cr && part_out) {
+        const int parts = (d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;
+        hipLaunchKernelGGL((k_svm_rbf_h<true, true>), dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
+                           (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
+                           list_counter, list_cap, part_out, part_stride);
+        hipLaunchKernelGGL(k_svm_h_combine_cr, dim3(1024), dim3(256), 0, s, part_out, part_stride, parts, ax, Lbuf, evalcell, counters, *cr, dec,
+                           labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap);
+        return;
+    }
     if (idx_list) {
         const int parts = (part_out && d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;     // engine.cpp: guard_acc_l follows this rule
         double *po = parts > 1 ? part_out : nullptr;
@@ -2827,6 +2920,91 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
             }
         }
         __syncthreads();
+    }
+}
+
+// The same tier when the HOST knows the list's length (it does whenever the tier runs behind the others: the counters came back with
+// the roll records) -- spread out: a workgroup per (group of kRB evaluations, chunk of kRChunk support vectors) writes the products
+// coef_n K_n to a scratch row per evaluation, then a workgroup per evaluation adds them IN MODEL ORDER (one thread, chunk by chunk
+// through LDS).  Every operation and the order of the sum are k_recheck's; only who computes which K differs.  A model of 8964 SVs
+// kept one workgroup busy for 4.3 ms (35 chunks one after the other) for the four evaluations a C5 request leaves within 2^-40 S
+// of zero; spread over 35 workgroups + the sum it is ~0.15 ms.
+__global__ __launch_bounds__(256) void k_recheck_terms(const float *__restrict__ ii, const int *__restrict__ evalcell,
+                                                       const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
+                                                       const double *__restrict__ coef64, ExactParams p,
+                                                       const int *__restrict__ flag_list, int list_off, int n_win,
+                                                       double *__restrict__ terms_out, Dims d)
+{
+    __shared__ double xs[kRB][kKP];
+    const int H = d.H, W = d.W;
+    const rsrc_t iir = make_ii_rsrc(ii, d);
+    const int tid = threadIdx.x, g = blockIdx.y, n0 = blockIdx.x * kRChunk;
+    for (int it = tid; it < kRB * p.kx; it += 256) {
+        const int ev = it / p.kx, f = it - ev * p.kx;
+        const int slot = g * kRB + ev;
+        double x = 0.0;
+        if (slot < n_win && f < d.nf && !fd[f].skip)
+            x = attribute_value(SrcBuf<false>{iir, window_origin(evalcell[flag_list[list_off + slot]], H, W)}, fd[f], p.lower, p.upper, hafq::GlobalTabs());
+        xs[ev][f] = x;
+    }
+    __syncthreads();
+    const int n = n0 + tid;
+    if (n >= p.n_sv) return;
+    double sum[kRB];
+#pragma unroll
+    for (int ev = 0; ev < kRB; ev++) sum[ev] = 0.0;
+    const double *col = sv64 + n;
+    for (int k = 0; k < p.kx; k++) {
+        const double sv = col[(size_t)k * p.n_sv_pad];
+#pragma unroll
+        for (int ev = 0; ev < kRB; ev++) {
+            double dd = __dsub_rn(xs[ev][k], sv);
+            sum[ev] = __dadd_rn(sum[ev], __dmul_rn(dd, dd));          // svm.cpp:333-334, 342, 347
+        }
+    }
+    const double c = coef64[n];
+#pragma unroll
+    for (int ev = 0; ev < kRB; ev++) {
+        const int slot = g * kRB + ev;
+        if (slot < n_win) terms_out[(size_t)slot * p.n_sv_pad + n] = __dmul_rn(c, exp(__dmul_rn(-p.gamma, sum[ev])));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_recheck_sum(const double *__restrict__ terms_in, ExactParams p, const int *__restrict__ evalcell,
+                                                     const int *__restrict__ flag_list, int list_off, int n_win,
+                                                     double *__restrict__ dec_exact, int8_t *__restrict__ labels)
+{
+    __shared__ double t[kRChunk];
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    if (slot >= n_win) return;
+    const double *row = terms_in + (size_t)slot * p.n_sv_pad;
+    double s = 0.0;
+    for (int n0 = 0; n0 < p.n_sv; n0 += kRChunk) {
+        if (n0 + tid < p.n_sv) t[tid] = row[n0 + tid];
+        __syncthreads();
+        if (tid == 0) {
+            const int cnt = min(kRChunk, p.n_sv - n0);
+            for (int q = 0; q < cnt; q++) s = __dadd_rn(s, t[q]);      // model order (2509-2512)
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double dv = __dsub_rn(s, p.rho);                         // 2513
+        dec_exact[list_off + slot] = dv;
+        labels[evalcell[flag_list[list_off + slot]]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
+    }
+}
+
+void launch_recheck_known(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
+                          ExactParams p, const int *flag_list, int n_flag, double *terms, int terms_slots,
+                          double *dec_exact, int8_t *labels, Dims d, hipStream_t s)
+{
+    const int chunks = (p.n_sv + kRChunk - 1) / kRChunk;
+    for (int off = 0; off < n_flag; off += terms_slots) {
+        const int n_win = std::min(terms_slots, n_flag - off);
+        hipLaunchKernelGGL(k_recheck_terms, dim3((unsigned)chunks, (unsigned)((n_win + kRB - 1) / kRB)), dim3(256), 0, s, ii, evalcell, fd, sv64,
+                           coef64, p, flag_list, off, n_win, terms, d);
+        hipLaunchKernelGGL(k_recheck_sum, dim3((unsigned)n_win), dim3(256), 0, s, terms, p, evalcell, flag_list, off, n_win, dec_exact, labels);
     }
 }
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rolls", type=int, default=36)
     ap.add_argument("--hard", action="store_true")
+    ap.add_argument("--trained", action="store_true", help="the 8964-SV trained model (tests/golden/trained.model.npz)")
     ap.add_argument("--no-ab", action="store_true", help="only the default build behaviour")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -42,10 +43,14 @@ def main():
     cases = [("seed%d" % int(s), int(s)) for s in a.seeds.split(",") if s.strip()]
     if a.hard:
         cases.append(("hard", None))
+    if a.trained:
+        cases.append(("trained", "trained"))
     rows = []
     for name, seed in cases:
         mp = os.path.join(tmp, name + ".model")
-        if seed is None:
+        if seed == "trained":
+            models.unpack_trained_model(os.path.join(ROOT, "tests", "golden", "trained.model.npz"), mp)
+        elif seed is None:
             models.write_replicated_model(mp, os.path.join(ROOT, "tests", "golden", "surrogate.model"), copies=24, jitter=0.01, seed=5)
         else:
             models.write_random_model(mp, a.nsv, D=323, seed=seed, balanced=True)
