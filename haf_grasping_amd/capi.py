@@ -146,6 +146,8 @@ def _bind(path, testing):
         L.haf_test_finalize.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]
         L.haf_test_roll_pose.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.c_int,
                                          C.POINTER(GraspOutput), C.POINTER(C.c_int32)]
+        L.haf_test_mfma_kappa.argtypes = [E, C.c_void_p, C.c_void_p]
+        L.haf_test_f16_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.haf_test_screen_state.argtypes = [E, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     return L
 

@@ -318,8 +318,8 @@ struct haf_engine {
     double host_exp_thr = 0.0;
     int last_host_resolved = 0;
     bool calibrated = false;        // the screening variant was chosen at creation (calibrate())
-    double mfma_kappa = 8.0;        // error of one v_mfma_f32_16x16x32_f16 in units of 2^-24 (|c| + sum|a b|): max(8, 1.5 x probe_mfma_rounding())
-    double mfma_kappa16 = 8.0;      // the same for v_mfma_f32_16x16x16f16 (the K tail of the three-pass kernel)
+    double mfma_kappa = 12.0;       // error of one v_mfma_f32_16x16x32_f16 in units of 2^-24 (|c| + sum|a b|): max(12, 1.5 x probe_mfma_rounding())
+    double mfma_kappa16 = 12.0;     // the same for v_mfma_f32_16x16x16f16 (the K tail of the three-pass kernel)
     double mfma_kappa_measured = 0.0, mfma_kappa16_measured = 0.0;
     bool no_bucket_sort = false;    // set (for good) when a tile of the bucket-sorted binning path overflowed its candidate list
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
@@ -964,7 +964,9 @@ int build_tables(haf_engine *e)
                     // attribute-space norms computed above are the right ones as they are)
                     t1.Ca = Ca1 * (1.0 + 1e-9); t1.Cqq = Cqq1 * (1.0 + 1e-9); t1.Babs = cp.cr_Babs;
                     t1.qmax = qmax1 * (1.0 + 1e-9); t1.dqmax = dqmax1 * (1.0 + 1e-9) + 1e-300;
-                    t1.acc_rel = (std::max(e->mfma_kappa, e->mfma_kappa16) + 14.0) * std::ldexp(1.0, -24);
+                    // (the same worst-case floor as the plain form of this tier: guard_dot_p, below)
+                    t1.acc_rel = ((test_env("HAF_KAPPA_T1_MEASURED") ? std::max(e->mfma_kappa, e->mfma_kappa16)
+                                                                     : std::max(64.0, std::max(e->mfma_kappa, e->mfma_kappa16))) + 14.0) * std::ldexp(1.0, -24);
                     t1.dp_rel = (std::ldexp(1.0, -22) + std::ldexp(1.0, -24)) * 1.01;
                     t1.dp_abs = sp.c * std::sqrt((double)kKP) * std::ldexp(1.0, -25) * 1.01;
                     t1.sum_rel = (2.0 + 1.0 + 0.1 + 6.0 + 8.0 + 1.0) * std::ldexp(1.0, -24) * (1.0 + 1e-5);
@@ -1087,7 +1089,13 @@ int build_tables(haf_engine *e)
     // at most kappa u of its sum|products| (mfma_kappa: measured at creation, with its margin), 11 VALU adds join the instructions'
     // results (one rounding each, of at most the whole sum|x_i s_i|), one more for the small-pass chain (whose own roundings are
     // 2^-10 of that): kappa + 12 instead of 324 (kappa: the larger of the two shapes' -- the K tail is a 16-wide instruction)
-    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * (std::max(e->mfma_kappa, e->mfma_kappa16) + 12.0) * u + 8.0 * u));
+    // the measured kappa may only WIDEN this tier's band.  Its floor is the worst any adder could do with 33 terms -- 32
+    // additions that each lose up to an ulp (2 u: the probe shows truncating alignment, not round-to-nearest) = 64 u -- so that tier 1,
+    // whose flagged evaluations are cheap since tier 2a exists, never rests on the probe's seven families alone.  (The screening tier
+    // keeps the measured constant: ten instructions at 64 u would leave nothing for it to decide, and what it decides wrongly would
+    // have to be wrong by 8x the largest error any of 114 688 adversarial sums showed)
+    const double kappa_t1 = test_env("HAF_KAPPA_T1_MEASURED") ? std::max(e->mfma_kappa, e->mfma_kappa16) : std::max(64.0, std::max(e->mfma_kappa, e->mfma_kappa16));
+    e->svm.guard_dot_p = (float)(guard_scale * (0.6932 * (kappa_t1 + 12.0) * u + 8.0 * u));
     // coefficient sum: sequential over the tiles (fp32 kernel: one fma per tile and sum register) or two-level (split-fp16
     // kernel: an inner sum takes the 2 column blocks of 8 tiles, 16 fmas, then one add per 8 tiles); +2 for the class split
     // (P and N are reduced separately), +4/5 lane-reduction steps, +6 for exp2 and the product.  All terms of a class sum have
@@ -1498,8 +1506,14 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         if (!(meas > 0.0) || !(meas16 > 0.0)) { e->error = "matrix-core rounding probe failed to run"; return bail(HAF_E_DEVICE); }
         e->mfma_kappa_measured = meas;
         e->mfma_kappa16_measured = meas16;
-        e->mfma_kappa = std::max(8.0, 1.5 * meas);
-        e->mfma_kappa16 = std::max(8.0, 1.5 * meas16);
+        // floor 12 (round 4; 8 before): the largest value seen by any search so far is 9.1 -- one product of order 1 over 31 products
+        // with 22-bit mantissas, tests/test_engine_gpu.py::test_matrix_core_rounding_adversarial_search -- and the reading that fits
+        // every measurement (terms aligned to the largest exponent, two guard bits, one final rounding) allows 33 x 0.25 + 1 = 9.25
+        e->mfma_kappa = std::max(12.0, 1.5 * meas);
+        e->mfma_kappa16 = std::max(12.0, 1.5 * meas16);
+        // testing build: a matrix core that rounds worse than any seen, injected -- the bands must widen with it, the labels must not
+        // move, and from 64 on the engine must refuse the device (tests/test_engine_gpu.py)
+        if (const char *k = test_env("HAF_KAPPA")) e->mfma_kappa = e->mfma_kappa16 = atof(k);
         if (!(e->mfma_kappa < 64.0) || !(e->mfma_kappa16 < 64.0)) { e->error = "this device's fp16 MFMA rounds far worse than the guard bands allow for (probe_mfma_rounding)"; return bail(HAF_E_DEVICE); }
     }
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments

@@ -64,7 +64,8 @@ DEC_REL_SCREEN = 2.0 ** -8
 # environment switches of the TESTING build (libhafgrasp_testing.so, -DHAF_TESTING); the product library ignores them
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
-              "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE")
+              "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
+              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -689,6 +690,46 @@ def test_every_form_of_the_screening_pass_gives_the_oracles_labels(data_dir, sur
     assert refined[("surrogate", 2)] < 0.4 < refined[("surrogate", 0)]
     assert refined[("trained", "auto")][0] == 3 and refined[("trained", 3)] < 0.2 and min(refined[("trained", v)] for v in (0, 1, 2)) > 0.95
     assert refined[("random", 2)] <= refined[("random", 0)] + 0.01
+
+
+def test_a_worse_matrix_core_widens_the_bands_and_a_far_worse_one_is_refused(data_dir, surrogate, orc, monkeypatch, tmp_path):
+    """VERDICT r3 item 2b.  The one measured constant in the bands is kappa, the rounding of one fp16 MFMA instruction in units of
+    2^-24 (|c| + sum|a b|), taken as max(12, 1.5 x what haf_create's probe sees).  Injected (HAF_KAPPA, testing build): 20, 40 -- the
+    screening band must widen monotonically (more evaluations handed on), every label must stay the oracle's; from 64 on haf_create
+    must refuse the device with the documented text.  Both for the plain form and for the centred-remainder form, on a random model
+    and on the surrogate.  (Tier 1 does not narrow on the measurement at all since round 4: its band has the worst case of 32
+    truncating additions, 64 u, as a floor -- ADVICE r3 -- so the injected values below 64 leave its hand-over count unchanged.)"""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    f, r = _files(data_dir)
+    rnd = str(tmp_path / "rand600.model")
+    models.write_random_model(rnd, 600, seed=3, balanced=True)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "pcd3.pcd"))
+    inp = dict(grasp_area_length_x=32, grasp_area_length_y=44)
+    seen = {}
+    for name, model, o, variant in (("random/plain", rnd, O.Oracle(f, r, rnd), 0), ("random/cr", rnd, O.Oracle(f, r, rnd), 2), ("surrogate/cr", surrogate, orc, 2)):
+        monkeypatch.setenv("HAF_SCREEN_VARIANT", str(variant))
+        refined, rechecked = [], []
+        for kappa in (None, 20, 40):
+            if kappa is None:
+                monkeypatch.delenv("HAF_KAPPA", raising=False)
+            else:
+                monkeypatch.setenv("HAF_KAPPA", str(kappa))
+            eng = make_engine(data_dir, model)
+            meas, used = (C.c_double * 2)(), (C.c_double * 2)()
+            assert eng._L.haf_test_mfma_kappa(eng._h, meas, used) == 0
+            assert used[0] == (kappa if kappa is not None else max(12.0, 1.5 * meas[0])) and 0 < meas[0] < 12
+            compare_full(eng, o, xyz, dict(n_rolls=12), inp, check_dec=False)
+            cnt = eng.last_counts()
+            refined.append(cnt["n_refined"])
+            rechecked.append(cnt["n_rechecked"])
+            eng.close()
+        assert refined[0] < refined[1] < refined[2] < cnt["n_evals"], (name, refined)
+        seen[name] = dict(refined=refined, rechecked=rechecked)
+    monkeypatch.setenv("HAF_KAPPA", "70")
+    with pytest.raises(capi.HafError) as ei:
+        make_engine(data_dir, rnd)
+    assert ei.value.code == capi.HAF_E_DEVICE and "rounds far worse than the guard bands allow" in str(ei.value)
+    STATS["kappa_injection"] = seen
 
 
 def test_exact_integer_tier(data_dir, surrogate, orc, monkeypatch, tmp_path):
@@ -1344,7 +1385,7 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption(data_dir, sur
     v_mfma_f32_16x16x32_f16 deviates from the exact c + sum a_k b_k by at most kappa 2^-24 (|c| + sum |a_k b_k|), so a chain of ten
     that starts from C by at most 10 kappa 2^-24 (|C| + sum |a_k b_k|).  The products are exact in fp32; how the matrix core adds
     them is not documented.  Round 3: kappa is MEASURED at haf_create on the device the engine runs on (screen.hip:
-    probe_mfma_rounding, adversarial families) and used with a margin, kappa = max(8, 1.5 x measured).  Evidence, not proof:
+    probe_mfma_rounding, adversarial families) and used with a margin, kappa = max(12, 1.5 x measured) since round 4.  Evidence, not proof:
     (1) what the engine measured here (5.5 on the devices seen so far) and what it uses; (2) the chain of k_svm_screen (same
     builtin, same operand layout, same start-value mechanism) on 2 048 trials x 256 outputs of operands made to hurt --
     magnitudes over the whole fp16 range the operands can take, signs arranged for near-total cancellation, start values like
@@ -1357,7 +1398,7 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption(data_dir, sur
     assert L.haf_test_mfma_kappa(eng._h, meas, used) == 0
     eng.close()
     for k in range(2):
-        assert 0.5 <= meas[k] <= 8.0 and used[k] == max(8.0, 1.5 * meas[k]), (k, meas[k], used[k])
+        assert 0.5 <= meas[k] <= 12.0 and used[k] == max(12.0, 1.5 * meas[k]), (k, meas[k], used[k])
     budget = 10.0 * used[0] * 2.0 ** -24
     STATS["mfma_rounding_kappa"] = {"measured_32": meas[0], "used_32": used[0], "measured_16": meas[1], "used_16": used[1]}
     rng = np.random.RandomState(77)
@@ -1388,6 +1429,99 @@ def test_matrix_core_accumulation_stays_inside_the_band_assumption(data_dir, sur
     assert np.isfinite(out).all() and ratio.max() <= 1.0, float(ratio.max())
     STATS["mfma_accumulation_error_as_fraction_of_the_10_kappa_u_budget"] = {"max": float(ratio.max()),
                                                                           "by_kind": [float(ratio[k::4].max()) for k in range(4)]}
+
+
+def test_matrix_core_rounding_adversarial_search(data_dir, surrogate):
+    """the probe at haf_create uses seven fixed families.  Here ONE v_mfma_f32_16x16x32_f16 is attacked by a seeded search
+    instead: random exponent spreads (every product's magnitude drawn from 2^-24 .. 2^4 independently), multi-way cancellation (3 to
+    8 large products that sum to nearly nothing over many small ones, the accumulator among them or not), ladders, and hill
+    climbing from the worst cases found (perturb exponents and signs, keep what raises the ratio).  The largest
+    |d - exact| / (2^-24 (|c| + sum|a_k b_k|)) over ~2 M sums must stay below the kappa the bands use and within 15 % of what the
+    probe itself measures.  (Round 4: the first version of this search found 6.4, then -- with the "dense" family: one product of
+    order 1 over 31 products with 22-bit mantissas -- 9.0, where the probe's seven families reached 5.5 and the bands used 8.2: the
+    probe got that family (it measures 7.6 .. 9 with its 64 trials) and the bands use max(12, 1.5 x that) since.  Two guard bits below the largest exponent allow 33 x 0.25 + 1.)"""
+    L = capi.testlib()
+    eng = make_engine(data_dir, surrogate, 0, testing=True)
+    meas, used = (C.c_double * 2)(), (C.c_double * 2)()
+    assert L.haf_test_mfma_kappa(eng._h, meas, used) == 0
+    eng.close()
+    rng = np.random.RandomState(2026)
+    u = 2.0 ** -24
+
+    def run(a, b, c):
+        T = a.shape[0]
+        a16, b16 = np.ascontiguousarray(a.astype(np.float16)), np.ascontiguousarray(b.astype(np.float16))
+        c32 = np.ascontiguousarray(c.astype(np.float32))
+        d = np.zeros((T, 16, 16), np.float32)
+        assert L.haf_test_f16_mfma(a16.ctypes.data, b16.ctypes.data, c32.ctypes.data, d.ctypes.data, T, 1) == 0
+        A, B, Cc = a16.astype(np.float64), b16.astype(np.float64), c32.astype(np.float64)
+        prod = np.transpose(A[:, :, :, None] * B[:, None, :, :], (0, 1, 3, 2))          # [T][16][16][32], exact in fp64
+        terms = np.concatenate([prod, Cc[:, :, :, None]], axis=3).astype(np.longdouble)
+        order = np.argsort(np.abs(terms), axis=3)
+        s = np.take_along_axis(terms, order, axis=3).sum(axis=3)                       # smallest first, long double
+        scale = np.abs(terms).sum(axis=3).astype(np.float64)
+        ratio = np.abs(d.astype(np.longdouble) - s).astype(np.float64) / (u * np.maximum(scale, 1e-300))
+        assert np.isfinite(d).all()
+        return ratio                                                                   # [T][16][16]
+
+    def family(kind, T):
+        a = np.ones((T, 16, 32)); b = np.zeros((T, 32, 16)); c = np.zeros((T, 16, 16))
+        sg = lambda *sh: rng.choice([-1.0, 1.0], sh)                                   # noqa: E731
+        if kind == "spread":                       # every product its own exponent
+            a = sg(T, 16, 32) * 2.0 ** rng.uniform(-12, 2, (T, 16, 32)); b = sg(T, 32, 16) * 2.0 ** rng.uniform(-12, 2, (T, 32, 16))
+            c = sg(T, 16, 16) * 2.0 ** rng.uniform(-24, 4, (T, 16, 16))
+        elif kind == "cancel":                     # k large products (and maybe c) that nearly cancel, the rest small
+            b = (0.5 + 0.5 * rng.uniform(size=(T, 32, 16))) * 2.0 ** rng.uniform(-16, -9, (T, 32, 1))
+            for t in range(T):
+                k = rng.randint(3, 9)
+                idx = rng.choice(32, k, replace=False)
+                big = 2.0 ** rng.randint(0, 11) * (1.0 + rng.randint(0, 1024, k) / 1024.0)
+                sgn = rng.choice([-1.0, 1.0], k)
+                b[t, idx, :] = (sgn * big)[:, None]
+                if rng.uniform() < 0.5:
+                    c[t] = -float((sgn * big).sum()) * (1.0 + rng.uniform(-1e-3, 1e-3, (16, 16)))
+        elif kind == "ladder":
+            b = sg(T, 32, 16) * 2.0 ** (-np.arange(32)[None, :, None] * rng.uniform(0.3, 1.0, (T, 1, 1))) * (1.0 + rng.randint(0, 1024, (T, 32, 16)) / 1024.0)
+            c = sg(T, 16, 16) * 2.0 ** rng.uniform(-30, 2, (T, 16, 16))
+        elif kind == "cheavy":                     # accumulator far above or far below the products
+            b = sg(T, 32, 16) * (1.0 + rng.uniform(size=(T, 32, 16))) * 2.0 ** rng.uniform(-20, 0, (T, 1, 1))
+            c = sg(T, 16, 16) * (1.0 + rng.uniform(size=(T, 16, 16))) * 2.0 ** rng.uniform(-10, 12, (T, 1, 1))
+        else:                                      # "dense": one product of order 1, 31 products 2^-14 .. 2^-30 of it with 22-bit mantissas
+            e = rng.randint(-30, -13, (T, 1, 1))
+            a = (1.5 + rng.randint(0, 512, (T, 16, 32)) / 1024.0) * 2.0 ** (e // 2)
+            b = rng.choice([-1.0, 1.0], (T, 1, 1)) * (1.5 + rng.randint(0, 512, (T, 32, 16)) / 1024.0) * 2.0 ** (e - e // 2)
+            a[:, :, 0] = 1.0
+            b[:, 0, :] = 1.0 + rng.randint(0, 1024, (T, 16)) / 1024.0
+        return a, b, c
+
+    worst, by_kind, n_sums = 0.0, {}, 0
+    pool = []
+    for kind in ("spread", "cancel", "ladder", "cheavy", "dense"):
+        a, b, c = family(kind, 768)
+        r = run(a, b, c)
+        n_sums += r.size
+        by_kind[kind] = float(r.max())
+        top = np.argsort(r.reshape(len(r), -1).max(1))[-32:]
+        pool += [(a[t], b[t], c[t]) for t in top]
+    # hill climbing from the worst trials of every family
+    for _ in range(6):
+        a = np.stack([q[0] for q in pool]); b = np.stack([q[1] for q in pool]); c = np.stack([q[2] for q in pool])
+        reps = 6
+        a, b, c = np.repeat(a, reps, 0), np.repeat(b, reps, 0), np.repeat(c, reps, 0)
+        T = a.shape[0]
+        flip = rng.uniform(size=b.shape) < 0.05
+        b = np.where(flip, -b, b) * 2.0 ** np.where(rng.uniform(size=b.shape) < 0.1, rng.randint(-3, 4, b.shape), 0)
+        c = c * 2.0 ** np.where(rng.uniform(size=c.shape) < 0.2, rng.randint(-2, 3, c.shape), 0) * (1.0 + rng.uniform(-1e-3, 1e-3, c.shape))
+        b = np.clip(b, -60000.0, 60000.0)
+        r = run(a, b, c)
+        n_sums += r.size
+        rt = r.reshape(T, -1).max(1)
+        keep = np.argsort(rt)[-len(pool):]
+        pool = [(a[t], b[t], c[t]) for t in keep]
+        by_kind["climb"] = max(by_kind.get("climb", 0.0), float(rt.max()))
+    worst = max(by_kind.values())
+    STATS["mfma_rounding_adversarial_search"] = {"sums": int(n_sums), "worst_ratio": worst, "by_kind": by_kind, "kappa_used": used[0], "probe_measured": meas[0]}
+    assert worst < 0.85 * used[0] and worst <= 1.3 * meas[0], (worst, used[0], meas[0], by_kind)
 
 
 # ---- probability-output mode (SURVEY.md §8 f4, HAF_FLAG_PROBABILITY) -----------------------------------------------------
