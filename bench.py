@@ -128,14 +128,20 @@ def cabi_child(args):
         out = me.score_sharded(cloud, inp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    tim = []
     for _ in range(args.steps):
         out = me.score_sharded(cloud, inp)
+        tim.append(me.last_timing())
     dt = time.perf_counter() - t0
     stage = [me.shard_stage_ms(s) for s in range(n)]
     me.close()
     print(json.dumps({"value": out["n_evals"] * args.steps / dt, "unit": "evals/s", "ms_per_request": 1e3 * dt / args.steps,
                       "n_devices": n, "rccl_ranks": info["n_ranks"], "rccl_version": info["rccl_version"], "scaling": "strong",
                       "evals_per_request": out["n_evals"], "shard_svm_ms": [st["svm"] if st else None for st in stage],
+                      "bcast_us": float(np.median([t["bcast_us"] for t in tim])), "gather_us": float(np.median([t["collective_us"] for t in tim])),
+                      "shard_ms": [float(np.median([t["shard_ms"][s] for t in tim])) for s in range(n)],
+                      "timing_note": "host wall-clock inside haf_score_sharded (haf_multi_last_timing), medians over the steps: ncclBroadcast of the "
+                                     "device-resident cloud, every shard's own haf_score_rolls, the ncclAllGather + the copy of the gathered records to the host",
                       "best": {"eval": out["eval"], "row": out["best_row"], "col": out["best_col"], "roll": out["best_roll"]},
                       "workload": "ONE C5 request (cloud on device 0 -> ncclBroadcast), rolls sharded over %d GPUs in one process, "
                                   "one ncclAllGather of the 16-byte roll records, haf_finalize" % n}), flush=True)
@@ -253,16 +259,25 @@ def latency_small(feat, rng_file, device, flags):
     def one(name, pcd, inp, **cfg):
         xyz = capi.load_pcd(os.path.join(data, pcd))
         eng = capi.Engine(feat, rng_file, model, device=device, flags=flags, max_points=1 << 18, **cfg)
-        for _ in range(3):
-            out = eng.score(xyz, inp)
-        ts = []
-        for _ in range(30):
-            t0 = time.perf_counter()
-            out = eng.score(xyz, inp)
-            ts.append(time.perf_counter() - t0)
+        res = {}
+        for registered in (False, True):
+            if registered:
+                eng.register_host(xyz)         # haf_register_host_cloud: the caller's buffer page-locked once, on_device = 2
+            for _ in range(3):
+                out = eng.score(xyz, inp)
+            ts = []
+            for _ in range(30):
+                t0 = time.perf_counter()
+                out = eng.score(xyz, inp)
+                ts.append(time.perf_counter() - t0)
+            res[registered] = (1e3 * float(np.median(ts)), 1e3 * float(np.min(ts)))
+        form = eng.screen_form()
         eng.close()
-        return dict(workload=name % xyz.shape[0], ms_median=1e3 * float(np.median(ts)), ms_min=1e3 * float(np.min(ts)),
-                    evals=out["n_evals"], eval=out["eval"])
+        return dict(workload=name % xyz.shape[0], ms_median=res[False][0], ms_min=res[False][1],
+                    ms_median_registered_host=res[True][0], ms_min_registered_host=res[True][1],
+                    evals=out["n_evals"], eval=out["eval"], screening_form=form,
+                    note="ms_median: the cloud in ordinary (pageable) host memory, staged through the engine's pinned block; "
+                         "ms_median_registered_host: the same numpy buffer page-locked once with haf_register_host_cloud (on_device = 2)")
 
     c2 = one("C2: pcd2.pcd %d pts, 32x32 cm, 12 rolls, surrogate model nSV=172, host cloud (PCIe included)", "pcd2.pcd",
              capi.default_input(grasp_area_length_x=32, grasp_area_length_y=32))
@@ -336,20 +351,27 @@ def main():
         torch.cuda.synchronize()
 
     def run(eng, steps, warmup, collective):
+        coll_us = []                                        # host wall-clock of the step's one collective (incl. its sync)
+
         def step():
             if args.shard == "rolls" and collective:
                 first, count = hd.roll_shard(args.rolls, world, rank)
                 local = eng.score_rolls([cloud], [inp], first, count)
+                tc = time.perf_counter()
                 full = hd.gather_roll_records(local, args.rolls, device="cuda")[0]   # one all-gather of 16 B per roll
+                coll_us.append(1e6 * (time.perf_counter() - tc))
                 return local[0], eng.finalize(inp, full)
             rec = eng.score_rolls([cloud], [inp], 0, args.rolls)[0]
             out = eng.finalize(inp, rec)
             if collective:
+                tc = time.perf_counter()
                 hd.best_of_batch(out["best_vote"], tag=rank, device="cuda")   # one 8-byte all-reduce(max) over xGMI (RCCL)
+                coll_us.append(1e6 * (time.perf_counter() - tc))
             return rec, out
         for _ in range(warmup):
             step()
         svm_ms, stage_acc, evals, rechecked, strict, refined, n_i8, n_fp64 = [], {}, 0, 0, 0, 0, 0, 0
+        del coll_us[:]
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -367,7 +389,7 @@ def main():
             for k, v in st.items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
         fence()
-        return dict(elapsed=time.perf_counter() - t0, evals=evals, steps=steps, svm_s=float(np.mean(svm_ms)) * 1e-3,
+        return dict(elapsed=time.perf_counter() - t0, coll_us=float(np.median(coll_us)) if coll_us else None, evals=evals, steps=steps, svm_s=float(np.mean(svm_ms)) * 1e-3,
                     stage_ms={k: v / steps for k, v in stage_acc.items()}, rechecked=rechecked / steps,
                     strict=strict / steps, refined=refined / steps, exact_integer=n_i8 / steps, fp64=n_fp64 / steps, out=out)
 
@@ -396,10 +418,16 @@ def main():
         eng.close()
         t = torch.tensor([r["elapsed"]], dtype=torch.float64, device="cuda")
         ev = torch.tensor([r["evals"]], dtype=torch.int64, device="cuda")
+        per_rank = None
         if use_dist:
+            # every rank's own step time and collective time (so that a multi-GPU run explains itself), then the reductions of the contract
+            mine = torch.tensor([1e3 * r["elapsed"] / args.steps, r["coll_us"] or 0.0, r["svm_s"] * 1e3], dtype=torch.float64, device="cuda")
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [[float(v) for v in q.tolist()] for q in allr]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(ev, op=dist.ReduceOp.SUM)
-        runs.append(dict(seed=sd, model=mp, res=r, elapsed=float(t.item()), total_evals=int(ev.item())))
+        runs.append(dict(seed=sd, model=mp, res=r, elapsed=float(t.item()), total_evals=int(ev.item()), per_rank=per_rank))
     ranked = sorted(runs, key=lambda q: q["total_evals"] / q["elapsed"])
     med = ranked[(len(ranked) - 1) // 2]                    # lower median: never better than half of the seeds
     res, elapsed, total_evals, model_path = med["res"], med["elapsed"], med["total_evals"], med["model"]
@@ -585,6 +613,11 @@ def main():
                                                {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision])
         line["ranks"] = {"world_size": world, "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                          ("bench.py (self-spawned ranks)" if world > 1 else "single process"),
+                         "per_rank_ms_per_step": [q[0] for q in med["per_rank"]] if med["per_rank"] else [1e3 * elapsed / args.steps],
+                         "per_rank_collective_us": [q[1] for q in med["per_rank"]] if med["per_rank"] else None,
+                         "per_rank_kernel_ms": [q[2] for q in med["per_rank"]] if med["per_rank"] else [res["svm_s"] * 1e3],
+                         "collective": ("one all-gather of the 16-byte roll records per step" if args.shard == "rolls" else
+                                        "one 8-byte all-reduce(max) per step") + " (host wall-clock incl. its synchronisation, median over the steps of the median seed)",
                          "rccl_world_size": dist.get_world_size() if use_dist else 1,
                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if use_dist else None}
     if use_dist:

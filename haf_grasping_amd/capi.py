@@ -104,6 +104,8 @@ def _bind(path, testing):
     L.haf_last_strict_host.argtypes = [E, C.POINTER(C.c_int64)]
     L.haf_last_exact_tiers.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.haf_screen_form.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.haf_register_host_cloud.argtypes = [E, C.c_void_p, C.c_size_t]
+    L.haf_unregister_host_cloud.argtypes = [E, C.c_void_p]
     L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
                                C.c_size_t]
     L.haf_free.argtypes = [C.c_void_p]
@@ -119,6 +121,7 @@ def _bind(path, testing):
     L.haf_multi_engine.restype = C.c_void_p
     L.haf_multi_engine.argtypes = [E, C.c_int32]
     L.haf_multi_last_records.argtypes = [E, C.c_int32, C.c_void_p]
+    L.haf_multi_last_timing.argtypes = [E, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]
     if testing:
         L.haf_test_decq_host.restype = C.c_double
         L.haf_test_decq_host.argtypes = [C.c_double, C.c_int]
@@ -249,15 +252,33 @@ class Engine:
         if rc != HAF_OK:
             raise HafError(rc, (self._L.haf_last_error(self._h) or b"").decode())
 
-    @staticmethod
-    def _cloud(xyz):
-        """numpy float32 [N, >=3] (host) or (device_ptr, n_points, stride_floats) tuple (HBM resident)."""
+    def register_host(self, arr):
+        """haf_register_host_cloud: page-locks the numpy array's buffer; clouds passed as views into it then go with on_device = 2
+        (DMA straight from the caller's memory).  The array must outlive the registration."""
+        assert isinstance(arr, np.ndarray) and arr.flags["C_CONTIGUOUS"]
+        self._check(self._L.haf_register_host_cloud(self._h, C.c_void_p(arr.ctypes.data), arr.nbytes))
+        if not hasattr(self, "_regs"):
+            self._regs = []
+        self._regs.append((arr.ctypes.data, arr.nbytes, arr))
+
+    def unregister_host(self, arr):
+        self._check(self._L.haf_unregister_host_cloud(self._h, C.c_void_p(arr.ctypes.data)))
+        self._regs = [r for r in getattr(self, "_regs", []) if r[0] != arr.ctypes.data]
+
+    def _cloud(self, xyz):
+        """numpy float32 [N, >=3] (host; inside a register_host buffer: page-locked, on_device = 2) or (device_ptr, n_points,
+        stride_floats) tuple (HBM resident)."""
         if isinstance(xyz, tuple):
             ptr, n, stride = xyz
             return Cloud(C.c_void_p(ptr), n, stride, 1), None
         a = np.ascontiguousarray(xyz, dtype=np.float32)
         assert a.ndim == 2 and a.shape[1] >= 3
-        return Cloud(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0), a
+        where = 0
+        if a.shape[1] == 3:
+            for base, nbytes, _ in getattr(self, "_regs", []):
+                if base <= a.ctypes.data and a.ctypes.data + a.nbytes <= base + nbytes:
+                    where = 2
+        return Cloud(a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], where), a
 
     def model_info(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
@@ -413,7 +434,7 @@ class MultiEngine:
         return dict(n_shards=a.value, n_ranks=b.value, rccl_version=c.value)
 
     def score_sharded(self, xyz, grasp_input):
-        cl, keep = Engine._cloud(xyz)
+        cl, keep = Engine._cloud(self, xyz)
         out = GraspOutput()
         self._check(self._L.haf_score_sharded(self._h, C.byref(cl), C.byref(grasp_input), C.byref(out)))
         return output_to_dict(out)
@@ -423,13 +444,20 @@ class MultiEngine:
         keep = []
         arr = (Cloud * n)()
         for i, c in enumerate(clouds):
-            arr[i], k = Engine._cloud(c)
+            arr[i], k = Engine._cloud(self, c)
             keep.append(k)
         gi = (GraspInput * n)(*inputs)
         out = (GraspOutput * n)()
         best = C.c_int32(-1)
         self._check(self._L.haf_score_batch_sharded(self._h, n, arr, gi, out, C.byref(best)))
         return [output_to_dict(o) for o in out], best.value
+
+    def last_timing(self):
+        """haf_multi_last_timing: host wall-clock of the last sharded call's parts."""
+        n = self.info()["n_shards"]
+        tot, bc, co, sh = C.c_float(), C.c_float(), C.c_float(), (C.c_float * n)()
+        self._check(self._L.haf_multi_last_timing(self._h, C.byref(tot), C.byref(bc), C.byref(co), sh))
+        return dict(total_ms=tot.value, bcast_us=bc.value, collective_us=co.value, shard_ms=list(sh))
 
     def last_records(self, rank):
         rec = np.zeros(self.cfg.n_rolls, dtype=ROLL_RECORD_DTYPE)

@@ -324,6 +324,8 @@ struct haf_engine {
     bool no_bucket_sort = false;    // set (for good) when a tile of the bucket-sorted binning path overflowed its candidate list
     bool no_fused_pre = false;      // testing build: HAF_NO_FUSED_PRE keeps the separate pre-stage kernels on small grids too
 
+    std::vector<std::pair<const char *, size_t>> host_regs;   // haf_register_host_cloud: page-locked caller buffers
+
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
     int last_evals = 0, last_flagged = 0, last_flagged2 = 0, last_flagged0 = 0, last_inexact = 0;
@@ -1299,6 +1301,8 @@ void haf_destroy(haf_engine *e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &r : e->host_regs) (void)hipHostUnregister((void *)r.first);
+    e->host_regs.clear();
     e->d_in.release(); e->d_out.release(); e->d_sorted.release(); e->d_bkt.release(); e->d_heights.release(); e->d_rowsum.release(); e->d_inexact.release();
     e->d_ii.release(); e->d_mask.release(); e->d_rowcount.release(); e->d_rowoff.release(); e->d_brcount.release();
     e->d_evalcell.release(); e->d_flag_list.release(); e->d_X.release(); e->d_ax.release();
@@ -1548,6 +1552,30 @@ int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_
     return HAF_OK;
 }
 
+int haf_register_host_cloud(haf_engine *e, const void *ptr, size_t bytes)
+{
+    if (!e) return HAF_E_ARG;
+    if (!ptr || !bytes) return fail(e, HAF_E_ARG, "haf_register_host_cloud: null or empty buffer");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    for (auto &r : e->host_regs) if (r.first == ptr) return fail(e, HAF_E_ARG, "haf_register_host_cloud: buffer is registered already");
+    HIPCHK(e, hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault));
+    e->host_regs.emplace_back(reinterpret_cast<const char *>(ptr), bytes);
+    return HAF_OK;
+}
+
+int haf_unregister_host_cloud(haf_engine *e, const void *ptr)
+{
+    if (!e) return HAF_E_ARG;
+    for (size_t i = 0; i < e->host_regs.size(); i++)
+        if (e->host_regs[i].first == ptr) {
+            if (e->stream) (void)hipStreamSynchronize(e->stream);
+            HIPCHK(e, hipHostUnregister(const_cast<void *>(ptr)));
+            e->host_regs.erase(e->host_regs.begin() + (long)i);
+            return HAF_OK;
+        }
+    return fail(e, HAF_E_ARG, "haf_unregister_host_cloud: buffer was not registered");
+}
+
 int haf_screen_form(const haf_engine *e, int32_t *form, int32_t *active)
 {
     if (!e) return HAF_E_ARG;
@@ -1684,7 +1712,14 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         if (clouds[b].n_points && !clouds[b].xyz) return fail(e, HAF_E_ARG, "cloud with null xyz");
         if (clouds[b].stride_floats < 3) return fail(e, HAF_E_ARG, "stride_floats must be >= 3");
         if (clouds[b].n_points > (size_t)INT32_MAX) return fail(e, HAF_E_CAPACITY, "cloud too large");
-        if (!clouds[b].on_device) host_pts += clouds[b].n_points;
+        if (clouds[b].on_device == 2) {
+            const char *p0 = reinterpret_cast<const char *>(clouds[b].xyz), *p1 = p0 + clouds[b].n_points * 12;
+            bool inside = false;
+            for (auto &r : e->host_regs) inside = inside || (p0 >= r.first && p1 <= r.first + r.second);
+            if (clouds[b].stride_floats != 3 || (clouds[b].n_points && !inside))
+                return fail(e, HAF_E_ARG, "on_device = 2 needs a packed xyz cloud inside a buffer registered with haf_register_host_cloud");
+        }
+        if (clouds[b].on_device != 1) host_pts += clouds[b].n_points;
         max_n = std::max(max_n, (int)clouds[b].n_points);
     }
     if (host_pts > (size_t)c.max_points) return fail(e, HAF_E_CAPACITY, "more host points than max_points");
@@ -1709,7 +1744,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         cd.bucket_off = b * e->bkt_ints;
         total_n += (long)clouds[b].n_points;
         cd.n = (int)clouds[b].n_points;
-        if (clouds[b].on_device) {
+        if (clouds[b].on_device == 1) {
             cd.xyz = clouds[b].xyz;
             cd.stride = (int)clouds[b].stride_floats;
         } else {
@@ -1738,7 +1773,19 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             return HAF_OK;
         };
         for (int b = 0; b < B; b++) {
-            if (clouds[b].on_device || clouds[b].n_points == 0) continue;
+            if (clouds[b].on_device == 1 || clouds[b].n_points == 0) continue;
+            if (clouds[b].on_device == 2 && clouds[b].n_points * 12 >= kPiece) {
+                // (a small cloud is cheaper packed into the one staged copy than as a DMA transfer of its own: ~10 us each)
+                // page-locked caller memory: whatever has been packed so far goes out, then the DMA engine takes this cloud from
+                // where it lies (the staging block keeps the same layout, its share of it stays unused)
+                const int rc = flush(false);
+                if (rc != HAF_OK) return rc;
+                const size_t bytes = clouds[b].n_points * 12;
+                HIPCHK(e, hipMemcpyAsync(e->d_in.p + pts_off + staged, clouds[b].xyz, bytes, hipMemcpyHostToDevice, s));
+                staged += bytes;
+                sent = staged;
+                continue;
+            }
             const float *src = clouds[b].xyz;
             const size_t st = clouds[b].stride_floats, n = clouds[b].n_points;
             for (size_t i0 = 0; i0 < n;) {
@@ -1833,10 +1880,16 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
                                 e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, sp_now, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
             mark(e, HAF_ST_SVM);
+            // A small request with a small model (small_exact): what the screening pass leaves goes STRAIGHT to the one-launch exact kernel
+            // (k_small_direct in list mode: exact attributes + fp64 MFMA decision, 9 ns per listed evaluation at 192 SVs) -- the list
+            // is written where that kernel reads it.  Tier 1 in between was a feature kernel and a contraction launch at their latency
+            // floors (C3: 44 + 36 us for 4 072 evaluations, of which it decided nine tenths) in front of the same exact kernel.
+            const bool straight = small_exact;
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, cr ? e->d_svt0_cr.p : e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                              e->d_flag0_words.p, e->d_flag0_wgcount.p, e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,
-                              e->screen_variant, e->crp, s);
+                              e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,
+                              e->screen_variant, e->crp, s, straight ? CNT_FLAGGED : -1);
             mark(e, HAF_ST_REFINE);
+            if (!straight) {
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
             // workgroups beyond the list's end exit at once)
@@ -1851,6 +1904,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             launch_svm_h(e->d_X1.p, e->d_ax1.p, t1cr ? e->d_svt_h_cr.p : e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
                          e->d_part1.p, e->part1_stride, s, t1cr ? &e->crt1 : nullptr, t1cr ? e->d_t1_L.p : nullptr);
+            }
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, nullptr, s);

@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -121,6 +122,9 @@ struct haf_multi {
     std::vector<std::vector<haf_roll_record>> h_all;   // every rank's copy (haf_multi_last_records)
     std::string error;
     int rccl_version = 0;
+    // host wall-clock of the last sharded call's parts (haf_multi_last_timing): so that the first multi-GPU run explains itself
+    float last_bcast_us = 0.0f, last_collective_us = 0.0f, last_total_ms = 0.0f;
+    std::vector<float> last_shard_ms;
 };
 
 namespace {
@@ -333,9 +337,16 @@ int score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *i
     if (!cloud || !in || !out) return mfail(m, HAF_E_ARG, "haf_score_sharded: null argument");
     if (m->mode != HAF_SHARD_ROLLS) return mfail(m, HAF_E_ARG, "haf_score_sharded needs a handle created with HAF_SHARD_ROLLS");
     const int n = (int)m->shards.size(), n_ranks = (int)m->ranks.size(), R = m->cfg.n_rolls;
+    typedef std::chrono::steady_clock clk;
+    auto us_since = [](clk::time_point t0) { return (float)std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+    const clk::time_point t_call = clk::now();
+    m->last_bcast_us = 0.0f;
+    m->last_shard_ms.assign((size_t)n, 0.0f);
     std::vector<const float *> dev_ptr;
-    if (cloud->on_device) {
+    if (cloud->on_device == 1) {
+        const clk::time_point t0 = clk::now();
         if (int rc = broadcast_cloud(m, cloud, dev_ptr)) return rc;
+        m->last_bcast_us = us_since(t0);
     }
     const size_t rec_bytes = sizeof(haf_roll_record), block = (size_t)m->block_records * rec_bytes;
 
@@ -344,9 +355,12 @@ int score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *i
         int first, count;
         roll_range(R, n, (int)(&sh - m->shards.data()), &first, &count);
         haf_cloud c = *cloud;
-        if (cloud->on_device) c.xyz = dev_ptr[(size_t)sh.rank];
+        if (cloud->on_device == 1) c.xyz = dev_ptr[(size_t)sh.rank];
+        else c.on_device = 0;          // (a buffer registered with ONE engine is plain host memory to the shards' engines)
         std::vector<haf_roll_record> rec((size_t)count);
+        const clk::time_point t0 = clk::now();
         sh.rc = haf_score_rolls(sh.eng, 1, &c, in, first, count, rec.data());
+        m->last_shard_ms[(size_t)(&sh - m->shards.data())] = us_since(t0) * 1e-3f;
         if (sh.rc != HAF_OK) { sh.err = haf_last_error(sh.eng); return; }
         Rank &rk = m->ranks[(size_t)sh.rank];
         hipStream_t s = haf::engine_stream(sh.eng);
@@ -360,6 +374,7 @@ int score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *i
 
     // ONE all-gather of the roll records: afterwards every rank holds the records of all n_rolls rolls
     const size_t send_bytes = block * (size_t)m->shards_per_rank;
+    const clk::time_point t_gather = clk::now();
     MNCCL(m, ncclGroupStart());
     for (int r = 0; r < n_ranks; r++) {
         Rank &rk = m->ranks[(size_t)r];
@@ -384,6 +399,7 @@ int score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *i
             memcpy(all.data() + first, src, (size_t)count * rec_bytes);
         }
     }
+    m->last_collective_us = us_since(t_gather);       // the all-gather and every rank's copy of the gathered records to the host
     m->h_gather = m->h_all[0];
     // the sequential cross-roll rule and the pose on the full record set (what any rank could do now; rank 0 does)
     int rc = haf_finalize(m->shards[0].eng, in, m->h_gather.data(), out);
@@ -395,6 +411,7 @@ int score_sharded(haf_multi *m, const haf_cloud *cloud, const haf_grasp_input *i
         rechecked += b;
     }
     out->n_rechecked = rechecked;
+    m->last_total_ms = us_since(t_call) * 1e-3f;
     return HAF_OK;
 }
 
@@ -407,7 +424,12 @@ int score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds,
     if (n_clouds > m->cfg.max_clouds) return mfail(m, HAF_E_CAPACITY, "more clouds than max_clouds");
     const int n = (int)m->shards.size(), n_ranks = (int)m->ranks.size();
     for (int b = 0; b < n_clouds; b++)
-        if (clouds[b].on_device) return mfail(m, HAF_E_ARG, "haf_score_batch_sharded takes host clouds (each goes to its GPU over that GPU's PCIe link)");
+        if (clouds[b].on_device == 1) return mfail(m, HAF_E_ARG, "haf_score_batch_sharded takes host clouds (each goes to its GPU over that GPU's PCIe link)");
+    typedef std::chrono::steady_clock clk;
+    auto us_since = [](clk::time_point t0) { return (float)std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+    const clk::time_point t_call = clk::now();
+    m->last_bcast_us = 0.0f;
+    m->last_shard_ms.assign((size_t)n, 0.0f);
     // cloud b -> shard b % n: independent requests, no data-path exchange at all
     std::vector<unsigned long long> shard_key((size_t)n, 0ull);
     run_on_all(m, [&](Shard &sh) {
@@ -415,11 +437,13 @@ int score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds,
         std::vector<haf_cloud> cl;
         std::vector<haf_grasp_input> gi;
         std::vector<int> idx;
-        for (int b = s; b < n_clouds; b += n) { cl.push_back(clouds[b]); gi.push_back(in[b]); idx.push_back(b); }
+        for (int b = s; b < n_clouds; b += n) { cl.push_back(clouds[b]); cl.back().on_device = 0; gi.push_back(in[b]); idx.push_back(b); }
         sh.rc = HAF_OK;
         if (cl.empty()) return;
         std::vector<haf_grasp_output> o(cl.size());
+        const clk::time_point t0 = clk::now();
         sh.rc = haf_score_batch(sh.eng, (int)cl.size(), cl.data(), gi.data(), o.data());
+        m->last_shard_ms[(size_t)s] = us_since(t0) * 1e-3f;
         if (sh.rc != HAF_OK) { sh.err = haf_last_error(sh.eng); return; }
         unsigned long long key = 0;
         for (size_t k = 0; k < o.size(); k++) {
@@ -432,6 +456,7 @@ int score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds,
     });
     if (int rc = first_error(m, "haf_score_batch_sharded")) return rc;
     // ONE all-reduce(max) of the packed best-grasp key (north_star: "a single RCCL all-reduce of the best-grasp score")
+    const clk::time_point t_red = clk::now();
     for (int r = 0; r < n_ranks; r++) {
         Rank &rk = m->ranks[(size_t)r];
         unsigned long long key = 0;
@@ -458,6 +483,8 @@ int score_batch_sharded(haf_multi *m, int32_t n_clouds, const haf_cloud *clouds,
         else if (k != best) return mfail(m, HAF_E_INTERNAL, "ranks disagree on the all-reduced best-grasp key");
     }
     if (best_cloud) *best_cloud = (int32_t)(0x7FFFFFFF - (unsigned)(best & 0xFFFFFFFFu));
+    m->last_collective_us = us_since(t_red);
+    m->last_total_ms = us_since(t_call) * 1e-3f;
     return HAF_OK;
 }
 
@@ -534,6 +561,16 @@ haf_engine *haf_multi_engine(haf_multi *m, int32_t shard)
 {
     if (!m || shard < 0 || shard >= (int32_t)m->shards.size()) return nullptr;
     return m->shards[(size_t)shard].eng;
+}
+
+int haf_multi_last_timing(const haf_multi *m, float *total_ms, float *bcast_us, float *collective_us, float *shard_ms)
+{
+    if (!m) return HAF_E_ARG;
+    if (total_ms) *total_ms = m->last_total_ms;
+    if (bcast_us) *bcast_us = m->last_bcast_us;
+    if (collective_us) *collective_us = m->last_collective_us;
+    if (shard_ms) for (size_t s = 0; s < m->shards.size(); s++) shard_ms[s] = s < m->last_shard_ms.size() ? m->last_shard_ms[s] : 0.0f;
+    return HAF_OK;
 }
 
 int haf_multi_last_records(const haf_multi *m, int32_t rank, haf_roll_record *records)

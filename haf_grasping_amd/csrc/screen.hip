@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_count(const unsigned l
 
 __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned long long *__restrict__ words,
                                                                   const int *__restrict__ wgcount, int n_wg,
-                                                                  int *__restrict__ list, int cap, int *__restrict__ counters)
+                                                                  int *__restrict__ list, int cap, int *__restrict__ counters, int also_counter)
 {
     __shared__ int part[kCompactWords];
     __shared__ int s_base;
@@ -492,7 +492,10 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned
             if (t < o) part[t] += part[t + o];
             __syncthreads();
         }
-        if (t == 0) counters[CNT_FLAGGED0] = part[0];
+        if (t == 0) {
+            counters[CNT_FLAGGED0] = part[0];
+            if (also_counter >= 0) counters[also_counter] = min(part[0], cap);    // small requests: the list IS the exact tier's (engine.cpp)
+        }
         __syncthreads();
     }
     const int w = blockIdx.x * kCompactWords + t;
@@ -691,7 +694,8 @@ double probe_mfma_rounding(hipStream_t s, double *worst16)
 
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
-                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s)
+                       int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,
+                       int also_counter)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
@@ -709,7 +713,7 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
     hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw);
+                       counters_rw, also_counter);
 }
 
 }  // namespace haf

@@ -613,6 +613,48 @@ def test_recheck_tiers_forced(data_dir, surrogate, orc, monkeypatch):
             monkeypatch.delenv("HAF_GUARD2_REL")
 
 
+def test_small_requests_go_from_the_screening_pass_straight_to_the_exact_kernel(data_dir, surrogate, orc):
+    """Round 4: a request whose evaluations x support vectors stay under 2^25 (BASELINE C3: 31 093 x 192) hands
+    what the screening pass cannot decide straight to the one-launch exact kernel (exact attributes + fp64 MFMA decision): no
+    three-pass tier in between (n_rechecked == n_refined), every stage and label the oracle's; C3 0.33 -> 0.25 ms."""
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    kw = dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0))
+    eng = make_engine(data_dir, surrogate, 0, n_rolls=20, roll_step_deg=9, max_points=1 << 18)
+    assert eng.screen_form() == "centred-remainder/exp"
+    compare_full(eng, orc, xyz, dict(n_rolls=20, roll_step_deg=9), kw, check_dec=False)
+    cnt = eng.last_counts()
+    assert 0 < cnt["n_refined"] == cnt["n_rechecked"] < 0.3 * cnt["n_evals"], cnt
+    eng.close()
+
+
+def test_registered_host_cloud(data_dir, surrogate, orc):
+    """haf_register_host_cloud / haf_cloud.on_device = 2: a cloud inside a page-locked caller buffer is read by the DMA engine where
+    it lies (large clouds) or staged like any host cloud (small ones): same result either way; a cloud outside every registered
+    buffer, or one with a stride, is refused."""
+    f, r = _files(data_dir)
+    kw = dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0))
+    for name, cfg in (("table1_mult_obj_rcs_1428580506606673", dict(n_rolls=20, roll_step_deg=9)), ("pcd2", dict(n_rolls=12))):
+        xyz = np.ascontiguousarray(pcdio.load_pcd(os.path.join(data_dir, name + ".pcd")), dtype=np.float32)
+        eng = make_engine(data_dir, surrogate, 0, max_points=1 << 18, **cfg)
+        inp = capi.default_input(**kw)
+        a = eng.score(xyz, inp)
+        eng.register_host(xyz)
+        cl, _ = eng._cloud(xyz)
+        assert cl.on_device == 2
+        b = eng.score(xyz, inp)
+        assert a == b, (name, a, b)
+        other = xyz.copy()
+        bad = capi.Cloud(other.ctypes.data_as(C.c_void_p), other.shape[0], 3, 2)
+        out = capi.GraspOutput()
+        assert eng._L.haf_score(eng._h, C.byref(bad), C.byref(inp), C.byref(out)) == capi.HAF_E_ARG
+        eng.unregister_host(xyz)
+        cl, _ = eng._cloud(xyz)
+        assert cl.on_device == 0
+        assert eng._L.haf_unregister_host_cloud(eng._h, C.c_void_p(xyz.ctypes.data)) == capi.HAF_E_ARG
+        assert eng.score(xyz, inp) == a
+        eng.close()
+
+
 def test_model_is_classified_at_creation(data_dir, surrogate, orc, monkeypatch, tmp_path):
     """Round 3: haf_create scores a synthetic table scene and settles the form of the screening pass for the MODEL
     before the first goal, so identical calls report identical counters from the first one on.  Round 4: the ill-conditioned
