@@ -389,7 +389,7 @@ class Engine:
         polynomial), whether the pass is on, and the undecided share of every form on the calibration scene (-1: not tried)."""
         v, a, sh = C.c_int(), C.c_int(), (C.c_double * 4)()
         self._check(self._L.haf_test_screen_state(self._h, C.byref(v), C.byref(a), sh))
-        return dict(variant=v.value, active=bool(a.value), shares=list(sh))
+        return dict(variant=v.value & 15, tier0b=bool(v.value & 16), tier1_skipped=bool(v.value & 32), active=bool(a.value), shares=list(sh))
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._L.haf_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

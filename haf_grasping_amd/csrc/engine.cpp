@@ -228,6 +228,12 @@ struct haf_engine {
     bool cr_available = false;   // the centred-remainder tables exist (screen_cr, d_svt0_cr, ...)
     bool variant_forced = false; // testing build: HAF_SCREEN_VARIANT pins the variant (no adaptive rule)
     bool variant_settled = false;   // every form has been seen (at calibration or on requests) and the engine has chosen: no more switching
+    // "tier 0b": behind the PLAIN / SUMSQ form, the centred-remainder form (SCREEN_CR_EXP) runs once more on the first pass's LIST --
+    // a few per cent of the evaluations at the price of a per cent of the first pass -- when calibration saw it decide much more.
+    // t1_skip: what the screening passes leave goes straight to the exact tiers (tier 1's band has a worst-case floor since round 4 --
+    // 76 u of sum|x s| -- and decides little of what a centred-remainder pass could not: measured at calibration)
+    bool use_t0b = false, t1_skip = false;
+    DevBuf<int> d_flag0b_list;
     double variant_share[SCREEN_VARIANTS] = {-1.0, -1.0, -1.0, -1.0};   // undecided share of each variant on the calibration scene (-1: not tried)
     ScreenParams screen{};
     ScreenParams screen_cr{};    // the centred-remainder form's constants and descriptor tables
@@ -867,11 +873,11 @@ int build_tables(haf_engine *e)
             // sigma(diag(sqrt|b|) .)^2; g = sum b_n q_n
             {
                 const int K = kS0K;
-                std::vector<double> Nm((size_t)K * K, 0.0), Mm((size_t)K * K, 0.0), Rh((size_t)m.n_sv * K), Rd((size_t)m.n_sv * K);
+                std::vector<double> Nm((size_t)K * K, 0.0), Mm((size_t)K * K, 0.0), Rh((size_t)m.n_sv * K), Rd((size_t)m.n_sv * K), Ra((size_t)m.n_sv * K);
                 for (int n = 0; n < m.n_sv; n++) {
                     const double *q = Q.data() + (size_t)n * K, *h = Qh.data() + (size_t)n * K;
                     const double sb = std::sqrt(std::fabs(b[(size_t)n]));
-                    for (int l = 0; l < K; l++) { Rh[(size_t)n * K + l] = sb * h[l]; Rd[(size_t)n * K + l] = sb * (h[l] - q[l]); }
+                    for (int l = 0; l < K; l++) { Rh[(size_t)n * K + l] = sb * h[l]; Rd[(size_t)n * K + l] = sb * (h[l] - q[l]); Ra[(size_t)n * K + l] = sb * std::fabs(h[l]); }
                     for (int k = 0; k < K; k++) {
                         const double a = b[(size_t)n] * q[k];
                         if (a == 0.0) continue;
@@ -887,6 +893,8 @@ int build_tables(haf_engine *e)
                 const double sh = sigma_upper_bound(Rh.data(), m.n_sv, K), sdq = sigma_upper_bound(Rd.data(), m.n_sv, K);
                 cp.cr_nHabs = sh * sh * (1.0 + 1e-6);
                 cp.cr_nDabs = sdq * sdq * (1.0 + 1e-6);
+                const double sa = sigma_upper_bound(Ra.data(), m.n_sv, K);
+                cp.cr_nHaa = sa * sa * (1.0 + 1e-6);
             }
             double gn = 0.0;
             std::vector<ScrCorr> scc((size_t)kS0K * 2);
@@ -928,6 +936,7 @@ int build_tables(haf_engine *e)
                         tab[(size_t)k] = (sl >= 0 && sl < S) ? mu[(size_t)sl] / sp.c : 0.0;
                     }
                     std::vector<char> imgh((size_t)e->n_sv_tiles * kHSvTileBytes, 0);
+                    std::vector<double> Ra1((size_t)m.n_sv * kKP, 0.0);          // sqrt|b_n| c |q~_nk|: the attribute-space |Q~| of cr_nHaa
                     double qmax1 = 0.0, dqmax1 = 0.0, Ca1 = 0.0, Cqq1 = 0.0, Dabs1 = 0.0;
                     for (int n = 0; n < m.n_sv; n++) {
                         const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
@@ -944,6 +953,7 @@ int build_tables(haf_engine *e)
                             const double se = (double)(float)h + (double)(float)l;
                             q2 += sc * sc; h2 += se * se; d2 += (se - sc) * (se - sc);
                             if (k < kKP) Gr[(size_t)k] += (long double)b[(size_t)n] * (long double)sc;
+                            if (k < kKP) Ra1[(size_t)n * kKP + k] = std::sqrt(std::fabs(b[(size_t)n])) * sp.c * std::fabs(se);
                         }
                         float *tail = reinterpret_cast<float *>(tile + 2 * kHMatBytes);
                         tail[j] = 0.0f;
@@ -962,6 +972,7 @@ int build_tables(haf_engine *e)
                     t1.nM = (sH + sD) * sD1 * (1.0 + 1e-9) + 1e-300;
                     t1.nHabs = (sH + sD + sD1) * (sH + sD + sD1) * (1.0 + 1e-9);
                     t1.nDabs = sD1 * sD1 * (1.0 + 1e-9) + 1e-300;
+                    { const double sa1 = sigma_upper_bound(Ra1.data(), m.n_sv, kKP); t1.nHaa = sa1 * sa1 * (1.0 + 1e-6); }
                     // (Ca, Cqq, qmax, dqmax bound sums over ATTRIBUTES -- the three passes multiply attribute by attribute -- so the
                     // attribute-space norms computed above are the right ones as they are)
                     t1.Ca = Ca1 * (1.0 + 1e-9); t1.Cqq = Cqq1 * (1.0 + 1e-9); t1.Babs = cp.cr_Babs;
@@ -1199,6 +1210,7 @@ int alloc_buffers(haf_engine *e)
         if (e->t1_cr_available) ok &= hipSuccess == e->d_t1_L.alloc(slots);
         ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad * kBandFloats);
         ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
+        if (e->cr_available) ok &= hipSuccess == e->d_flag0b_list.alloc((size_t)e->flag0_cap);
         ok &= hipSuccess == e->d_flag0_words.alloc((size_t)e->max_evals_pad / 64);
         ok &= hipSuccess == e->d_flag0_wgcount.alloc((size_t)e->max_evals_pad / 64 / 256 + 1);
     } else {
@@ -1312,7 +1324,7 @@ void haf_destroy(haf_engine *e)
     e->d_sv_i8.release(); e->d_flagi_list.release(); e->d_dec_exacti.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
-    e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release();
+    e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release(); e->d_flag0b_list.release();
     e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
@@ -1410,9 +1422,20 @@ static int calibrate(haf_engine *e)
             const double ne = (double)std::max(1, e->last_evals);
             const double share = e->last_screened ? (double)e->last_flagged0 / ne : 1.0;
             e->variant_share[v] = share;
-            const double cost = kVariantCost[v] + kUndecidedCost * share;
-            if (cost < best_cost) { best_cost = cost; best = v; }
             if (share < 0.001) break;                    // nothing a later form could win back
+        }
+        // The choice: kernel cost + what the undecided evaluations cost behind it.  A PLAIN / SUMSQ first pass may have the
+        // centred-remainder form as a SECOND pass on its list (tier 0b: ~1.6 screened evaluations per listed one -- its own feature
+        // kernel and a contraction launch at a fraction of the chip), after which only what that form leaves is undecided: for a
+        // well-conditioned model (a few per cent after the first pass) cheaper than the centred-remainder form over everything.
+        for (int v = 0; v < SCREEN_VARIANTS && rc == HAF_OK; v++) {
+            const double share = e->variant_share[v];
+            if (share < 0.0) continue;
+            double cost = kVariantCost[v] + kUndecidedCost * share;
+            const double s_cr = e->variant_share[SCREEN_CR_EXP];
+            if ((v == SCREEN_PLAIN || v == SCREEN_SUMSQ) && e->cr_available && s_cr >= 0.0 && s_cr < share)
+                cost = std::min(cost, kVariantCost[v] + 1.6 * share + kUndecidedCost * s_cr);
+            if (cost < best_cost) { best_cost = cost; best = v; }
         }
         e->variant_forced = false;
         if (rc == HAF_OK) {
@@ -1421,6 +1444,26 @@ static int calibrate(haf_engine *e)
         }
     } else {
         rc = score_rolls_impl(e, 1, &cl, &in, 0, R, rec.data());
+    }
+    if (rc == HAF_OK && e->screen_active) {
+        // tier 0b behind a PLAIN / SUMSQ first pass: when the centred-remainder form left less than half as much undecided on the scene
+        const int v = e->screen_variant;
+        const char *f0b = test_env("HAF_T0B"), *fsk = test_env("HAF_T1_SKIP");
+        // (the scene is small and tame -- the C5 bench leaves five times the share of the 56 x 56 scene undecided -- so the rule is
+        // "whenever it decided more there", not a threshold)
+        e->use_t0b = e->cr_available && (v == SCREEN_PLAIN || v == SCREEN_SUMSQ) && e->variant_share[SCREEN_CR_EXP] >= 0.0 &&
+                     e->variant_share[SCREEN_CR_EXP] < e->variant_share[v];
+        if (f0b) e->use_t0b = atoi(f0b) != 0 && e->cr_available;
+        // is tier 1 of use behind the screening passes of this model?  One request in the final configuration: how much of what they
+        // left did the three-pass kernel decide
+        const bool forced1 = e->variant_forced;
+        e->variant_forced = true;
+        e->t1_skip = false;
+        rc = score_rolls_impl(e, 1, &cl, &in, 0, R, rec.data());
+        e->variant_forced = forced1;
+        if (rc == HAF_OK && e->last_screened && e->last_flagged0 >= 32)
+            e->t1_skip = (double)(e->last_flagged0 - e->last_flagged) < 0.35 * (double)e->last_flagged0;
+        if (fsk) e->t1_skip = atoi(fsk) != 0;
     }
     e->direct_work = keep_direct;
     e->calibrated = true;
@@ -1860,7 +1903,9 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     }
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
     bool i8_used = false;                                    // the exact-integer tier ran in the last decide()
+    bool t0b_used = false;                                   // tier 0b ran in the last decide()
     auto decide = [&](int mode, bool reuse_operands) -> int {
+        t0b_used = false;
         mark(e, HAF_ST_FEATURES);
         const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
         if (direct) {
@@ -1884,13 +1929,35 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             // (k_small_direct in list mode: exact attributes + fp64 MFMA decision, 9 ns per listed evaluation at 192 SVs) -- the list
             // is written where that kernel reads it.  Tier 1 in between was a feature kernel and a contraction launch at their latency
             // floors (C3: 44 + 36 us for 4 072 evaluations, of which it decided nine tenths) in front of the same exact kernel.
-            const bool straight = small_exact;
+            // The same hand-over when calibration found tier 1 of little use behind the screening passes (t1_skip).
+            const bool t0b = e->use_t0b && e->cr_available && !cr && !small_exact;
+            const bool straight = small_exact || (e->t1_skip && !t0b);
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, cr ? e->d_svt0_cr.p : e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,
                               e->screen_variant, e->crp, s, straight ? CNT_FLAGGED : -1);
             mark(e, HAF_ST_REFINE);
-            if (!straight) {
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
+            const int *t1_list = e->d_flag0_list.p;
+            int t1_counter = CNT_FLAGGED0;
+            bool t1_run = !straight;
+            if (t0b) {
+                // tier 0b: the centred-remainder form on the LIST of the first pass (its own operand images: translated attributes,
+                // centred support vectors; band, common factor and images indexed by list slot)
+                ScreenParams sp_b = e->screen_cr;
+                sp_b.cr_poly = 0;
+                launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_gband.p, d, e->range.lower,
+                                e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SCREEN, sp_b, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
+                                false, list_cap, nullptr, e->d_ax.p, s);
+                const bool skip1 = e->t1_skip;
+                launch_svm_screen(e->d_X1.p, e->d_gband.p, e->d_ax.p, e->d_svt0_cr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                                  e->d_flag0_words.p, e->d_flag0_wgcount.p, skip1 ? e->d_flag_list.p : e->d_flag0b_list.p, e->flag0_cap, e->d_counters.p, d,
+                                  list_cap, e->d_margin.p, SCREEN_CR_EXP, e->crp, s, skip1 ? CNT_FLAGGED : -1, e->d_flag0_list.p, CNT_FLAGGED0, CNT_FLAGGED0B);
+                t1_list = e->d_flag0b_list.p;
+                t1_counter = CNT_FLAGGED0B;
+                t1_run = !skip1;
+                t0b_used = true;
+            }
+            if (t1_run) {
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
             // workgroups beyond the list's end exit at once)
             // behind the polynomial centred-remainder form (a model whose decisions are 1e-7 of sum|coef|K) tier 1 runs in that form too:
@@ -1899,10 +1966,10 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             ScreenParams sp_t1 = e->screen;
             if (t1cr) { sp_t1.cr_t1_tab = e->d_t1_tab.p; sp_t1.cr_t1_L = e->d_t1_L.p; }
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_ax1.p, d, e->range.lower,
-                            e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, sp_t1, e->d_flag0_list.p, CNT_FLAGGED0,
+                            e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SPLIT, sp_t1, t1_list, t1_counter,
                             e->flag0_cap, false, list_cap, e->d_attr.p, nullptr, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, t1cr ? e->d_svt_h_cr.p : e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                         e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
+                         e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, t1_list, t1_counter, e->flag0_cap,
                          e->d_part1.p, e->part1_stride, s, t1cr ? &e->crt1 : nullptr, t1cr ? e->d_t1_L.p : nullptr);
             }
         } else if (mode == MODE_SPLIT) {
@@ -2062,7 +2129,8 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         // stay with it; when none is left (or the variant is pinned by a test), the three-pass kernel for every evaluation of
         // this call (same labels by construction) -- and, unless pinned, no screening pass for this model from now on.
         while (undecided() > e->flag0_cap && !e->variant_forced && next_variant(e->screen_variant) >= 0) {
-            const bool reuse = e->screen_variant == SCREEN_PLAIN;
+            const bool reuse = e->screen_variant == SCREEN_PLAIN && !t0b_used;     // (tier 0b writes its bands where the first pass's were)
+            t0b_used = false;
             e->screen_variant = next_variant(e->screen_variant);
             HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
             rc = decide(MODE_SCREEN, reuse);
@@ -2108,10 +2176,10 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     e->last_evals = e->h_counters[CNT_EVALS];
     e->last_flagged = e->h_counters[CNT_FLAGGED];
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
-    e->last_flagged0 = e->h_counters[CNT_FLAGGED0];
+    e->last_flagged0 = t0b_used ? std::min(e->h_counters[CNT_FLAGGED0B], e->h_counters[CNT_FLAGGED0]) : e->h_counters[CNT_FLAGGED0];   // what leaves the screening passes
     e->last_flaggedi = i8_used ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
     e->last_inexact = inexact_grids;
-    e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->last_flagged0 <= e->flag0_cap;
+    e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->h_counters[CNT_FLAGGED0] <= e->flag0_cap;
     // zero the counters for the next request now, behind this one's copy-out: off that request's critical path
     if (hipMemsetAsync(e->d_counters.p, 0, CNT_COUNT * sizeof(int), s) == hipSuccess) e->counters_clean = true;
     e->last_inputs.assign(in, in + B);
@@ -2693,7 +2761,7 @@ int haf_test_i8_mfma(const signed char *a, const signed char *b, int *c)
 int haf_test_screen_state(haf_engine *e, int *variant, int *active, double *shares /* [4] */)
 {
     if (!e) return HAF_E_ARG;
-    if (variant) *variant = e->screen_variant;
+    if (variant) *variant = e->screen_variant | (e->use_t0b ? 16 : 0) | (e->t1_skip ? 32 : 0);
     if (active) *active = e->screen_active ? 1 : 0;
     if (shares) for (int i = 0; i < SCREEN_VARIANTS; i++) shares[i] = e->variant_share[i];
     return HAF_OK;

@@ -131,6 +131,8 @@ struct ScreenParams {
     int    cr_poly;               // the band is written for the polynomial epilogue (SCREEN_CR_POLY): truncation instead of the v_exp_f32 term
     double cr_nN, cr_nM;          // |N|_2, |sym M|_2
     double cr_nHabs, cr_nDabs;    // |Q^' |B| Q^|_2, |dQ' |B| dQ|_2   (second order)
+    double cr_nHaa;               // | |Q^|' |B| |Q^| |_2 (entries' magnitudes): sum|b_n||z_n||a_n| <= acc_rel sqrt(p'H_abs p) sqrt(|p^|'H_aa|p^|),
+                                  // since |a_n| <= acc_rel sum_k |p^_k q^_nk| -- for support vectors spread in all directions far below acc_rel |p^||p| C_a
     double cr_Ca, cr_Cq1, cr_Cqq; // sum|b||q^||q|, sum|b||q^|, sum|b||q^|^2   (accumulation inside the matrix core; sum|b|2^z through sum|b||z|)
     double cr_Babs;               // sum|b_n|
     double cr_qmax, cr_dqmax;     // max_n |q^_n|, max_n |q^_n - q_n|
@@ -146,7 +148,7 @@ struct ScreenParams {
 struct CrT1Params {
     double B0, rho;
     double c;                     // sqrt(2 gamma log2 e): |p| = c |x - m|
-    double nN, nM, nHabs, nDabs, Ca, Cqq, Babs, qmax, dqmax;   // as ScreenParams::cr_*, with Q~ = hi + lo of fl32(s - m) in place of Q^
+    double nN, nM, nHabs, nDabs, nHaa, Ca, Cqq, Babs, qmax, dqmax;   // as ScreenParams::cr_*, with Q~ = hi + lo of fl32(s - m) in place of Q^
     double acc_rel;               // (kappa + 14) 2^-24
     double dp_rel, dp_abs;        // |p~ - p| <= dp_rel |p| + dp_abs (fp32 rounding of x - m, fp16 hi + lo, flushed lo subnormals)
     double sum_rel;               // fp32 part of the coefficient sum + the polynomial's roundings, relative to S_psi
@@ -268,6 +270,7 @@ struct ExactParams {
 enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAGGED0 = 4,
        CNT_INEXACT = 5,    // (cloud, roll) grids whose integral image needed the sequential summation order
        CNT_FLAGGEDI = 6,   // evaluations the exact-integer tier (exact8.hip) handed on to the fp64 MFMA tier
+       CNT_FLAGGED0B = 7,  // evaluations the second screening pass (centred-remainder form on the first one's list, "tier 0b") could not decide
        CNT_COUNT = 8 };
 
 // ---- tier 2a: the decision function on EXACT integer dot products (exact8.hip) ------------------------------------------
@@ -357,7 +360,9 @@ int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnorm
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,
-                       int also_counter = -1);   // >= 0: the compacted list's length is published in this counter too (capped at flag0_cap)
+                       int also_counter = -1,    // >= 0: the compacted list's length is published in this counter too (capped at flag0_cap)
+                       const int *idx_list = nullptr, int count_slot = CNT_EVALS,   // list mode: slot j of X0 / gband / nax holds evaluation idx_list[j], counters[count_slot] of them
+                       int out_slot = CNT_FLAGGED0);                               // the counter that receives the length of the compacted list
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);

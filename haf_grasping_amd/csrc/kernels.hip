@@ -1398,7 +1398,11 @@ __device__ __forceinline__ void screen_finish_cr(double su2, double sd2, double 
     const double zmax = ph * sp.cr_qmax + eps;                                                 // sup_n of |z^_n| and |z_n|
     const double zf = floor(zmax);
     const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();   // >= 2^zmax (chord of the convex 2^x)
-    const double quad1 = ln2 * ln2 * (sp.cr_nN * un * dn + sp.cr_nM * un * un + sp.acc_rel * ph * un * sp.cr_Ca);
+    // accumulation inside the matrix core: |a_n| <= acc_rel sum_k|p^_k q^_nk|; per SV through Cauchy-Schwarz (C_a) or over the SVs
+    // through the spectral norms of sqrt|b| Q and sqrt|b| |Q^| (kernels.h: cr_nHaa), whichever is smaller
+    const double sHq = sqrt_upper(sp.cr_nHabs) + sqrt_upper(sp.cr_nDabs);
+    const double acc_sum = fmin(ph * un * sp.cr_Ca, sHq * un * sqrt_upper(sp.cr_nHaa) * ph);
+    const double quad1 = ln2 * ln2 * (sp.cr_nN * un * dn + sp.cr_nM * un * un + sp.acc_rel * acc_sum);
     const double quad2 = 1.5 * ln2 * ln2 * (sp.cr_nHabs * dn * dn + sp.cr_nDabs * un * un + sp.acc_rel * sp.acc_rel * ph * ph * sp.cr_Cqq);
     const double cub2 = ln2 * ln2 * (p2 - 1.0) * eps * eps * sp.cr_Babs * 1.01;
     // L: fl32 of p' and of ln2 g, 320 fp32 fmas (|sum of the terms' magnitudes| <= |p'||g|), p' against p
@@ -2791,7 +2795,8 @@ __global__ __launch_bounds__(256) void k_svm_h_combine_cr(const double *__restri
         const double zmax = ph * c.qmax + eps;
         const double zf = floor(zmax);
         const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();
-        const double quad1 = ln2 * ln2 * (c.nN * un * dn + c.nM * un * un + (c.acc_rel + 2.0 * u24) * ph * un * c.Ca);
+        const double acc_sum = fmin(ph * un * c.Ca, sqrt_upper(c.nHabs) * un * sqrt_upper(c.nHaa) * ph);    // (screen_finish_cr: the same two bounds)
+        const double quad1 = ln2 * ln2 * (c.nN * un * dn + c.nM * un * un + (c.acc_rel + 2.0 * u24) * acc_sum);
         const double quad2 = 1.5 * ln2 * ln2 * (c.nHabs * dn * dn + c.nDabs * un * un + c.acc_rel * c.acc_rel * ph * ph * c.Cqq);
         const double cub2 = ln2 * ln2 * (p2 - 1.0) * eps * eps * c.Babs * 1.01;
         const double t = ln2 * zmax;

@@ -220,12 +220,15 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
                                                                const int *__restrict__ counters, SvmParams p,
                                                                float *__restrict__ dec, int8_t *__restrict__ labels,
                                                                unsigned long long *__restrict__ flag0_words, Dims d,
-                                                               float *__restrict__ margin, CrParams crp)
+                                                               float *__restrict__ margin, CrParams crp,
+                                                               const int *__restrict__ idx_list, int count_slot)
 {
+    // LIST mode (idx_list != nullptr; round 4, "tier 0b"): the operand images, bands and common factors are indexed by list slot
+    // (the feature kernel's list mode wrote them), slot j holds evaluation idx_list[j], counters[count_slot] says how many
     constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CRE = VAR == SCREEN_CR_EXP, CRP = VAR == SCREEN_CR_POLY, CR = CRE || CRP;
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
     __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
-    const int n_evals = counters[CNT_EVALS];
+    const int n_evals = counters[count_slot];
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -423,10 +426,11 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         val = centred ? dvc : dv;
         err = centred ? err2 : err1;
         }
-        dec[e] = val;
-        labels[evalcell[e]] = (int8_t)(val > 0.0f ? p.gv0 : p.gv1);
+        const long eid = idx_list ? (long)idx_list[e] : e;          // the evaluation this slot holds
+        dec[eid] = val;
+        labels[evalcell[eid]] = (int8_t)(val > 0.0f ? p.gv0 : p.gv1);
         flagged = !(fabsf(val) > err);                              // also catches NaN
-        if (margin) margin[e] = flagged ? 0.0f : fabsf(val) / err;  // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
+        if (margin) margin[eid] = flagged ? 0.0f : fabsf(val) / err;  // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
     }
     // one 64-bit word per wave (64 consecutive evaluations): k_screen_compact turns the words into the ORDERED list of
     // undecided evaluations -- neighbours in the list are neighbours on the grid, so the feature kernel that follows reads
@@ -441,16 +445,16 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
 // the list's capacity (the host then falls back to the three-pass kernel for everything).
 constexpr int kCompactWords = 256;
 
-__device__ __forceinline__ int screen_words(const int *counters)
+__device__ __forceinline__ int screen_words(const int *counters, int count_slot)
 {
-    return (counters[CNT_EVALS] + kS0BlockEvals - 1) / kS0BlockEvals * (kS0BlockEvals / 64);
+    return (counters[count_slot] + kS0BlockEvals - 1) / kS0BlockEvals * (kS0BlockEvals / 64);
 }
 
 __global__ __launch_bounds__(kCompactWords) void k_screen_count(const unsigned long long *__restrict__ words,
-                                                                int *__restrict__ wgcount, const int *__restrict__ counters)
+                                                                int *__restrict__ wgcount, const int *__restrict__ counters, int count_slot)
 {
     __shared__ int red[kCompactWords / 64];
-    const int n_words = screen_words(counters);
+    const int n_words = screen_words(counters, count_slot);
     const int w = blockIdx.x * kCompactWords + threadIdx.x;
     int c = (w < n_words) ? __popcll(words[w]) : 0;
 #pragma unroll
@@ -462,11 +466,12 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_count(const unsigned l
 
 __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned long long *__restrict__ words,
                                                                   const int *__restrict__ wgcount, int n_wg,
-                                                                  int *__restrict__ list, int cap, int *__restrict__ counters, int also_counter)
+                                                                  int *__restrict__ list, int cap, int *__restrict__ counters, int also_counter,
+                                                                  const int *__restrict__ idx_list, int count_slot, int out_slot)
 {
     __shared__ int part[kCompactWords];
     __shared__ int s_base;
-    const int n_words = screen_words(counters);
+    const int n_words = screen_words(counters, count_slot);
     const int t = threadIdx.x;
     // slots taken by the preceding workgroups (the last workgroup also publishes the total)
     int before = 0;
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned
             __syncthreads();
         }
         if (t == 0) {
-            counters[CNT_FLAGGED0] = part[0];
+            counters[out_slot] = part[0];
             if (also_counter >= 0) counters[also_counter] = min(part[0], cap);    // small requests: the list IS the exact tier's (engine.cpp)
         }
         __syncthreads();
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned
     while (m) {
         const int b = __ffsll((long long)m) - 1;
         m &= m - 1;
-        if (slot < cap) list[slot] = w * 64 + b;
+        if (slot < cap) list[slot] = idx_list ? idx_list[w * 64 + b] : w * 64 + b;   // (list mode: slots back to evaluations, still in ascending order)
         slot++;
     }
 }
@@ -695,13 +700,13 @@ double probe_mfma_rounding(hipStream_t s, double *worst16)
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,
-                       int also_counter)
+                       int also_counter, const int *idx_list, int count_slot, int out_slot)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
 #define HAF_SCREEN_LAUNCH(V)                                                                                                      \
     hipLaunchKernelGGL(k_svm_screen<V>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,          \
-                       (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr)
+                       (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot)
     switch (variant) {
         case SCREEN_SUMSQ: HAF_SCREEN_LAUNCH(SCREEN_SUMSQ); break;
         case SCREEN_CR_EXP: HAF_SCREEN_LAUNCH(SCREEN_CR_EXP); break;
@@ -711,9 +716,9 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
 #undef HAF_SCREEN_LAUNCH
     // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
-    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters);
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, count_slot);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw, also_counter);
+                       counters_rw, also_counter, idx_list, count_slot, out_slot);
 }
 
 }  // namespace haf

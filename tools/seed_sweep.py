@@ -68,6 +68,8 @@ def main():
                     for k, v in eng.stage_ms().items():
                         acc[k] = acc.get(k, 0.0) + v / a.steps
                     cnt = eng.last_counts()
+            st = eng.screen_state()
+            ex = eng.last_exact_tiers()
             eng.close()
             key = [(int(r["vote"]), int(r["row"]), int(r["col"])) for r in rec]
             if ref is None:
@@ -75,11 +77,12 @@ def main():
             row = dict(model=name, variant=variant, ms=sum(acc.values()), features=acc.get("features"), svm=acc.get("svm"),
                        refine=acc.get("refine"), recheck=acc.get("recheck"), n_evals=cnt["n_evals"], refined=cnt["n_refined"],
                        refined_share=cnt["n_refined"] / max(1, cnt["n_evals"]), fp64=cnt["n_rechecked"], strict=cnt["n_strict"],
-                       same_records=(key == ref))
+                       same_records=(key == ref), state=st, exact=ex)
             rows.append(row)
-            print("%-9s %-8s step %.2f ms  features %.2f svm %.2f refine %.2f recheck %.2f  refined %.3f %% (%d)  fp64 %d strict %d  same %s"
+            print("%-9s %-8s step %.2f ms  features %.2f svm %.2f refine %.2f recheck %.2f  refined %.3f %% (%d)  exact tiers %d (i8 %d fp64 %d) strict %d  same %s  form %d%s%s"
                   % (name, variant, row["ms"], row["features"], row["svm"], row["refine"], row["recheck"], 100 * row["refined_share"],
-                     row["refined"], row["fp64"], row["strict"], row["same_records"]), flush=True)
+                     row["refined"], row["fp64"], ex["n_integer"], ex["n_fp64"], row["strict"], row["same_records"], st["variant"],
+                     "+0b" if st["tier0b"] else "", " t1-skip" if st["tier1_skipped"] else ""), flush=True)
     if a.out:
         with open(a.out, "w") as f:
             json.dump(rows, f, indent=1)
