@@ -2029,7 +2029,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             // blocked host thread costs more than the request's last kernels
             if (short_request) {
                 hipError_t q;
-                while ((q = hipStreamQuery(s)) == hipErrorNotReady) { }
+                while ((q = hipStreamQuery(s)) == hipErrorNotReady) __builtin_ia32_pause();   // (spin politely: the sibling hyper-thread may be the driver's)
                 HIPCHK(e, q);
             } else {
                 HIPCHK(e, hipStreamSynchronize(s));
@@ -2288,7 +2288,18 @@ static int score_batch_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
     if (!e) return HAF_E_ARG;
     if (!out) return fail(e, HAF_E_ARG, "haf_score_batch: null output");
     std::vector<haf_roll_record> rec((size_t)std::max(1, n_clouds) * e->cfg.n_rolls);
-    int rc = haf_score_rolls(e, n_clouds, clouds, in, 0, e->cfg.n_rolls, rec.data());
+    // A request whose every budget is negative runs no roll in the reference (server.cpp:367-374: the loop breaks before roll 0 and the
+    // goal still succeeds with the untouched overall best): nothing for the device to do -- empty records, finalised below
+    bool none_runs = in != nullptr && clouds != nullptr && n_clouds >= 1 && n_clouds <= e->cfg.max_clouds;
+    for (int b = 0; none_runs && b < n_clouds; b++) none_runs = (int)in[b].max_calculation_time < 0;
+    int rc = HAF_OK;
+    if (none_runs) {
+        e->last_B = e->last_R = e->last_roll_first = 0;
+        e->last_evals = e->last_flagged = e->last_flagged2 = e->last_flagged0 = e->last_flaggedi = e->last_inexact = e->last_host_resolved = 0;
+        e->last_i8 = e->last_screened = false;
+    } else {
+        rc = haf_score_rolls(e, n_clouds, clouds, in, 0, e->cfg.n_rolls, rec.data());
+    }
     if (rc != HAF_OK) return rc;
     for (int b = 0; b < n_clouds; b++) {
         rc = haf_finalize(e, &in[b], rec.data() + (size_t)b * e->cfg.n_rolls, &out[b]);

@@ -65,7 +65,7 @@ DEC_REL_SCREEN = 2.0 ** -8
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
-              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1")
+              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -732,6 +732,40 @@ def test_every_form_of_the_screening_pass_gives_the_oracles_labels(data_dir, sur
     assert refined[("surrogate", 2)] < 0.4 < refined[("surrogate", 0)]
     assert refined[("trained", "auto")][0] == 3 and refined[("trained", 3)] < 0.2 and min(refined[("trained", v)] for v in (0, 1, 2)) > 0.95
     assert refined[("random", 2)] <= refined[("random", 0)] + 0.01
+
+
+@pytest.mark.parametrize("t0b,skip", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_second_screening_pass_and_tier_1_hand_over(data_dir, tmp_path, monkeypatch, t0b, skip):
+    """Round 4: behind a PLAIN first pass the centred-remainder form may run once more on the first pass's LIST (tier 0b: k_svm_screen in
+    list mode, operand images / bands / common factors indexed by list slot), and what the screening passes leave may skip tier 1 and
+    go straight to the exact tiers (t1_skip).  All four combinations pinned (HAF_T0B, HAF_T1_SKIP): every stage and label the
+    oracle's; with tier 0b fewer evaluations leave the screening passes; with the skip every one of them reaches the exact tiers."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    monkeypatch.setenv("HAF_SCREEN_VARIANT", "0")
+    monkeypatch.setenv("HAF_T0B", str(t0b))
+    monkeypatch.setenv("HAF_T1_SKIP", str(skip))
+    f, r = _files(data_dir)
+    path = str(tmp_path / "rand900.model")
+    models.write_random_model(path, 900, seed=11, balanced=True)
+    o = O.Oracle(f, r, path)
+    eng = make_engine(data_dir, path)
+    st = eng.screen_state()
+    assert st["variant"] == 0 and st["tier0b"] == bool(t0b) and st["tier1_skipped"] == bool(skip), st
+    for name, cfg, inp in (("pcd3", dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=44)),
+                           ("table2_mult_obj_rcs_1428580941635676", dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56))):
+        xyz = pcdio.load_pcd(os.path.join(data_dir, name + ".pcd"))
+        compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+        cnt = eng.last_counts()
+        STATS.setdefault("tier0b_counts", {})["%s/t0b%d/skip%d" % (name, t0b, skip)] = cnt
+        assert 0 < cnt["n_refined"] < 0.3 * cnt["n_evals"]
+        if skip:
+            assert cnt["n_rechecked"] == cnt["n_refined"]
+        else:
+            assert cnt["n_rechecked"] <= cnt["n_refined"]
+    eng.close()
+    ref = STATS["tier0b_counts"].get("pcd3/t0b0/skip0")
+    if t0b and ref:
+        assert STATS["tier0b_counts"]["pcd3/t0b1/skip%d" % skip]["n_refined"] < ref["n_refined"]
 
 
 def test_a_worse_matrix_core_widens_the_bands_and_a_far_worse_one_is_refused(data_dir, surrogate, orc, monkeypatch, tmp_path):

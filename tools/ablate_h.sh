@@ -8,12 +8,15 @@
 cd $GRAFT_REPO_ROOT
 if [ "$1" = build ]; then
     mkdir -p haf_grasping_amd/abl
+    # (the variants are linked under the product names on the way; whatever happens -- an error, an interrupt -- the real
+    # build is put back before this script ends, and a library built with experiment flags never stays under those names)
+    restore() { unset HAF_EXPERIMENT_FLAGS; python3 -c "from haf_grasping_amd import build; build.build(verbose=False, force=True)"; }
+    trap restore EXIT INT TERM
     for n in ${VARIANTS:-0 1 2 3 4 5}; do
         HAF_EXPERIMENT_FLAGS="-DHAF_ABL=$n" python3 -c "from haf_grasping_amd import build; build.build(verbose=False, force=True)" || exit 1
         cp haf_grasping_amd/libhafgrasp_testing.so haf_grasping_amd/abl/libhafgrasp_testing_abl$n.so
     done
-    python3 -c "from haf_grasping_amd import build; build.build(verbose=False, force=True)"
-    exit 0
+    exit 0          # (the trap restores the real build)
 fi
 S=${2:-11}
 for n in ${VARIANTS:-0 1 2 3 4 5}; do

@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-P=profiles/${ROUND:-r03}_bench_c5_nsv4096
+R=${ROUND:-r04}
+P=profiles/${R}_bench_c5_nsv4096
 newest() { ls -t $1 | head -1; }
 cp $F/bench_default.json ${P}_default.json
 for m in "" _f16x3 _f32; do
@@ -18,6 +19,23 @@ cp "$(newest "$F/lds/*/*counter_collection.csv")" ${P}_f16s_pmc_LDS_TCC.csv
 cp "$(newest "$F/ta/*/*counter_collection.csv")" ${P}_f16s_pmc_TA.csv
 cp "$(newest "$F/tcp/*/*counter_collection.csv")" ${P}_f16s_pmc_TCP.csv
 cp "$(newest "$F/sqf/*/*counter_collection.csv")" ${P}_f16s_pmc_SQ_insts.csv
+# round 4: full-size kernel averages (bench.py: roofline.frac_rocprof), seed 11 / trained model steps, tier-kernel counters, latency traces
+python - <<PY
+import json
+d = json.load(open("$F/kernel_avg.json"))
+d["workload"] = {"grid": 512, "rolls": 36, "n_sv": 4096, "seed": 42}
+json.dump(d, open("profiles/${R}_kernel_avg.json", "w"), indent=1, sort_keys=True)
+PY
+for S in 11 trained; do
+  cp "$(newest "$F/kt_s$S/*/*kernel_stats.csv")" profiles/${R}_seed${S}_kernel_stats.csv
+  cp $F/kernel_avg_s$S.json profiles/${R}_seed${S}_kernel_avg.json
+done
+cp "$(newest "$F/sq_s11/*/*counter_collection.csv")" profiles/${R}_seed11_pmc_SQ.csv
+cp "$(newest "$F/lds_s11/*/*counter_collection.csv")" profiles/${R}_seed11_pmc_LDS.csv
+for C in C2 C3; do
+  c=$(echo $C | tr A-Z a-z)
+  cp "$(newest "$F/lat_$C/*/*kernel_stats.csv")" profiles/${R}_latency_${c}_kernel_stats.csv
+done
 python tools/pmc_summary.py --fetch ${P}_f16s_pmc_FETCH_SIZE.csv --write ${P}_f16s_pmc_WRITE_SIZE.csv \
   --fetch-f32 ${P}_f32_pmc_FETCH_SIZE.csv --write-f32 ${P}_f32_pmc_WRITE_SIZE.csv \
   --fetch-f16x3 ${P}_f16x3_pmc_FETCH_SIZE.csv --write-f16x3 ${P}_f16x3_pmc_WRITE_SIZE.csv \
