@@ -1082,6 +1082,7 @@ int build_tables(haf_engine *e)
         e->prob.A = m.probA; e->prob.B = m.probB;
         e->prob.gv0 = e->gv0; e->prob.gv1 = e->gv1;       // (int)atof(two characters) == atoi(two characters) for "%g" of an int
         e->prob.hdr = header_grid_value(m.label[0], m.label[1]);
+        e->prob.host_all = test_env("HAF_PROB_HOST_ALL") ? 1 : 0;
     }
 
     e->svm.two_gamma2 = (float)(2.0 * m.gamma * log2e);
@@ -1149,6 +1150,7 @@ int build_tables(haf_engine *e)
     e->i8.gv0 = e->gv0; e->i8.gv1 = e->gv1;
     e->svm.sqrt_cmax = (float)(e->screen.sqrt_cmax * (1.0 + 1e-7));
     e->host_exp_thr = std::ldexp(e->sum_abs_coef, -44);        // 256 x the largest difference a last-bit exp error can make
+    e->prob.dec_slack = std::ldexp(e->sum_abs_coef, -50);       // probability mode: 4 x what the two libsvm-order sums can differ by
     if (test_env("HAF_HOST_EXP_ALL")) e->host_exp_thr = INFINITY;   // tests: every strict-tier evaluation through the host path
     e->exact.gamma = m.gamma; e->exact.rho = m.rho;
     e->exact.lower = e->range.lower; e->exact.upper = e->range.upper;
@@ -1736,6 +1738,97 @@ static int host_resolve_strict(haf_engine *e, const Dims &d, hipStream_t s, bool
     return HAF_OK;
 }
 
+// svm_predict_probability for two classes on the HOST, operation for operation as svm.cpp:2550-2587 (sigmoid_predict 1818-1826 with
+// the C library's exp, the [1e-7, 1 - 1e-7] clamp, multiclass_probability 1829-1888 for k = 2); this TU is built with -ffp-contract=off
+static int host_probability(double dec, double A, double B, double p[2])
+{
+    const double fApB = dec * A + B;
+    double s = fApB >= 0.0 ? std::exp(-fApB) / (1.0 + std::exp(-fApB)) : 1.0 / (1.0 + std::exp(fApB));
+    const double min_prob = 1e-7;
+    s = std::min(std::max(s, min_prob), 1.0 - min_prob);
+    const int k = 2;
+    double r[2][2] = {{0.0, s}, {1.0 - s, 0.0}}, Q[2][2], Qp[2], pQp;
+    const double eps = 0.005 / k;
+    for (int t = 0; t < k; t++) {
+        p[t] = 1.0 / k;
+        Q[t][t] = 0.0;
+        for (int j = 0; j < t; j++) { Q[t][t] += r[j][t] * r[j][t]; Q[t][j] = Q[j][t]; }
+        for (int j = t + 1; j < k; j++) { Q[t][t] += r[j][t] * r[j][t]; Q[t][j] = -r[j][t] * r[t][j]; }
+    }
+    for (int iter = 0; iter < 100; iter++) {
+        pQp = 0.0;
+        for (int t = 0; t < k; t++) {
+            Qp[t] = 0.0;
+            for (int j = 0; j < k; j++) Qp[t] += Q[t][j] * p[j];
+            pQp += p[t] * Qp[t];
+        }
+        double max_error = 0.0;
+        for (int t = 0; t < k; t++) max_error = std::max(max_error, std::fabs(Qp[t] - pQp));
+        if (max_error < eps) break;
+        for (int t = 0; t < k; t++) {
+            const double diff = (-Qp[t] + pQp) / Q[t][t];
+            p[t] += diff;
+            pQp = (pQp + diff * (diff * Q[t][t] + 2.0 * Qp[t])) / (1.0 + diff) / (1.0 + diff);
+            for (int j = 0; j < k; j++) { Qp[j] = (Qp[j] + diff * Q[t][j]) / (1.0 + diff); p[j] /= (1.0 + diff); }
+        }
+    }
+    return p[1] > p[0] ? 1 : 0;
+}
+
+// Probability mode: the estimates k_prob_eval could not vouch for (a last-bit difference between the device's exp and glibc's could
+// move their label or a printed digit; CNT_FLAGGED / d_flag_list) are finished HERE: the libsvm-order decision value with the C
+// library's exp from the device's attributes (as host_resolve_strict does), svm_predict_probability with the C library's exp, the
+// "%g" forms by the host build of decq (pinned to glibc's printf + strtod).  Writes what k_prob_eval writes.
+static int host_resolve_probability(haf_engine *e, const Dims &d, hipStream_t s)
+{
+    e->last_host_resolved = 0;
+    const int n = std::min(e->h_counters[CNT_FLAGGED], e->list_cap);
+    if (n <= 0) return HAF_OK;
+    const SvmModel &m = e->model;
+    const int kx = e->kx;
+    std::vector<int> ev((size_t)n);
+    HIPCHK(e, hipMemcpyAsync(ev.data(), e->d_flag_list.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    for (int off = 0; off < n; off += e->flag_cap) {
+        const int nw = std::min(e->flag_cap, n - off);
+        launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, reinterpret_cast<float *>(e->d_x64.p), nullptr, d, e->range.lower,
+                        e->range.upper, 0.0f, nw, XMODE_F64, ScreenParams{}, e->d_flag_list.p + off, CNT_FLAGGED, nw, false, nw, nullptr, nullptr, s, off);
+        const size_t groups = ((size_t)nw + 15) / 16;
+        std::vector<double> x64(groups * kKP * 16);
+        HIPCHK(e, hipMemcpyAsync(x64.data(), e->d_x64.p, x64.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipStreamSynchronize(s));
+        for (int i = 0; i < nw; i++) {
+            const double *xg = x64.data() + (size_t)(i >> 4) * kKP * 16 + (i & 15);
+            double sum = 0.0;
+            for (int nn = 0; nn < m.n_sv; nn++) {                    // svm.cpp:2509-2512
+                double d2 = 0.0;
+                for (int k = 0; k < kx; k++) {
+                    const double sv = k < m.dim ? m.sv[(size_t)nn * m.dim + k] : 0.0;
+                    const double dd = xg[(size_t)k * 16] - sv;
+                    d2 += dd * dd;
+                }
+                sum += m.coef[(size_t)nn] * std::exp(-m.gamma * d2);
+            }
+            const double dv = sum - m.rho;
+            double p[2];
+            const int idx = host_probability(dv, e->prob.A, e->prob.B, p);
+            const double q[2] = {hafq::decq(p[0], 6), hafq::decq(p[1], 6)};
+            const int res = idx ? e->prob.gv1 : e->prob.gv0;
+            const float own = (float)res * (float)(res > 0 ? q[1] : q[0]);
+            const int8_t lab = (int8_t)res;
+            const int evi = ev[(size_t)(off + i)];
+            int cell = 0;
+            HIPCHK(e, hipMemcpy(&cell, e->d_evalcell.p + evi, sizeof(int), hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(e->d_own.p + cell, &own, sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(e, hipMemcpy(e->d_labels.p + cell, &lab, 1, hipMemcpyHostToDevice));
+            HIPCHK(e, hipMemcpy(e->d_ptext.p + 2 * (size_t)evi, q, 2 * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(e, hipMemcpy(e->d_dec_exact2.p + evi, &dv, sizeof(double), hipMemcpyHostToDevice));
+            e->last_host_resolved++;
+        }
+    }
+    return HAF_OK;
+}
+
 static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, const haf_grasp_input *in, int32_t roll_first,
                             int32_t roll_count, haf_roll_record *records)
 {
@@ -2091,6 +2184,17 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
         launch_prob_list(e->d_counters.p, CNT_FLAGGED2, e->d_flag2_list.p, e->list_cap, s);
         launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
                        e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+        // the estimates; those a last-bit exp difference could move come back as a list and are finished on the host (round 4)
+        launch_probability_eval(e->d_dec_exact2.p, e->d_evalcell.p, e->d_counters.p, e->prob, e->d_labels.p, e->d_own.p, e->d_ptext.p,
+                                e->d_flag_list.p, e->list_cap, e->d_counters.p, evals_cap, s);
+        HIPCHK(e, hipMemcpyAsync(e->h_out, e->d_out.p, kCntBytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipStreamSynchronize(s));
+        if (e->h_counters[CNT_FLAGGED] > 0) {
+            const int rc = host_resolve_probability(e, d, s);
+            if (rc != HAF_OK) return rc;
+        } else {
+            e->last_host_resolved = 0;
+        }
         mark(e, HAF_ST_VOTE);
         launch_probability(e->d_dec_exact2.p, e->d_evalcell.p, e->d_counters.p, e->prob, e->d_labels.p, e->d_mask.p, e->d_rowcount.p,
                            e->d_brcount.p, reinterpret_cast<const float *>(e->d_heights.p), e->d_own.p, e->d_ptext.p, e->d_gridf.p,
@@ -2174,7 +2278,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
 
     e->last_B = B; e->last_R = R; e->last_roll_first = roll_first;
     e->last_evals = e->h_counters[CNT_EVALS];
-    e->last_flagged = e->h_counters[CNT_FLAGGED];
+    e->last_flagged = e->prob_mode ? 0 : e->h_counters[CNT_FLAGGED];      // (probability mode: the counter holds the estimates the host finished)
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
     e->last_flagged0 = t0b_used ? std::min(e->h_counters[CNT_FLAGGED0B], e->h_counters[CNT_FLAGGED0]) : e->h_counters[CNT_FLAGGED0];   // what leaves the screening passes
     e->last_flaggedi = i8_used ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];

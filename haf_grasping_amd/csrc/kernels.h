@@ -315,7 +315,11 @@ struct ProbParams {
     double A, B;          // probA, probB of the model
     int gv0, gv1;         // (int)atof(first two characters of "%g" of label[0] / label[1])  (server.cpp:833)
     float hdr;            // what the "labels a b" header line parses to: the value of the first masked cell of a roll
+    int host_all;         // testing build (HAF_PROB_HOST_ALL): every estimate is finished on the host
+    double dec_slack;     // how far the device's libsvm-order decision value may be from glibc's: 4 x 2^-52 sum|coef| (k_prob_eval)
 };
+void launch_probability_eval(const double *dec_exact, const int *evalcell, const int *counters, ProbParams P, int8_t *labels, float *own,
+                             double *ptext, int *near_list, int near_cap, int *counters_rw, long evals_cap, hipStream_t s);
 void launch_prob_list(int *counters, int slot, int *list, int cap, hipStream_t s);
 void launch_probability(const double *dec_exact, const int *evalcell, const int *counters, ProbParams P, int8_t *labels,
                         const uint8_t *mask, const int *rowcount, const int *brcount, const float *heights, float *own,

@@ -29,14 +29,16 @@ __global__ __launch_bounds__(256) void k_prob_list(int *__restrict__ counters, i
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[slot] = n;
 }
 
-__device__ __forceinline__ double sigmoid_predict(double dec, double A, double B)          // svm.cpp:1818-1826
+// `bend` multiplies the exp() result: 1 in the estimate itself; 1 +- 2^-50 where k_prob_eval asks whether a last-bit difference
+// between this exp and the C library's could move a printed digit
+__device__ __forceinline__ double sigmoid_predict(double dec, double A, double B, double bend = 1.0)          // svm.cpp:1818-1826
 {
     const double fApB = __dadd_rn(__dmul_rn(dec, A), B);
     if (fApB >= 0.0) {
-        const double t = exp(-fApB);
+        const double t = exp(-fApB) * bend;
         return __ddiv_rn(t, __dadd_rn(1.0, t));
     }
-    return __ddiv_rn(1.0, __dadd_rn(1.0, exp(fApB)));
+    return __ddiv_rn(1.0, __dadd_rn(1.0, exp(fApB) * (2.0 - bend)));      // (1 / bend to first order: a larger bend raises the estimate in both branches)
 }
 
 // multiclass_probability (svm.cpp:1829-1888) for k = 2: the same loops, the same operations in the same order
@@ -78,23 +80,51 @@ __device__ __forceinline__ void multiclass_probability2(const double r[2][2], do
     }
 }
 
+// svm_predict_probability for two classes from a decision value: p[0], p[1] and the index of the first maximum
+__device__ __forceinline__ int prob_estimates(double dec, const ProbParams &P, double bend, double p[2])
+{
+    const double min_prob = 1e-7;
+    double s = sigmoid_predict(dec, P.A, P.B, bend);
+    s = s > min_prob ? s : min_prob;                                          // max(.., min_prob)       svm.cpp:2569
+    const double hi = __dsub_rn(1.0, min_prob);
+    s = s < hi ? s : hi;                                                      // min(.., 1 - min_prob)
+    double r[2][2] = {{0.0, s}, {__dsub_rn(1.0, s), 0.0}};
+    multiclass_probability2(r, p);
+    return p[1] > p[0] ? 1 : 0;                                               // first maximum (2575-2578)
+}
+
 // per evaluation: probability estimates, the label svm_predict_probability returns, the "%g" forms, and the value a grid cell
-// would take from this evaluation's output line
+// would take from this evaluation's output line.  Round 4: the device's exp is not glibc's -- both are within an
+// ulp, and so are the two libsvm-order decision values (2^-52 sum|coef|, `dec_slack` carries 4x that).  The estimate is therefore
+// formed three times -- as is, and with the decision value and the exp result pushed to either side by more than the two
+// libraries can differ -- and where the label or a printed digit is not the same in all three, the evaluation goes on the list of
+// those the HOST finishes with the C library's exp (engine.cpp: host_resolve_probability).
 __global__ __launch_bounds__(256) void k_prob_eval(const double *__restrict__ dec_exact, const int *__restrict__ evalcell,
                                                    const int *__restrict__ counters, ProbParams P, int8_t *__restrict__ labels,
-                                                   float *__restrict__ own, double *__restrict__ ptext)
+                                                   float *__restrict__ own, double *__restrict__ ptext,
+                                                   int *__restrict__ near_list, int near_cap, int *__restrict__ counters_rw)
 {
     const int n = counters[CNT_EVALS];
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const double min_prob = 1e-7;
-        double s = sigmoid_predict(dec_exact[e], P.A, P.B);
-        s = s > min_prob ? s : min_prob;                                      // max(.., min_prob)       svm.cpp:2569
-        const double hi = __dsub_rn(1.0, min_prob);
-        s = s < hi ? s : hi;                                                  // min(.., 1 - min_prob)
-        double r[2][2] = {{0.0, s}, {__dsub_rn(1.0, s), 0.0}}, p[2];
-        multiclass_probability2(r, p);
-        const int idx = p[1] > p[0] ? 1 : 0;                                  // first maximum (2575-2578)
+        double p[2];
+        const double dec = dec_exact[e];
+        const int idx = prob_estimates(dec, P, 1.0, p);
         const double q0 = hafq::decq(p[0], 6), q1 = hafq::decq(p[1], 6);      // " %g" (svm-predict.c:116), read back by atof
+        if (near_list) {
+            bool near = P.host_all != 0;
+            const double bend = 8.8817841970012523e-16;                       // 2^-50
+            for (int side = 0; side < 2 && !near; side++) {
+                double pb[2];
+                const double sgn = side ? -1.0 : 1.0;
+                // (the estimate is monotone in the decision value and in the exp result: the two extreme combinations bracket it)
+                const int ib = prob_estimates(dec + sgn * P.dec_slack * (P.A < 0.0 ? 1.0 : -1.0), P, 1.0 + sgn * bend, pb);
+                near = ib != idx || hafq::decq(pb[0], 6) != q0 || hafq::decq(pb[1], 6) != q1;
+            }
+            if (near) {
+                const int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
+                if (slot < near_cap) near_list[slot] = e;
+            }
+        }
         const int res = idx ? P.gv1 : P.gv0;                                  // (int)atof(line.substr(0,2))  server.cpp:833
         const float prob = (float)(res > 0 ? q1 : q0);                        // 834-840
         const int cell = evalcell[e];
@@ -230,12 +260,19 @@ __global__ __launch_bounds__(1024) void k_prob_pick(const float *__restrict__ ev
     }
 }
 
+void launch_probability_eval(const double *dec_exact, const int *evalcell, const int *counters, ProbParams P, int8_t *labels, float *own,
+                             double *ptext, int *near_list, int near_cap, int *counters_rw, long evals_cap, hipStream_t s)
+{
+    const int eb = (int)std::min<long>(4096, (evals_cap + 255) / 256);
+    if (eb > 0) hipLaunchKernelGGL(k_prob_eval, dim3(eb), dim3(256), 0, s, dec_exact, evalcell, counters, P, labels, own, ptext, near_list,
+                                   near_cap, counters_rw);
+}
+
 void launch_probability(const double *dec_exact, const int *evalcell, const int *counters, ProbParams P, int8_t *labels,
                         const uint8_t *mask, const int *rowcount, const int *brcount, const float *heights, float *own,
                         double *ptext, float *gridf, float *evf, RollRecordDev *rec, long evals_cap, Dims d, hipStream_t s)
 {
-    const int eb = (int)std::min<long>(4096, (evals_cap + 255) / 256);
-    if (eb > 0) hipLaunchKernelGGL(k_prob_eval, dim3(eb), dim3(256), 0, s, dec_exact, evalcell, counters, P, labels, own, ptext);
+    (void)dec_exact; (void)evalcell; (void)counters; (void)labels; (void)ptext; (void)evals_cap;   // (the estimates: launch_probability_eval)
     hipLaunchKernelGGL(k_prob_grid, dim3(d.B * d.R), dim3(256), 0, s, mask, rowcount, own, gridf, P.hdr, d);
     const size_t cells = (size_t)d.B * d.R * d.H * d.W;
     hipLaunchKernelGGL(k_prob_vote_cells, dim3((unsigned)std::min<size_t>(8192, (cells + 255) / 256)), dim3(256), 0, s, gridf, evf, d);
