@@ -6,9 +6,9 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/quick
 rm -rf $O; mkdir -p $O
-B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side"
+B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-trained-side --no-cabi-side"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/kt.log 2>&1
-B1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side"
+B1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-trained-side --no-cabi-side"
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAIT_ANY --output-format csv -d $O/sq -- python3 $B1 > $O/sq.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/sq2 -- python3 $B1 > $O/sq2.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq3 -- python3 $B1 > $O/sq3.log 2>&1

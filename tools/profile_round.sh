@@ -7,8 +7,8 @@ rm -rf $O; mkdir -p $O
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 # (the profiled runs take ONE model seed -- the median seed of the default run above, 42 -- so that the kernel statistics are those
 # of the headline line; the calibration request of haf_create adds one small launch of every kernel to the call counts)
-B="bench.py --steps 3 --warmup 1 --seeds ${SEED:-42} --no-label-stats --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side"
-B1="bench.py --steps 1 --warmup 0 --seeds ${SEED:-42} --no-label-stats --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-cabi-side"
+B="bench.py --steps 3 --warmup 1 --seeds ${SEED:-42} --no-label-stats --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-trained-side --no-cabi-side"
+B1="bench.py --steps 1 --warmup 0 --seeds ${SEED:-42} --no-label-stats --no-cpu-baseline --no-latency --no-f32-side --no-hard-side --no-trained-side --no-cabi-side"
 # default (screened) mode: kernel trace + PMC passes (counters in their own runs)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $B > $O/kt.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $B1 > $O/fetch.log 2>&1
