@@ -34,6 +34,26 @@ def write_random_model(path, nsv, D=323, seed=0, gamma=None, rho=0.1, density=1.
     return path
 
 
+def write_clustered_model(path, nsv, D=323, seed=0, gamma=1e-4, coef_scale=1000.0, spread=0.25, rho=0.3):
+    """An ILL-CONDITIONED synthetic model of the trained kind: support vectors clustered around one centre
+    (every attribute N(centre_k, spread)), coefficients coef_scale * U(0.5, 1) with sum 0, a small gamma: the kernel values are all
+    close to one another, sum|coef|K is 1e5..1e7 times the decision values, z = p.q stays small -- what the centred-remainder form of
+    the screening pass is for, and nothing an fp32 coefficient sum can decide."""
+    rng = np.random.RandomState(seed)
+    n0 = nsv // 2
+    centre = rng.uniform(-0.6, 0.6, D)
+    sv = centre[None, :] + rng.standard_normal((nsv, D)) * spread
+    coef = coef_scale * rng.uniform(0.5, 1.0, nsv)
+    coef[n0:] *= -1.0
+    coef[n0:] *= coef[:n0].sum() / -coef[n0:].sum()
+    with open(path, "w") as f:
+        f.write("svm_type c_svc\nkernel_type rbf\ngamma %g\nnr_class 2\ntotal_sv %d\nrho %g\nlabel -1 1\nnr_sv %d %d\nSV\n"
+                % (gamma, nsv, rho, n0, nsv - n0))
+        for i in range(nsv):
+            f.write("%.16g " % coef[i] + "".join("%d:%.8g " % (k + 1, sv[i, k]) for k in range(D)) + "\n")
+    return path
+
+
 def synthetic_cloud(grid=512, k=2, seed=0, cell=0.01):
     """SURVEY.md §8(d) C5 cloud: for each 1 cm cell of a grid x grid area centred on the origin, k points at
     uniform-random xy inside the cell, z = 0.05 + 0.20*smooth(x,y) + U(0,0.005) with smooth = mean of 8 seeded

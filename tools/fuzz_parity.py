@@ -51,7 +51,15 @@ def random_cloud(rng, half):
 
 
 def random_model(rng, path, idx, big=False):
-    kind = idx % 6
+    kind = idx % 7
+    if kind == 6:
+        # round 4: ill-conditioned models of the trained kind (clustered SVs, huge coefficients, small gamma): the centred-remainder forms
+        nsv = int(rng.choice([64, 300, 900] + ([2500] if big else [])))
+        gamma = float(rng.choice([1e-4, 3e-4, 1e-3]))
+        scale = float(rng.choice([50.0, 500.0, 2000.0]))
+        models.write_clustered_model(path, nsv, seed=int(rng.randint(1 << 30)), gamma=gamma, coef_scale=scale, spread=float(rng.choice([0.15, 0.3])),
+                                     rho=float(rng.uniform(-1.0, 1.0)))
+        return path, "clustered nsv=%d gamma=%.4g scale=%g" % (nsv, gamma, scale)
     if kind == 0:
         return os.path.join(GOLDEN, "surrogate.model"), "surrogate"
     if kind == 1:
@@ -83,6 +91,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="haf_fuzz_")
     t0 = time.time()
     done, evals, by_mode, by_model, failure = 0, 0, {}, {}, None
+    by_form = {}                                    # default mode: which form of the screening pass served the model (haf_screen_form)
     mode_list = [(capi.FLAG_FP32_MFMA, "f32mfma"), (capi.FLAG_SPLIT_F16, "splitf16"), (0, "screen")]
     dec_stats = {n: dict(max_err_over_S=0.0, max_abs_err=0.0, values=0, outside_in_range_bound=0) for _, n in mode_list}
     mi = 0
@@ -101,6 +110,7 @@ def main():
             mode, mname = capi.FLAG_PROBABILITY, "probability"
             by_mode.setdefault(mname, 0)
         eng = T.make_engine(DATA, path, mode, grid_h=H, grid_w=W, n_rolls=n_rolls, roll_step_deg=step, max_points=1 << 17)
+        form = eng.screen_form() if mode == 0 else mname
         n_here = 0
         for _ in range(a.per_model):
             if done >= a.cases or time.time() - t0 >= a.budget:
@@ -153,11 +163,12 @@ def main():
             evals += int(want["n_evals"])
             by_mode[mname] = by_mode.get(mname, 0) + 1
         by_model[what.split(" nsv")[0]] = by_model.get(what.split(" nsv")[0], 0) + n_here
+        by_form[form] = by_form.get(form, 0) + n_here
         eng.close()
-        print("[%6.1f s] %4d cases, %9d evaluations compared; last model: %s, %dx%d, %d rolls of %d deg, %s"
-              % (time.time() - t0, done, evals, what, H, W, n_rolls, step, mname), flush=True)
+        print("[%6.1f s] %4d cases, %9d evaluations compared; last model: %s, %dx%d, %d rolls of %d deg, %s (%s)"
+              % (time.time() - t0, done, evals, what, H, W, n_rolls, step, mname, form), flush=True)
     summary = dict(seed=a.seed, cases=done, evaluations_compared=evals, seconds=round(time.time() - t0, 1), by_mode=by_mode,
-                   by_model=by_model, mismatches=0 if failure is None else 1, failure=failure, decision_values=dec_stats,
+                   by_model=by_model, by_screening_form=by_form, mismatches=0 if failure is None else 1, failure=failure, decision_values=dec_stats,
                    compared="heights, integral image, mask, labels, vote grid, per-roll winners, overall grasp (bit-exact / "
                             "identical), grasp points (1e-4 m); decision values recorded against S = sum |coef| K")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
