@@ -140,6 +140,48 @@ def check_exp_hazard(lib=None, verbose=False):
     return rep
 
 
+READELF = os.path.join(ROCM, "lib", "llvm", "bin", "llvm-readelf")
+# kernels that live at the edge of the register file (two waves of ~250 VGPRs per SIMD): a scratch spill in their inner loops
+# would be a silent 2x -- the build refuses it (round 4: a packed-fp32 form of the polynomial epilogue compiled to 54 spills)
+NO_SPILL_KERNELS = ["k_svm_screen", "k_svm_rbf_h", "k_svm_rbf", "k_recheck_i8"]
+
+
+def check_no_spills(lib=None, verbose=False):
+    """{kernel symbol: (vgprs, spills)} of the kernels in NO_SPILL_KERNELS from the code objects' metadata; raises on any spill."""
+    import glob
+    import shutil
+    import tempfile
+    lib = lib or LIB
+    tmp = tempfile.mkdtemp(prefix="haf_meta_")
+    report = {}
+    try:
+        shutil.copy(lib, os.path.join(tmp, "lib.so"))
+        subprocess.check_call([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, stdout=subprocess.DEVNULL)
+        for co in sorted(glob.glob(os.path.join(tmp, "*gfx950*"))):
+            text = subprocess.check_output([READELF, "--notes", co]).decode(errors="replace")
+            name = vg = None
+            for line in text.splitlines():
+                line = line.strip()
+                if line.startswith(".name:"):
+                    name = line.split(":", 1)[1].strip()
+                elif line.startswith(".vgpr_count:"):
+                    vg = int(line.split(":", 1)[1])
+                elif line.startswith(".vgpr_spill_count:") and name:
+                    if any(k in name for k in NO_SPILL_KERNELS):
+                        report[name] = (vg, int(line.split(":", 1)[1]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    bad = {k: v for k, v in report.items() if v[1] != 0}
+    if verbose:
+        for k, v in sorted(report.items()):
+            print("  %-60s %3d VGPRs, %d spilled" % (k[:60], v[0] or -1, v[1]))
+    if bad:
+        raise RuntimeError("register spills in a contraction kernel: %r" % bad)
+    if not report:
+        raise RuntimeError("check_no_spills: no contraction kernel found in %s" % lib)
+    return report
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return LIB
@@ -175,6 +217,7 @@ def build(force=False, verbose=False):
             if os.path.exists(out):
                 os.remove(out)                  # whatever happens below, a stale library must not survive a failed build
         check_exp_hazard(staged[0][0], verbose=verbose)
+        check_no_spills(staged[0][0], verbose=verbose)
         for tmp, out in staged:
             os.replace(tmp, out)
     finally:

@@ -519,6 +519,7 @@ def test_failed_exp_hazard_check_leaves_no_library(tmp_path, monkeypatch):
         with open(cmd[cmd.index("-o") + 1], "w") as f:
             f.write("built")
     monkeypatch.setattr(b.subprocess, "check_call", fake_call)
+    monkeypatch.setattr(b, "check_no_spills", lambda *a, **k: {})       # (the faked libraries have no code objects)
 
     def failing(*a, **k):
         raise RuntimeError("build check failed: hazard")
@@ -532,6 +533,21 @@ def test_failed_exp_hazard_check_leaves_no_library(tmp_path, monkeypatch):
     monkeypatch.setattr(b, "check_exp_hazard", lambda *a, **k: {})
     b.build()
     assert open(b.LIB).read() == "built" and open(b.LIB_TESTING).read() == "built" and b.up_to_date()
+
+
+def test_contraction_kernels_do_not_spill():
+    """Round 4: build() also reads the code objects' metadata and refuses a library whose contraction kernels spill registers (they
+    live at two waves of ~250 VGPRs per SIMD; a packed-fp32 form of the polynomial epilogue once compiled to 54 spills).  On the
+    library as built: every instance of k_svm_screen / k_svm_rbf_h / k_svm_rbf / k_recheck_i8 is there, none spills, all fit 256."""
+    from haf_grasping_amd import build as b
+    if not b.up_to_date():
+        b.build()
+    rep = b.check_no_spills()
+    names = " ".join(rep)
+    for k in ("k_svm_screenILi0", "k_svm_screenILi1", "k_svm_screenILi2", "k_svm_screenILi3", "k_svm_rbf_hILb1ELb0", "k_svm_rbf_hILb1ELb1",
+              "k_svm_rbf_hILb0ELb0", "k_recheck_i8"):
+        assert k in names, (k, sorted(rep))
+    assert all(sp == 0 and 0 < vg <= 256 for vg, sp in rep.values()), rep
 
 
 def test_ros_adapter_translation_unit_parses():
