@@ -982,7 +982,7 @@ int build_tables(haf_engine *e)
                                                                      : std::max(64.0, std::max(e->mfma_kappa, e->mfma_kappa16))) + 14.0) * std::ldexp(1.0, -24);
                     t1.dp_rel = (std::ldexp(1.0, -22) + std::ldexp(1.0, -24)) * 1.01;
                     t1.dp_abs = sp.c * std::sqrt((double)kKP) * std::ldexp(1.0, -25) * 1.01;
-                    t1.sum_rel = (2.0 + 1.0 + 0.1 + 6.0 + 8.0 + 1.0) * std::ldexp(1.0, -24) * (1.0 + 1e-5);
+                    t1.sum_rel = (2.0 + 1.0 + 0.1 + 6.0 + 10.0 + 1.0) * std::ldexp(1.0, -24) * (1.0 + 1e-5);
                     t1.scale = 1.001;
                     if (hipSuccess != e->d_svt_h_cr.alloc(imgh.size()) || hipSuccess != e->d_t1_tab.alloc(tab.size()))
                         return fail(e, HAF_E_DEVICE, "hipMalloc(centred-remainder tier-1 tables)");

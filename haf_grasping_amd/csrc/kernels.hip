@@ -1410,10 +1410,11 @@ __device__ __forceinline__ void screen_finish_cr(double su2, double sd2, double 
     double c_abs = quad1 + quad2 + cub2 + cL;
     double k_psi = ln2 * eps * 1.01;
     if (sp.cr_poly) {
-        // psi(t) = t^2 (1/2 + t/6 + t^2/24 + t^3/120), t = z ln2: the dropped tail is at most 4.1 t^4/360 of psi for |t| <= 1; eight
-        // fp32 roundings per element of the Horner form and the two products
+        // psi(t) = t^2 (1/2 + t/6 + t^2/24 + t^3/120), t = z ln2: the dropped tail is at most 4.1 t^4/360 of psi for |t| <= 1; the fp32
+        // roundings per element -- z^2, the four constants b a_k (folded per block), three Horner steps whose partial sums are at most
+        // 1.95 P(z) for z < 0 -- come to less than 8 u of |b| psi; 10 u charged
         const double t = ln2 * zmax;
-        k_psi += 4.1 * t * t * t * t / 360.0 + 8.0 * 5.97e-8;
+        k_psi += 4.1 * t * t * t * t / 360.0 + 10.0 * 5.97e-8;
         if (!(t <= 1.0)) k_psi = (double)__builtin_inff();
     } else {
         // 2^z by v_exp_f32 (an ulp of 2^z: taken as 2^-22), the constant ln2 in fp32: relative to sum|b_n| 2^z_n <= S_psi + B_abs + ln2 sum|b_n||z_n|

@@ -93,7 +93,7 @@ __device__ __forceinline__ void stage_sv_tile_s0(const TileDma &d, unsigned lane
 // CR_EXP / CR_POLY (round 4, kernels.h: the centred-remainder form): the chains start from 0, the accumulator is z = p^.q^_n and the
 // epilogue accumulates b_n psi(z), psi(z) = 2^z - 1 - z ln2 -- by v_exp_f32, a subtraction and an fma (CR_EXP: three VALU
 // instructions behind the exp, like SUMSQ), or with no transcendental at all as z^2 (a2 + a3 z + a4 z^2 + a5 z^3), a_k = ln2^k / k!
-// (CR_POLY: six VALU instructions per element, for models whose z stay small and whose sum|b| is so large that an ulp of 2^z is
+// (CR_POLY: five VALU instructions per element -- the coefficient is folded into the constants per block --, for models whose z stay small and whose sum|b| is so large that an ulp of 2^z is
 // too much: relative accuracy instead of absolute).
 constexpr float kLn2f = 0.693147180559945f;
 constexpr float kPsiA2 = 0.240226506959101f, kPsiA3 = 0.0555041086648216f, kPsiA4 = 0.00961812910762848f, kPsiA5 = 0.00133335581464284f;
@@ -106,6 +106,9 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);                               // DMA issue and address arithmetic stay in front
     const f32x4 t4 = {t, t, t, t};                                   // rows differ, the column (this lane's SV) is the same
+    // CR_POLY: b psi(z) = z^2 (b a2 + b a3 z + b a4 z^2 + b a5 z^3) -- the coefficient of the PREVIOUS block's column folded into the
+    // four constants once per block (four multiplications per lane) instead of one per element: five VALU instructions per element
+    const float ba2 = CRP ? cf_old * kPsiA2 : 0.0f, ba3 = CRP ? cf_old * kPsiA3 : 0.0f, ba4 = CRP ? cf_old * kPsiA4 : 0.0f, ba5 = CRP ? cf_old * kPsiA5 : 0.0f;
     if (n == 0) b = *reinterpret_cast<const half8 *>(bl);            // B[k = 32s + 8(lane>>4) + j][col 16n + (lane&15)]
     float k0 = 0.0f, k1 = 0.0f;                                      // exp2 of the pair issued in the previous k-step
     // The issue order of every k-step is pinned instruction by instruction (a scheduling barrier after each): B read of the
@@ -130,9 +133,9 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             const float z = old[e0 >> 2][e0 & 3];
             pt0 = z * z;
             HAF_SB();
-            ph0 = fmaf(z, kPsiA5, kPsiA4);
+            ph0 = fmaf(z, ba5, ba4);
             HAF_SB();
-            ph0 = fmaf(ph0, z, kPsiA3);
+            ph0 = fmaf(ph0, z, ba3);
             HAF_SB();
         }
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][1], b, s == 0 ? t4 : acc[1], 0, 0, 0);
@@ -143,9 +146,9 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             const float z = old[e1 >> 2][e1 & 3];
             pt1 = z * z;
             HAF_SB();
-            ph1 = fmaf(z, kPsiA5, kPsiA4);
+            ph1 = fmaf(z, ba5, ba4);
             HAF_SB();
-            ph1 = fmaf(ph1, z, kPsiA3);
+            ph1 = fmaf(ph1, z, ba3);
             HAF_SB();
         }
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][2], b, s == 0 ? t4 : acc[2], 0, 0, 0);
@@ -169,11 +172,9 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             HAF_SB();
         }
         if (ex && CRP) {
-            ph0 = fmaf(ph0, old[e0 >> 2][e0 & 3], kPsiA2);
+            ph0 = fmaf(ph0, old[e0 >> 2][e0 & 3], ba2);
             HAF_SB();
-            const float w = cf_old * pt0;
-            HAF_SB();
-            sum[e0 >> 2][e0 & 3] = fmaf(w, ph0, sum[e0 >> 2][e0 & 3]);
+            sum[e0 >> 2][e0 & 3] = fmaf(pt0, ph0, sum[e0 >> 2][e0 & 3]);
             HAF_SB();
         }
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][3], b, s == 0 ? t4 : acc[3], 0, 0, 0);
@@ -196,11 +197,9 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
             HAF_SB();
         }
         if (ex && CRP) {
-            ph1 = fmaf(ph1, old[e1 >> 2][e1 & 3], kPsiA2);
+            ph1 = fmaf(ph1, old[e1 >> 2][e1 & 3], ba2);
             HAF_SB();
-            const float w = cf_old * pt1;
-            HAF_SB();
-            sum[e1 >> 2][e1 & 3] = fmaf(w, ph1, sum[e1 >> 2][e1 & 3]);
+            sum[e1 >> 2][e1 & 3] = fmaf(pt1, ph1, sum[e1 >> 2][e1 & 3]);
             HAF_SB();
         }
         k0 = q0;
