@@ -18,10 +18,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhafgrasp.so")
 LIB_TESTING = os.path.join(HERE, "libhafgrasp_testing.so")
-SOURCES = ["kernels.hip", "screen.hip", "prob.hip", "exact8.hip", "engine.cpp", "parsers.cpp", "multi.cpp"]
+SOURCES = ["prestages.hip", "features.hip", "contraction.hip", "screen.hip", "recheck.hip", "exact8.hip", "vote.hip", "prob.hip",
+           "engine.cpp", "parsers.cpp", "multi.cpp"]
 # per-file extra flags (screen.hip: see its header)
 EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["kernels.h", "parsers.h", "decq.h", "engine_internal.h", "testkernels.hip", os.path.join("..", "..", "include", "hafgrasp.h"),
+HEADERS = ["kernels.h", "device_common.h", "feature_device.h", "parsers.h", "decq.h", "engine_internal.h", "testkernels.hip", os.path.join("..", "..", "include", "hafgrasp.h"),
            os.path.join("..", "cli", "haf_grasp_cli.cpp"), os.path.join("..", "..", "ros_shim", "shim_core.h")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -196,9 +197,13 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         return obj
 
-    objs = {src: compile_one(src) for src in SOURCES}
-    engine_testing = compile_one("engine.cpp", "_testing", ["-DHAF_TESTING"])
-    test_kernels = compile_one("testkernels.hip")                  # device code of the testing build only
+    # the translation units are independent: compile them side by side (HAF_BUILD_JOBS, default 4 -- a device compile holds ~1 GiB)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(src, "", ()) for src in SOURCES] + [("engine.cpp", "_testing", ("-DHAF_TESTING",)), ("testkernels.hip", "", ())]
+    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("HAF_BUILD_JOBS", "4")))) as pool:
+        done = list(pool.map(lambda j: compile_one(*j), jobs))
+    objs = dict(zip(SOURCES, done[:len(SOURCES)]))
+    engine_testing, test_kernels = done[len(SOURCES)], done[len(SOURCES) + 1]    # testkernels.hip: device code of the testing build only
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"]
     libs = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     # The libraries are linked under temporary names and get their real ones only after the v_exp_f32 check has passed: a build

@@ -21,7 +21,7 @@
 // to IEEE division for every N in [10^3,10^4] U [10^5,10^6] and k in 0..22, tools/divtest.c), and the general SLOW path
 // (loops, true divisions) for everything else.
 //
-// The same source is compiled for the device (kernels.hip) and for the host (engine.cpp -> unit tests).
+// The same source is compiled for the device (features.hip, recheck.hip, prob.hip) and for the host (engine.cpp -> unit tests).
 #pragma once
 
 #include <math.h>
@@ -273,7 +273,7 @@ HAF_HD double decq4_float(float v, const Tabs &tb)
 }
 HAF_HD double decq4_float(float v) { return decq4_float(v, GlobalTabs()); }
 
-// ---- "%.4g" of an fp32 value for the SCREENING pass (kernels.hip: screening features) ----------------------------
+// ---- "%.4g" of an fp32 value for the SCREENING pass (features.hip: screening features) ----------------------------
 // Table-driven and branch-free: the fp32 exponent byte E picks {thr, i0} from a 256-entry table, where thr is the smallest
 // float >= 10^(e0+1) (e0 = floor((E-127) log10 2); floor(log10 |v|) is e0 or e0+1, decided exactly by |v| >= thr) and i0
 // the slot of k = 3 - e0 in a table of {10^k, RN(10^-k)} pairs; the digits are N = rint(|v| 10^k), exact for k <= 12 as in

@@ -3,7 +3,7 @@
 // What stays on the host, and why: the per-roll 4x4 transform and the rotated-rectangle scalars of pnt_in_box
 // (a few dozen fp32 operations per roll that use glibc sinf/cosf/atan2f exactly as the reference does), the
 // sequential cross-roll rule, and the final grasp pose (once per goal).  Everything that scales with points, cells
-// or support vectors runs in kernels.hip.  There is no CPU implementation of those stages in this library.
+// or support vectors runs in the .hip translation units next to this file.  There is no CPU implementation of those stages in this library.
 #include "../../include/hafgrasp.h"
 #include "kernels.h"
 #include "parsers.h"
@@ -256,12 +256,12 @@ struct haf_engine {
     DevBuf<char> d_out;
     char *h_out = nullptr;
     bool counters_clean = false;    // the counters were zeroed behind the previous request's copy-out (off the next request's critical path)
-    DevBuf<float> d_sorted;         // bucket-sorted copy of the clouds (binning of large grids, kernels.hip)
+    DevBuf<float> d_sorted;         // bucket-sorted copy of the clouds (binning of large grids, prestages.hip)
     DevBuf<int> d_bkt;              // 3 x max_clouds x kBktInts bucket counters / offsets / cursors
     int bkt_ints = 0;
     DevBuf<int> d_heights;          // ordered keys during binning, fp32 heights afterwards
     DevBuf<double> d_rowsum;        // integral image: band totals of the parallel form / row sums of the sequential fallback
-    DevBuf<int> d_inexact;          // per (cloud, roll): the parallel integral image was not exact -> sequential order (kernels.hip)
+    DevBuf<int> d_inexact;          // per (cloud, roll): the parallel integral image was not exact -> sequential order (prestages.hip)
     DevBuf<float> d_ii;
     DevBuf<uint8_t> d_mask;
     DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_evalcell, d_flag_list, d_flag2_list;
@@ -608,7 +608,7 @@ int build_tables(haf_engine *e)
         std::vector<FeatDesc> fds_keep;
         double ea2_keep = 0.0;
         {
-            // screening attribute u' = fma(q4, scr_mul, scr_add), scr_add = c*lower - fmin*scr_mul (kernels.hip: screen_attribute).
+            // screening attribute u' = fma(q4, scr_mul, scr_add), scr_add = c*lower - fmin*scr_mul (feature_device.h: screen_attribute).
             // Against c*x' in exact arithmetic it is off by the 2^-52 of q4 = N * RN(10^-k) (|q4| < 1e4, the decimal path's
             // range) amplified by scr_mul, by the rounding of scr_mul times |q4 - fmin|, by the rounding of scr_add (formed in long
             // double: half an ulp of |c*lower| + |fmin*scr_mul| at most) and by the one rounding of the fma; the norm over the
@@ -1517,7 +1517,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
 
 #ifndef HAF_FLUSH_F16_SUBNORMALS
     if (contraction_mode(e->cfg) == MODE_SCREEN) {
-        // the screening operands keep fp16 subnormals (kernels.hip: screen_operand): make sure the matrix core does too
+        // the screening operands keep fp16 subnormals (features.hip: screen_operand): make sure the matrix core does too
         static std::mutex probe_mutex;                // one probe per DEVICE and process, whichever thread gets there first
         static int probed[64];                        // 0: not yet; else result + 2
         int keeps;
@@ -2161,7 +2161,7 @@ static int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *cl
             if (rc != HAF_OK) return rc;
             strict_ran = e->h_counters[CNT_FLAGGED2] > 0;
         } else if (e->h_counters[CNT_FLAGGED2] > 0) {
-            // (the host knows the list's length here: the spread form of the tier, kernels.hip)
+            // (the host knows the list's length here: the spread form of the tier, recheck.hip)
             launch_recheck_known(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p,
                                  std::min(e->h_counters[CNT_FLAGGED2], e->list_cap), e->d_strict_terms.p, kStrictSlots, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();

@@ -1,4 +1,4 @@
-// kernels.h -- device data layout and launch wrappers shared by engine.cpp and kernels.hip.
+// kernels.h -- device data layout and launch wrappers shared by engine.cpp and the kernel translation units (prestages.hip, features.hip, contraction.hip, screen.hip, recheck.hip, exact8.hip, vote.hip, prob.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -138,7 +138,7 @@ struct ScreenParams {
     double cr_qmax, cr_dqmax;     // max_n |q^_n|, max_n |q^_n - q_n|
     double cr_gnorm;              // |g|_2
     double cr_mu_norm, cr_mu_norm_t;   // |mu| in slot space / over all attributes: |u'| <= |p'| + |mu| (the missing "%g" round trip is relative to u')
-    // tier 1 in the centred-remainder form (the three-pass list kernel behind SCREEN_CR_POLY, kernels.hip): the exact-form feature
+    // tier 1 in the centred-remainder form (the three-pass list kernel behind SCREEN_CR_POLY, contraction.hip): the exact-form feature
     // kernel subtracts the centre (raw attribute units) before the hi/lo split and sums L = sum (x_f - m_f) gl_f in fp64
     const double *cr_t1_tab;      // device: [kKP] centre m_f, then [kKP] gl_f = ln2 * 2 gamma' * sum_n b_n (s_nf - m_f);  nullptr: plain form
     double *cr_t1_L;              // device: L per list slot
@@ -164,7 +164,7 @@ enum { SCREEN_PLAIN = 0, SCREEN_SUMSQ = 1, SCREEN_CR_EXP = 2, SCREEN_CR_POLY = 3
 // feature (beyond the feature file, norm slots) is all zero and evaluates to exactly 0.
 struct ScrDesc {
     int    off[8];                // BYTE offsets of the corners of regions 0 and 1 (A-B-C+D each) from the window origin, in
-                                  // the LDS band of a wave (kBandPitch floats per row, kernels.hip: screen_quad)
+                                  // the LDS band of a wave (kBandPitch floats per row, features.hip: screen_quad)
     float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
     double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
     double scr_add;               // c * lower - fmin * scr_mul                   (0 likewise):  u' = fma(q4, scr_mul, scr_add)
@@ -326,7 +326,7 @@ void launch_probability(const double *dec_exact, const int *evalcell, const int 
                         double *ptext, float *gridf, float *evf, RollRecordDev *rec, long evals_cap, Dims d, hipStream_t s);
 
 void launch_fill_i32(int *p, int v, size_t n, hipStream_t s);
-// scratch of the bucket-sorted binning path (large grids): see kernels.hip
+// scratch of the bucket-sorted binning path (large grids): see prestages.hip
 struct BinScratch {
     float *sorted;       // [total points][3] the clouds' points grouped by bucket (original coordinates)
     int *bkt_count;      // [B][nb*nb + 1]
@@ -383,7 +383,7 @@ void launch_recheck(const float *ii, const int *evalcell, const FeatDesc *fd, co
                     ExactParams p, const int *flag_list, int flag_cap, const int *counters, int counter_slot,
                     double *dec_exact, int8_t *labels, Dims d, hipStream_t s);
 // the same tier for a list whose length the host knows: spread over (evaluation groups x SV chunks), terms = scratch of
-// terms_slots x n_sv_pad doubles (kernels.hip)
+// terms_slots x n_sv_pad doubles (recheck.hip)
 void launch_recheck_known(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, const double *coef64,
                           ExactParams p, const int *flag_list, int n_flag, double *terms, int terms_slots,
                           double *dec_exact, int8_t *labels, Dims d, hipStream_t s);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         float val, err;
         if (CR) {
             // centred-remainder form: dec^ = A^ (B0 + L + R^) - rho in fp64 (B0 + L cancels against rho), R^ = the two class sums of
-            // b psi(z^), S_psi^ = their difference; band {L, c_abs, k_psi, cm} from screen_finish_cr (kernels.hip)
+            // b psi(z^), S_psi^ = their difference; band {L, c_abs, k_psi, cm} from screen_finish_cr (features.hip)
             const double T = (crp.B0 + (double)g.x) + ((double)Ps + (double)Ns);
             const double dvd = (double)sc * T - crp.rho;
             val = (float)dvd;

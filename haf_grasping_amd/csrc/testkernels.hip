@@ -7,6 +7,7 @@
 // runs the chain exactly as k_svm_screen does (same builtin, same operand layout, C operand of the first instruction = start
 // value) on data the host chose, and returns the raw accumulators; the host compares with an fp64 evaluation.
 #include "kernels.h"
+#include "decq.h"
 
 namespace haf {
 
@@ -271,6 +272,34 @@ void launch_f16_mfma_probe(const void *a, const void *b, const float *c, float *
 void launch_i8_layout_probe(const void *a, const void *b, int *c, hipStream_t s)
 {
     hipLaunchKernelGGL(k_i8_layout_probe, dim3(1), dim3(64), 0, s, (const signed char *)a, (const signed char *)b, c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device-side checks of the decimal round-trip arithmetic (tests/test_engine_gpu.py)
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_decq_test(const double *__restrict__ in, double *__restrict__ out, int n, int P)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (P == 40) ? hafq::decq4_float((float)in[i]) : hafq::decq(in[i], P);   // 40: the fp32 "%.4g" entry
+}
+void launch_decq_test(const double *in, double *out, int n, int P, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decq_test, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, P);
+}
+
+__global__ void k_scale_test(const double *__restrict__ q4, const double *__restrict__ fmin, const double *__restrict__ fmax,
+                             double lower, double upper, double *__restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double range = fmax[i] - fmin[i];
+        out[i] = hafq::scale_q6(q4[i], fmin[i], fmax[i], range, 1.0 / range, lower, upper);
+    }
+}
+void launch_scale_test(const double *q4, const double *fmin, const double *fmax, double lower, double upper, double *out,
+                       int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scale_test, dim3((n + 255) / 256), dim3(256), 0, s, q4, fmin, fmax, lower, upper, out, n);
 }
 
 }  // namespace haf

@@ -481,7 +481,8 @@ def test_host_paths_under_address_and_ub_sanitizers(golden_dir, tmp_path):
     if not os.path.exists(clang):
         pytest.skip("no ROCm clang")
     csrc = os.path.join(ROOT, "haf_grasping_amd", "csrc")
-    objs = [os.path.join(csrc, o) for o in ("kernels.o", "screen.o", "prob.o", "exact8.o", "multi.o", "testkernels.o")]
+    from haf_grasping_amd import build as B
+    objs = [os.path.join(csrc, os.path.splitext(src)[0] + ".o") for src in B.SOURCES + ["testkernels.hip"] if src not in ("engine.cpp", "parsers.cpp")]
     if not all(os.path.exists(o) for o in objs):
         from haf_grasping_amd import build as b
         b.build(force=True)

@@ -1,4 +1,4 @@
-# Timing experiments on the three-pass list kernel k_svm_rbf_h<true> (kernels.hip: HAF_ABL): what does its time hang on?
+# Timing experiments on the three-pass list kernel k_svm_rbf_h<true> (contraction.hip: HAF_ABL): what does its time hang on?
 #   here (no GPU):   bash tools/ablate_h.sh build      -> haf_grasping_amd/abl/libhafgrasp_testing_abl{0..4}.so, then restores the real build
 #   on the GPU box:  bash tools/ablate_h.sh run [seed] -> per-variant kernel times (rocprofv3 --kernel-trace --stats)
 # Variants: 0 as shipped; 1 without the VALU adds of sweep 2; 2 without the sixteen v_exp_f32; 3 without sweep 1 (80 of 132 MFMAs);
