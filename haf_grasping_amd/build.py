@@ -1,7 +1,7 @@
 """Builds the gfx950 libraries with hipcc, in-tree, so the .so files travel to the GPU box.
 
   libhafgrasp.so           the product: C-ABI of include/hafgrasp.h, nothing else exported for tests or experiments
-  libhafgrasp_testing.so   the same objects + engine.cpp compiled with -DHAF_TESTING: haf_test_* hooks and the
+  libhafgrasp_testing.so   the same kernels + the engine*.cpp units compiled with -DHAF_TESTING (+ engine_testing.cpp): haf_test_* hooks and the
                            environment switches that scale the guard bands (tests/ only)
   haf_grasp_cli            ROS-free command line front end (C++ over the C-ABI)
 
@@ -18,11 +18,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhafgrasp.so")
 LIB_TESTING = os.path.join(HERE, "libhafgrasp_testing.so")
-SOURCES = ["prestages.hip", "features.hip", "contraction.hip", "screen.hip", "recheck.hip", "exact8.hip", "vote.hip", "prob.hip",
-           "engine.cpp", "parsers.cpp", "multi.cpp"]
+# the engine's host side: every one of these is compiled twice, without and with -DHAF_TESTING (csrc/engine_state.h: test_env)
+ENGINE_SOURCES = ["engine.cpp", "engine_tables.cpp", "engine_request.cpp", "engine_geometry.cpp", "engine_debug.cpp"]
+TESTING_ONLY = ["engine_testing.cpp", "testkernels.hip"]         # libhafgrasp_testing.so only
+SOURCES = ["prestages.hip", "features.hip", "contraction.hip", "screen.hip", "recheck.hip", "exact8.hip", "vote.hip", "prob.hip"] + \
+          ENGINE_SOURCES + ["parsers.cpp", "multi.cpp"]
 # per-file extra flags (screen.hip: see its header)
 EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["kernels.h", "device_common.h", "feature_device.h", "parsers.h", "decq.h", "engine_internal.h", "testkernels.hip", os.path.join("..", "..", "include", "hafgrasp.h"),
+HEADERS = ["kernels.h", "device_common.h", "feature_device.h", "parsers.h", "decq.h", "engine_internal.h", "engine_state.h"] + TESTING_ONLY + [ os.path.join("..", "..", "include", "hafgrasp.h"),
            os.path.join("..", "cli", "haf_grasp_cli.cpp"), os.path.join("..", "..", "ros_shim", "shim_core.h")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -199,11 +202,11 @@ def build(force=False, verbose=False):
 
     # the translation units are independent: compile them side by side (HAF_BUILD_JOBS, default 4 -- a device compile holds ~1 GiB)
     from concurrent.futures import ThreadPoolExecutor
-    jobs = [(src, "", ()) for src in SOURCES] + [("engine.cpp", "_testing", ("-DHAF_TESTING",)), ("testkernels.hip", "", ())]
+    jobs = [(src, "", ()) for src in SOURCES] + [(src, "_testing", ("-DHAF_TESTING",)) for src in ENGINE_SOURCES + TESTING_ONLY]
     with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("HAF_BUILD_JOBS", "4")))) as pool:
         done = list(pool.map(lambda j: compile_one(*j), jobs))
     objs = dict(zip(SOURCES, done[:len(SOURCES)]))
-    engine_testing, test_kernels = done[len(SOURCES)], done[len(SOURCES) + 1]    # testkernels.hip: device code of the testing build only
+    testing_objs = dict(zip(ENGINE_SOURCES + TESTING_ONLY, done[len(SOURCES):]))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"]
     libs = ["-L" + os.path.join(ROCM, "lib"), "-lrccl", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     # The libraries are linked under temporary names and get their real ones only after the v_exp_f32 check has passed: a build
@@ -211,9 +214,13 @@ def build(force=False, verbose=False):
     # mistake it for an up-to-date one.
     staged = []
     try:
-        for out, eng in ((LIB, objs["engine.cpp"]), (LIB_TESTING, engine_testing)):
+        for out in (LIB, LIB_TESTING):
             tmp = out + ".unchecked"
-            cmd = link + [eng if s == "engine.cpp" else objs[s] for s in SOURCES] + ([test_kernels] if out == LIB_TESTING else []) + libs + ["-o", tmp]
+            if out == LIB:
+                members = [objs[s] for s in SOURCES]
+            else:
+                members = [testing_objs.get(s, objs[s]) for s in SOURCES] + [testing_objs[s] for s in TESTING_ONLY]
+            cmd = link + members + libs + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -70,7 +70,7 @@ TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EV
 
 def make_engine(data_dir, model, mode=0, **cfg):
     """The product library, unless a test has set one of the guard-band / kernel-choice switches: those exist in the
-    testing build only (same kernels, same objects; engine.cpp compiled with -DHAF_TESTING)."""
+    testing build only (same kernels; the engine's host units compiled with -DHAF_TESTING)."""
     f, r = _files(data_dir)
     cfg.setdefault("flags", capi.FLAG_KEEP_DEBUG | capi.FLAG_PROFILE)
     cfg["flags"] |= mode

@@ -472,7 +472,7 @@ def test_hostile_files_return_errors_not_exceptions(data_dir, golden_dir, tmp_pa
 
 
 def test_host_paths_under_address_and_ub_sanitizers(golden_dir, tmp_path):
-    """CPU sanitizer job (GPU sanitizers are not available on the pool): engine.cpp + parsers.cpp built with
+    """CPU sanitizer job (GPU sanitizers are not available on the pool): the engine's host translation units + parsers.cpp built with
     -fsanitize=address,undefined by the ROCm clang (host only) and driven over the parsers with truncated / bit-flipped
     files, the roll geometry, the cross-roll rule and the poses (tests/sanitize/host_paths.cpp).  Any report fails."""
     import shutil
@@ -482,15 +482,16 @@ def test_host_paths_under_address_and_ub_sanitizers(golden_dir, tmp_path):
         pytest.skip("no ROCm clang")
     csrc = os.path.join(ROOT, "haf_grasping_amd", "csrc")
     from haf_grasping_amd import build as B
-    objs = [os.path.join(csrc, os.path.splitext(src)[0] + ".o") for src in B.SOURCES + ["testkernels.hip"] if src not in ("engine.cpp", "parsers.cpp")]
+    host = B.ENGINE_SOURCES + ["engine_testing.cpp", "parsers.cpp"]           # compiled here, instrumented
+    objs = [os.path.join(csrc, os.path.splitext(src)[0] + ".o") for src in B.SOURCES if src not in host] + \
+           [os.path.join(csrc, "testkernels_testing.o")]
     if not all(os.path.exists(o) for o in objs):
         from haf_grasping_amd import build as b
         b.build(force=True)
     exe = str(tmp_path / "host_paths")
     flags = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
              "-fno-omit-frame-pointer", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-DHAF_TESTING", "-I/opt/rocm/include"]
-    cmd = [clang] + flags + [os.path.join(csrc, "engine.cpp"), os.path.join(csrc, "parsers.cpp"),
-                             os.path.join(ROOT, "tests", "sanitize", "host_paths.cpp"), "-x", "none"] + objs + \
+    cmd = [clang] + flags + [os.path.join(csrc, f) for f in host] + [os.path.join(ROOT, "tests", "sanitize", "host_paths.cpp"), "-x", "none"] + objs + \
           ["-fsanitize=address,undefined", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     scratch = tmp_path / "fuzz"
