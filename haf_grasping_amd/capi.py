@@ -152,6 +152,7 @@ def _bind(path, testing):
         L.haf_test_mfma_kappa.argtypes = [E, C.c_void_p, C.c_void_p]
         L.haf_test_f16_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.haf_test_screen_state.argtypes = [E, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.haf_test_set_screen_inactive.argtypes = [E]
     return L
 
 
@@ -390,6 +391,10 @@ class Engine:
         v, a, sh = C.c_int(), C.c_int(), (C.c_double * 4)()
         self._check(self._L.haf_test_screen_state(self._h, C.byref(v), C.byref(a), sh))
         return dict(variant=v.value & 15, tier0b=bool(v.value & 16), tier1_skipped=bool(v.value & 32), active=bool(a.value), shares=list(sh))
+
+    def set_screen_inactive(self):
+        """TESTING build: switches the screening pass off as the adaptive rule does after a request every form failed on."""
+        self._check(self._L.haf_test_set_screen_inactive(self._h))
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._L.haf_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

@@ -315,6 +315,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         test_env("HAF_HOST_EXP_ALL") || test_env("HAF_NO_I8") || test_env("HAF_GUARD_I8_REL"))
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
+    if (const char *v = test_env("HAF_REPROBE_EVERY")) e->reprobe_every = std::max(1, atoi(v));
     if (const char *v = test_env("HAF_SCREEN_VARIANT")) { e->screen_variant = std::max(0, std::min(SCREEN_VARIANTS - 1, atoi(v))); e->variant_forced = true; e->direct_work = 0; }
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);

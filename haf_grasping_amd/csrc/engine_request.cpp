@@ -360,6 +360,9 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                 // centred support vectors; band, common factor and images indexed by list slot)
                 ScreenParams sp_b = e->screen_cr;
                 sp_b.cr_poly = 0;
+                // (the group-parallel feature kernel even for lists of 10^5: one evaluation per lane on SCATTERED cells -- k_features_serial in
+                // list mode -- was measured at 7.7 ns per evaluation against 2.1 ns, its 2 400 corner loads per lane being 64 separate
+                // L1 accesses each)
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_gband.p, d, e->range.lower,
                                 e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SCREEN, sp_b, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
                                 false, list_cap, nullptr, e->d_ax.p, s);
@@ -529,7 +532,17 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
         return HAF_OK;
     };
     int mode = contraction_mode(c);
-    if (mode == MODE_SCREEN && !e->screen_active) mode = MODE_SPLIT;
+    bool reprobe = false;
+    if (mode == MODE_SCREEN && !e->screen_active) {
+        // (the switch-off used to be for the engine's lifetime) every reprobe_every-th request that is large enough to judge by
+        // runs the screening pass again; it costs that request one wasted pass at worst
+        if (!e->variant_forced && !e->prob_mode && !direct && evals_sel >= 4096 && ++e->inactive_calls >= e->reprobe_every) {
+            e->inactive_calls = 0;
+            reprobe = true;
+        } else {
+            mode = MODE_SPLIT;
+        }
+    }
     int rc = e->prob_mode ? decide_probability() : decide(mode, false);
     if (rc != HAF_OK) return rc;
     if (e->h_counters[CNT_ERROR] != 0 && !e->no_bucket_sort) {
@@ -568,6 +581,10 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));
             rc = decide(MODE_SPLIT, false);
             if (rc != HAF_OK) return rc;
+        } else if (reprobe) {
+            const double share = ne > 0 ? (double)undecided() / (double)ne : 1.0;
+            e->variant_share[e->screen_variant] = share;
+            if (ne >= 256 && share <= 0.6) e->screen_active = true;
         } else if (ne >= 256 && !e->variant_forced && !e->variant_settled) {
             // Adaptive rule on real requests (an engine that was not calibrated, or whose calibration scene misjudged the model): a form
             // that leaves more than a quarter undecided makes room for the next untried one; when all have been seen the engine

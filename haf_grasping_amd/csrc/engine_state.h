@@ -104,8 +104,12 @@ struct haf_engine {
     int list_cap = 0;
     int flag_cap = 0;
     int flag0_cap = 0;      // screening pass: evaluations that go on to the three-pass kernel
-    bool screen_active = true;   // default mode only: cleared (for good) once more than 60 % of a call's evaluations fell inside
-                                 // the screening band even with the measured |w|_2 -- for such a model the single pass is wasted work
+    bool screen_active = true;   // default mode only: cleared once more than 60 % of a call's evaluations fell inside the band of every
+                                 // form of the screening pass -- for such a model the single pass is wasted work.  Not for good: every
+                                 // reprobe_every-th full-size request afterwards tries the pass again (the judgement may have come from
+                                 // the synthetic calibration scene or from one unusual cloud) and switches it back on when it pays
+    int inactive_calls = 0;      // full-size requests served without the screening pass since it was switched off / last re-tried
+    int reprobe_every = 64;      // (testing build: HAF_REPROBE_EVERY)
     // which form of the screening pass serves this model (kernels.h: SCREEN_*): chosen at creation (calibrate()) and re-chosen
     // by the adaptive rule when a call leaves too much undecided.  PLAIN: |w|_2 through its bound; SUMSQ: |w|_2 measured
     // (ill-conditioned models: large coefficients whose kernel values are small); CR_EXP / CR_POLY: the centred-remainder

@@ -218,6 +218,16 @@ int haf_test_screen_state(haf_engine *e, int *variant, int *active, double *shar
     return HAF_OK;
 }
 
+// switches the screening pass off as the adaptive rule would after a request that every form of the pass failed on (tests of the
+// periodic re-try)
+int haf_test_set_screen_inactive(haf_engine *e)
+{
+    if (!e) return HAF_E_ARG;
+    e->screen_active = false;
+    e->inactive_calls = 0;
+    return HAF_OK;
+}
+
 // the engine's matrix-core rounding constant: what the probe measured and what the bands use
 int haf_test_mfma_kappa(haf_engine *e, double *measured, double *used)      // [0]: 16x16x32, [1]: 16x16x16
 {

@@ -65,7 +65,7 @@ DEC_REL_SCREEN = 2.0 ** -8
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
-              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL")
+              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -766,6 +766,36 @@ def test_second_screening_pass_and_tier_1_hand_over(data_dir, tmp_path, monkeypa
     ref = STATS["tier0b_counts"].get("pcd3/t0b0/skip0")
     if t0b and ref:
         assert STATS["tier0b_counts"]["pcd3/t0b1/skip%d" % skip]["n_refined"] < ref["n_refined"]
+
+
+def test_screening_pass_switched_off_is_tried_again(data_dir, tmp_path, monkeypatch):
+    """the adaptive rule's switch-off of the screening pass used to last for the engine's lifetime.  Now every
+    reprobe_every-th full-size request (64; HAF_REPROBE_EVERY=3 here) runs the pass again and switches it back on when it leaves at
+    most 60 % undecided.  The switch-off is injected (testing hook) on a model the pass serves well: two requests run in the three-pass
+    mode, the third re-tries and re-enables; every request's stages and labels are the oracle's."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    monkeypatch.setenv("HAF_REPROBE_EVERY", "3")
+    f, r = _files(data_dir)
+    path = str(tmp_path / "rand900.model")
+    models.write_random_model(path, 900, seed=11, balanced=True)
+    o = O.Oracle(f, r, path)
+    eng = make_engine(data_dir, path)
+    assert eng.screen_state()["active"]
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table2_mult_obj_rcs_1428580941635676.pcd"))
+    cfg, inp = dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56)
+    compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+    screened = eng.last_counts()
+    eng.set_screen_inactive()
+    seen = []
+    for _ in range(4):
+        compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+        seen.append((eng.screen_state()["active"], eng.last_counts()["n_refined"]))
+    # requests 1, 2: three passes for everything (nothing is "refined" behind a screening pass); request 3 re-tries and re-enables;
+    # request 4 is served like the one before the switch-off
+    assert [a for a, _ in seen] == [False, False, True, True], seen
+    assert seen[3][1] == screened["n_refined"] and seen[2][1] == screened["n_refined"], (seen, screened)
+    assert eng.screen_form() != "off"
+    eng.close()
 
 
 def test_a_worse_matrix_core_widens_the_bands_and_a_far_worse_one_is_refused(data_dir, surrogate, orc, monkeypatch, tmp_path):
