@@ -14,6 +14,9 @@ DATA = os.path.join(GOLDEN, "data")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the checker's one parallel region (rows of a roll are independent: oracle/haf_oracle.c, HAFO_THREADS; per-row arithmetic and
+    # order untouched) on a few cores: the decision stage of the 4096- and 8964-SV parity cases is most of the suite's wall time
+    os.environ.setdefault("HAFO_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2))))
     # The product library and the checker are built in-tree; build them when the suite runs on a fresh checkout
     # (hipcc cross-compiles gfx950 without a GPU, ~15 s).  Nothing here falls back to another implementation.
     from haf_grasping_amd import build as _b
