@@ -73,7 +73,7 @@ void haf_destroy(haf_engine *e)
     e->d_sv_i8.release(); e->d_flagi_list.release(); e->d_dec_exacti.release();
     e->d_coef64.release(); e->d_ev16.release(); e->d_attr.release(); e->d_margin.release(); e->d_topkey.release(); e->d_rowmax.release(); e->d_fd.release();
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
-    e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release(); e->d_flag0b_list.release();
+    e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release(); e->d_flag0b_list.release(); e->d_screen_part.release();
     e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
@@ -316,6 +316,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     if (const char *v = test_env("HAF_REPROBE_EVERY")) e->reprobe_every = std::max(1, atoi(v));
+    if (const char *v = test_env("HAF_SCREEN_PARTS")) e->screen_parts = std::max(0, atoi(v));
     if (const char *v = test_env("HAF_SCREEN_VARIANT")) { e->screen_variant = std::max(0, std::min(SCREEN_VARIANTS - 1, atoi(v))); e->variant_forced = true; e->direct_work = 0; }
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);

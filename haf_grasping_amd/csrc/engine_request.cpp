@@ -349,7 +349,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             const bool straight = small_exact || (e->t1_skip && !t0b);
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, cr ? e->d_svt0_cr.p : e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,
-                              e->screen_variant, e->crp, s, straight ? CNT_FLAGGED : -1);
+                              e->screen_variant, e->crp, s, straight ? CNT_FLAGGED : -1, nullptr, CNT_EVALS, CNT_FLAGGED0, e->d_screen_part.p, e->screen_parts);
             mark(e, HAF_ST_REFINE);
             const long list_cap = std::min<long>(e->flag0_cap, evals_cap);
             const int *t1_list = e->d_flag0_list.p;
@@ -369,7 +369,8 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                 const bool skip1 = e->t1_skip;
                 launch_svm_screen(e->d_X1.p, e->d_gband.p, e->d_ax.p, e->d_svt0_cr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                                   e->d_flag0_words.p, e->d_flag0_wgcount.p, skip1 ? e->d_flag_list.p : e->d_flag0b_list.p, e->flag0_cap, e->d_counters.p, d,
-                                  list_cap, e->d_margin.p, SCREEN_CR_EXP, e->crp, s, skip1 ? CNT_FLAGGED : -1, e->d_flag0_list.p, CNT_FLAGGED0, CNT_FLAGGED0B);
+                                  list_cap, e->d_margin.p, SCREEN_CR_EXP, e->crp, s, skip1 ? CNT_FLAGGED : -1, e->d_flag0_list.p, CNT_FLAGGED0, CNT_FLAGGED0B,
+                                  e->d_screen_part.p, e->screen_parts);
                 t1_list = e->d_flag0b_list.p;
                 t1_counter = CNT_FLAGGED0B;
                 t1_run = !skip1;

@@ -124,6 +124,9 @@ struct haf_engine {
     // 76 u of sum|x s| -- and decides little of what a centred-remainder pass could not: measured at calibration)
     bool use_t0b = false, t1_skip = false;
     DevBuf<int> d_flag0b_list;
+    // partial class sums of the screening kernel's PART form (requests that do not fill the chip are split over SV ranges: screen.hip)
+    DevBuf<char> d_screen_part;
+    int screen_parts = 0;        // 0: by the live evaluation count; testing build (HAF_SCREEN_PARTS): 1 = never, n = forced
     double variant_share[SCREEN_VARIANTS] = {-1.0, -1.0, -1.0, -1.0};   // undecided share of each variant on the calibration scene (-1: not tried)
     ScreenParams screen{};
     ScreenParams screen_cr{};    // the centred-remainder form's constants and descriptor tables

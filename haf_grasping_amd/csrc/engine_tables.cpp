@@ -824,6 +824,7 @@ int alloc_buffers(haf_engine *e)
         ok &= hipSuccess == e->d_gband.alloc((size_t)e->max_evals_pad * kBandFloats);
         ok &= hipSuccess == e->d_flag0_list.alloc((size_t)e->flag0_cap);
         if (e->cr_available) ok &= hipSuccess == e->d_flag0b_list.alloc((size_t)e->flag0_cap);
+        ok &= hipSuccess == e->d_screen_part.alloc(screen_part_bytes());
         ok &= hipSuccess == e->d_flag0_words.alloc((size_t)e->max_evals_pad / 64);
         ok &= hipSuccess == e->d_flag0_wgcount.alloc((size_t)e->max_evals_pad / 64 / 256 + 1);
     } else {

@@ -366,7 +366,9 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,
                        int also_counter = -1,    // >= 0: the compacted list's length is published in this counter too (capped at flag0_cap)
                        const int *idx_list = nullptr, int count_slot = CNT_EVALS,   // list mode: slot j of X0 / gband / nax holds evaluation idx_list[j], counters[count_slot] of them
-                       int out_slot = CNT_FLAGGED0);                               // the counter that receives the length of the compacted list
+                       int out_slot = CNT_FLAGGED0,
+                       void *part_buf = nullptr, int parts = 0);   // SV-range split of requests that do not fill the chip (screen.hip: PART form): a buffer of screen_part_bytes(); parts 0 = by the live count, 1 = never, n = forced (tests)
+size_t screen_part_bytes();                               // the counter that receives the length of the compacted list
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s);

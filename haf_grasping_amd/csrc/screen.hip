@@ -211,7 +211,84 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
     __builtin_amdgcn_sched_barrier(0);                               // nothing crosses from one column block into the next
 }
 
-template <int VAR>
+// The decision tail of one evaluation (slot e of the operand images / bands): the two class sums (and the sum of squares) -> decision
+// value, band, label; returns "undecided".  COMBINED: the sums are fp64 sums of k_svm_screen<., PART>'s partial sums (k_screen_combine).
+template <int VAR, bool COMBINED>
+__device__ __forceinline__ bool screen_tail(double Psd, double Nsd, float qs, long e, const float *__restrict__ gband, const float *__restrict__ nax,
+                                            const SvmParams &p, const CrParams &crp, const int *__restrict__ idx_list,
+                                            const int *__restrict__ evalcell, float *__restrict__ dec, int8_t *__restrict__ labels,
+                                            float *__restrict__ margin)
+{
+    constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CR = VAR == SCREEN_CR_EXP || VAR == SCREEN_CR_POLY;
+    const float Ps = (float)Psd, Ns = (float)Nsd;
+    {
+        // the common factor 2^(-|u|^2/2) of every term of both sums (its v_exp_f32 is consumed many instructions later:
+        // the LDS reads and their wait sit in between)
+        float sc = __builtin_amdgcn_exp2f(nax[e]);
+        const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
+        const float4 g2 = *reinterpret_cast<const float4 *>(gband + kBandFloats * e + 4);
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
+        float val, err;
+        if (CR) {
+            // centred-remainder form: dec^ = A^ (B0 + L + R^) - rho in fp64 (B0 + L cancels against rho), R^ = the two class sums of
+            // b psi(z^), S_psi^ = their difference; band {L, c_abs, k_psi, cm} from screen_finish_cr (features.hip)
+            const double T = (crp.B0 + (double)g.x) + (Psd + Nsd);
+            const double dvd = (double)sc * T - crp.rho;
+            val = (float)dvd;
+            const float spsi = COMBINED ? (float)(Psd - Nsd) * 1.0000003f : Ps - Ns;   // sum |b| psi, raw (before the common factor)
+            // fp32 class sums: two-level, as in the plain variant (guard_acc0); the casts of this tail: 3 u of the terms
+            const float raw = g.y + (p.guard_acc0 * 1.04f + g.z) * spsi + 1.8e-7f * (fabsf(g.x) + fabsf(Ps) + fabsf(Ns));
+            err = (raw * sc * 1.002f + (g.w + 2.4e-7f) * (fabsf(val) + fabsf((float)crp.rho))) * 1.002f + p.guard_abs;
+        } else {
+        const float P = Ps * sc, N = Ns * sc;
+        const float dv = (P + N) - p.rho;
+        const float sabs = P - N;                                   // sum |coef| K
+        // {gA, gB, gC, cm} (screen_finish): linear term through the spectral norms (~sqrt(S)) or per SV (~S), whichever is
+        // smaller; S-proportional terms; the common factor on (|dec^| + |rho|)
+        const float adv = fabsf(dv);
+        // |w|_2 of w_n = coef_n K_n: measured (SUMSQ; the common factor enters squared) or bounded by sqrt(max|coef| * S)
+        const float w2 = SUMSQ ? sqrtf(qs) * sc : p.sqrt_cmax * sqrtf(sabs);
+        const float lin = fminf(g.x * w2, g.z * sabs);
+        const float gacc = SUMSQ ? p.guard_acc0_s : p.guard_acc0;   // single- / two-level coefficient sum
+        // (COMBINED: the partial class sums were added in fp64 and rounded to fp32 once more: one more unit of S)
+        const float sterm = (gacc * 1.04f + g.y + (COMBINED ? 1.2e-7f : 0.0f)) * sabs;
+        const float err1 = (lin + sterm + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
+        // the centred estimate (kernels.h): the first-order error of the evaluation-independent part of w is subtracted, the rest
+        // of the bilinear term is the absolute bound g2.y; the two fp32 operations here go with the common factor's term
+        const float corr = g2.x * sc;
+        const float dvc = dv - corr;
+        const float err2 = (g2.y * sc + sterm + (g.w + 2.4e-7f) * (fabsf(dvc) + fabsf(corr) + fabsf(p.rho))) * 1.002f + p.guard_abs;
+        const bool centred = err2 < err1;                           // decide from the estimate with the narrower band
+        val = centred ? dvc : dv;
+        err = centred ? err2 : err1;
+        }
+        const long eid = idx_list ? (long)idx_list[e] : e;          // the evaluation this slot holds
+        dec[eid] = val;
+        labels[evalcell[eid]] = (int8_t)(val > 0.0f ? p.gv0 : p.gv1);
+        const bool flagged = !(fabsf(val) > err);                   // also catches NaN
+        if (margin) margin[eid] = flagged ? 0.0f : fabsf(val) / err;  // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
+        return flagged;
+    }
+}
+
+// number of SV ranges a request of n_evals evaluations is split over (PART form of k_svm_screen, below): as many as it takes to put
+// ~512 workgroups on the chip, at most kS0MaxParts, and never more than either coefficient group has tiles
+constexpr int kS0MaxParts = 16;
+constexpr int kS0PartBlocks = 256;                                   // requests of up to this many workgroups take the PART form
+__device__ __forceinline__ int screen_parts(int n_evals, const Dims &d, int forced)
+{
+    const int blocks = (n_evals + kS0BlockEvals - 1) / kS0BlockEvals;
+    int k = forced > 0 ? forced : (blocks > 0 ? 512 / blocks : 1);
+    k = min(k, kS0MaxParts);
+    k = min(k, min(d.sv_tile_neg, d.n_sv_tiles - d.sv_tile_neg));
+    return max(k, 1);
+}
+
+// PART = true (round 4: requests that do not fill the chip -- up to 65 536 evaluations, e.g. C3 against a model of thousands of SVs):
+// the grid is (workgroups, kS0MaxParts); workgroup (x, k) sweeps the k-th slice of the non-negative tiles and the k-th slice of the
+// negative ones (K = screen_parts(), from the LIVE evaluation count: no host round trip) and writes its two class sums (and the sum
+// of squares) to part_out[k][evaluation]; k_screen_combine adds the K partial sums in fp64 and runs the same decision tail.
+template <int VAR, bool PART>
 __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__restrict__ X0, const float *__restrict__ gband,
                                                                const float *__restrict__ nax,
                                                                const char *__restrict__ svt0,
@@ -220,11 +297,12 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
                                                                float *__restrict__ dec, int8_t *__restrict__ labels,
                                                                unsigned long long *__restrict__ flag0_words, Dims d,
                                                                float *__restrict__ margin, CrParams crp,
-                                                               const int *__restrict__ idx_list, int count_slot)
+                                                               const int *__restrict__ idx_list, int count_slot,
+                                                               float4 *__restrict__ part_out, int forced_parts)
 {
     // LIST mode (idx_list != nullptr; round 4, "tier 0b"): the operand images, bands and common factors are indexed by list slot
     // (the feature kernel's list mode wrote them), slot j holds evaluation idx_list[j], counters[count_slot] says how many
-    constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CRE = VAR == SCREEN_CR_EXP, CRP = VAR == SCREEN_CR_POLY, CR = CRE || CRP;
+    constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CRE = VAR == SCREEN_CR_EXP, CRP = VAR == SCREEN_CR_POLY;
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
     __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
     const int n_evals = counters[count_slot];
@@ -233,7 +311,18 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long tile32 = (base >> 5) + 2 * wave;                      // this wave's two 32-eval operand images
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
-    const int nt = d.n_sv_tiles;
+    // the tiles this workgroup sweeps: ring positions 0..nt-1 hold tiles tile_of(0..nt-1), the first np of them non-negative
+    int np = d.sv_tile_neg, nt = d.n_sv_tiles, p0 = 0, n0 = d.sv_tile_neg;
+    if (PART) {
+        const int K = screen_parts(n_evals, d, forced_parts), k = blockIdx.y;
+        if (k >= K) return;
+        const int nn = d.n_sv_tiles - d.sv_tile_neg;
+        p0 = d.sv_tile_neg * k / K;
+        np = d.sv_tile_neg * (k + 1) / K - p0;
+        n0 = d.sv_tile_neg + nn * k / K;
+        nt = np + (d.sv_tile_neg + nn * (k + 1) / K - n0);
+    }
+    auto tile_of = [&](int i) { return PART ? (i < np ? p0 + i : n0 + (i - np)) : i; };
     float *pos = reinterpret_cast<float *>(lds + kS0Buffers * kS0SvTileBytes) + wave * kS0WaveEvals;
     float *fin = pos + kS0Waves * kS0WaveEvals;
     float *qrow = fin + kS0Waves * kS0WaveEvals;                     // SUMSQ: sum of (coef K)^2 over both sweeps
@@ -244,11 +333,15 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
 #pragma unroll
     for (int q = 0; q < kS0WavePieces; q++) poff[q] = (wave_u + kS0Waves * q) * 1024;    // pieces 0..19, each exactly once
     static_assert(kS0Waves * kS0WavePieces * 1024 == kS0MatBytes && kS0MatBytes + 1024 == kS0SvTileBytes, "20 image pieces + 1 tail piece");
-    stage_sv_tile_s0(tile_dma(svt0, lds0, poff), lane16);                                                      // tile 0
-    if (wave_u == 0) dma_piece(svt0 + kS0MatBytes, lds0 + kS0MatBytes, lane16);
+    {
+        const char *g0 = svt0 + (size_t)tile_of(0) * kS0SvTileBytes;
+        stage_sv_tile_s0(tile_dma(g0, lds0, poff), lane16);                                                    // tile 0
+        if (wave_u == 0) dma_piece(g0 + kS0MatBytes, lds0 + kS0MatBytes, lane16);
+    }
     if (nt > 1) {                                                                                              // tile 1
-        stage_sv_tile_s0(tile_dma(svt0 + (size_t)kS0SvTileBytes, lds0 + kS0SvTileBytes, poff), lane16);
-        if (wave_u == 0) dma_piece(svt0 + (size_t)kS0SvTileBytes + kS0MatBytes, lds0 + kS0SvTileBytes + kS0MatBytes, lane16);
+        const char *g1 = svt0 + (size_t)tile_of(1) * kS0SvTileBytes;
+        stage_sv_tile_s0(tile_dma(g1, lds0 + kS0SvTileBytes, poff), lane16);
+        if (wave_u == 0) dma_piece(g1 + kS0MatBytes, lds0 + kS0SvTileBytes + kS0MatBytes, lane16);
     }
 
     // A fragments: row block m = 0..3 (rows 16m..16m+15 of the wave's 64); lane holds A[16m + (lane&15)][32s + 8(lane>>4) + j]
@@ -287,7 +380,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     // P = sum_{coef>0} coef*K and the second N = sum_{coef<0} coef*K; dec = P + N - rho and the guard scale
     // sum|coef|K = P - N come from the same registers.  The DMA ring runs on across the two sweeps.
     for (int ph = 0; ph < 2; ph++) {
-        const int t_end = ph ? nt : d.sv_tile_neg;
+        const int t_end = ph ? nt : np;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             acc1[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -296,11 +389,11 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
         }
         int fold = 0;
         float cf_prev = 0.0f;                                        // the first deferred epilogue adds 0 * exp2(0)
-        for (int t = ph ? d.sv_tile_neg : 0; t < t_end; t++) {
+        for (int t = ph ? np : 0; t < t_end; t++) {
             const char *cur = lds + (t % kS0Buffers) * kS0SvTileBytes;
             // always the same DMA pieces per wave and tile, so the wait below is one constant per wave: past the last tile the
             // ring slot that nobody reads any more is refilled with tile (t+2) mod nt
-            const int tn = (t + 2) % nt;
+            const int tn = tile_of((t + 2) % nt);
             const TileDma dma = tile_dma(svt0 + (size_t)tn * kS0SvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kS0SvTileBytes, poff);
             // wave 0: the tail piece of that tile, here -- in front of the MFMA stream, where a branch does no harm
             if (wave_u == 0) dma_piece(svt0 + (size_t)tn * kS0SvTileBytes + kS0MatBytes,
@@ -382,60 +475,50 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
     __syncthreads();
     // one evaluation per lane from here: coalesced stores, one flag word per wave
     const long e = base + wave * kS0WaveEvals + lane;
+    if (PART) {                                                      // partial sums of this slice; the tail runs in k_screen_combine
+        part_out[(size_t)blockIdx.y * ((size_t)gridDim.x * kS0BlockEvals) + e] = float4{pos[lane], fin[lane], SUMSQ ? qrow[lane] : 0.0f, 0.0f};
+        return;
+    }
     const bool live = e < n_evals;
     bool flagged = false;
-    if (live) {
-        // the common factor 2^(-|u|^2/2) of every term of both sums (its v_exp_f32 is consumed many instructions later:
-        // the LDS reads and their wait sit in between)
-        float sc = __builtin_amdgcn_exp2f(nax[e]);
-        const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
-        const float4 g2 = *reinterpret_cast<const float4 *>(gband + kBandFloats * e + 4);
-        const float Ps = pos[lane], Ns = fin[lane];
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
-        float val, err;
-        if (CR) {
-            // centred-remainder form: dec^ = A^ (B0 + L + R^) - rho in fp64 (B0 + L cancels against rho), R^ = the two class sums of
-            // b psi(z^), S_psi^ = their difference; band {L, c_abs, k_psi, cm} from screen_finish_cr (features.hip)
-            const double T = (crp.B0 + (double)g.x) + ((double)Ps + (double)Ns);
-            const double dvd = (double)sc * T - crp.rho;
-            val = (float)dvd;
-            const float spsi = Ps - Ns;                             // sum |b| psi, raw (before the common factor)
-            // fp32 class sums: two-level, as in the plain variant (guard_acc0); the casts of this tail: 3 u of the terms
-            const float raw = g.y + (p.guard_acc0 * 1.04f + g.z) * spsi + 1.8e-7f * (fabsf(g.x) + fabsf(Ps) + fabsf(Ns));
-            err = (raw * sc * 1.002f + (g.w + 2.4e-7f) * (fabsf(val) + fabsf((float)crp.rho))) * 1.002f + p.guard_abs;
-        } else {
-        const float P = Ps * sc, N = Ns * sc;
-        const float dv = (P + N) - p.rho;
-        const float sabs = P - N;                                   // sum |coef| K
-        // {gA, gB, gC, cm} (screen_finish): linear term through the spectral norms (~sqrt(S)) or per SV (~S), whichever is
-        // smaller; S-proportional terms; the common factor on (|dec^| + |rho|)
-        const float adv = fabsf(dv);
-        // |w|_2 of w_n = coef_n K_n: measured (SUMSQ; the common factor enters squared) or bounded by sqrt(max|coef| * S)
-        const float w2 = SUMSQ ? sqrtf(qrow[lane]) * sc : p.sqrt_cmax * sqrtf(sabs);
-        const float lin = fminf(g.x * w2, g.z * sabs);
-        const float gacc = SUMSQ ? p.guard_acc0_s : p.guard_acc0;   // single- / two-level coefficient sum
-        const float sterm = (gacc * 1.04f + g.y) * sabs;
-        const float err1 = (lin + sterm + g.w * (adv + fabsf(p.rho))) * 1.002f + p.guard_abs;
-        // the centred estimate (kernels.h): the first-order error of the evaluation-independent part of w is subtracted, the rest
-        // of the bilinear term is the absolute bound g2.y; the two fp32 operations here go with the common factor's term
-        const float corr = g2.x * sc;
-        const float dvc = dv - corr;
-        const float err2 = (g2.y * sc + sterm + (g.w + 2.4e-7f) * (fabsf(dvc) + fabsf(corr) + fabsf(p.rho))) * 1.002f + p.guard_abs;
-        const bool centred = err2 < err1;                           // decide from the estimate with the narrower band
-        val = centred ? dvc : dv;
-        err = centred ? err2 : err1;
-        }
-        const long eid = idx_list ? (long)idx_list[e] : e;          // the evaluation this slot holds
-        dec[eid] = val;
-        labels[evalcell[eid]] = (int8_t)(val > 0.0f ? p.gv0 : p.gv1);
-        flagged = !(fabsf(val) > err);                              // also catches NaN
-        if (margin) margin[eid] = flagged ? 0.0f : fabsf(val) / err;  // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
-    }
+    if (live) flagged = screen_tail<VAR, false>((double)pos[lane], (double)fin[lane], SUMSQ ? qrow[lane] : 0.0f, e, gband, nax, p, crp, idx_list,
+                                                evalcell, dec, labels, margin);
     // one 64-bit word per wave (64 consecutive evaluations): k_screen_compact turns the words into the ORDERED list of
     // undecided evaluations -- neighbours in the list are neighbours on the grid, so the feature kernel that follows reads
     // overlapping windows, and the list (hence every later tile) is the same from run to run
     const unsigned long long bal = __ballot(flagged);
     if (lane == 0) flag0_words[(base >> 6) + wave] = bal;
+}
+
+// The K partial sums of k_svm_screen<VAR, true> -> decision, band, label, flag words: one evaluation per thread, workgroups of 256 like
+// the tail of the unsplit kernel (same flag-word layout).  The partial sums are added in fp64, in the order of the slices.
+template <int VAR>
+__global__ __launch_bounds__(kS0BlockEvals) void k_screen_combine(const float4 *__restrict__ part_out, const float *__restrict__ gband,
+                                                                  const float *__restrict__ nax, const int *__restrict__ evalcell,
+                                                                  const int *__restrict__ counters, SvmParams p, float *__restrict__ dec,
+                                                                  int8_t *__restrict__ labels, unsigned long long *__restrict__ flag0_words,
+                                                                  Dims d, float *__restrict__ margin, CrParams crp,
+                                                                  const int *__restrict__ idx_list, int count_slot, int forced_parts)
+{
+    const int n_evals = counters[count_slot];
+    const long base = (long)blockIdx.x * kS0BlockEvals;
+    if (base >= n_evals) return;
+    const long e = base + threadIdx.x;
+    const int K = screen_parts(n_evals, d, forced_parts);
+    const size_t stride = (size_t)gridDim.x * kS0BlockEvals;
+    bool flagged = false;
+    if (e < n_evals) {
+        double Ps = 0.0, Ns = 0.0, qs = 0.0;
+        for (int k = 0; k < K; k++) {
+            const float4 v = part_out[(size_t)k * stride + e];
+            Ps += (double)v.x;
+            Ns += (double)v.y;
+            qs += (double)v.z;
+        }
+        flagged = screen_tail<VAR, true>(Ps, Ns, (float)qs, e, gband, nax, p, crp, idx_list, evalcell, dec, labels, margin);
+    }
+    const unsigned long long bal = __ballot(flagged);
+    if ((threadIdx.x & 63) == 0) flag0_words[(base >> 6) + (threadIdx.x >> 6)] = bal;
 }
 
 // Ordered compaction of the screening pass's flag words in two small launches: k_screen_count sums the popcounts of
@@ -699,13 +782,25 @@ double probe_mfma_rounding(hipStream_t s, double *worst16)
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,
-                       int also_counter, const int *idx_list, int count_slot, int out_slot)
+                       int also_counter, const int *idx_list, int count_slot, int out_slot, void *part_buf, int parts)
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
+    // parts: 0 = the engine's rule (requests of up to kS0PartBlocks workgroups are split over SV ranges, as many as the live count asks
+    // for), 1 = never, > 1 = that many (tests); the buffer holds kS0MaxParts x kS0PartBlocks x 256 partial sums (screen_part_bytes())
+    const bool split = part_buf && parts != 1 && blocks <= kS0PartBlocks;
 #define HAF_SCREEN_LAUNCH(V)                                                                                                      \
-    hipLaunchKernelGGL(k_svm_screen<V>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,          \
-                       (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot)
+    if (split) {                                                                                                                  \
+        hipLaunchKernelGGL((k_svm_screen<V, true>), dim3((unsigned)blocks, kS0MaxParts), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax, \
+                           (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot,      \
+                           (float4 *)part_buf, parts);                                                                            \
+        hipLaunchKernelGGL(k_screen_combine<V>, dim3((unsigned)blocks), dim3(kS0BlockEvals), 0, s, (const float4 *)part_buf, gband, nax,   \
+                           evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot, parts);           \
+    } else {                                                                                                                      \
+        hipLaunchKernelGGL((k_svm_screen<V, false>), dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,     \
+                           (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot,      \
+                           (float4 *)nullptr, 0);                                                                                 \
+    }
     switch (variant) {
         case SCREEN_SUMSQ: HAF_SCREEN_LAUNCH(SCREEN_SUMSQ); break;
         case SCREEN_CR_EXP: HAF_SCREEN_LAUNCH(SCREEN_CR_EXP); break;
@@ -719,5 +814,7 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
                        counters_rw, also_counter, idx_list, count_slot, out_slot);
 }
+
+size_t screen_part_bytes() { return (size_t)kS0MaxParts * kS0PartBlocks * kS0BlockEvals * sizeof(float4); }
 
 }  // namespace haf

@@ -65,7 +65,7 @@ DEC_REL_SCREEN = 2.0 ** -8
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
-              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY")
+              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -732,6 +732,45 @@ def test_every_form_of_the_screening_pass_gives_the_oracles_labels(data_dir, sur
     assert refined[("surrogate", 2)] < 0.4 < refined[("surrogate", 0)]
     assert refined[("trained", "auto")][0] == 3 and refined[("trained", 3)] < 0.2 and min(refined[("trained", v)] for v in (0, 1, 2)) > 0.95
     assert refined[("random", 2)] <= refined[("random", 0)] + 0.01
+
+
+def test_sv_range_split_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
+    """Round 4: a request that does not fill the chip (up to 65 536 evaluations: every reference-sized request against a model of
+    thousands of SVs) is split over SV ranges -- workgroup (x, k) of k_svm_screen<., PART> sweeps the k-th slice of either coefficient
+    group, k_screen_combine adds the partial class sums in fp64 and runs the same decision tail; the number of slices follows the
+    LIVE evaluation count on the device.  Pinned here (HAF_SCREEN_PARTS: 1 = never, 2, 16; unset = the engine's rule) for all four
+    forms of the pass and for its list mode (tier 0b): every stage and label the oracle's, and the bands the same up to the one extra
+    rounding of the combined sums (the undecided counts agree within 2 %)."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    f, r = _files(data_dir)
+    rnd = str(tmp_path / "rand900.model")
+    models.write_random_model(rnd, 900, seed=11, balanced=True)
+    clu = str(tmp_path / "clustered700.model")
+    models.write_clustered_model(clu, 700, seed=5)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table2_mult_obj_rcs_1428580941635676.pcd"))
+    cfg, inp = dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56)
+    counts = {}
+    for model, forms in ((rnd, (0, 1, 2)), (clu, (2, 3))):
+        o = O.Oracle(f, r, model)
+        for v in forms:
+            monkeypatch.setenv("HAF_SCREEN_VARIANT", str(v))
+            monkeypatch.setenv("HAF_T0B", "1" if v == 0 else "0")          # (plain form: the list mode behind it as well)
+            for parts in ("1", "2", "16", None):
+                if parts is None:
+                    monkeypatch.delenv("HAF_SCREEN_PARTS", raising=False)
+                else:
+                    monkeypatch.setenv("HAF_SCREEN_PARTS", parts)
+                eng = make_engine(data_dir, model, testing=True)
+                assert eng.screen_state()["variant"] == v
+                compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+                c = eng.last_counts()
+                counts[(os.path.basename(model), v, parts or "auto")] = c["n_refined"]
+                assert c["n_refined"] < c["n_evals"] and (c["n_refined"] > 0 or v == 3), (model, v, parts, c)
+                eng.close()
+            base = counts[(os.path.basename(model), v, "1")]
+            for parts in ("2", "16", "auto"):
+                assert abs(counts[(os.path.basename(model), v, parts)] - base) <= 0.02 * base + 2, (model, v, parts, counts)
+    STATS["sv_range_split_refined"] = {"%s/form%d/parts-%s" % k: n for k, n in counts.items()}
 
 
 @pytest.mark.parametrize("t0b,skip", [(0, 0), (1, 0), (1, 1), (0, 1)])

@@ -1,0 +1,22 @@
+import os, sys, time, tempfile
+import numpy as np
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import models
+from haf_grasping_amd import capi
+G = os.path.join(ROOT, "tests", "golden"); D = os.path.join(G, "data")
+tmp = tempfile.mkdtemp()
+tr = os.path.join(tmp, "trained.model"); models.unpack_trained_model(os.path.join(G, "trained.model.npz"), tr)
+rnd = os.path.join(tmp, "rand4096.model"); models.write_random_model(rnd, 4096, seed=42, balanced=True)
+xyz = capi.load_pcd(os.path.join(D, "table1_mult_obj_rcs_1428580506606673.pcd"))
+inp = capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0))
+for name, m in (("trained", tr), ("rand4096", rnd)):
+    for flags in (capi.FLAG_PROFILE, 0):
+        eng = capi.Engine(os.path.join(D, "Features.txt"), os.path.join(D, "range21062012_allfeatures"), m, flags=flags, max_points=1 << 18, n_rolls=20, roll_step_deg=9)
+        for _ in range(3): out = eng.score(xyz, inp)
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter(); out = eng.score(xyz, inp); ts.append(time.perf_counter() - t0)
+        print(name, "profile" if flags else "plain", "median %.3f ms" % (1e3 * np.median(ts)), eng.screen_form(), eng.last_tiers() if hasattr(eng, "last_tiers") else "", flush=True)
+        if flags: print("   ", {k: round(v, 3) for k, v in eng.stage_ms().items()})
+        eng.close()
