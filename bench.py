@@ -267,7 +267,7 @@ def reference_tools_baseline(o, O, rng_file, model_path, xyz, args):
                        "%d evals; features+text %.2f s, svm-scale %.2f s, svm-predict %.2f s" % (c, c, args.nsv, n, t_feat, t_scale, t_pred))
 
 
-def latency_small(feat, rng_file, device, flags, trained_model=None):
+def latency_small(feat, rng_file, device, flags, trained_model=None, headline_model=None):
     """BASELINE configs C2 (pcd2.pcd, 32x32 cm area, 12 rolls) and C3 (table1_mult_obj, 56x56 cm, 20 rolls of 9 degrees), surrogate
     model, host-resident cloud: wall time of one haf_score call including the PCIe copies -- the second half of the metric."""
     from haf_grasping_amd import capi
@@ -309,6 +309,13 @@ def latency_small(feat, rng_file, device, flags, trained_model=None):
                                "(tests/golden/trained.model.npz), host cloud (PCIe included)", "table1_mult_obj_rcs_1428580506606673.pcd",
                                capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)),
                                model=trained_model, n_rolls=20, roll_step_deg=9)
+    if headline_model is not None:
+        # ... and against the headline's random model (median seed, nSV = 4096): a reference-sized request with a model of thousands of
+        # SVs does not fill the chip -- the screening pass and the three-pass tier are cut into SV ranges by the live counts (round 4)
+        c2["c3_headline_model"] = one("C3 request (table1_mult_obj %d pts, 56x56 cm, 20 rolls x 9 deg) against the headline's random model "
+                                      "(median seed, nSV=4096), host cloud (PCIe included)", "table1_mult_obj_rcs_1428580506606673.pcd",
+                                      capi.default_input(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)),
+                                      model=headline_model, n_rolls=20, roll_step_deg=9)
     # C4: the eight pcd files as ONE batched call (haf_score_batch), 20 rolls of 9 degrees each: what a server that collects goals pays per cloud
     clouds = [capi.load_pcd(os.path.join(data, "pcd%d.pcd" % i)) for i in range(1, 9)]
     inputs = [capi.default_input() for _ in clouds]
@@ -644,7 +651,8 @@ def main():
                 if not os.path.exists(tr_lat):
                     models.unpack_trained_model(os.path.join(ROOT, "tests", "golden", "trained.model.npz"), tr_lat)
             line["grasp_latency"] = latency_small(feat, rng_file, local_rank,
-                                               {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision], tr_lat)
+                                               {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision], tr_lat,
+                                               model_path if args.nsv >= 1024 else None)
         line["ranks"] = {"world_size": world, "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                          ("bench.py (self-spawned ranks)" if world > 1 else "single process"),
                          "per_rank_ms_per_step": [q[0] for q in med["per_rank"]] if med["per_rank"] else [1e3 * elapsed / args.steps],

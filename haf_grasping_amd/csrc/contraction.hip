@@ -213,6 +213,19 @@ __device__ __forceinline__ f32x4 h_fma4s(float s, f32x4 v, f32x4 c)        // fm
 // -gamma'|s|^2), the epilogue accumulates b psi(z), z = 2 gamma' (x - m).(s - m), psi(z) = z^2 (a2 + a3 z + a4 z^2 + a5 z^3) -- no
 // transcendental, relative accuracy -- and k_svm_h_combine_cr forms dec = 2^(a_x) (B0 + L + P + N) - rho with its band.
 constexpr float kPsiA2h = 0.240226506959101f, kPsiA3h = 0.0555041086648216f, kPsiA4h = 0.00961812910762848f, kPsiA5h = 0.00133335581464284f;
+// List mode: the number of SV tile ranges a list of n evaluations is cut into.  gridDim.y = kHListParts for the long lists of a
+// bench-sized request; a request that cannot fill the chip anyway (the host launches gridDim.y = kHListPartsShort then) takes as many
+// ranges as put ~512 workgroups on the chip -- from the LIVE length, on the device.  More than kHListParts ranges use a quarter of the
+// part buffer's stride (the buffer holds 2 x kHListParts x part_stride sums): only for lists that a quarter stride holds.
+constexpr int kHListPartsShort = 16;
+__device__ __forceinline__ int h_list_parts(int n_evals, int max_parts, long part_stride)
+{
+    if (max_parts <= kHListParts || n_evals > part_stride / (kHListPartsShort / kHListParts)) return min(max_parts, kHListParts);
+    const int blocks = (n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
+    return min(max_parts, max(kHListParts, blocks > 0 ? 512 / blocks : max_parts));
+}
+__device__ __forceinline__ long h_list_stride(long part_stride, int parts) { return parts > kHListParts ? part_stride / (kHListPartsShort / kHListParts) : part_stride; }
+
 template <bool PRECISE, bool CRP = false>
 __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__restrict__ X, const float *__restrict__ ax,
                                                               const char *__restrict__ svt,
@@ -236,8 +249,11 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
     // part_out (list mode): the SV tiles are cut into gridDim.y ranges and workgroup (x, y) sums range y only; its two class
     // sums go to part_out and k_svm_h_combine finishes the evaluation.  A list of 150 k evaluations is 589 workgroups for
     // 512 slots: whole sweeps would run as two rounds with the second one 15 % full, quarter sweeps pack the slots.
-    const int t0 = part_out ? (int)((long)d.n_sv_tiles * blockIdx.y / gridDim.y) : 0;
-    const int nt = part_out ? (int)((long)d.n_sv_tiles * (blockIdx.y + 1) / gridDim.y) : d.n_sv_tiles;
+    const int n_parts = part_out ? h_list_parts(n_evals, (int)gridDim.y, part_stride) : 1;
+    if ((int)blockIdx.y >= n_parts) return;
+    part_stride = h_list_stride(part_stride, n_parts);
+    const int t0 = part_out ? (int)((long)d.n_sv_tiles * blockIdx.y / n_parts) : 0;
+    const int nt = part_out ? (int)((long)d.n_sv_tiles * (blockIdx.y + 1) / n_parts) : d.n_sv_tiles;
     float *axs = reinterpret_cast<float *>(lds + kHBuffers * kHSvTileBytes) + wave * kTile;
     double *pos = reinterpret_cast<double *>(lds + kHBuffers * kHSvTileBytes + 8 * kTile * 4) + wave * kTile;
 
@@ -585,6 +601,8 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const double *__restrict_
                                                        int list_counter, int list_cap)
 {
     const int n_evals = min(counters[list_counter], list_cap);
+    parts = h_list_parts(n_evals, parts, part_stride);
+    part_stride = h_list_stride(part_stride, parts);
     for (long es = (long)blockIdx.x * 256 + threadIdx.x; es < n_evals; es += (long)gridDim.x * 256) {
         double P = 0.0, N = 0.0;                        // the ranges are added in fp64 like the sums inside them
         for (int y = 0; y < parts; y++) {
@@ -614,6 +632,8 @@ __global__ __launch_bounds__(256) void k_svm_h_combine_cr(const double *__restri
                                                           const int *__restrict__ idx_list, int list_counter, int list_cap)
 {
     const int n_evals = min(counters[list_counter], list_cap);
+    parts = h_list_parts(n_evals, parts, part_stride);
+    part_stride = h_list_stride(part_stride, parts);
     const double ln2 = 0.69314718056, u24 = 5.9604644775390625e-08;
     for (long es = (long)blockIdx.x * 256 + threadIdx.x; es < n_evals; es += (long)gridDim.x * 256) {
         double P = 0.0, N = 0.0;
@@ -665,8 +685,12 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
+    // SV tile ranges of the list mode: kHListParts for long lists; for a request that cannot fill the chip (at most 256 workgroups even
+    // if everything were listed) up to kHListPartsShort, settled on the device from the live length (h_list_parts)
+    const bool short_req = blocks <= 256 && d.n_sv_tiles >= 2 * kHListPartsShort;
+    const int list_parts = d.n_sv_tiles >= 4 * kHListParts ? (short_req ? kHListPartsShort : kHListParts) : 1;
     if (idx_list && cr && part_out) {
-        const int parts = (d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;
+        const int parts = list_parts;
         hipLaunchKernelGGL((k_svm_rbf_h<true, true>), dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
                            (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
                            list_counter, list_cap, part_out, part_stride);
@@ -675,7 +699,7 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
         return;
     }
     if (idx_list) {
-        const int parts = (part_out && d.n_sv_tiles >= 4 * kHListParts) ? kHListParts : 1;     // engine.cpp: guard_acc_l follows this rule
+        const int parts = part_out ? list_parts : 1;     // engine.cpp: guard_acc_l follows this rule
         double *po = parts > 1 ? part_out : nullptr;
         hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
                            (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,

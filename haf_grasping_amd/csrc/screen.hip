@@ -275,11 +275,13 @@ __device__ __forceinline__ bool screen_tail(double Psd, double Nsd, float qs, lo
 // ~512 workgroups on the chip, at most kS0MaxParts, and never more than either coefficient group has tiles
 constexpr int kS0MaxParts = 16;
 constexpr int kS0PartBlocks = 256;                                   // requests of up to this many workgroups take the PART form
+constexpr int kS0MinPartTiles = 8;                                   // ... if the model has at least four times this many SV tiles (1024 SVs)
 __device__ __forceinline__ int screen_parts(int n_evals, const Dims &d, int forced)
 {
     const int blocks = (n_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     int k = forced > 0 ? forced : (blocks > 0 ? 512 / blocks : 1);
     k = min(k, kS0MaxParts);
+    if (forced <= 0) k = min(k, d.n_sv_tiles / kS0MinPartTiles);       // a slice worth a workgroup's prologue (A fragments, ring start)
     k = min(k, min(d.sv_tile_neg, d.n_sv_tiles - d.sv_tile_neg));
     return max(k, 1);
 }
@@ -788,7 +790,7 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
     if (blocks <= 0) return;
     // parts: 0 = the engine's rule (requests of up to kS0PartBlocks workgroups are split over SV ranges, as many as the live count asks
     // for), 1 = never, > 1 = that many (tests); the buffer holds kS0MaxParts x kS0PartBlocks x 256 partial sums (screen_part_bytes())
-    const bool split = part_buf && parts != 1 && blocks <= kS0PartBlocks;
+    const bool split = part_buf && parts != 1 && blocks <= kS0PartBlocks && (parts > 1 || d.n_sv_tiles >= 4 * kS0MinPartTiles);
 #define HAF_SCREEN_LAUNCH(V)                                                                                                      \
     if (split) {                                                                                                                  \
         hipLaunchKernelGGL((k_svm_screen<V, true>), dim3((unsigned)blocks, kS0MaxParts), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax, \

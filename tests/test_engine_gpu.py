@@ -743,10 +743,10 @@ def test_sv_range_split_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
     rounding of the combined sums (the undecided counts agree within 2 %)."""
     monkeypatch.setenv("HAF_NO_DIRECT", "1")
     f, r = _files(data_dir)
-    rnd = str(tmp_path / "rand900.model")
-    models.write_random_model(rnd, 900, seed=11, balanced=True)
-    clu = str(tmp_path / "clustered700.model")
-    models.write_clustered_model(clu, 700, seed=5)
+    rnd = str(tmp_path / "rand1200.model")                    # (38 SV tiles: the engine's own rule splits from 32 tiles on)
+    models.write_random_model(rnd, 1200, seed=3, balanced=True)
+    clu = str(tmp_path / "clustered1100.model")
+    models.write_clustered_model(clu, 1100, seed=5)
     xyz = pcdio.load_pcd(os.path.join(data_dir, "table2_mult_obj_rcs_1428580941635676.pcd"))
     cfg, inp = dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56)
     counts = {}
@@ -771,6 +771,20 @@ def test_sv_range_split_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
             for parts in ("2", "16", "auto"):
                 assert abs(counts[(os.path.basename(model), v, parts)] - base) <= 0.02 * base + 2, (model, v, parts, counts)
     STATS["sv_range_split_refined"] = {"%s/form%d/parts-%s" % k: n for k, n in counts.items()}
+    # the three-pass tier's list mode cuts short lists into up to sixteen SV ranges as well (models of >= 1024 SVs: h_list_parts)
+    big = rnd
+    o = O.Oracle(f, r, big)
+    monkeypatch.setenv("HAF_SCREEN_VARIANT", "0")
+    monkeypatch.setenv("HAF_T0B", "0")
+    monkeypatch.setenv("HAF_T1_SKIP", "0")
+    monkeypatch.delenv("HAF_SCREEN_PARTS", raising=False)
+    eng = make_engine(data_dir, big, testing=True)
+    for name, cf, ip in (("pcd3", dict(n_rolls=12), dict(grasp_area_length_x=32, grasp_area_length_y=44)),
+                         ("table2_mult_obj_rcs_1428580941635676", cfg, inp)):
+        compare_full(eng, o, pcdio.load_pcd(os.path.join(data_dir, name + ".pcd")), cf, ip, check_dec=False)
+        c = eng.last_counts()
+        assert 0 < c["n_rechecked"] < c["n_refined"] < c["n_evals"], c
+    eng.close()
 
 
 @pytest.mark.parametrize("t0b,skip", [(0, 0), (1, 0), (1, 1), (0, 1)])
