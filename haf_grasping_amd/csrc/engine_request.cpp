@@ -319,6 +319,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
     // features -> decision tiers -> vote -> records on the host, for one contraction mode
     bool i8_used = false;                                    // the exact-integer tier ran in the last decide()
     bool t0b_used = false;                                   // tier 0b ran in the last decide()
+    bool lr_used = false;                                    // the screening pass of the last decide() ran in the low-rank form
     auto decide = [&](int mode, bool reuse_operands) -> int {
         t0b_used = false;
         mark(e, HAF_ST_FEATURES);
@@ -336,17 +337,32 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             const bool cr = e->screen_variant == SCREEN_CR_EXP || e->screen_variant == SCREEN_CR_POLY;
             ScreenParams sp_now = cr ? e->screen_cr : e->screen;
             sp_now.cr_poly = e->screen_variant == SCREEN_CR_POLY;
+            // Low-rank form of the centred-remainder pass (kernels.h: kLrK): whole requests large enough for the thread-per-evaluation
+            // feature kernel on grids that went through the parallel integral image (whose pass records negative heights), when the
+            // centred-remainder form serves the model; the 10-step images go through k_project, the sweep runs on 6-step images.
+            const bool lr = cr && large && e->lr_available && e->lr_enabled && !fused_pre && (long)H * W > 8192 && !reuse_operands;
+            lr_used = lr;
+            if (lr) { sp_now.lr = 1; sp_now.lr_negflags = e->d_inexact.p; }
             if (!reuse_operands)
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
                                 e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, sp_now, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
+            char *y_img = reinterpret_cast<char *>(e->d_X.p) + (size_t)(e->max_evals_pad / kTile) * (size_t)kS0MatBytes;   // behind the 10-step images (the buffer holds the 42 KiB three-pass form)
             mark(e, HAF_ST_SVM);
+            if (lr) launch_project(e->d_X.p, e->d_lr_btiles.p, y_img, e->d_gband.p, e->d_counters.p, evals_cap, s);   // (counted with the sweep it feeds)
             // A small request with a small model (small_exact): what the screening pass leaves goes STRAIGHT to the one-launch exact kernel
             // (k_small_direct in list mode: exact attributes + fp64 MFMA decision, 9 ns per listed evaluation at 192 SVs) -- the list
             // is written where that kernel reads it.  Tier 1 in between was a feature kernel and a contraction launch at their latency
             // floors (C3: 44 + 36 us for 4 072 evaluations, of which it decided nine tenths) in front of the same exact kernel.
             // The same hand-over when calibration found tier 1 of little use behind the screening passes (t1_skip).
-            const bool t0b = e->use_t0b && e->cr_available && !cr && !small_exact;
+            // (behind the low-rank pass the full-rank centred-remainder form runs once more on its list: the waves it cannot bound --
+            // the borders of the grid, waves that are not a run of neighbours -- and what its slightly wider band leaves)
+            const bool t0b = e->use_t0b && e->cr_available && !small_exact && (!cr || (lr && e->screen_variant == SCREEN_CR_EXP));
             const bool straight = small_exact || (e->t1_skip && !t0b);
+            if (lr)
+                launch_svm_screen_lr(y_img, e->d_gband.p, e->d_ax.p, e->d_svt_lr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                                     e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d,
+                                     evals_cap, e->d_margin.p, e->screen_variant, e->crp, e->lr_band, s, straight ? CNT_FLAGGED : -1);
+            else
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, cr ? e->d_svt0_cr.p : e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,
                               e->screen_variant, e->crp, s, straight ? CNT_FLAGGED : -1, nullptr, CNT_EVALS, CNT_FLAGGED0, e->d_screen_part.p, e->screen_parts);
@@ -620,6 +636,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
     e->last_evals = e->h_counters[CNT_EVALS];
     e->last_flagged = e->prob_mode ? 0 : e->h_counters[CNT_FLAGGED];      // (probability mode: the counter holds the estimates the host finished)
     e->last_flagged2 = e->h_counters[CNT_FLAGGED2];
+    e->last_lr = lr_used;
     e->last_flagged0 = t0b_used ? std::min(e->h_counters[CNT_FLAGGED0B], e->h_counters[CNT_FLAGGED0]) : e->h_counters[CNT_FLAGGED0];   // what leaves the screening passes
     e->last_flaggedi = i8_used ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
     e->last_inexact = inexact_grids;

@@ -163,6 +163,16 @@ struct haf_engine {
     DevBuf<char> d_svt_h;            // split-fp16 SV tile images
     DevBuf<char> d_svt0;             // screening-pass SV tile images
     DevBuf<char> d_svt0_cr;          // the same for the centred-remainder form: fp16(w_n - mu), t_n = 0, coefficient b_n
+    // low-rank form of the centred-remainder pass (kernels.h: kLrK; large requests only): projection tiles (rows of B^'), 6-step SV
+    // tile images of q~_n, the band's constants, per (cloud, roll) "a height is negative" flags (prestages.hip)
+    bool lr_available = false;
+    bool lr_enabled = true;          // testing build: HAF_NO_LR switches it off; HAF_LR_ALWAYS lifts the request-size rule
+    bool lr_always = false;
+    int lr_rank = 0;                 // dimension of the HAF slots' linear span (158 for the reference's Features.txt)
+    DevBuf<char> d_lr_btiles, d_svt_lr;
+    DevBuf<int> d_negflags;
+    LrBand lr_band{};
+    bool last_lr = false;            // the last request's screening pass ran in the low-rank form
     DevBuf<FeatDesc> d_fd_slot_cr;
     DevBuf<ScrDesc> d_sd_cr;
     DevBuf<ScrDesc3> d_sd3_cr;

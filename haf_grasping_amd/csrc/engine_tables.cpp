@@ -258,6 +258,9 @@ int build_tables(haf_engine *e)
                     }
                     sdesc.scr_mul = d.scr_mul; sdesc.scr_add = d.scr_add;
                     sdesc.extra = (float)extra[(size_t)sl];
+                    // low-rank form: |scr_mul| rounded up for a slot that is a linear functional of the window (HAF), 0 for a SHAF slot
+                    const float mul_up = d.shaf ? 0.0f : std::nextafterf((float)std::fabs(d.scr_mul), INFINITY);
+                    sdesc.pad = mul_up;
                     ScrDesc3 &s3 = sd3[(size_t)sl];
                     for (int k = 0; k < 3; k++) {
                         s3.w[k] = d.w[k];
@@ -266,8 +269,10 @@ int build_tables(haf_engine *e)
                     s3.shaf = d.shaf;
                     s3.scr_mul = d.scr_mul; s3.scr_add = d.scr_add;
                     s3.extra = (float)extra[(size_t)sl];
+                    s3.pad[0] = mul_up;
                     fds[(size_t)sl] = d;
                     fds[(size_t)sl].scr_extra = (float)extra[(size_t)sl];
+                    fds[(size_t)sl].pad2 = mul_up;
                     if (extra[(size_t)sl]) sp.extra_groups |= 1ull << g;
                 }
                 if (fast) sp.fast_groups |= 1ull << g;
@@ -427,6 +432,85 @@ int build_tables(haf_engine *e)
                 if (wsum > 0.0) for (int sl = 0; sl < S; sl++) mu[(size_t)sl] = acc[(size_t)sl] / (wsum * mult[(size_t)sl]);
                 if (test_env("HAF_CR_NO_CENTRE")) std::fill(mu.begin(), mu.end(), 0.0);
             }
+            // ---- low-rank form (kernels.h: kLrK): an orthonormal basis B of the span of the HAF slots' linear functionals ----
+            // Slot sl (HAF) is u'_sl = scr_mul_sl * feature_sl + scr_add_sl with feature_sl = sum_k w_k (A - B - C + D)_k a LINEAR functional of
+            // the 225 window corners up to the "%.4g" round trip and fp32 roundings: the columns of Ms (slots x 225) span what the exactly
+            // linear part of the operand can move in.  Modified Gram-Schmidt with pivoting and re-orthogonalisation in long double; the
+            // SHAF slots (not linear: fv.cpp:187-191) get identity columns.  The centre mu is then moved INTO the affine subspace
+            // {scr_add + range(Ms)} (any centre gives the same decision function), so that the centred linear part lies in range(B).
+            const int KL = kLrK;
+            std::vector<double> Bm((size_t)kS0K * KL, 0.0);                  // B, row-major [slot][k]
+            int lr_cols = 0, lr_rank = 0;
+            double lr_rho = 0.0;
+            bool lr_basis = false;
+            if (!test_env("HAF_NO_LR") && !test_env("HAF_CR_NO_CENTRE")) {
+                std::vector<int> lin((size_t)kS0K, 0), pass((size_t)kS0K, 0);
+                std::vector<long double> Ms((size_t)225 * kS0K, 0.0L);         // column j of the map = Ms[j * kS0K ...]
+                static const long double sgn[4] = {1.0L, -1.0L, -1.0L, 1.0L};
+                for (int sl = 0; sl < S; sl++) {
+                    const FeatDesc &d0 = fds_keep[(size_t)sl];
+                    if (d0.skip || d0.scr_mul == 0.0) continue;
+                    if (d0.shaf) { pass[(size_t)sl] = 1; continue; }
+                    lin[(size_t)sl] = 1;
+                    for (int k = 0; k < 3; k++) {
+                        if (!(d0.active & (1 << k))) continue;
+                        for (int j = 0; j < 4; j++) Ms[(size_t)d0.offw[k][j] * kS0K + sl] += sgn[j] * (long double)d0.w[k] * (long double)d0.scr_mul;
+                    }
+                }
+                std::vector<long double> Rs = Ms;                             // residual columns
+                std::vector<std::vector<long double>> basis;
+                auto nrm2 = [&](const long double *v) { long double t = 0; for (int sl = 0; sl < kS0K; sl++) t += v[sl] * v[sl]; return t; };
+                long double first = 0.0L;
+                for (int it = 0; it < 225; it++) {
+                    int best = -1; long double bn = 0.0L;
+                    for (int j = 0; j < 225; j++) { const long double t = nrm2(Rs.data() + (size_t)j * kS0K); if (t > bn) { bn = t; best = j; } }
+                    if (it == 0) first = bn;
+                    if (best < 0 || !(bn > 1e-24L * first)) break;
+                    std::vector<long double> v(Rs.begin() + (size_t)best * kS0K, Rs.begin() + (size_t)(best + 1) * kS0K);
+                    for (int pass2 = 0; pass2 < 2; pass2++)                    // re-orthogonalise against the basis so far
+                        for (const auto &bv : basis) { long double dp = 0; for (int sl = 0; sl < kS0K; sl++) dp += bv[(size_t)sl] * v[(size_t)sl]; for (int sl = 0; sl < kS0K; sl++) v[(size_t)sl] -= dp * bv[(size_t)sl]; }
+                    const long double nv = std::sqrt(nrm2(v.data()));
+                    if (!(nv > 0.0L)) break;
+                    for (auto &x : v) x /= nv;
+                    for (int j = 0; j < 225; j++) {
+                        long double *rc = Rs.data() + (size_t)j * kS0K;
+                        long double dp = 0; for (int sl = 0; sl < kS0K; sl++) dp += v[(size_t)sl] * rc[sl];
+                        for (int sl = 0; sl < kS0K; sl++) rc[sl] -= dp * v[(size_t)sl];
+                    }
+                    basis.push_back(v);
+                }
+                lr_rank = (int)basis.size();
+                int n_pass = 0;
+                for (int sl = 0; sl < S; sl++) n_pass += pass[(size_t)sl];
+                if (lr_rank > 0 && lr_rank + n_pass <= KL) {
+                    for (int k = 0; k < lr_rank; k++) for (int sl = 0; sl < kS0K; sl++) Bm[(size_t)sl * KL + k] = (double)basis[(size_t)k][(size_t)sl];
+                    int kp = lr_rank;
+                    for (int sl = 0; sl < S; sl++) if (pass[(size_t)sl]) Bm[(size_t)sl * KL + kp++] = 1.0;
+                    lr_cols = kp;
+                    // what the ORIGINAL columns leave outside range(B) once B is rounded to fp64: sum of the residual norms (per unit of the
+                    // largest corner: |(I - BB')Ms w| <= sum_j |res_j| |w_j|)
+                    long double rs = 0.0L;
+                    for (int j = 0; j < 225; j++) {
+                        std::vector<long double> c0(Ms.begin() + (size_t)j * kS0K, Ms.begin() + (size_t)(j + 1) * kS0K);
+                        for (int k = 0; k < lr_rank; k++) {
+                            long double dp = 0; for (int sl = 0; sl < kS0K; sl++) dp += (long double)Bm[(size_t)sl * KL + k] * Ms[(size_t)j * kS0K + sl];
+                            for (int sl = 0; sl < kS0K; sl++) c0[(size_t)sl] -= dp * (long double)Bm[(size_t)sl * KL + k];
+                        }
+                        rs += std::sqrt(nrm2(c0.data()));
+                    }
+                    lr_rho = (double)rs * 1.01 + 1e-300;
+                    // centre into the affine subspace: (scr_add - mu) restricted to the linear slots must lie in range(B)
+                    std::vector<long double> am((size_t)kS0K, 0.0L);
+                    for (int sl = 0; sl < S; sl++) if (lin[(size_t)sl]) am[(size_t)sl] = (long double)fds_keep[(size_t)sl].scr_add - (long double)mu[(size_t)sl];
+                    std::vector<long double> pr((size_t)kS0K, 0.0L);
+                    for (int k = 0; k < lr_rank; k++) {
+                        long double dp = 0; for (int sl = 0; sl < kS0K; sl++) dp += (long double)Bm[(size_t)sl * KL + k] * am[(size_t)sl];
+                        for (int sl = 0; sl < kS0K; sl++) pr[(size_t)sl] += dp * (long double)Bm[(size_t)sl * KL + k];
+                    }
+                    for (int sl = 0; sl < S; sl++) if (lin[(size_t)sl]) mu[(size_t)sl] = (double)((long double)fds_keep[(size_t)sl].scr_add - pr[(size_t)sl]);
+                    lr_basis = true;
+                }
+            }
             cp.cr_mu_norm = cp.cr_mu_norm_t = 0.0;
             for (int sl = 0; sl < S; sl++) { cp.cr_mu_norm += mu[(size_t)sl] * mu[(size_t)sl]; cp.cr_mu_norm_t += mult[(size_t)sl] * mu[(size_t)sl] * mu[(size_t)sl]; }
             cp.cr_mu_norm = std::sqrt(cp.cr_mu_norm) * (1.0 + 1e-12); cp.cr_mu_norm_t = std::sqrt(cp.cr_mu_norm_t) * (1.0 + 1e-12);
@@ -537,6 +621,149 @@ int build_tables(haf_engine *e)
                 cp.corr = e->d_corr_cr.p;
                 cp.corr2 = reinterpret_cast<const ScrCorr2 *>(e->d_corr_cr.p + kS0K);
                 e->cr_available = true;
+                // ---- low-rank form: projection tiles, images of q~_n = (B'B^)^-1 B'q_n, r_n = (I - BB')q_n - (B^ - B)q~_n, the band's constants ----
+                if (lr_basis) {
+                    const int K = kS0K, KL2 = kLrK, kc = lr_cols;
+                    std::vector<double> Bh((size_t)K * KL2, 0.0);
+                    for (size_t i = 0; i < Bh.size(); i++) {
+                        _Float16 h = (_Float16)(float)Bm[i];
+                        if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+                        Bh[i] = (double)(float)h;
+                    }
+                    // G = B'B^ (kc x kc), inverted by Gauss-Jordan with partial pivoting in long double (G = I + O(2^-11))
+                    std::vector<long double> Gm((size_t)kc * kc, 0.0L), Gi((size_t)kc * kc, 0.0L);
+                    for (int a2 = 0; a2 < kc; a2++)
+                        for (int b2 = 0; b2 < kc; b2++) {
+                            long double t = 0.0L;
+                            for (int sl = 0; sl < K; sl++) t += (long double)Bm[(size_t)sl * KL2 + a2] * (long double)Bh[(size_t)sl * KL2 + b2];
+                            Gm[(size_t)a2 * kc + b2] = t;
+                        }
+                    for (int a2 = 0; a2 < kc; a2++) Gi[(size_t)a2 * kc + a2] = 1.0L;
+                    bool inv_ok = true;
+                    for (int col = 0; col < kc && inv_ok; col++) {
+                        int piv = col;
+                        for (int r2 = col + 1; r2 < kc; r2++) if (fabsl(Gm[(size_t)r2 * kc + col]) > fabsl(Gm[(size_t)piv * kc + col])) piv = r2;
+                        if (!(fabsl(Gm[(size_t)piv * kc + col]) > 0.25L)) { inv_ok = false; break; }
+                        if (piv != col) for (int c2 = 0; c2 < kc; c2++) { std::swap(Gm[(size_t)piv * kc + c2], Gm[(size_t)col * kc + c2]); std::swap(Gi[(size_t)piv * kc + c2], Gi[(size_t)col * kc + c2]); }
+                        const long double iv = 1.0L / Gm[(size_t)col * kc + col];
+                        for (int c2 = 0; c2 < kc; c2++) { Gm[(size_t)col * kc + c2] *= iv; Gi[(size_t)col * kc + c2] *= iv; }
+                        for (int r2 = 0; r2 < kc; r2++) {
+                            if (r2 == col) continue;
+                            const long double f = Gm[(size_t)r2 * kc + col];
+                            if (f == 0.0L) continue;
+                            for (int c2 = 0; c2 < kc; c2++) { Gm[(size_t)r2 * kc + c2] -= f * Gm[(size_t)col * kc + c2]; Gi[(size_t)r2 * kc + c2] -= f * Gi[(size_t)col * kc + c2]; }
+                        }
+                    }
+                    LrBand lb{};
+                    std::vector<double> Qt((size_t)m.n_sv * KL2, 0.0), Qth((size_t)m.n_sv * KL2, 0.0), dQt((size_t)m.n_sv * KL2, 0.0), Rm((size_t)m.n_sv * K, 0.0);
+                    std::vector<char> imgl((size_t)e->n_sv_tiles * kLrSvTileBytes, 0);
+                    if (inv_ok) {
+                        std::vector<long double> bq((size_t)kc), qt((size_t)kc);
+                        for (int n = 0; n < m.n_sv; n++) {
+                            const double *q = Q.data() + (size_t)n * K;
+                            for (int a2 = 0; a2 < kc; a2++) { long double t = 0.0L; for (int sl = 0; sl < K; sl++) t += (long double)Bm[(size_t)sl * KL2 + a2] * (long double)q[sl]; bq[(size_t)a2] = t; }
+                            for (int a2 = 0; a2 < kc; a2++) { long double t = 0.0L; for (int b2 = 0; b2 < kc; b2++) t += Gi[(size_t)a2 * kc + b2] * bq[(size_t)b2]; qt[(size_t)a2] = t; }
+                            const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
+                            char *tile = imgl.data() + (size_t)t * kLrSvTileBytes;
+                            double h2 = 0.0, d2 = 0.0, q2 = 0.0, r2n = 0.0;
+                            for (int a2 = 0; a2 < kc; a2++) {
+                                const double v = (double)qt[(size_t)a2];
+                                _Float16 h = (_Float16)(float)v;
+                                if (std::fabs((float)h) < kF16MinNormal) h = (_Float16)0.0f;
+                                memcpy(tile + h_image_offset(j, a2), &h, 2);
+                                const double hd = (double)(float)h;
+                                Qt[(size_t)n * KL2 + a2] = v; Qth[(size_t)n * KL2 + a2] = hd; dQt[(size_t)n * KL2 + a2] = hd - v;
+                                h2 += hd * hd; d2 += (hd - v) * (hd - v);
+                            }
+                            // r_n = q_n - B (B'q_n) - (B^ - B) q~_n
+                            for (int sl = 0; sl < K; sl++) {
+                                long double t = (long double)q[sl];
+                                for (int a2 = 0; a2 < kc; a2++) {
+                                    const double bv = Bm[(size_t)sl * KL2 + a2], bhv = Bh[(size_t)sl * KL2 + a2];
+                                    if (bv == 0.0 && bhv == 0.0) continue;
+                                    t -= (long double)bv * bq[(size_t)a2] + (long double)(bhv - bv) * qt[(size_t)a2];
+                                }
+                                Rm[(size_t)n * K + sl] = (double)t;
+                                r2n += (double)(t * t);
+                                q2 += q[sl] * q[sl];
+                            }
+                            reinterpret_cast<float *>(tile + kLrMatBytes)[j] = 0.0f;
+                            reinterpret_cast<float *>(tile + kLrMatBytes)[kTile + j] = (float)b[(size_t)n];
+                            const double ab = std::fabs(b[(size_t)n]), qhn = std::sqrt(h2), qn = std::sqrt(q2);
+                            lb.Ca += ab * qhn * qn; lb.Cq1 += ab * qhn; lb.Cqq += ab * h2; lb.Babs += ab;
+                            lb.qmax = std::max(lb.qmax, qhn); lb.dqmax = std::max(lb.dqmax, std::sqrt(d2)); lb.rmax = std::max(lb.rmax, std::sqrt(r2n));
+                        }
+                        // signed first-order matrices and the unsigned second-order ones
+                        std::vector<double> N1((size_t)K * KL2, 0.0), M1((size_t)K * KL2, 0.0), N2((size_t)K * K, 0.0);
+                        std::vector<double> Rh((size_t)m.n_sv * KL2), Rd((size_t)m.n_sv * KL2), Ra((size_t)m.n_sv * KL2), Rq((size_t)m.n_sv * K), Rr((size_t)m.n_sv * K);
+                        for (int n = 0; n < m.n_sv; n++) {
+                            const double *q = Q.data() + (size_t)n * K, *h = Qth.data() + (size_t)n * KL2, *dq = dQt.data() + (size_t)n * KL2, *rr = Rm.data() + (size_t)n * K;
+                            const double sb = std::sqrt(std::fabs(b[(size_t)n]));
+                            for (int l = 0; l < KL2; l++) { Rh[(size_t)n * KL2 + l] = sb * h[l]; Rd[(size_t)n * KL2 + l] = sb * dq[l]; Ra[(size_t)n * KL2 + l] = sb * std::fabs(h[l]); }
+                            for (int l = 0; l < K; l++) { Rq[(size_t)n * K + l] = sb * q[l]; Rr[(size_t)n * K + l] = sb * rr[l]; }
+                            for (int k = 0; k < K; k++) {
+                                const double a = b[(size_t)n] * q[k];
+                                if (a == 0.0) continue;
+                                double *n1 = N1.data() + (size_t)k * KL2, *m1 = M1.data() + (size_t)k * KL2, *n2 = N2.data() + (size_t)k * K;
+                                for (int l = 0; l < KL2; l++) { n1[l] += a * h[l]; m1[l] += a * dq[l]; }
+                                for (int l = 0; l < K; l++) n2[l] += a * rr[l];
+                            }
+                        }
+                        // sym(M1 B^') (K x K)
+                        std::vector<double> MB((size_t)K * K, 0.0);
+                        for (int k = 0; k < K; k++)
+                            for (int l = 0; l < K; l++) {
+                                double t = 0.0;
+                                for (int a2 = 0; a2 < kc; a2++) t += M1[(size_t)k * KL2 + a2] * Bh[(size_t)l * KL2 + a2];
+                                MB[(size_t)k * K + l] = t;
+                            }
+                        for (int k = 0; k < K; k++)
+                            for (int l = 0; l < k; l++) { const double sy = 0.5 * (MB[(size_t)k * K + l] + MB[(size_t)l * K + k]); MB[(size_t)k * K + l] = MB[(size_t)l * K + k] = sy; }
+                        std::vector<double> Bab((size_t)K * KL2);
+                        for (size_t i = 0; i < Bab.size(); i++) Bab[i] = std::fabs(Bh[i]);
+                        const double up = 1.0 + 1e-6;
+                        lb.nN1 = sigma_upper_bound(N1.data(), K, KL2) * up;
+                        lb.nM1 = sigma_upper_bound(MB.data(), K, K) * up;
+                        lb.nN2 = sigma_upper_bound(N2.data(), K, K) * up;
+                        { const double x = sigma_upper_bound(Rh.data(), m.n_sv, KL2); lb.nHabs = x * x * up; }
+                        { const double x = sigma_upper_bound(Rd.data(), m.n_sv, KL2); lb.nDabs = x * x * up; }
+                        { const double x = sigma_upper_bound(Rr.data(), m.n_sv, K); lb.nRabs = x * x * up; }
+                        lb.sQb = sigma_upper_bound(Rq.data(), m.n_sv, K) * up;
+                        lb.sQtaa = sigma_upper_bound(Ra.data(), m.n_sv, KL2) * up;
+                        lb.sigB = sigma_upper_bound(Bh.data(), K, KL2) * up;
+                        lb.sigAbsB = sigma_upper_bound(Bab.data(), K, KL2) * up;
+                        for (double *x : {&lb.Ca, &lb.Cq1, &lb.Cqq, &lb.Babs, &lb.qmax, &lb.dqmax, &lb.rmax}) *x *= 1.0 + 1e-9;
+                        lb.rmax += 1e-300;
+                        lb.acc10 = cp.acc_rel;
+                        lb.acc6 = cp.acc_rel * (double)kLrSteps / (double)(kS0K / 32);
+                        lb.gnorm = cp.cr_gnorm;
+                        lb.mu_norm = cp.cr_mu_norm; lb.mu_norm_t = cp.cr_mu_norm_t;
+                        lb.eta_abs = cp.eta_abs + 1e-14 * (1.0 + cp.cr_mu_norm);     // + the roundings of the centre's projection into the affine subspace
+                        lb.scale = cp.scale;
+                        // projection tiles: output slot k -> tile k / 32, row 16 n + 4 g + r with w = k % 32, g = w / 8, n = (w % 8) / 4, r = w % 4 (screen.hip: k_project)
+                        std::vector<char> bt((size_t)kLrSteps * kLrProjTileBytes, 0);
+                        for (int k = 0; k < KL2; k++) {
+                            const int w = k & 31, g = w >> 3, nn = (w & 7) >> 2, r = w & 3, j = 16 * nn + 4 * g + r;
+                            char *tile = bt.data() + (size_t)(k >> 5) * kLrProjTileBytes;
+                            for (int sl = 0; sl < K; sl++) {
+                                const _Float16 h = (_Float16)(float)Bh[(size_t)sl * KL2 + k];
+                                memcpy(tile + h_image_offset(j, sl), &h, 2);
+                            }
+                        }
+                        const bool fin2 = std::isfinite(lb.nN1) && std::isfinite(lb.nM1) && std::isfinite(lb.nN2) && std::isfinite(lb.nHabs) && std::isfinite(lb.nRabs) &&
+                                          std::isfinite(lb.sigB) && lb.qmax < 60000.0 && lb.sigB < 1.5;
+                        if (fin2) {
+                            if (hipSuccess != e->d_lr_btiles.alloc(bt.size()) || hipSuccess != e->d_svt_lr.alloc(imgl.size()))
+                                return fail(e, HAF_E_DEVICE, "hipMalloc(low-rank tables)");
+                            HIPCHK(e, hipMemcpy(e->d_lr_btiles.p, bt.data(), bt.size(), hipMemcpyHostToDevice));
+                            HIPCHK(e, hipMemcpy(e->d_svt_lr.p, imgl.data(), imgl.size(), hipMemcpyHostToDevice));
+                            e->lr_band = lb;
+                            e->lr_rank = lr_rank;
+                            cp.lr_rho = lr_rho;
+                            e->lr_available = true;
+                        }
+                    }
+                }
                 // ---- tier 1 in the same form (kernels.h: CrT1Params): hi/lo fp16 images of fl32(s - m) in raw attribute units, the
                 // centre and the linear term's constants per attribute for the exact-form feature kernel ----
                 if (!test_env("HAF_NO_CR_T1")) {
@@ -747,6 +974,7 @@ int build_tables(haf_engine *e)
     e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * sweep_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
     e->screen_cr.scale = 1.001 * guard0_scale;
+    e->lr_band.scale = 1.001 * guard0_scale;
     e->crt1.scale = 1.001 * guard_scale;
     e->crt1.guard_abs = e->svm.guard_abs;
     e->crt1.gv0 = e->gv0; e->crt1.gv1 = e->gv1;

@@ -111,6 +111,43 @@ __device__ __forceinline__ double screen_attribute(const Src &src, const FeatDes
     return fma(hafq::decq4_float_scr(v, st), f.scr_mul, f.scr_add);
 }
 
+// The same with the low-rank form's noise bound (kernels.h: kLrK; features.hip: k_features_serial, LR) for a lane of a wave that is
+// not a run of neighbours: nb >= |u' - u_lin| -- the "%.4g" rounding, the products' rounding errors (exact, by fma) and the sums'
+// -- and, for a region whose sum is not provably EXACT in the reference's order ((a - b) - c) + d, the worst its three roundings can
+// add (region_round_bound).  The exactness test, per region, for a grid without negative heights (monotone integral image, R >= 0):
+// a - b by Sterbenz (a <= 2b) or b = 0; then s2 = s1 - c = R - d and s3 = R are multiples of ulp(d) below d when R < d
+// (c = d = 0: nothing to round).  A SHAF slot (pad2 = 0) is passed through as it is and needs none.
+// what the three roundings of ((a - b) - c) + d can add up to when the region does not pass the exactness test: u (|s1| + |s2| + |R|)
+// (each operation is off by at most half an ulp of its own result) -- 0 when it passes.  neg: the grid holds a negative height.
+__device__ __forceinline__ float region_round_bound(float a, float b, float c, float d, float s1, float s2, float R, bool neg)
+{
+    const bool exact = !neg && (a <= 2.0f * b || b == 0.0f) && ((c == 0.0f && d == 0.0f) || R < d);
+    return exact ? 0.0f : 6.1e-8f * (fabsf(s1) + fabsf(s2) + fabsf(R));
+}
+template <class Src>
+__device__ __forceinline__ double screen_attribute_lr(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st, float &nb, bool neg)
+{
+    if (f.shaf) { nb = 0.0f; return screen_attribute(src, f, st); }
+    float rv = 0.0f, ee = 0.0f, esum = 0.0f;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (f.active & (1 << k)) {
+            const float a = src.corner(f, k, 0), b = src.corner(f, k, 1), c = src.corner(f, k, 2), d = src.corner(f, k, 3);
+            const float s1 = __fsub_rn(a, b), s2 = __fsub_rn(s1, c);
+            const float R = __fadd_rn(s2, d);
+            esum = fmaf(fabsf(f.w[k]), region_round_bound(a, b, c, d, s1, s2, R, neg), esum);
+            const float p = __fmul_rn(f.w[k], R);
+            ee += fmaf(f.w[k], R, -p);
+            rv = __fadd_rn(rv, p);
+            if (!first) esum = fmaf(6.1e-8f, fabsf(rv), esum);           // (0 + p is exact; every later addition rounds its result once)
+            first = false;
+        }
+    const double q4 = hafq::decq4_float_scr(rv, st);
+    nb = f.pad2 * (fabsf((float)q4 - rv) + fabsf(ee) * 1.000001f + esum + 6.1e-8f * fabsf(rv));
+    return fma(q4, f.scr_mul, f.scr_add);
+}
+
 // ---- the fast form of the screening feature pass ------------------------------------------------------------------
 // What bounds the per-lane form (buffer loads at window origin + corner offset) is the vector L1: the texture addresser
 // coalesces 16 lanes at a time, 64 consecutive floats at an arbitrary alignment cost ~7.5 tag accesses per load, and with
@@ -131,7 +168,12 @@ constexpr int kBandFloats4 = kBandRows * kBandPitch;  // per wave
 typedef const ScrDesc __attribute__((address_space(4))) *ScrDescK;
 __device__ __forceinline__ ScrDescK constant_ptr(const ScrDesc *p) { return (ScrDescK)(unsigned long long)p; }
 
-__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud)
+// NB (low-rank form, kernels.h: kLrK): nb[q] >= |u' - u_lin| of the slot, u_lin the EXACTLY linear functional of the window behind
+// the attribute -- the "%.4g" rounding |q4 - v| (formed in fp32: its cast costs another u |q4|) plus the fp32 roundings of the
+// products and of their sum (<= 3.1 u sum|w_k R_k|), valid when the region sums themselves are exact (k_features_serial checks that
+// per wave), times |scr_mul| (ScrDesc::pad, rounded up; 0 for a SHAF slot, which is passed through as it is).
+template <int NB>
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2, bool neg = false)
 {
     float c[4][8];
     unsigned adr[4][8];                               // all descriptor words first: a volatile asm pins what follows it
@@ -154,12 +196,30 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
                           "+v"(c[q][7]));
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const float r0 = __fmul_rn(sd[q].w[0], __fadd_rn(__fsub_rn(__fsub_rn(c[q][0], c[q][1]), c[q][2]), c[q][3]));
-        const float r1 = __fmul_rn(sd[q].w[1], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4], c[q][5]), c[q][6]), c[q][7]));
+        const float s10 = __fsub_rn(c[q][0], c[q][1]), s20 = __fsub_rn(s10, c[q][2]), s11 = __fsub_rn(c[q][4], c[q][5]), s21 = __fsub_rn(s11, c[q][6]);
+        const float R0 = __fadd_rn(s20, c[q][3]);
+        const float R1 = __fadd_rn(s21, c[q][7]);
+        const float r0 = __fmul_rn(sd[q].w[0], R0);
+        const float r1 = __fmul_rn(sd[q].w[1], R1);
         const float v = __fadd_rn(r0, r1);      // 0.0f + r0 first (fv.cpp:164) only turns a -0 into +0: same decimal, same u'
-        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
+        const double q4 = hafq::decq4_float_scr(v, st);
+        ud[q] = fma(q4, sd[q].scr_mul, sd[q].scr_add);
+        if (NB) {
+            // the products' rounding errors EXACTLY (fma), the sum's and the cast's bounded: u |v| + u |q4| <= 1.3e-7 |v| (|q4 - v| <= 5e-4 |v|)
+            const float e0 = fmaf(sd[q].w[0], R0, -r0), e1 = fmaf(sd[q].w[1], R1, -r1);
+            float ar = 0.0f;                               // NB == 2: a wave that did not pass the exactness test as a whole (features.hip)
+            if (NB == 2)
+                ar = fabsf(sd[q].w[0]) * region_round_bound(c[q][0], c[q][1], c[q][2], c[q][3], s10, s20, R0, neg) +
+                     fabsf(sd[q].w[1]) * region_round_bound(c[q][4], c[q][5], c[q][6], c[q][7], s11, s21, R1, neg);
+            const float nbq = sd[q].pad * (fabsf((float)q4 - v) + fabsf(e0 + e1) * 1.000001f + 1.3e-7f * fabsf(v) + ar);
+            nu2 = fmaf(nbq, nbq, nu2);
+            // (the sum is tied to the sequence of the volatile LDS reads: left to float, the temporaries of eight slots stay alive until
+            // the sums are finally formed -- 45 registers, two waves of occupancy)
+            asm volatile("" : "+v"(nu2));
+        }
     }
 }
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f; screen_quad<0>(band, sd, st, ud, dummy); }
 
 // Two attribute slots of any other group, from the band: three regions each, the HAF sum or the SHAF rule (feature_value).
 // A slot of a dropped or absent attribute has scr_mul = scr_add = 0: its u' is 0 (NaN if its feature value left the decimal
@@ -167,16 +227,19 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
 typedef const ScrDesc3 __attribute__((address_space(4))) *ScrDesc3K;
 __device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (ScrDesc3K)(unsigned long long)p; }
 
-__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud)
+// (NQ slots per call: two in the plain form; ONE with the low-rank form's noise bound, whose temporaries would otherwise cost the
+// kernel 48 registers -- a wave of occupancy -- for the four groups of 40 that take this path)
+template <int NB, int NQ>
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud, float &nu2, bool neg = false)
 {
-    float c[2][12];
-    unsigned adr[2][12];
+    float c[NQ][12];
+    unsigned adr[NQ][12];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int j = 0; j < 12; j++) adr[q][j] = band + (unsigned)sd[q].off[j];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const unsigned a = adr[q][j];
@@ -185,14 +248,19 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[0][4]), "+v"(c[0][5]), "+v"(c[0][6]), "+v"(c[0][7]),
                    "+v"(c[0][8]), "+v"(c[0][9]), "+v"(c[0][10]), "+v"(c[0][11]));
-    asm volatile("" : "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]), "+v"(c[1][4]), "+v"(c[1][5]), "+v"(c[1][6]), "+v"(c[1][7]),
-                      "+v"(c[1][8]), "+v"(c[1][9]), "+v"(c[1][10]), "+v"(c[1][11]));
+    if (NQ > 1)
+        asm volatile("" : "+v"(c[NQ - 1][0]), "+v"(c[NQ - 1][1]), "+v"(c[NQ - 1][2]), "+v"(c[NQ - 1][3]), "+v"(c[NQ - 1][4]), "+v"(c[NQ - 1][5]), "+v"(c[NQ - 1][6]), "+v"(c[NQ - 1][7]),
+                          "+v"(c[NQ - 1][8]), "+v"(c[NQ - 1][9]), "+v"(c[NQ - 1][10]), "+v"(c[NQ - 1][11]));
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        float r[3];
+    for (int q = 0; q < NQ; q++) {
+        float r[3], Rk[3], ar = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-            r[k] = __fmul_rn(sd[q].w[k], __fadd_rn(__fsub_rn(__fsub_rn(c[q][4 * k], c[q][4 * k + 1]), c[q][4 * k + 2]), c[q][4 * k + 3]));
+        for (int k = 0; k < 3; k++) {
+            const float s1 = __fsub_rn(c[q][4 * k], c[q][4 * k + 1]), s2 = __fsub_rn(s1, c[q][4 * k + 2]);
+            Rk[k] = __fadd_rn(s2, c[q][4 * k + 3]);
+            r[k] = __fmul_rn(sd[q].w[k], Rk[k]);
+            if (NB == 2) ar = fmaf(fabsf(sd[q].w[k]), region_round_bound(c[q][4 * k], c[q][4 * k + 1], c[q][4 * k + 2], c[q][4 * k + 3], s1, s2, Rk[k], neg), ar);
+        }
         float v;
         if (sd[q].shaf) {                                              // wave-uniform
             v = -1.0f;
@@ -203,9 +271,18 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
         } else {
             v = __fadd_rn(__fadd_rn(r[0], r[1]), r[2]);
         }
-        ud[q] = fma(hafq::decq4_float_scr(v, st), sd[q].scr_mul, sd[q].scr_add);
+        const double q4 = hafq::decq4_float_scr(v, st);
+        ud[q] = fma(q4, sd[q].scr_mul, sd[q].scr_add);
+        if (NB) {
+            // (HAF slots only -- pad[0] = 0 for SHAF: exact product errors, the partial sum r0 + r1 and the total rounded once each)
+            const float ee = fmaf(sd[q].w[0], Rk[0], -r[0]) + fmaf(sd[q].w[1], Rk[1], -r[1]) + fmaf(sd[q].w[2], Rk[2], -r[2]);
+            const float nbq = sd[q].pad[0] * (fabsf((float)q4 - v) + fabsf(ee) * 1.000001f + 6.1e-8f * fabsf(r[0] + r[1]) + 1.3e-7f * fabsf(v) + ar);
+            nu2 = fmaf(nbq, nbq, nu2);
+            asm volatile("" : "+v"(nu2));
+        }
     }
 }
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f; screen_pair3<0, 2>(band, sd, st, ud, dummy); }
 
 // the decimal tables (95 doubles) in LDS: call from every thread of the workgroup before any divergent return
 __device__ __forceinline__ hafq::PtrTabs load_decimal_tables(double *lds_tab)

@@ -308,7 +308,15 @@ __device__ __forceinline__ void i8_store(float *X, long e, int g, const unsigned
 
 // Large requests: one thread per evaluation walks all attributes (best throughput: no per-workgroup tail, 35 k
 // workgroups for C5).  Small requests use k_features below.
-template <int MODE>
+// LR (screening form only; kernels.h: kLrK, ScreenParams::lr): the wave also sums nu2 >= |p' - p_lin|^2 over the HAF slots and the
+// kernel leaves the RAW sums {su2, sd2, sx2, L, nu2} where the finished band would go (k_project adds |y^ - y32|^2, the sweep's tail
+// finishes the band: screen_band.h).  nu2 is finite only for a wave whose region sums are provably EXACT in the reference's own order
+// ((a - b) - c) + d (fv.cpp:161-162): no negative height in the grid (integral image monotone, region sums R >= 0), bottom row of
+// the band <= 2 x its top row in every column (a - b exact by Sterbenz), and the window's total <= its top-left corner (then
+// |s2| = d - R <= d and s3 = R <= d are multiples of ulp(d) below 2^24 ulp(d): representable).  Such a wave's feature differs from
+// the exactly linear functional only by the roundings of the products w_k R_k and of their sum; every other wave (the borders of
+// the grid, waves that are not a run of 64 neighbours) gets nu2 = inf and is left to the tiers behind.
+template <int MODE, bool LR>
 __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
@@ -335,6 +343,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     __shared__ float s_band[MODE == XMODE_SCREEN ? (256 / 64) * kBandFloats4 : 1];
     bool fastwave = false;
     unsigned band = 0;
+    bool lr_exact = false, lr_neg = false;
+    float lr_M = 0.0f;
     if (MODE == XMODE_SCREEN && !idx_list) {
         const int lane = threadIdx.x & 63;
         const int cell = (e < n_evals) ? evalcell[e] : -1;
@@ -354,6 +364,26 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             }
             band = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)bw);
             asm volatile("" :: "v"(bw) : "memory");       // the band is read by asm only: keep its stores, and keep them here
+            if (LR) {
+                const volatile float *vb = bw;
+                const float tl = vb[lane], bl = vb[14 * kBandPitch + lane], tr = vb[lane + 14], br = vb[14 * kBandPitch + lane + 14];
+                // per column of the band: bottom row <= 2 x top row (78 bits); a lane's window needs its own 15 columns
+                const unsigned long long colok0 = __ballot(bl <= 2.0f * tl);
+                const unsigned long long colok1 = __ballot(lane >= 14 || vb[14 * kBandPitch + 64 + lane] <= 2.0f * vb[64 + lane]) & 0x3fffull;
+                const unsigned long long mine = (lane == 0) ? colok0 : ((colok0 >> lane) | (colok1 << (64 - lane)));
+                bool ok = (mine & 0x7fffull) == 0x7fffull;
+                const float T = __fsub_rn(__fsub_rn(br, tr), __fsub_rn(bl, tl));      // the window's total (exact under the first condition; 1e-6 to spare)
+                // every region's d = II[x1][y1] is at least the window's first corner -- or, for the window that starts in column 0 of the
+                // integral image (which is all zeros: a region with y1 = 0 has c = d = 0 and nothing to round), its second
+                const int broll = cell0 / (d.H * d.W);
+                const int col0 = cell0 - (cell0 / d.W) * d.W - 7;                      // first column of the band
+                const float dmin = (col0 == 0 && lane == 0) ? vb[1] : tl;
+                ok = ok && T * 1.000001f < dmin;
+                lr_neg = (sp.lr_negflags[broll] & 2) != 0;
+                lr_exact = __ballot(ok) == ~0ull && !lr_neg;
+                lr_M = vb[14 * kBandPitch + 77];           // the band's largest corner (monotone integral image)
+                asm volatile("" ::: "memory");
+            }
         }
     }
     if (e >= n_evals) {                       // padding rows of the last block: zeros
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         } else {
             for (int k = 0; k < kKP; k++) xcol[k * kTile] = 0.0f;
         }
-        if (MODE == XMODE_SCREEN) { const float zb[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; store_band(ax + kBandFloats * e, zb); ax2[e] = 0.0f; }
+        if (MODE == XMODE_SCREEN) { const float zb[kBandFloats] = {0.0f, 0.0f, 0.0f, 0.0f, LR ? __builtin_inff() : 0.0f, 0.0f, 0.0f, 0.0f}; store_band(ax + kBandFloats * e, zb); ax2[e] = 0.0f; }
         else ax[e] = 0.0f;
         return;
     }
@@ -377,14 +407,41 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     if (MODE == XMODE_SCREEN) {
         ScreenSums2 acc2{};
         float sx = 0.0f;
+        const bool lr_nb = LR && fastwave && lr_exact;    // wave-uniform: every region sum of the wave is exact
+        if (LR && !fastwave) lr_neg = (sp.lr_negflags[evalcell[e_src] / (d.H * d.W)] & 2) != 0;   // per lane
+        float nu2 = 0.0f;
         for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
             double ud[8];
-            if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
+            if (lr_nb) {
+                if ((sp.fast_groups >> g) & 1) {
+                    screen_quad<1>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2);
+                    screen_quad<1>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) screen_pair3<1, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2);
+                }
+            } else if (LR && fastwave) {                  // a wave with regions that may round: bounded region by region
+                if ((sp.fast_groups >> g) & 1) {
+                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2, lr_neg);
+                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2, lr_neg);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) screen_pair3<2, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2, lr_neg);
+                }
+            } else if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
                 screen_quad(band, constant_ptr(sp.sd) + g * 8, st, ud);
                 screen_quad(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4);
             } else if (fastwave) {
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) screen_pair3(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q);
+            } else if (LR && !fastwave) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const FeatDesc &F = fd[g * 8 + q];
+                    float nbq = 0.0f;
+                    ud[q] = F.skip ? 0.0 : screen_attribute_lr(SrcBuf<true>{iir, w0}, F, st, nbq, lr_neg);
+                    nu2 = fmaf(nbq, nbq, nu2);
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
@@ -403,7 +460,22 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         }
         const ScreenSums acc = screen_sums(acc2);
         float band[kBandFloats], nax;
-        screen_finish((double)acc.su2, (double)acc.sd2, (double)acc.su2 + (double)sx, (double)acc.cr, (double)acc.ub, sp, band, nax);
+        if (LR) {
+            // raw sums; the part of the slots' linear map that the fp64 roundings of the basis leave outside range(B): lr_rho per unit of the largest corner
+            if (!fastwave) {
+                // (this lane's own window: largest corner = its bottom-right one, the integral image being monotone)
+                lr_M = fabsf(ii_load<false>(iir, w0, 14 * (d.W + 1) + 14));
+                if (lr_neg) nu2 = __builtin_inff();            // (not monotone: the corner need not be the largest; such a grid is left to the tiers behind)
+            }
+            if (fastwave && lr_neg) nu2 = __builtin_inff();
+            const float rho = (float)sp.lr_rho * lr_M * 1.000001f;
+            nu2 = fmaf(rho, rho, nu2);
+            const float sx2 = acc.su2 + sx;                                   // (one more fp32 rounding of |p'|^2: inside kF32Acc's 326)
+            band[0] = acc.su2; band[1] = acc.sd2; band[2] = sx2; band[3] = acc.cr; band[4] = nu2; band[5] = 0.0f; band[6] = 0.0f; band[7] = 0.0f;
+            nax = -0.5f * sx2;
+        } else {
+            screen_finish((double)acc.su2, (double)acc.sd2, (double)acc.su2 + (double)sx, (double)acc.cr, (double)acc.ub, sp, band, nax);
+        }
         store_band(ax + kBandFloats * e, band);
         ax2[e] = nax;
         return;
@@ -883,8 +955,12 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
     if (large && MODE != XMODE_F64) {
         // enough evaluations to fill the chip with one thread each
         long blocks = (max_evals + kBlock - 1) / kBlock * (kBlock / 256);
-        hipLaunchKernelGGL(k_features_serial<MODE>, dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
-                           lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
+        if (MODE == XMODE_SCREEN && sp.lr && !idx_list)
+            hipLaunchKernelGGL((k_features_serial<MODE, MODE == XMODE_SCREEN>), dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                               lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
+        else
+            hipLaunchKernelGGL((k_features_serial<MODE, false>), dim3((unsigned)blocks), dim3(256), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                               lower, upper, neg_gamma2, sp, idx_list, list_counter, list_cap, dbg, ax2);
         return;
     }
     // small requests -- and every list of the fp64 tier, which is short unless the model is ill-conditioned: a third of the

@@ -66,6 +66,19 @@ constexpr int kS0SvTileBytes = 21504;                 // fp16 image (20480 B) + 
 constexpr int kS0Pieces = kS0SvTileBytes / 1024;      // 21 LDS-DMA wave instructions
 constexpr int kS0Buffers = 3;
 constexpr float kF16MinNormal = 6.103515625e-05f;     // 2^-14: smaller fp16 magnitudes are flushed in software
+// ---- low-rank form of the screening pass (round 4, second half; DESIGN.md 2 "projected operand") ----
+// The 299 HAF slots are LINEAR functionals of the 15x15 integral-image window (fv.cpp:141-199) up to the "%.4g" round trip and the
+// fp32 roundings of the reference's own arithmetic; with the reference's Features.txt those functionals span 158 dimensions.  The
+// centred operand p therefore lies within |nu| of a 158 + 21 (SHAF, passed through) = 179-dimensional subspace range(B), B with
+// orthonormal columns: p.q_n = (B^'p).q~_n + p_perp.r_n with q~_n = (B'B^)^-1 B'q_n, r_n = (I - BB')q_n - (B^ - B)q~_n.  k_project
+// forms y^ = fp16(B^'p^) on the matrix core (6 k-steps instead of 10 in the sweep that follows), the sweep runs on y^ and the
+// images of q~_n, and the band carries |p_perp| <= |nu| (feature kernel) and the rounding of y (measured by k_project).
+constexpr int kLrK = 192;                             // slots of the projected operand: 6 k-steps of 32
+constexpr int kLrSteps = kLrK / 32;
+constexpr int kLrMatBytes = kLrSteps * 2048;          // one 32 x 192 fp16 operand image = 12 KiB (h_image_offset, k < 192)
+constexpr int kLrSvTileBytes = kLrMatBytes + 1024;    // + 32 floats t_n (0) + 32 coefficients b_n, padded to 13 KiB
+constexpr int kLrWavePieces = 3;                      // LDS-DMA pieces of the image per wave and tile (4 x 3 = 12 KiB)
+constexpr int kLrProjTileBytes = kHFull * 2048;       // one projection tile: 32 output slots x 320 input slots of B^' = 20 KiB (an "SV tile" of the 10-step form)
 
 // a = h + (m + l) * 2^-12 with fp16 h, m, l (subnormal halves flushed to 0, so the value is the same whether or not the
 // matrix core honours fp16 denormals); returns the value the three products actually add up to
@@ -142,6 +155,25 @@ struct ScreenParams {
     // kernel subtracts the centre (raw attribute units) before the hi/lo split and sums L = sum (x_f - m_f) gl_f in fp64
     const double *cr_t1_tab;      // device: [kKP] centre m_f, then [kKP] gl_f = ln2 * 2 gamma' * sum_n b_n (s_nf - m_f);  nullptr: plain form
     double *cr_t1_L;              // device: L per list slot
+    // ---- low-rank form (cr != 0 only; lr != 0: k_features_serial leaves the RAW sums {su2, sd2, sx2, L, nu2} where the band goes and
+    // k_svm_screen<., ., kLrSteps> finishes the band in its tail: screen_finish_cr_lr, features.hip / screen_band.h) ----
+    int    lr;
+    double lr_rho;                // what the columns of the slots' linear map stick out of range(B) (fp64 roundings of the basis), per unit of the largest window corner
+    const int *lr_negflags;       // device, per (cloud, roll): the grid holds a negative height (the exactness argument of the region sums needs heights >= 0)
+};
+// constants of the low-rank band (LrBand: by value to k_svm_screen's low-rank instantiation; everything rounded up at load)
+struct LrBand {
+    double sigB, sigAbsB;         // sigma(B^), sigma(|B^|) (entries' magnitudes: accumulation error of the projection)
+    double acc10, acc6;           // 10 kappa u / 6 kappa u: the projection's and the sweep's chains
+    double qmax, dqmax, rmax;     // max_n |q~^_n|, max_n |q~^_n - q~_n|, max_n |r_n|
+    double nN1, nM1, nN2;         // |Q'b Q~^|, |sym(Q'b dQ~ B^')|, |Q'b R|   (signed: the classes cancel)
+    double nHabs, nDabs, nRabs;   // sigma(sqrt|b| Q~^)^2, sigma(sqrt|b| dQ~)^2, sigma(sqrt|b| R)^2
+    double sQb, sQtaa;            // sigma(sqrt|b| Q), sigma(sqrt|b| |Q~^|): spectral form of the accumulation term
+    double Ca, Cq1, Cqq, Babs;    // sum|b||q~^||q|, sum|b||q~^|, sum|b||q~^|^2, sum|b|
+    double gnorm;                 // |g|
+    double mu_norm, mu_norm_t;    // as ScreenParams::cr_mu_norm*
+    double eta_abs, scale;
+    int poly, pad;
 };
 // constants of tier 1's centred-remainder band (k_svm_h_combine_cr): the same bound as screen_finish_cr with the operands'
 // errors those of the hi+lo split (2^-22 relative) and the accumulation that of the PRECISE three-pass form ((kappa + 14) u)
@@ -169,7 +201,7 @@ struct ScrDesc {
     double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
     double scr_add;               // c * lower - fmin * scr_mul                   (0 likewise):  u' = fma(q4, scr_mul, scr_add)
     float  extra;                 // attributes sharing this slot beyond the first (0 almost everywhere): |u|^2 counts u'^2 that often more
-    float  pad;
+    float  pad;                   // low-rank form: |scr_mul| rounded up (0 for a slot that is not a linear functional of the window: passed through)
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
 // per-slot constants of the centred band (ScreenParams): one 16-byte scalar load
@@ -182,7 +214,7 @@ struct ScrDesc3 {
     int    shaf;                  // fv.cpp:187-191 instead of the weighted sum
     double scr_mul, scr_add;
     float  extra;                 // as in ScrDesc
-    float  pad[3];
+    float  pad[3];                // pad[0]: as ScrDesc::pad
 };
 static_assert(sizeof(ScrDesc3) == 96, "ScrDesc3 layout");
 constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded
@@ -228,7 +260,7 @@ struct FeatDesc {
     double range, inv_range;      // fmax - fmin and RN(1 / (fmax - fmin))
     double scr_mul, scr_add;      // screening pass (ScrDesc below): u' = fma(q4, scr_mul, scr_add)
     float  scr_extra;             // fd_slot entries only: attributes sharing the slot beyond the first
-    float  pad2;
+    float  pad2;                  // fd_slot entries only: |scr_mul| rounded up (low-rank form; as ScrDesc::pad)
 };
 
 // haf_attr_record of include/hafgrasp.h: the three stages of one attribute of one evaluation (HAF_FLAG_KEEP_DEBUG)
@@ -361,6 +393,12 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
                      int list_off = 0);            // list mode: idx_list points at entry list_off of the list counted by list_counter
 double probe_mfma_rounding(hipStream_t s, double *worst16);  // largest error of one v_mfma_f32_16x16x32_f16 (*worst16: 16x16x16f16) in units of 2^-24 (|c| + sum|a b|) over adversarial inputs; < 0: HIP error
 int probe_f16_subnormal_mfma(hipStream_t s);   // 1: the MFMA takes fp16 subnormal operands at their value, 0: it flushes, -1: HIP error
+// low-rank form: Y = fp16(B^' X) per evaluation (X: 10-step operand images, Y: 6-step images), |y^ - y|^2 into raw[kBandFloats e + 5]
+void launch_project(const void *X0, const void *btiles, void *Y, float *raw, const int *counters, long max_evals, hipStream_t s);
+void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
+                          SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
+                          int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, LrBand lb,
+                          hipStream_t s, int also_counter = -1);
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_integral_seq(int *hk, double *__restric
                                                       const int *__restrict__ inexact_flags, int *__restrict__ counters, Dims d)
 {
     const int br = blockIdx.x;
-    if (!inexact_flags[br]) return;                       // the parallel form was exact for this grid (the normal case)
+    if (!(inexact_flags[br] & 1)) return;                 // the parallel form was exact for this grid (the normal case); bit 1: a negative height (low-rank form)
     if (threadIdx.x == 0) atomicAdd(&counters[CNT_INEXACT], 1);
     const int H = d.H, W = d.W, W1 = W + 1;
     int *keys = hk + (size_t)br * H * W;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
     double *tot = band_tot + ((size_t)br * n_bands + band) * W;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row0 = band * kIBandRows;
-    bool inexact = false;
+    bool inexact = false, negative = false;
     if (tid == 0) carry = 0.0;
     __syncthreads();
     for (int c0 = 0; c0 < W; c0 += kIThreads) {
@@ -493,7 +493,11 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
             for (int r = 0; r < kIBandRows; r++) kr[r] = (row0 + r < H) ? keys[(size_t)(row0 + r) * W + c] : 0;   // all loads first, then the dependent adds
 #pragma unroll
             for (int r = 0; r < kIBandRows; r++)
-                if (row0 + r < H) v = add_checked(v, (double)final_height(kr[r]), inexact);
+                if (row0 + r < H) {
+                    const float hh = final_height(kr[r]);
+                    negative |= !(hh >= 0.0f);            // (also a NaN height)
+                    v = add_checked(v, (double)hh, inexact);
+                }
         }
         double incl = v;                                  // inclusive scan over the 512 columns of this pass
 #pragma unroll
@@ -512,6 +516,9 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
         __syncthreads();
     }
     if (__syncthreads_or(inexact) && tid == 0) atomicOr(&inexact_flags[br], 1);
+    // bit 1: the grid holds a negative height (heights in (-0.99, 0) survive generate_grid, server.cpp:522-528): the integral image is
+    // then not monotone and the exactness argument of the low-rank screening form (features.hip: k_features_serial, LR) does not hold
+    if (__syncthreads_or(negative) && tid == 0) atomicOr(&inexact_flags[br], 2);
 }
 
 // Row sums of the band (wave scans), carry = totals of the bands above, column scan inside the band, fp32 store (601); also

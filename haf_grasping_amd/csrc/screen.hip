@@ -2,6 +2,7 @@
 // built with -fno-slp-vectorize: hipcc's SLP pass packs pairs of the epilogue's fp32 FMAs into v_pk_fma_f32, which
 // cannot be placed one by one between the MFMAs (and measured wrong sums on gfx950 when fed straight from v_exp_f32).
 #include "kernels.h"
+#include "screen_band.h"
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -214,20 +215,14 @@ __device__ __forceinline__ void screen_block(const char *cur, int n, int lane, c
 // The decision tail of one evaluation (slot e of the operand images / bands): the two class sums (and the sum of squares) -> decision
 // value, band, label; returns "undecided".  COMBINED: the sums are fp64 sums of k_svm_screen<., PART>'s partial sums (k_screen_combine).
 template <int VAR, bool COMBINED>
-__device__ __forceinline__ bool screen_tail(double Psd, double Nsd, float qs, long e, const float *__restrict__ gband, const float *__restrict__ nax,
-                                            const SvmParams &p, const CrParams &crp, const int *__restrict__ idx_list,
-                                            const int *__restrict__ evalcell, float *__restrict__ dec, int8_t *__restrict__ labels,
-                                            float *__restrict__ margin)
+__device__ __forceinline__ bool screen_tail_vals(double Psd, double Nsd, float qs, long e, float4 g, float4 g2, float sc,
+                                                 const SvmParams &p, const CrParams &crp, const int *__restrict__ idx_list,
+                                                 const int *__restrict__ evalcell, float *__restrict__ dec, int8_t *__restrict__ labels,
+                                                 float *__restrict__ margin)
 {
     constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CR = VAR == SCREEN_CR_EXP || VAR == SCREEN_CR_POLY;
     const float Ps = (float)Psd, Ns = (float)Nsd;
     {
-        // the common factor 2^(-|u|^2/2) of every term of both sums (its v_exp_f32 is consumed many instructions later:
-        // the LDS reads and their wait sit in between)
-        float sc = __builtin_amdgcn_exp2f(nax[e]);
-        const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
-        const float4 g2 = *reinterpret_cast<const float4 *>(gband + kBandFloats * e + 4);
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
         float val, err;
         if (CR) {
             // centred-remainder form: dec^ = A^ (B0 + L + R^) - rho in fp64 (B0 + L cancels against rho), R^ = the two class sums of
@@ -269,6 +264,20 @@ __device__ __forceinline__ bool screen_tail(double Psd, double Nsd, float qs, lo
         if (margin) margin[eid] = flagged ? 0.0f : fabsf(val) / err;  // HAF_FLAG_KEEP_DEBUG only: how far outside its band the tier decided
         return flagged;
     }
+}
+template <int VAR, bool COMBINED>
+__device__ __forceinline__ bool screen_tail(double Psd, double Nsd, float qs, long e, const float *__restrict__ gband, const float *__restrict__ nax,
+                                            const SvmParams &p, const CrParams &crp, const int *__restrict__ idx_list,
+                                            const int *__restrict__ evalcell, float *__restrict__ dec, int8_t *__restrict__ labels,
+                                            float *__restrict__ margin)
+{
+    // the common factor 2^(-|u|^2/2) of every term of both sums (its v_exp_f32 is consumed many instructions later:
+    // the LDS reads and their wait sit in between)
+    float sc = __builtin_amdgcn_exp2f(nax[e]);
+    const float4 g = *reinterpret_cast<const float4 *>(gband + kBandFloats * e);
+    const float4 g2 = *reinterpret_cast<const float4 *>(gband + kBandFloats * e + 4);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
+    return screen_tail_vals<VAR, COMBINED>(Psd, Nsd, qs, e, g, g2, sc, p, crp, idx_list, evalcell, dec, labels, margin);
 }
 
 // number of SV ranges a request of n_evals evaluations is split over (PART form of k_svm_screen, below): as many as it takes to put
@@ -781,6 +790,299 @@ double probe_mfma_rounding(hipStream_t s, double *worst16)
     return worst;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Low-rank form (kernels.h: kLrK; DESIGN.md 2, "projected operand").  k_project: Y = fp16(B^' P^) on the matrix core -- per 32
+// output slots one "projection tile" (the rows of B^' as a 10-step fp16 image, exactly the layout of an SV tile of the 10-step
+// form) through a double-buffered LDS slot; the tile's fragments are the A operand (rows = output slots), the evaluations' 10-step
+// images the B operand (columns = evaluations), so D[output slot][evaluation] comes out with FOUR CONSECUTIVE output slots per lane
+// for evaluation lane & 15: the host permutes the rows of B^' such that MFMA row 4g + r of block 2s' (2s' + 1) is output slot
+// 32 s' + 8 g + r (+ 4), and the two blocks of a pair are, converted to fp16, exactly the lane's 8 halves of the 6-step A-operand
+// image the sweep reads (h_image_offset): no transpose.  |y^ - y32|^2 per evaluation (exact differences, fp32 sum) goes to raw[5].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kS0Waves * 64, 2) void k_project(const char *__restrict__ X0, const char *__restrict__ btiles, char *__restrict__ Y,
+                                                            float *__restrict__ raw, const int *__restrict__ counters)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * kLrProjTileBytes];
+    const int n_evals = counters[CNT_EVALS];
+    const long base = (long)blockIdx.x * kS0BlockEvals;
+    if (base >= n_evals) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long tile32 = (base >> 5) + 2 * wave;
+    half8 a[kHFull][4];
+    {
+        const char *xt = X0 + (size_t)tile32 * kS0MatBytes;
+#pragma unroll
+        for (int s = 0; s < kHFull; s++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                a[s][m] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(xt + (m >> 1) * kS0MatBytes + (s * 2 + (m & 1)) * 1024 + lane * 16));
+    }
+    // tile 0 into slot 0 (plain loads + stores: 20 KiB per workgroup and tile, 5 x 16 bytes per thread)
+    auto stage = [&](int t, int slot) {
+        const char *g = btiles + (size_t)t * kLrProjTileBytes;
+        char *l = lds + slot * kLrProjTileBytes;
+#pragma unroll
+        for (int q = 0; q < kLrProjTileBytes / (kS0Waves * 64 * 16); q++) {
+            const int o = (q * kS0Waves * 64 + tid) * 16;
+            *reinterpret_cast<float4 *>(l + o) = *reinterpret_cast<const float4 *>(g + o);
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    float sdy[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    char *yt = Y + (size_t)tile32 * kLrMatBytes;
+    for (int sp = 0; sp < kLrSteps; sp++) {
+        if (sp + 1 < kLrSteps) stage(sp + 1, (sp + 1) & 1);
+        const char *cur = lds + (sp & 1) * kLrProjTileBytes;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[n][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < kHFull; s++) {
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const half8 bf = *reinterpret_cast<const half8 *>(cur + (s * 2 + n) * 1024 + lane * 16);
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, a[s][m], acc[n][m], 0, 0, 0);
+            }
+        }
+        // lane (g = lane >> 4, e = lane & 15): output slots 32 sp + 8 g + 0..3 (block 0) and + 4..7 (block 1) of evaluation 16 m + e
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            half8 h;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float y0 = acc[0][m][r], y1 = acc[1][m][r];
+                const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;     // RN; subnormals stay (probe_f16_subnormal_mfma)
+                h[r] = h0; h[4 + r] = h1;
+                const float d0 = (float)h0 - y0, d1 = (float)h1 - y1;    // exact
+                sdy[m] = fmaf(d0, d0, sdy[m]);
+                sdy[m] = fmaf(d1, d1, sdy[m]);
+            }
+            __builtin_nontemporal_store(h, reinterpret_cast<half8 *>(yt + (m >> 1) * kLrMatBytes + (sp * 2 + (m & 1)) * 1024 + lane * 16));
+        }
+        __syncthreads();                                                 // the next tile has been stored; this one may be overwritten
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        float v = sdy[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const long e = base + wave * kS0WaveEvals + 16 * m + (lane & 15);
+        if (lane < 16) raw[kBandFloats * e + 5] = v;
+    }
+}
+
+void launch_project(const void *X0, const void *btiles, void *Y, float *raw, const int *counters, long max_evals, hipStream_t s)
+{
+    const long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_project, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, (const char *)btiles, (char *)Y, raw, counters);
+}
+
+// One column block (16 SVs) of the 6-step sweep: 24 MFMAs; the epilogue of the PREVIOUS block's 16 elements rides between them --
+// element j's v_exp_f32 behind MFMA j (j < 16), its three VALU instructions behind MFMA j + 4 (a whole k-step later: the hazard note
+// above); the polynomial form has no exp and puts element j's five instructions behind MFMA j + 2.
+template <int FIRST, int COUNT, int VAR>
+__device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane, const half8 (&a)[kLrSteps][4], f32x4 (&acc)[4],
+                                                const f32x4 (&old)[4], float cf_old, float (&sum)[4][4],
+                                                const TileDma &dma, unsigned lane16, half8 &b, half8 &b1)
+{
+    constexpr bool CRP = VAR == SCREEN_CR_POLY;
+    static_assert(VAR == SCREEN_CR_EXP || VAR == SCREEN_CR_POLY, "the low-rank form serves the centred-remainder variants");
+    const char *bl = cur + n * 1024 + lane * 16;
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float ba2 = CRP ? cf_old * kPsiA2 : 0.0f, ba3 = CRP ? cf_old * kPsiA3 : 0.0f, ba4 = CRP ? cf_old * kPsiA4 : 0.0f, ba5 = CRP ? cf_old * kPsiA5 : 0.0f;
+    if (n == 0) b = *reinterpret_cast<const half8 *>(bl);
+    float kq[16];                                                    // exp2 results in flight (CR_EXP): at most five live at a time
+#define HAF_SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int s = 0; s < kLrSteps; s++) {
+        if (s + 1 < kLrSteps) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
+        else if (n == 0) b1 = *reinterpret_cast<const half8 *>(bl + 1024);
+        HAF_SB();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = 4 * s + i;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][i], b, s == 0 ? z4 : acc[i], 0, 0, 0);
+            HAF_SB();
+            if (s == 0 && i < COUNT) { dma_piece(dma.g[FIRST + i], dma.l[FIRST + i], lane16); HAF_SB(); }
+            if (!CRP) {
+                if (j < 16) { kq[j] = __builtin_amdgcn_exp2f(old[j >> 2][j & 3]); HAF_SB(); }
+                if (j >= 4 && j < 20) {
+                    const int e = j - 4;
+                    const float em1 = kq[e] - 1.0f;
+                    HAF_SB();
+                    const float ps = fmaf(old[e >> 2][e & 3], -kLn2f, em1);
+                    HAF_SB();
+                    sum[e >> 2][e & 3] = fmaf(cf_old, ps, sum[e >> 2][e & 3]);
+                    HAF_SB();
+                }
+            } else if (j >= 2 && j < 18) {
+                const int e = j - 2;
+                const float z = old[e >> 2][e & 3];
+                const float pt = z * z;
+                HAF_SB();
+                float ph = fmaf(z, ba5, ba4);
+                HAF_SB();
+                ph = fmaf(ph, z, ba3);
+                HAF_SB();
+                ph = fmaf(ph, z, ba2);
+                HAF_SB();
+                sum[e >> 2][e & 3] = fmaf(pt, ph, sum[e >> 2][e & 3]);
+                HAF_SB();
+            }
+        }
+        b = b1;
+    }
+#undef HAF_SB
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The sweep of the low-rank form: k_svm_screen's structure (two 4-wave workgroups per CU, 3-deep LDS-DMA ring, epilogue of a column
+// block between the MFMAs of the next, two sign-grouped sweeps, two-level coefficient sum) on 6-step images; the tail finishes the band
+// from the raw sums (lr_finish_band) before the usual decision tail.  Whole requests only (no list mode, no SV-range split).
+template <int VAR>
+__global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen_lr(const char *__restrict__ Y, const float *__restrict__ raw,
+                                                                  const float *__restrict__ nax, const char *__restrict__ svt,
+                                                                  const int *__restrict__ evalcell, const int *__restrict__ counters,
+                                                                  SvmParams p, float *__restrict__ dec, int8_t *__restrict__ labels,
+                                                                  unsigned long long *__restrict__ flag0_words, Dims d,
+                                                                  float *__restrict__ margin, CrParams crp, LrBand lb)
+{
+    constexpr bool CRP = VAR == SCREEN_CR_POLY;
+    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kLrSvTileBytes + 2 * kS0Waves * kS0WaveEvals * 4];
+    const int n_evals = counters[CNT_EVALS];
+    const long base = (long)blockIdx.x * kS0BlockEvals;
+    if (base >= n_evals) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long tile32 = (base >> 5) + 2 * wave;
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    const int np = d.sv_tile_neg, nt = d.n_sv_tiles;
+    float *pos = reinterpret_cast<float *>(lds + kS0Buffers * kLrSvTileBytes) + wave * kS0WaveEvals;
+    float *fin = pos + kS0Waves * kS0WaveEvals;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int poff[kS0WavePieces];                                         // (TileDma is sized for the 10-step form: three pieces used)
+#pragma unroll
+    for (int q = 0; q < kS0WavePieces; q++) poff[q] = (q < kLrWavePieces) ? (wave_u + kS0Waves * q) * 1024 : 0;
+    static_assert(kS0Waves * kLrWavePieces * 1024 == kLrMatBytes && kLrMatBytes + 1024 == kLrSvTileBytes, "12 image pieces + 1 tail piece");
+    auto stage3 = [&](const char *g, unsigned l) {
+        asm volatile("s_nop 4");
+#pragma unroll
+        for (int q = 0; q < kLrWavePieces; q++) dma_piece(g + poff[q], l + (unsigned)poff[q], lane16);
+    };
+    {
+        stage3(svt, lds0);
+        if (wave_u == 0) dma_piece(svt + kLrMatBytes, lds0 + kLrMatBytes, lane16);
+    }
+    if (nt > 1) {
+        const char *g1 = svt + (size_t)kLrSvTileBytes;
+        stage3(g1, lds0 + kLrSvTileBytes);
+        if (wave_u == 0) dma_piece(g1 + kLrMatBytes, lds0 + kLrSvTileBytes + kLrMatBytes, lane16);
+    }
+    half8 a[kLrSteps][4];
+    {
+        const char *xt = Y + (size_t)tile32 * kLrMatBytes;
+#pragma unroll
+        for (int s = 0; s < kLrSteps; s++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                a[s][m] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(xt + (m >> 1) * kLrMatBytes + (s * 2 + (m & 1)) * 1024 + lane * 16));
+    }
+#pragma unroll
+    for (int s = 0; s < kLrSteps; s++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) asm volatile("" : "+v"(a[s][m]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float sum[4][4], part[4][4];
+    f32x4 acc0[4], acc1[4];
+    for (int ph = 0; ph < 2; ph++) {
+        const int t_end = ph ? nt : np;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            acc1[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; r++) { sum[m][r] = 0.0f; part[m][r] = 0.0f; }
+        }
+        int fold = 0;
+        float cf_prev = 0.0f;
+        for (int t = ph ? np : 0; t < t_end; t++) {
+            const char *cur = lds + (t % kS0Buffers) * kLrSvTileBytes;
+            const int tn = (t + 2) % nt;
+            const TileDma dma = tile_dma(svt + (size_t)tn * kLrSvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kLrSvTileBytes, poff);
+            if (wave_u == 0) dma_piece(svt + (size_t)tn * kLrSvTileBytes + kLrMatBytes,
+                                       lds0 + ((t + 2) % kS0Buffers) * kLrSvTileBytes + kLrMatBytes, lane16);
+            const float *tt = reinterpret_cast<const float *>(cur + kLrMatBytes);
+            const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];
+            half8 bf0, bf1;
+            screen_block_lr<0, 2, VAR>(cur, 0, lane, a, acc0, acc1, cf_prev, sum, dma, lane16, bf0, bf1);
+            screen_block_lr<2, 1, VAR>(cur, 1, lane, a, acc1, acc0, cf0, sum, dma, lane16, bf0, bf1);
+            cf_prev = cf1;
+            if (++fold == 8) {
+                fold = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { part[m][r] += sum[m][r]; sum[m][r] = 0.0f; }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        float *dst = ph ? fin : pos;
+        f32x4 zz[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) zz[m] = acc1[m];
+        if (!CRP) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc1[m][r] = __builtin_amdgcn_exp2f(acc1[m][r]);
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float ck;
+                if (!CRP) {
+                    ck = cf_prev * fmaf(zz[m][r], -kLn2f, acc1[m][r] - 1.0f);
+                } else {
+                    const float z = zz[m][r];
+                    ck = (cf_prev * (z * z)) * fmaf(fmaf(fmaf(z, kPsiA5, kPsiA4), z, kPsiA3), z, kPsiA2);
+                }
+                float v = ck + sum[m][r];
+                v += part[m][r];
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 1, 64);
+                if ((lane & 15) == 0) dst[16 * m + 4 * (lane >> 4) + r] = v;
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long e = base + wave * kS0WaveEvals + lane;
+    const bool live = e < n_evals;
+    bool flagged = false;
+    if (live) {
+        float sc = __builtin_amdgcn_exp2f(nax[e]);
+        float4 g, g2 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        lr_finish_band(raw + kBandFloats * e, lb, g.x, g.y, g.z, g.w);
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
+        flagged = screen_tail_vals<VAR, false>((double)pos[lane], (double)fin[lane], 0.0f, e, g, g2, sc, p, crp, nullptr, evalcell, dec, labels, margin);
+    }
+    const unsigned long long bal = __ballot(flagged);
+    if (lane == 0) flag0_words[(base >> 6) + wave] = bal;
+}
+
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,
@@ -815,6 +1117,26 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
     hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, count_slot);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
                        counters_rw, also_counter, idx_list, count_slot, out_slot);
+}
+
+void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
+                          SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
+                          int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, LrBand lb,
+                          hipStream_t s, int also_counter)
+{
+    const long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
+    if (blocks <= 0) return;
+    lb.poly = variant == SCREEN_CR_POLY;
+    if (variant == SCREEN_CR_POLY)
+        hipLaunchKernelGGL(k_svm_screen_lr<SCREEN_CR_POLY>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,
+                           (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb);
+    else
+        hipLaunchKernelGGL(k_svm_screen_lr<SCREEN_CR_EXP>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,
+                           (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb);
+    const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, CNT_EVALS);
+    hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
+                       counters_rw, also_counter, (const int *)nullptr, CNT_EVALS, CNT_FLAGGED0);
 }
 
 size_t screen_part_bytes() { return (size_t)kS0MaxParts * kS0PartBlocks * kS0BlockEvals * sizeof(float4); }

@@ -1,0 +1,66 @@
+// screen_band.h -- the guard band of the LOW-RANK centred-remainder form of the screening pass (kernels.h: kLrK, LrBand).
+// Evaluated in the tail of k_svm_screen's low-rank instantiation, one evaluation per lane, from the raw sums the feature kernel
+// (k_features_serial, ScreenParams::lr) and the projection (k_project) left behind:
+//   raw = {su2, sd2, sx2, L, nu2, sdy2, 0, 0}: |fl32(p')|^2 and |p^ - fl32(p')|^2 over the slots, |p'|^2 over all attributes, the
+//   linear term, an upper bound of |p' - p_lin|^2 (p_lin: the exactly linear part of the HAF slots, which lies in range(B)), and
+//   |y^ - y32|^2 (the fp16 rounding of the projected operand, exact differences summed in fp32).
+// With p the TRUE centred operand: p = B y* + p_perp, |p_perp| <= |p - p_lin| =: nun; y_e = B^'p; the sweep computes
+// z^_n = y^.q~^_n + a_n where z_n = p.q_n = y_e.q~_n + p_perp.r_n (q~_n = (B'B^)^-1 B'q_n, r_n = (I - BB')q_n - (B^ - B)q~_n), so
+//   eps_n = z^_n - z_n = dy.q~^_n + y_e.dq~_n + a_n - p_perp.r_n,
+//   dy = y^ - y_e = (y^ - y32) + (y32 - B^'p^) + B^'(p^ - p):  |dy| <= sqrt(sdy2) + acc10 sigma(|B^|) |p^| + sigma(B^) |p^ - p|.
+// The rest is screen_finish_cr (features.hip) term by term, with four error sources instead of three:
+//   quadratic part, first order:  ln2^2 [p'N1 dy + p'(M1 B^')p + sum b_n z_n a_n + p'N2 p_perp],  N1 = Q'bQ~^, M1 = Q'b dQ~, N2 = Q'bR (signed)
+//   second order:                 ln2^2/2 sum|b_n| eps_n^2 <= 2 ln2^2 (|H~abs||dy|^2 + |D~abs||y_e|^2 + acc6^2 |y^|^2 C~qq + |Rabs| nun^2)
+//   psi3 and the exp / polynomial terms: through eps = sup|eps_n| and zmax as before.
+#pragma once
+#include "device_common.h"
+#include "feature_device.h"
+
+namespace haf {
+
+// returns false when the evaluation must never be trusted (outside the range the bounds were derived for)
+__device__ __forceinline__ void lr_finish_band(const float *raw, const LrBand &lb, float &L, float &c_abs_out, float &k_psi_out, float &cm_out)
+{
+    constexpr double kF32Acc = 326.0 * 5.9604644775390625e-08 * 1.01;
+    const double ln2 = 0.69314718056;
+    const double su2 = (double)raw[0], sd2 = (double)raw[1], sx2 = (double)raw[2], lsum = (double)raw[3], nu2 = (double)raw[4], sdy2 = (double)raw[5];
+    const double a_x = 0.5 * sx2;
+    const double un_t = sqrt_upper(sx2 * (1.0 + kF32Acc));
+    const double eta_t = kScreenEtaRel * (un_t + lb.mu_norm_t) + lb.eta_abs;
+    const double un1 = sqrt_upper(su2 * (1.0 + kF32Acc));
+    const double dn1 = sqrt_upper(sd2 * (1.0 + kF32Acc)) + 5.97e-8 * un1 + 1e-17;
+    const double eta = kScreenEtaRel * (un1 + lb.mu_norm) + lb.eta_abs;
+    const double un = un1 + eta, dn = dn1 + eta, ph = un1 + dn1;                               // |p|, |p^ - p|, |p^|
+    const double D = (kF32Acc + 6.0e-8) * a_x + un_t * eta_t + 0.5 * eta_t * eta_t + 6.0e-7;
+    const double nun = sqrt_upper(nu2 * (1.0 + kF32Acc)) + eta;                                // |p - p_lin| >= |p_perp|
+    const double dyn = sqrt_upper(sdy2 * (1.0 + kF32Acc)) + lb.acc10 * lb.sigAbsB * ph + lb.sigB * dn;   // |y^ - y_e|
+    const double yen = lb.sigB * un, yhn = yen + dyn;                                           // |y_e|, |y^|
+    const double eps = dyn * lb.qmax + yen * lb.dqmax + lb.acc6 * yhn * lb.qmax + nun * lb.rmax;
+    const double zmax = yhn * lb.qmax + eps;
+    const double zf = floor(zmax);
+    const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();
+    const double acc_sum = fmin(yhn * un * lb.Ca, lb.sQb * un * lb.sQtaa * yhn);
+    const double quad1 = ln2 * ln2 * (lb.nN1 * un * dyn + lb.nM1 * un * un + lb.acc6 * acc_sum + lb.nN2 * un * nun);
+    const double quad2 = 2.0 * ln2 * ln2 * (lb.nHabs * dyn * dyn + lb.nDabs * yen * yen + lb.acc6 * lb.acc6 * yhn * yhn * lb.Cqq + lb.nRabs * nun * nun);
+    const double cub2 = ln2 * ln2 * (p2 - 1.0) * eps * eps * lb.Babs * 1.01;
+    const double cL = ln2 * lb.gnorm * (eta + 330.0 * 5.97e-8 * un1) * 1.01 + 1.2e-7 * fabs(lsum);
+    double c_abs = quad1 + quad2 + cub2 + cL;
+    double k_psi = ln2 * eps * 1.01;
+    if (lb.poly) {
+        const double t = ln2 * zmax;
+        k_psi += 4.1 * t * t * t * t / 360.0 + 10.0 * 5.97e-8;
+        if (!(t <= 1.0)) k_psi = (double)__builtin_inff();
+    } else {
+        const double uexp = 2.4e-7;
+        k_psi += uexp;
+        c_abs += uexp * (lb.Babs + ln2 * yhn * lb.Cq1) * 1.01;
+    }
+    const double infl = 1.0 + exp2m1_upper(D);
+    L = (float)lsum;
+    c_abs_out = (float)(c_abs * infl * lb.scale * (1.0 + 1e-6));
+    k_psi_out = (float)(k_psi * infl * lb.scale * (1.0 + 1e-6));
+    cm_out = (float)(exp2m1_upper(D) * lb.scale);
+    if (!(D < 0.05) || !(a_x < 30.0) || !(zmax < 60.0) || !(c_abs == c_abs)) c_abs_out = __builtin_inff();
+}
+
+}  // namespace haf
