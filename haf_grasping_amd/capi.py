@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("HAF_LIB", os.path.join(HERE, "libhafgrasp.so"))   # H
 TESTLIB_PATH = os.environ.get("HAF_TESTLIB", os.path.join(HERE, "libhafgrasp_testing.so"))   # HAF_TESTLIB: likewise (tools/ablate_h.sh)
 
 HAF_OK, HAF_E_ARG, HAF_E_IO, HAF_E_DEVICE, HAF_E_CAPACITY, HAF_E_BUDGET, HAF_E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
-FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16, FLAG_PROBABILITY = 1, 2, 4, 8, 16
+FLAG_KEEP_DEBUG, FLAG_PROFILE, FLAG_FP32_MFMA, FLAG_SPLIT_F16, FLAG_PROBABILITY, FLAG_FULL_RANK = 1, 2, 4, 8, 16, 32
 DBG_HEIGHTS, DBG_INTEGRAL, DBG_MASK, DBG_LABELS, DBG_DECISION, DBG_TRANSFORM, DBG_SCREEN_MARGIN, DBG_PROBABILITY, DBG_GRASPSGRID = range(9)
 SHARD_ROLLS, SHARD_CLOUDS = 0, 1
 STAGES = ["upload", "bin", "integral", "mask", "features", "svm", "refine", "recheck", "vote", "download"]
@@ -104,6 +104,7 @@ def _bind(path, testing):
     L.haf_last_strict_host.argtypes = [E, C.POINTER(C.c_int64)]
     L.haf_last_exact_tiers.argtypes = [E, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.haf_screen_form.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.haf_screen_low_rank.argtypes = [E, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.haf_register_host_cloud.argtypes = [E, C.c_void_p, C.c_size_t]
     L.haf_unregister_host_cloud.argtypes = [E, C.c_void_p]
     L.haf_pcd_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_char_p,
@@ -390,7 +391,14 @@ class Engine:
         polynomial), whether the pass is on, and the undecided share of every form on the calibration scene (-1: not tried)."""
         v, a, sh = C.c_int(), C.c_int(), (C.c_double * 4)()
         self._check(self._L.haf_test_screen_state(self._h, C.byref(v), C.byref(a), sh))
-        return dict(variant=v.value & 15, tier0b=bool(v.value & 16), tier1_skipped=bool(v.value & 32), active=bool(a.value), shares=list(sh))
+        return dict(variant=v.value & 15, tier0b=bool(v.value & 16), tier1_skipped=bool(v.value & 32), low_rank=bool(v.value & 64), active=bool(a.value),
+                    shares=list(sh))
+
+    def screen_low_rank(self):
+        """haf_screen_low_rank: (tables available, rank of the HAF attributes' span, the last request's screening pass ran in the low-rank form)."""
+        a, r, u = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.haf_screen_low_rank(self._h, C.byref(a), C.byref(r), C.byref(u)))
+        return dict(available=bool(a.value), rank=r.value, last_used=bool(u.value))
 
     def set_screen_inactive(self):
         """TESTING build: switches the screening pass off as the adaptive rule does after a request every form failed on."""

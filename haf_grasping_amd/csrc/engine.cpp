@@ -75,7 +75,7 @@ void haf_destroy(haf_engine *e)
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release(); e->d_flag0b_list.release(); e->d_screen_part.release();
     e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
-    e->d_lr_btiles.release(); e->d_svt_lr.release(); e->d_negflags.release();
+    e->d_lr_btiles.release(); e->d_svt_lr.release(); e->d_iiabs.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -177,10 +177,10 @@ static int calibrate(haf_engine *e)
         for (int v = 0; v < SCREEN_VARIANTS && rc == HAF_OK; v++) {
             const double share = e->variant_share[v];
             if (share < 0.0) continue;
-            double cost = kVariantCost[v] + kUndecidedCost * share;
+            double cost = variant_cost(e, v) + kUndecidedCost * share;
             const double s_cr = e->variant_share[SCREEN_CR_EXP];
             if ((v == SCREEN_PLAIN || v == SCREEN_SUMSQ) && e->cr_available && s_cr >= 0.0 && s_cr < share)
-                cost = std::min(cost, kVariantCost[v] + 1.6 * share + kUndecidedCost * s_cr);
+                cost = std::min(cost, variant_cost(e, v) + 1.6 * share + kUndecidedCost * s_cr);
             if (cost < best_cost) { best_cost = cost; best = v; }
         }
         e->variant_forced = false;
@@ -310,6 +310,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
         if (!(e->mfma_kappa < 64.0) || !(e->mfma_kappa16 < 64.0)) { e->error = "this device's fp16 MFMA rounds far worse than the guard bands allow for (probe_mfma_rounding)"; return bail(HAF_E_DEVICE); }
     }
     if (const char *v = test_env("HAF_LARGE_EVALS")) e->large_evals = atol(v);      // experiments
+    if (e->cfg.flags & HAF_FLAG_FULL_RANK) e->lr_enabled = false;
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
     if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_GUARD2_REL") ||
         test_env("HAF_LARGE_EVALS") || test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE") || test_env("HAF_FLAG_WINDOW") ||
@@ -373,6 +374,15 @@ int haf_screen_form(const haf_engine *e, int32_t *form, int32_t *active)
     const bool on = contraction_mode(e->cfg) == MODE_SCREEN && e->screen_active && !e->prob_mode;
     if (form) *form = e->screen_variant;
     if (active) *active = on ? 1 : 0;
+    return HAF_OK;
+}
+
+int haf_screen_low_rank(const haf_engine *e, int32_t *available, int32_t *rank, int32_t *last_used)
+{
+    if (!e) return HAF_E_ARG;
+    if (available) *available = (e->lr_available && e->lr_enabled) ? 1 : 0;
+    if (rank) *rank = e->lr_rank;
+    if (last_used) *last_used = e->last_lr ? 1 : 0;
     return HAF_OK;
 }
 

@@ -309,7 +309,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
         bs.bkt_cap = e->d_bkt.p ? c.max_clouds * e->bkt_ints : 0;
         launch_bin(d_clouds, h_clouds, max_n, total_n, d_geo, e->d_heights.p, d, r_row, r_col, bucket_ok && !e->no_bucket_sort, bs, e->d_counters.p, s);
         mark(e, HAF_ST_INTEGRAL);
-        launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, e->d_inexact.p, e->d_counters.p, d, s);
+        launch_integral(e->d_heights.p, e->d_rowsum.p, e->d_ii.p, e->d_inexact.p, e->d_counters.p, d, s, e->lr_available ? e->d_iiabs.p : nullptr);
         mark(e, HAF_ST_MASK);
         launch_mask_count(e->d_ii.p, d_geo, e->d_mask.p, e->d_rowcount.p, d, s);
         launch_scan(e->d_rowcount.p, e->d_rowoff.p, e->d_brcount.p, e->d_counters.p, d, s);
@@ -342,7 +342,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             // centred-remainder form serves the model; the 10-step images go through k_project, the sweep runs on 6-step images.
             const bool lr = cr && large && e->lr_available && e->lr_enabled && !fused_pre && (long)H * W > 8192 && !reuse_operands;
             lr_used = lr;
-            if (lr) { sp_now.lr = 1; sp_now.lr_negflags = e->d_inexact.p; }
+            if (lr) { sp_now.lr = 1; sp_now.lr_negflags = e->d_inexact.p; sp_now.lr_iiabs = e->d_iiabs.p; }
             if (!reuse_operands)
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
                                 e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, sp_now, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
@@ -618,7 +618,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                     double best_cost = 1e30;
                     for (int v = 0; v < SCREEN_VARIANTS; v++) {
                         if (e->variant_share[v] < 0.0) continue;
-                        const double cost = kVariantCost[v] + kUndecidedCost * e->variant_share[v];
+                        const double cost = variant_cost(e, v) + kUndecidedCost * e->variant_share[v];
                         if (cost < best_cost) { best_cost = cost; best = v; }
                     }
                     e->screen_variant = best;

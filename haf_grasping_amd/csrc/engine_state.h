@@ -170,7 +170,7 @@ struct haf_engine {
     bool lr_always = false;
     int lr_rank = 0;                 // dimension of the HAF slots' linear span (158 for the reference's Features.txt)
     DevBuf<char> d_lr_btiles, d_svt_lr;
-    DevBuf<int> d_negflags;
+    DevBuf<double> d_iiabs;          // per (cloud, roll): sum of |height| (k_integral_totals)
     LrBand lr_band{};
     bool last_lr = false;            // the last request's screening pass ran in the low-rank form
     DevBuf<FeatDesc> d_fd_slot_cr;
@@ -258,6 +258,10 @@ namespace haf_host {
 // behind it (seed 11 of the bench generator: 5.8 ms for 378 k evaluations against 14.1 ms for 7.9 M)
 constexpr double kVariantCost[SCREEN_VARIANTS] = {1.0, 1.12, 1.10, 1.16};
 constexpr double kUndecidedCost = 8.5;
+// with the low-rank form (kernels.h: kLrK) serving the engine's full-size requests the centred-remainder forms cost less than the plain
+// kernel: measured at C5 (projection + 6-step sweep against the 10-step kernels; the feature kernel's 0.75 ms of noise bounds included)
+// CR_EXP 12.2 + 0.75 against plain 13.8 ms at 4096 SVs, CR_POLY 25.0 + 0.75 against 28.9 ms (plain equivalent) at 8964
+constexpr double kVariantCostLr[SCREEN_VARIANTS] = {1.0, 1.12, 0.94, 0.90};
 
 constexpr int kStrictSlots = 64;     // evaluations per pass of the strict tier's spread form (a few per request reach it at most)
 
@@ -265,6 +269,15 @@ constexpr size_t kCntBytes = (CNT_COUNT * sizeof(int) + 15) / 16 * 16;      // t
 
 // contraction mode: default = screening pass + three-pass refinement; HAF_FLAG_SPLIT_F16 = three passes for everything;
 // HAF_FLAG_FP32_MFMA = one fp32 MFMA pass for everything
+// does the low-rank form serve this engine's full-size requests?  (engine_request.cpp applies it per request: whole requests of at
+// least large_evals evaluations on grids that go through the parallel integral image)
+inline bool lr_typical(const haf_engine *e)
+{
+    const haf_config &c = e->cfg;
+    return e->lr_available && e->lr_enabled && (long)c.grid_h * c.grid_w > 8192 &&
+           (long)(c.grid_h - 14) * (c.grid_w - 14) * e->max_rolls >= e->large_evals;
+}
+inline double variant_cost(const haf_engine *e, int v) { return lr_typical(e) ? kVariantCostLr[v] : kVariantCost[v]; }
 enum { MODE_SCREEN = 0, MODE_SPLIT = 1, MODE_F32 = 2 };
 inline int contraction_mode(const haf_config &c)
 {

@@ -658,11 +658,16 @@ int build_tables(haf_engine *e)
                     std::vector<double> Qt((size_t)m.n_sv * KL2, 0.0), Qth((size_t)m.n_sv * KL2, 0.0), dQt((size_t)m.n_sv * KL2, 0.0), Rm((size_t)m.n_sv * K, 0.0);
                     std::vector<char> imgl((size_t)e->n_sv_tiles * kLrSvTileBytes, 0);
                     if (inv_ok) {
-                        std::vector<long double> bq((size_t)kc), qt((size_t)kc);
+                        // (fp64 from here: q~_n and r_n are DEFINED by these computed values -- z_n = y_e.q~_n + p_perp.r_n holds for any q~_n once
+                        // r_n = q_n - B q~'_n ... is formed from the same numbers; what fp64 rounding leaves in r_n is 1e-16 |q_n|, far inside rmax's margin)
+                        std::vector<double> Gid((size_t)kc * kc), bq((size_t)kc), qt((size_t)kc), Bt((size_t)KL2 * K), Bd((size_t)KL2 * K);
+                        for (size_t i = 0; i < Gid.size(); i++) Gid[i] = (double)Gi[i];
+                        for (int sl = 0; sl < K; sl++) for (int a2 = 0; a2 < KL2; a2++) { Bt[(size_t)a2 * K + sl] = Bm[(size_t)sl * KL2 + a2]; Bd[(size_t)a2 * K + sl] = Bh[(size_t)sl * KL2 + a2] - Bm[(size_t)sl * KL2 + a2]; }
+                        std::vector<double> rrow((size_t)K);
                         for (int n = 0; n < m.n_sv; n++) {
                             const double *q = Q.data() + (size_t)n * K;
-                            for (int a2 = 0; a2 < kc; a2++) { long double t = 0.0L; for (int sl = 0; sl < K; sl++) t += (long double)Bm[(size_t)sl * KL2 + a2] * (long double)q[sl]; bq[(size_t)a2] = t; }
-                            for (int a2 = 0; a2 < kc; a2++) { long double t = 0.0L; for (int b2 = 0; b2 < kc; b2++) t += Gi[(size_t)a2 * kc + b2] * bq[(size_t)b2]; qt[(size_t)a2] = t; }
+                            for (int a2 = 0; a2 < kc; a2++) { const double *bt = Bt.data() + (size_t)a2 * K; double t = 0.0; for (int sl = 0; sl < K; sl++) t += bt[sl] * q[sl]; bq[(size_t)a2] = t; }
+                            for (int a2 = 0; a2 < kc; a2++) { const double *gr = Gid.data() + (size_t)a2 * kc; double t = 0.0; for (int b2 = 0; b2 < kc; b2++) t += gr[b2] * bq[(size_t)b2]; qt[(size_t)a2] = t; }
                             const int t = slot_of[(size_t)n] / kTile, j = slot_of[(size_t)n] % kTile;
                             char *tile = imgl.data() + (size_t)t * kLrSvTileBytes;
                             double h2 = 0.0, d2 = 0.0, q2 = 0.0, r2n = 0.0;
@@ -676,15 +681,16 @@ int build_tables(haf_engine *e)
                                 h2 += hd * hd; d2 += (hd - v) * (hd - v);
                             }
                             // r_n = q_n - B (B'q_n) - (B^ - B) q~_n
+                            for (int sl = 0; sl < K; sl++) rrow[(size_t)sl] = q[sl];
+                            for (int a2 = 0; a2 < kc; a2++) {
+                                const double c1 = bq[(size_t)a2], c2 = qt[(size_t)a2];
+                                const double *bt = Bt.data() + (size_t)a2 * K, *bd = Bd.data() + (size_t)a2 * K;
+                                for (int sl = 0; sl < K; sl++) rrow[(size_t)sl] -= bt[sl] * c1 + bd[sl] * c2;
+                            }
                             for (int sl = 0; sl < K; sl++) {
-                                long double t = (long double)q[sl];
-                                for (int a2 = 0; a2 < kc; a2++) {
-                                    const double bv = Bm[(size_t)sl * KL2 + a2], bhv = Bh[(size_t)sl * KL2 + a2];
-                                    if (bv == 0.0 && bhv == 0.0) continue;
-                                    t -= (long double)bv * bq[(size_t)a2] + (long double)(bhv - bv) * qt[(size_t)a2];
-                                }
-                                Rm[(size_t)n * K + sl] = (double)t;
-                                r2n += (double)(t * t);
+                                const double t = rrow[(size_t)sl];
+                                Rm[(size_t)n * K + sl] = t;
+                                r2n += t * t;
                                 q2 += q[sl] * q[sl];
                             }
                             reinterpret_cast<float *>(tile + kLrMatBytes)[j] = 0.0f;
@@ -733,7 +739,10 @@ int build_tables(haf_engine *e)
                         lb.sigB = sigma_upper_bound(Bh.data(), K, KL2) * up;
                         lb.sigAbsB = sigma_upper_bound(Bab.data(), K, KL2) * up;
                         for (double *x : {&lb.Ca, &lb.Cq1, &lb.Cqq, &lb.Babs, &lb.qmax, &lb.dqmax, &lb.rmax}) *x *= 1.0 + 1e-9;
-                        lb.rmax += 1e-300;
+                        // (B is orthonormal and q~_n solves G q~_n = B'q_n only to fp64 roundings: what that leaves -- y*.(B'q_n - G q~_n) and
+                        // p_perp'B(B'q_n - q~_n) -- is 1e-15 of |p||q_n|: charged to the two per-SV bounds)
+                        lb.dqmax += 1e-13 * (1.0 + lb.qmax);
+                        lb.rmax += 1e-13 * (1.0 + lb.qmax) + 1e-300;
                         lb.acc10 = cp.acc_rel;
                         lb.acc6 = cp.acc_rel * (double)kLrSteps / (double)(kS0K / 32);
                         lb.gnorm = cp.cr_gnorm;
@@ -1032,6 +1041,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_heights.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rowsum.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_inexact.alloc(B * R);
+    ok &= hipSuccess == e->d_iiabs.alloc(B * R);
     ok &= hipSuccess == e->d_ii.alloc(B * R * (H + 1) * (W + 1));
     ok &= hipSuccess == e->d_mask.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_rowcount.alloc(B * R * H);

@@ -212,7 +212,7 @@ int haf_test_i8_mfma(const signed char *a, const signed char *b, int *c)
 int haf_test_screen_state(haf_engine *e, int *variant, int *active, double *shares /* [4] */)
 {
     if (!e) return HAF_E_ARG;
-    if (variant) *variant = e->screen_variant | (e->use_t0b ? 16 : 0) | (e->t1_skip ? 32 : 0);
+    if (variant) *variant = e->screen_variant | (e->use_t0b ? 16 : 0) | (e->t1_skip ? 32 : 0) | (e->last_lr ? 64 : 0);
     if (active) *active = e->screen_active ? 1 : 0;
     if (shares) for (int i = 0; i < SCREEN_VARIANTS; i++) shares[i] = e->variant_share[i];
     return HAF_OK;

@@ -118,14 +118,19 @@ __device__ __forceinline__ double screen_attribute(const Src &src, const FeatDes
 // a - b by Sterbenz (a <= 2b) or b = 0; then s2 = s1 - c = R - d and s3 = R are multiples of ulp(d) below d when R < d
 // (c = d = 0: nothing to round).  A SHAF slot (pad2 = 0) is passed through as it is and needs none.
 // what the three roundings of ((a - b) - c) + d can add up to when the region does not pass the exactness test: u (|s1| + |s2| + |R|)
-// (each operation is off by at most half an ulp of its own result) -- 0 when it passes.  neg: the grid holds a negative height.
-__device__ __forceinline__ float region_round_bound(float a, float b, float c, float d, float s1, float s2, float R, bool neg)
+// (each operation is off by at most half an ulp of its own result) -- 0 when it passes.
+// The test is LOCAL -- on the four corners and the computed sum alone, no assumption about the rest of the grid: a - b is exact by
+// Sterbenz (b/2 <= a <= 2b) or with b = 0; a, b, c >= d >= 0 makes a, b, c and therefore s1 and s2 = s1 - c = R - d multiples of
+// ulp(d), and 0 <= R < d keeps |s2| <= d and s3 = R below 2^24 ulp(d): representable.  (Were the arithmetic inexact the computed R
+// could not pass 0 <= R < d with a true R outside: s2 = fl(s1 - c) keeps the sign of s1 - c.)
+__device__ __forceinline__ float region_round_bound(float a, float b, float c, float d, float s1, float s2, float R)
 {
-    const bool exact = !neg && (a <= 2.0f * b || b == 0.0f) && ((c == 0.0f && d == 0.0f) || R < d);
-    return exact ? 0.0f : 6.1e-8f * (fabsf(s1) + fabsf(s2) + fabsf(R));
+    const bool e1 = (a <= 2.0f * b && b <= 2.0f * a) || b == 0.0f;
+    const bool e2 = (c == 0.0f && d == 0.0f) || (d >= 0.0f && fminf(fminf(a, b), c) >= d && R >= 0.0f && R < d);
+    return (e1 && e2) ? 0.0f : 6.1e-8f * (fabsf(s1) + fabsf(s2) + fabsf(R));
 }
 template <class Src>
-__device__ __forceinline__ double screen_attribute_lr(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st, float &nb, bool neg)
+__device__ __forceinline__ double screen_attribute_lr(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st, float &nb)
 {
     if (f.shaf) { nb = 0.0f; return screen_attribute(src, f, st); }
     float rv = 0.0f, ee = 0.0f, esum = 0.0f;
@@ -136,7 +141,7 @@ __device__ __forceinline__ double screen_attribute_lr(const Src &src, const Feat
             const float a = src.corner(f, k, 0), b = src.corner(f, k, 1), c = src.corner(f, k, 2), d = src.corner(f, k, 3);
             const float s1 = __fsub_rn(a, b), s2 = __fsub_rn(s1, c);
             const float R = __fadd_rn(s2, d);
-            esum = fmaf(fabsf(f.w[k]), region_round_bound(a, b, c, d, s1, s2, R, neg), esum);
+            esum = fmaf(fabsf(f.w[k]), region_round_bound(a, b, c, d, s1, s2, R), esum);
             const float p = __fmul_rn(f.w[k], R);
             ee += fmaf(f.w[k], R, -p);
             rv = __fadd_rn(rv, p);
@@ -173,7 +178,7 @@ __device__ __forceinline__ ScrDescK constant_ptr(const ScrDesc *p) { return (Scr
 // products and of their sum (<= 3.1 u sum|w_k R_k|), valid when the region sums themselves are exact (k_features_serial checks that
 // per wave), times |scr_mul| (ScrDesc::pad, rounded up; 0 for a SHAF slot, which is passed through as it is).
 template <int NB>
-__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2, bool neg = false)
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2)
 {
     float c[4][8];
     unsigned adr[4][8];                               // all descriptor words first: a volatile asm pins what follows it
@@ -209,8 +214,8 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
             const float e0 = fmaf(sd[q].w[0], R0, -r0), e1 = fmaf(sd[q].w[1], R1, -r1);
             float ar = 0.0f;                               // NB == 2: a wave that did not pass the exactness test as a whole (features.hip)
             if (NB == 2)
-                ar = fabsf(sd[q].w[0]) * region_round_bound(c[q][0], c[q][1], c[q][2], c[q][3], s10, s20, R0, neg) +
-                     fabsf(sd[q].w[1]) * region_round_bound(c[q][4], c[q][5], c[q][6], c[q][7], s11, s21, R1, neg);
+                ar = fabsf(sd[q].w[0]) * region_round_bound(c[q][0], c[q][1], c[q][2], c[q][3], s10, s20, R0) +
+                     fabsf(sd[q].w[1]) * region_round_bound(c[q][4], c[q][5], c[q][6], c[q][7], s11, s21, R1);
             const float nbq = sd[q].pad * (fabsf((float)q4 - v) + fabsf(e0 + e1) * 1.000001f + 1.3e-7f * fabsf(v) + ar);
             nu2 = fmaf(nbq, nbq, nu2);
             // (the sum is tied to the sequence of the volatile LDS reads: left to float, the temporaries of eight slots stay alive until
@@ -230,7 +235,7 @@ __device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (S
 // (NQ slots per call: two in the plain form; ONE with the low-rank form's noise bound, whose temporaries would otherwise cost the
 // kernel 48 registers -- a wave of occupancy -- for the four groups of 40 that take this path)
 template <int NB, int NQ>
-__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud, float &nu2, bool neg = false)
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud, float &nu2)
 {
     float c[NQ][12];
     unsigned adr[NQ][12];
@@ -259,7 +264,7 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
             const float s1 = __fsub_rn(c[q][4 * k], c[q][4 * k + 1]), s2 = __fsub_rn(s1, c[q][4 * k + 2]);
             Rk[k] = __fadd_rn(s2, c[q][4 * k + 3]);
             r[k] = __fmul_rn(sd[q].w[k], Rk[k]);
-            if (NB == 2) ar = fmaf(fabsf(sd[q].w[k]), region_round_bound(c[q][4 * k], c[q][4 * k + 1], c[q][4 * k + 2], c[q][4 * k + 3], s1, s2, Rk[k], neg), ar);
+            if (NB == 2) ar = fmaf(fabsf(sd[q].w[k]), region_round_bound(c[q][4 * k], c[q][4 * k + 1], c[q][4 * k + 2], c[q][4 * k + 3], s1, s2, Rk[k]), ar);
         }
         float v;
         if (sd[q].shaf) {                                              // wave-uniform

@@ -344,7 +344,6 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
     bool fastwave = false;
     unsigned band = 0;
     bool lr_exact = false, lr_neg = false;
-    float lr_M = 0.0f;
     if (MODE == XMODE_SCREEN && !idx_list) {
         const int lane = threadIdx.x & 63;
         const int cell = (e < n_evals) ? evalcell[e] : -1;
@@ -372,16 +371,17 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 const unsigned long long colok1 = __ballot(lane >= 14 || vb[14 * kBandPitch + 64 + lane] <= 2.0f * vb[64 + lane]) & 0x3fffull;
                 const unsigned long long mine = (lane == 0) ? colok0 : ((colok0 >> lane) | (colok1 << (64 - lane)));
                 bool ok = (mine & 0x7fffull) == 0x7fffull;
-                const float T = __fsub_rn(__fsub_rn(br, tr), __fsub_rn(bl, tl));      // the window's total (exact under the first condition; 1e-6 to spare)
+                // the window's total, rounded up past its own three roundings
+                const float tA = __fsub_rn(br, tr), tB = __fsub_rn(bl, tl);
+                const float T = (__fsub_rn(tA, tB) + 2.0e-7f * (fabsf(tA) + fabsf(tB))) * 1.0001f;
                 // every region's d = II[x1][y1] is at least the window's first corner -- or, for the window that starts in column 0 of the
                 // integral image (which is all zeros: a region with y1 = 0 has c = d = 0 and nothing to round), its second
                 const int broll = cell0 / (d.H * d.W);
                 const int col0 = cell0 - (cell0 / d.W) * d.W - 7;                      // first column of the band
                 const float dmin = (col0 == 0 && lane == 0) ? vb[1] : tl;
-                ok = ok && T * 1.000001f < dmin;
+                ok = ok && T < dmin;
                 lr_neg = (sp.lr_negflags[broll] & 2) != 0;
                 lr_exact = __ballot(ok) == ~0ull && !lr_neg;
-                lr_M = vb[14 * kBandPitch + 77];           // the band's largest corner (monotone integral image)
                 asm volatile("" ::: "memory");
             }
         }
@@ -408,7 +408,6 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         ScreenSums2 acc2{};
         float sx = 0.0f;
         const bool lr_nb = LR && fastwave && lr_exact;    // wave-uniform: every region sum of the wave is exact
-        if (LR && !fastwave) lr_neg = (sp.lr_negflags[evalcell[e_src] / (d.H * d.W)] & 2) != 0;   // per lane
         float nu2 = 0.0f;
         for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
             double ud[8];
@@ -422,11 +421,11 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 }
             } else if (LR && fastwave) {                  // a wave with regions that may round: bounded region by region
                 if ((sp.fast_groups >> g) & 1) {
-                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2, lr_neg);
-                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2, lr_neg);
+                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2);
+                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) screen_pair3<2, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2, lr_neg);
+                    for (int q = 0; q < 8; q++) screen_pair3<2, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2);
                 }
             } else if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
                 screen_quad(band, constant_ptr(sp.sd) + g * 8, st, ud);
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 for (int q = 0; q < 8; q++) {
                     const FeatDesc &F = fd[g * 8 + q];
                     float nbq = 0.0f;
-                    ud[q] = F.skip ? 0.0 : screen_attribute_lr(SrcBuf<true>{iir, w0}, F, st, nbq, lr_neg);
+                    ud[q] = F.skip ? 0.0 : screen_attribute_lr(SrcBuf<true>{iir, w0}, F, st, nbq);
                     nu2 = fmaf(nbq, nbq, nu2);
                 }
             } else {
@@ -462,12 +461,8 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         float band[kBandFloats], nax;
         if (LR) {
             // raw sums; the part of the slots' linear map that the fp64 roundings of the basis leave outside range(B): lr_rho per unit of the largest corner
-            if (!fastwave) {
-                // (this lane's own window: largest corner = its bottom-right one, the integral image being monotone)
-                lr_M = fabsf(ii_load<false>(iir, w0, 14 * (d.W + 1) + 14));
-                if (lr_neg) nu2 = __builtin_inff();            // (not monotone: the corner need not be the largest; such a grid is left to the tiers behind)
-            }
-            if (fastwave && lr_neg) nu2 = __builtin_inff();
+            // (no corner of the integral image exceeds the sum of |height| over its grid: prestages.hip, k_integral_totals)
+            const float lr_M = (float)sp.lr_iiabs[evalcell[e_src] / (d.H * d.W)] * 1.0001f;
             const float rho = (float)sp.lr_rho * lr_M * 1.000001f;
             nu2 = fmaf(rho, rho, nu2);
             const float sx2 = acc.su2 + sx;                                   // (one more fp32 rounding of |p'|^2: inside kF32Acc's 326)

@@ -470,7 +470,7 @@ __device__ __forceinline__ float final_height(int key)
 // so one column sum per thread (coalesced) and one scan of the band's 512-wide vector instead of sixteen row scans.  Every
 // addition is checked: the totals are then the true values whatever the association.
 __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__restrict__ hk, double *__restrict__ band_tot,
-                                                               int *__restrict__ inexact_flags, Dims d)
+                                                               int *__restrict__ inexact_flags, double *__restrict__ abs_total, Dims d)
 {
     __shared__ double wsum[kIThreads / 64];
     __shared__ double carry;
@@ -482,6 +482,7 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row0 = band * kIBandRows;
     bool inexact = false, negative = false;
+    double habs = 0.0;                                    // sum of |height| over this thread's cells: no corner of the integral image exceeds the grid's total
     if (tid == 0) carry = 0.0;
     __syncthreads();
     for (int c0 = 0; c0 < W; c0 += kIThreads) {
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
                 if (row0 + r < H) {
                     const float hh = final_height(kr[r]);
                     negative |= !(hh >= 0.0f);            // (also a NaN height)
+                    habs += (double)fabsf(hh);
                     v = add_checked(v, (double)hh, inexact);
                 }
         }
@@ -519,6 +521,11 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
     // bit 1: the grid holds a negative height (heights in (-0.99, 0) survive generate_grid, server.cpp:522-528): the integral image is
     // then not monotone and the exactness argument of the low-rank screening form (features.hip: k_features_serial, LR) does not hold
     if (__syncthreads_or(negative) && tid == 0) atomicOr(&inexact_flags[br], 2);
+    if (abs_total) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) habs += __shfl_xor(habs, o, 64);
+        if (lane == 0) atomicAdd(&abs_total[br], habs);   // (order of the additions differs from run to run: an upper bound with 1e-4 to spare is all that is read)
+    }
 }
 
 // Row sums of the band (wave scans), carry = totals of the bands above, column scan inside the band, fp32 store (601); also
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256) void k_integral_small(int *hk, float *__restri
     }
 }
 
-void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s)
+void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s, double *abs_total)
 {
     if (d.H * d.W <= kISmallCells) {
         const int pitch = ((d.W + 15) / 16) * 16 + 1;
@@ -669,7 +676,8 @@ void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int
     // scratch of the sequential fallback
     const int n_bands = (d.H + kIBandRows - 1) / kIBandRows;
     (void)hipMemsetAsync(inexact_flags, 0, (size_t)d.B * d.R * sizeof(int), s);
-    hipLaunchKernelGGL(k_integral_totals, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, inexact_flags, d);
+    if (abs_total) (void)hipMemsetAsync(abs_total, 0, (size_t)d.B * d.R * sizeof(double), s);
+    hipLaunchKernelGGL(k_integral_totals, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, inexact_flags, abs_total, d);
     hipLaunchKernelGGL(k_integral_band, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
     // sequential order for the grids whose parallel sums were not exact (practically never; the kernels exit at once otherwise)
     hipLaunchKernelGGL(k_integral_seq, dim3(d.B * d.R), dim3(256), 0, s, hk, rowsum, ii, inexact_flags, counters, d);

@@ -945,8 +945,12 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
 // The sweep of the low-rank form: k_svm_screen's structure (two 4-wave workgroups per CU, 3-deep LDS-DMA ring, epilogue of a column
 // block between the MFMAs of the next, two sign-grouped sweeps, two-level coefficient sum) on 6-step images; the tail finishes the band
 // from the raw sums (lr_finish_band) before the usual decision tail.  Whole requests only (no list mode, no SV-range split).
+#ifndef HAF_LR_WGS
+#define HAF_LR_WGS 2
+#endif
+constexpr bool kLrTwoLevel = HAF_LR_WGS < 3;   // three workgroups per CU need the sixteen registers of the second summation level (its band term is relative to S_psi: small either way)
 template <int VAR>
-__global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen_lr(const char *__restrict__ Y, const float *__restrict__ raw,
+__global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(const char *__restrict__ Y, const float *__restrict__ raw,
                                                                   const float *__restrict__ nax, const char *__restrict__ svt,
                                                                   const int *__restrict__ evalcell, const int *__restrict__ counters,
                                                                   SvmParams p, float *__restrict__ dec, int8_t *__restrict__ labels,
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen_lr(const char *
             screen_block_lr<0, 2, VAR>(cur, 0, lane, a, acc0, acc1, cf_prev, sum, dma, lane16, bf0, bf1);
             screen_block_lr<2, 1, VAR>(cur, 1, lane, a, acc1, acc0, cf0, sum, dma, lane16, bf0, bf1);
             cf_prev = cf1;
-            if (++fold == 8) {
+            if (kLrTwoLevel && ++fold == 8) {
                 fold = 0;
 #pragma unroll
                 for (int m = 0; m < 4; m++)
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen_lr(const char *
                     ck = (cf_prev * (z * z)) * fmaf(fmaf(fmaf(z, kPsiA5, kPsiA4), z, kPsiA3), z, kPsiA2);
                 }
                 float v = ck + sum[m][r];
-                v += part[m][r];
+                if (kLrTwoLevel) v += part[m][r];
                 v += __shfl_xor(v, 8, 64);
                 v += __shfl_xor(v, 4, 64);
                 v += __shfl_xor(v, 2, 64);
@@ -1072,6 +1076,7 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen_lr(const char *
     const long e = base + wave * kS0WaveEvals + lane;
     const bool live = e < n_evals;
     bool flagged = false;
+    if (!kLrTwoLevel) p.guard_acc0 = p.guard_acc0_s;                  // single-level coefficient sum: (2 tiles + 14) u instead of (34 + tiles / 8) u
     if (live) {
         float sc = __builtin_amdgcn_exp2f(nax[e]);
         float4 g, g2 = float4{0.0f, 0.0f, 0.0f, 0.0f};

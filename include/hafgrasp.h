@@ -74,6 +74,8 @@ typedef struct haf_config {
                                         show_predicted_gps reads them -- each masked cell takes the prediction of the masked cell
                                         before it -- and the fp32 vote with an int topval.  Needs a model with probA/probB
                                         (svm-train -b 1).  Every decision value comes from the strict tier: complete, not fast */
+#define HAF_FLAG_FULL_RANK  32u      /* the screening pass never runs in its low-rank form (haf_screen_low_rank): same labels; for A/B
+                                      * measurements and for a deployment that prefers the ten-step kernels it has run so far          */
 
 /* GraspInput (reference msg/GraspInput.msg:3-15) minus the cloud and the frame id: the cloud is passed
  * separately, already in the base frame (server.cpp:316). */
@@ -276,6 +278,12 @@ int haf_model_info(const haf_engine *e, int32_t *n_sv, int32_t *dim, int32_t *n_
  * exp / the polynomial epilogue (models with a large C, whose decisions are 1e-5..1e-8 of sum|coef|K); *active = 0 when no form can
  * decide enough and every evaluation takes the three-pass kernel.  Labels are identical in every case; for reporting only. */
 int haf_screen_form(const haf_engine *e, int32_t *form, int32_t *active);
+
+/* The low-rank form of the centred-remainder screening pass (round 4): the HAF attributes are linear functionals of the 15x15 window
+ * (fv.cpp:141-199) spanning *rank dimensions (158 for the reference's Features.txt), so whole requests on large grids are swept on a
+ * projected operand of rank + SHAF slots <= 192 instead of 320.  *available: the engine has the tables; *last_used: the last request's
+ * screening pass ran in this form.  Labels are identical in every case; for reporting only. */
+int haf_screen_low_rank(const haf_engine *e, int32_t *available, int32_t *rank, int32_t *last_used);
 
 /* PCD v0.7 reader (ascii / binary / binary_compressed; pcl::io::loadPCDFile in client.cpp:141).
  * Returns a malloc'ed packed xyz array (free with haf_free) and the point count. */

@@ -65,7 +65,8 @@ DEC_REL_SCREEN = 2.0 ** -8
 TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EVALS", "HAF_NO_FAST_GROUPS", "HAF_FLAG_WINDOW",
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
-              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS")
+              "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS",
+              "HAF_NO_LR")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -785,6 +786,58 @@ def test_sv_range_split_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
         c = eng.last_counts()
         assert 0 < c["n_rechecked"] < c["n_refined"] < c["n_evals"], c
     eng.close()
+
+
+def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
+    """Round 4: the 299 HAF slots are linear functionals of the 15 x 15 window (fv.cpp:141-199) spanning 158 dimensions, so whole requests
+    on large grids are swept on a projected operand (k_project: y = fp16(B'p); k_svm_screen_lr: 6 k-steps instead of 10) and the band
+    carries what the projection drops -- the "%.4g" rounding and the fp32 roundings of the reference's feature arithmetic, bounded per
+    evaluation -- and the rounding of y.  Against the oracle, stage by stage, on a 128 x 128 grid with rolled (partly empty) grids, both
+    centred-remainder forms, the fast and the general feature paths, a cloud with negative heights (the integral image is not
+    monotone: no wave passes the exactness test of the region sums as a whole, every region is tested on its own four corners) -- and
+    against the ten-step form (HAF_FLAG_FULL_RANK): the same labels, and about as many evaluations left undecided."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    monkeypatch.setenv("HAF_LARGE_EVALS", "1")                 # every request takes the thread-per-evaluation feature kernel
+    G = 128
+    f, r = _files(data_dir)
+    rnd = str(tmp_path / "rand300.model")
+    models.write_random_model(rnd, 300, seed=3, balanced=True)
+    clu = str(tmp_path / "clustered260.model")
+    models.write_clustered_model(clu, 260, seed=5)
+    xyz = models.synthetic_cloud(grid=G, k=2, seed=4)
+    neg = xyz.copy()
+    cells = np.arange(0, G * G, 53)                           # both points of every 53rd cell (the cloud holds the cells' points pairwise)
+    neg[2 * cells, 2] = neg[2 * cells + 1, 2] = -0.4           # heights in (-0.99, 0) survive generate_grid (server.cpp:522-528)
+    cfg = dict(n_rolls=4, roll_step_deg=25, grid_h=G, grid_w=G, max_points=2 * G * G)
+    inp = dict(grasp_area_length_x=G, grasp_area_length_y=G)
+    stats = {}
+    for model, v in ((rnd, 2), (clu, 3)):
+        o = O.Oracle(f, r, model)
+        monkeypatch.setenv("HAF_SCREEN_VARIANT", str(v))
+        left = {}
+        for name, cloud, flags, nofast in (("low-rank", xyz, 0, False), ("full-rank", xyz, capi.FLAG_FULL_RANK, False), ("low-rank/general groups", xyz, 0, True),
+                                           ("low-rank/negative heights", neg, 0, False)):
+            if nofast:
+                monkeypatch.setenv("HAF_NO_FAST_GROUPS", "1")
+            else:
+                monkeypatch.delenv("HAF_NO_FAST_GROUPS", raising=False)
+            eng = make_engine(data_dir, model, mode=flags, testing=True, **cfg)
+            lr = eng.screen_low_rank()
+            assert lr["available"] == (flags == 0) and lr["rank"] == 158, lr
+            compare_full(eng, o, cloud, cfg, inp, check_dec=False)
+            lr = eng.screen_low_rank()
+            assert lr["last_used"] == (flags == 0), (name, lr)
+            c = eng.last_counts()
+            left[name] = c["n_refined"]
+            assert c["n_refined"] <= c["n_evals"], (name, c)
+            eng.close()
+        # the projected operand leaves about as much undecided as the ten-step form (the borders of the grid and of the rolled cloud
+        # get a wider band)
+        assert left["low-rank"] <= 1.5 * left["full-rank"] + 0.02 * c["n_evals"], left
+        assert left["low-rank/general groups"] <= 1.5 * left["full-rank"] + 0.02 * c["n_evals"], left
+        assert left["low-rank/negative heights"] <= 0.25 * c["n_evals"], left
+        stats["form%d" % v] = left
+    STATS["low_rank_undecided"] = stats
 
 
 @pytest.mark.parametrize("t0b,skip", [(0, 0), (1, 0), (1, 1), (0, 1)])

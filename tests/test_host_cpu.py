@@ -566,3 +566,25 @@ def test_ros_adapter_translation_unit_parses():
     src = open(os.path.join(root, "ros_shim", "calc_grasppoints_action_server_hip.cpp")).read()
     for needle in ("on_grid", "preempted", "setPreempted", "visualization_marker_array", "run_goal"):
         assert needle in src
+
+
+def test_haf_attributes_span_158_dimensions(data_dir):
+    """What the low-rank form of the screening pass (kernels.h: kLrK) rests on: the 302 HAF rows of the reference's Features.txt are
+    linear functionals of the 225 corners of the 15 x 15 integral-image window (fv.cpp:155-164: sums of w * (A - B - C + D)) and span
+    158 dimensions; with the 21 SHAF rows (not linear: fv.cpp:187-191) that is 179 <= 192 operand slots."""
+    rows = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(data_dir, "Features.txt"))]
+    rows = [q for q in rows if len(q) >= 20]
+    assert len(rows) == 323
+    A = np.zeros((302, 225))
+    for a, q in enumerate(rows[:302]):
+        reg = [int(x) for x in q[:16]]
+        w = [float(np.float32(float(x))) for x in q[16:19]] + [0.0]          # the 4th weight is never assigned (CHaarFeature.cpp:56-60)
+        for k in range(4):
+            x1, x2, y1, y2 = reg[4 * k:4 * k + 4]
+            if w[k] == 0 or x2 < x1 or y2 < y1 or (x2 == 0 and y2 == 0):
+                continue
+            for (rr, cc, sg) in ((x2 + 1, y2 + 1, 1), (x1, y2 + 1, -1), (x2 + 1, y1, -1), (x1, y1, 1)):
+                A[a, rr * 15 + cc] += sg * w[k]
+    sv = np.linalg.svd(A, compute_uv=False)
+    assert int((sv > 1e-9 * sv[0]).sum()) == 158
+    assert sv[157] / sv[0] > 1e-4 and sv[158] / sv[0] < 1e-12
