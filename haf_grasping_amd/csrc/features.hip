@@ -310,12 +310,14 @@ __device__ __forceinline__ void i8_store(float *X, long e, int g, const unsigned
 // workgroups for C5).  Small requests use k_features below.
 // LR (screening form only; kernels.h: kLrK, ScreenParams::lr): the wave also sums nu2 >= |p' - p_lin|^2 over the HAF slots and the
 // kernel leaves the RAW sums {su2, sd2, sx2, L, nu2} where the finished band would go (k_project adds |y^ - y32|^2, the sweep's tail
-// finishes the band: screen_band.h).  nu2 is finite only for a wave whose region sums are provably EXACT in the reference's own order
-// ((a - b) - c) + d (fv.cpp:161-162): no negative height in the grid (integral image monotone, region sums R >= 0), bottom row of
-// the band <= 2 x its top row in every column (a - b exact by Sterbenz), and the window's total <= its top-left corner (then
-// |s2| = d - R <= d and s3 = R <= d are multiples of ulp(d) below 2^24 ulp(d): representable).  Such a wave's feature differs from
-// the exactly linear functional only by the roundings of the products w_k R_k and of their sum; every other wave (the borders of
-// the grid, waves that are not a run of 64 neighbours) gets nu2 = inf and is left to the tiers behind.
+// finishes the band: screen_band.h).  Per slot the bound is the "%.4g" rounding as it happened, the products' rounding errors exactly
+// and the sums' roundings (feature_device.h: screen_quad / screen_pair3 / screen_attribute_lr), plus, for a region whose sum is not
+// provably EXACT in the reference's own order ((a - b) - c) + d (fv.cpp:161-162), the three roundings of that order.  Three paths,
+// wave-uniform: (A) a run of 64 neighbours whose windows pass the exactness test AS A WHOLE -- no negative height in the grid (integral
+// image monotone), bottom row of the band <= 2 x its top row in each of the lane's 15 columns (a - b exact by Sterbenz), the window's
+// total below its top-left corner (then |s2| = d - R <= d and s3 = R are multiples of ulp(d) below 2^24 ulp(d)) -- pays three
+// instructions per slot; (B) any other run of neighbours tests every region on its own four corners (region_round_bound); (C) a wave
+// that is not a run of neighbours does the same through the per-lane loads.
 template <int MODE, bool LR>
 __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
