@@ -882,6 +882,14 @@ void launch_project(const void *X0, const void *btiles, void *Y, float *raw, con
     hipLaunchKernelGGL(k_project, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, (const char *)btiles, (char *)Y, raw, counters);
 }
 
+#ifndef HAF_LR_WGS
+#define HAF_LR_WGS 2
+#endif
+#ifndef HAF_LR_EXPLAG
+#define HAF_LR_EXPLAG 4
+#endif
+constexpr int kLrExpLag = HAF_LR_EXPLAG;        // MFMAs between an element's v_exp_f32 and its first consumer (>= 2: ten instructions)
+constexpr bool kLrTwoLevel = HAF_LR_WGS < 3;   // three workgroups per CU need the sixteen registers of the second summation level (its band term is relative to S_psi: small either way)
 // One column block (16 SVs) of the 6-step sweep: 24 MFMAs; the epilogue of the PREVIOUS block's 16 elements rides between them --
 // element j's v_exp_f32 behind MFMA j (j < 16), its three VALU instructions behind MFMA j + 4 (a whole k-step later: the hazard note
 // above); the polynomial form has no exp and puts element j's five instructions behind MFMA j + 2.
@@ -912,8 +920,8 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
             if (s == 0 && i < COUNT) { dma_piece(dma.g[FIRST + i], dma.l[FIRST + i], lane16); HAF_SB(); }
             if (!CRP) {
                 if (j < 16) { kq[j] = __builtin_amdgcn_exp2f(old[j >> 2][j & 3]); HAF_SB(); }
-                if (j >= 4 && j < 20) {
-                    const int e = j - 4;
+                if (j >= kLrExpLag && j < 16 + kLrExpLag) {
+                    const int e = j - kLrExpLag;
                     const float em1 = kq[e] - 1.0f;
                     HAF_SB();
                     const float ps = fmaf(old[e >> 2][e & 3], -kLn2f, em1);
@@ -945,10 +953,6 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
 // The sweep of the low-rank form: k_svm_screen's structure (two 4-wave workgroups per CU, 3-deep LDS-DMA ring, epilogue of a column
 // block between the MFMAs of the next, two sign-grouped sweeps, two-level coefficient sum) on 6-step images; the tail finishes the band
 // from the raw sums (lr_finish_band) before the usual decision tail.  Whole requests only (no list mode, no SV-range split).
-#ifndef HAF_LR_WGS
-#define HAF_LR_WGS 2
-#endif
-constexpr bool kLrTwoLevel = HAF_LR_WGS < 3;   // three workgroups per CU need the sixteen registers of the second summation level (its band term is relative to S_psi: small either way)
 template <int VAR>
 __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(const char *__restrict__ Y, const float *__restrict__ raw,
                                                                   const float *__restrict__ nax, const char *__restrict__ svt,

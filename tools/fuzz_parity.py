@@ -85,12 +85,20 @@ def main():
                     help="every third model with random probA/probB, served in the probability-output mode (HAF_FLAG_PROBABILITY)")
     ap.add_argument("--big", action="store_true", help="also grids beyond 128 x 128 (bucket-sorted binning, banded integral "
                                                        "image, large-grid vote) and models of a few thousand support vectors")
+    ap.add_argument("--low-rank", action="store_true",
+                    help="round 4: grids of more than 8192 cells, every request through the thread-per-evaluation feature kernel (testing build: "
+                         "HAF_LARGE_EVALS=1) and the default-mode models pinned to one of the two centred-remainder forms, so that the screening "
+                         "pass runs in its LOW-RANK form (k_project + k_svm_screen_lr); the summary counts the requests it served")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"))
     a = ap.parse_args()
+    if a.low_rank:
+        os.environ["HAF_LARGE_EVALS"] = "1"
+        os.environ["HAF_NO_DIRECT"] = "1"
     rng = np.random.RandomState(a.seed)
     tmp = tempfile.mkdtemp(prefix="haf_fuzz_")
     t0 = time.time()
     done, evals, by_mode, by_model, failure = 0, 0, {}, {}, None
+    lr_cases = lr_evals = lr_left = 0               # requests whose screening pass ran in the low-rank form, their evaluations, what it left undecided
     by_form = {}                                    # default mode: which form of the screening pass served the model (haf_screen_form)
     mode_list = [(capi.FLAG_FP32_MFMA, "f32mfma"), (capi.FLAG_SPLIT_F16, "splitf16"), (0, "screen")]
     dec_stats = {n: dict(max_err_over_S=0.0, max_abs_err=0.0, values=0, outside_in_range_bound=0) for _, n in mode_list}
@@ -100,6 +108,9 @@ def main():
         mi += 1
         orc = O.Oracle(os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_allfeatures"), path)
         sizes = [(56, 56), (56, 56), (64, 64), (61, 61), (96, 96)] + ([(130, 130), (160, 160), (200, 200)] if a.big else [])
+        if a.low_rank:
+            sizes = [(96, 96), (100, 91), (130, 130), (160, 160)] + ([(200, 200), (256, 256)] if a.big else [])
+            os.environ["HAF_SCREEN_VARIANT"] = str(2 + (mi % 2))
         H, W = sizes[rng.randint(len(sizes))]
         n_rolls, step = [(12, 15), (5, 36), (7, 25), (3, 60), (20, 9)][rng.randint(5)]
         mode, mname = mode_list[mi % 3] if mi % 2 else mode_list[2]           # two thirds of the models through the default path
@@ -136,6 +147,10 @@ def main():
                     continue
                 got, want = T.compare_full(eng, orc, xyz, dict(n_rolls=n_rolls, roll_step_deg=step, grid_h=H, grid_w=W), kw,
                                            check_dec=False)
+                if mode == 0 and eng.screen_low_rank()["last_used"]:
+                    lr_cases += 1
+                    lr_evals += int(want["n_evals"])
+                    lr_left += int(eng.last_counts()["n_refined"])
                 # decision values: recorded, not gated -- the tests' bound (2^-20 S, 2^-8 S for screened values) is for attributes
                 # inside the svm-scale range, and these requests leave it on purpose (steep approach vectors, far centres); the
                 # engine's own band grows with |x|^2, which is why the LABELS above are identical all the same
@@ -168,7 +183,8 @@ def main():
         print("[%6.1f s] %4d cases, %9d evaluations compared; last model: %s, %dx%d, %d rolls of %d deg, %s (%s)"
               % (time.time() - t0, done, evals, what, H, W, n_rolls, step, mname, form), flush=True)
     summary = dict(seed=a.seed, cases=done, evaluations_compared=evals, seconds=round(time.time() - t0, 1), by_mode=by_mode,
-                   by_model=by_model, by_screening_form=by_form, mismatches=0 if failure is None else 1, failure=failure, decision_values=dec_stats,
+                   by_model=by_model, by_screening_form=by_form,
+                   low_rank=dict(requests=lr_cases, evaluations=lr_evals, left_undecided=lr_left), mismatches=0 if failure is None else 1, failure=failure, decision_values=dec_stats,
                    compared="heights, integral image, mask, labels, vote grid, per-roll winners, overall grasp (bit-exact / "
                             "identical), grasp points (1e-4 m); decision values recorded against S = sum |coef| K")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
