@@ -348,7 +348,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                                 e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SCREEN, sp_now, nullptr, 0, 0, large, evals_sel, nullptr, e->d_ax.p, s);
             char *y_img = reinterpret_cast<char *>(e->d_X.p) + (size_t)(e->max_evals_pad / kTile) * (size_t)kS0MatBytes;   // behind the 10-step images (the buffer holds the 42 KiB three-pass form)
             mark(e, HAF_ST_SVM);
-            if (lr) launch_project(e->d_X.p, e->d_lr_btiles.p, y_img, e->d_gband.p, e->d_counters.p, evals_cap, s);   // (counted with the sweep it feeds)
+            if (lr && !e->lr_fused) launch_project(e->d_X.p, e->d_lr_btiles.p, y_img, e->d_gband.p, e->d_counters.p, evals_cap, s);   // (counted with the sweep it feeds)
             // A small request with a small model (small_exact): what the screening pass leaves goes STRAIGHT to the one-launch exact kernel
             // (k_small_direct in list mode: exact attributes + fp64 MFMA decision, 9 ns per listed evaluation at 192 SVs) -- the list
             // is written where that kernel reads it.  Tier 1 in between was a feature kernel and a contraction launch at their latency
@@ -359,9 +359,10 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             const bool t0b = e->use_t0b && e->cr_available && !small_exact && (!cr || (lr && e->screen_variant == SCREEN_CR_EXP));
             const bool straight = small_exact || (e->t1_skip && !t0b);
             if (lr)
-                launch_svm_screen_lr(y_img, e->d_gband.p, e->d_ax.p, e->d_svt_lr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
+                launch_svm_screen_lr(e->lr_fused ? reinterpret_cast<char *>(e->d_X.p) : y_img, e->d_gband.p, e->d_ax.p, e->d_svt_lr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                                      e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d,
-                                     evals_cap, e->d_margin.p, e->screen_variant, e->crp, e->lr_band, s, straight ? CNT_FLAGGED : -1);
+                                     evals_cap, e->d_margin.p, e->screen_variant, e->crp, e->lr_band, s, straight ? CNT_FLAGGED : -1,
+                                     e->lr_fused ? e->d_lr_btiles_in.p : nullptr);
             else
             launch_svm_screen(e->d_X.p, e->d_gband.p, e->d_ax.p, cr ? e->d_svt0_cr.p : e->d_svt0.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                               e->d_flag0_words.p, e->d_flag0_wgcount.p, straight ? e->d_flag_list.p : e->d_flag0_list.p, e->flag0_cap, e->d_counters.p, d, evals_cap, e->d_margin.p,

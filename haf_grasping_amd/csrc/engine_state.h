@@ -170,6 +170,8 @@ struct haf_engine {
     bool lr_always = false;
     int lr_rank = 0;                 // dimension of the HAF slots' linear span (158 for the reference's Features.txt)
     DevBuf<char> d_lr_btiles, d_svt_lr;
+    DevBuf<char> d_lr_btiles_in;     // the projection matrix by input k-step (fused form: the projection is the sweep's prologue)
+    bool lr_fused = true;            // testing build: HAF_LR_UNFUSED = k_project + sweep as two launches
     DevBuf<double> d_iiabs;          // per (cloud, roll): sum of |height| (k_integral_totals)
     LrBand lr_band{};
     bool last_lr = false;            // the last request's screening pass ran in the low-rank form

@@ -759,12 +759,28 @@ int build_tables(haf_engine *e)
                                 memcpy(tile + h_image_offset(j, sl), &h, 2);
                             }
                         }
+                        // the same matrix by INPUT k-step for the fused form (k_svm_screen_lr<., true>): tile s = the twelve 16-row blocks of output
+                        // slots (row i of block rb = output slot 32 (rb / 2) + 8 (i / 4) + 4 (rb % 2) + i % 4) for input slots 32 s .. 32 s + 31, lane
+                        // 16 kg + i holding the 8 inputs 32 s + 8 kg .. + 7: [rb][lane][8 halves] = 12 KiB, the SV tiles' piece layout
+                        std::vector<char> bti((size_t)kHFull * kLrMatBytes, 0);
+                        for (int st = 0; st < kHFull; st++)
+                            for (int rb = 0; rb < 2 * kLrSteps; rb++)
+                                for (int ln = 0; ln < 64; ln++) {
+                                    const int i = ln & 15, kg = ln >> 4;
+                                    const int ko = 32 * (rb >> 1) + 8 * (i >> 2) + 4 * (rb & 1) + (i & 3);
+                                    for (int jj = 0; jj < 8; jj++) {
+                                        const _Float16 h = (_Float16)(float)Bh[(size_t)(32 * st + 8 * kg + jj) * KL2 + ko];
+                                        memcpy(bti.data() + (size_t)st * kLrMatBytes + (size_t)rb * 1024 + (size_t)ln * 16 + (size_t)jj * 2, &h, 2);
+                                    }
+                                }
                         const bool fin2 = std::isfinite(lb.nN1) && std::isfinite(lb.nM1) && std::isfinite(lb.nN2) && std::isfinite(lb.nHabs) && std::isfinite(lb.nRabs) &&
                                           std::isfinite(lb.sigB) && lb.qmax < 60000.0 && lb.sigB < 1.5;
                         if (fin2) {
-                            if (hipSuccess != e->d_lr_btiles.alloc(bt.size()) || hipSuccess != e->d_svt_lr.alloc(imgl.size()))
+                            if (hipSuccess != e->d_lr_btiles.alloc(bt.size()) || hipSuccess != e->d_svt_lr.alloc(imgl.size()) || hipSuccess != e->d_lr_btiles_in.alloc(bti.size()))
                                 return fail(e, HAF_E_DEVICE, "hipMalloc(low-rank tables)");
                             HIPCHK(e, hipMemcpy(e->d_lr_btiles.p, bt.data(), bt.size(), hipMemcpyHostToDevice));
+                            HIPCHK(e, hipMemcpy(e->d_lr_btiles_in.p, bti.data(), bti.size(), hipMemcpyHostToDevice));
+                            e->lr_fused = !test_env("HAF_LR_UNFUSED");
                             HIPCHK(e, hipMemcpy(e->d_svt_lr.p, imgl.data(), imgl.size(), hipMemcpyHostToDevice));
                             e->lr_band = lb;
                             e->lr_rank = lr_rank;

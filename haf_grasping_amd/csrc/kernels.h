@@ -400,7 +400,8 @@ void launch_project(const void *X0, const void *btiles, void *Y, float *raw, con
 void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
                           SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                           int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, LrBand lb,
-                          hipStream_t s, int also_counter = -1);
+                          hipStream_t s, int also_counter = -1,
+                          const void *ptiles = nullptr);   // != nullptr: the FUSED form -- Y holds the 10-step images, ptiles the projection tiles by input k-step (no launch_project)
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,

@@ -953,16 +953,23 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
 // The sweep of the low-rank form: k_svm_screen's structure (two 4-wave workgroups per CU, 3-deep LDS-DMA ring, epilogue of a column
 // block between the MFMAs of the next, two sign-grouped sweeps, two-level coefficient sum) on 6-step images; the tail finishes the band
 // from the raw sums (lr_finish_band) before the usual decision tail.  Whole requests only (no list mode, no SV-range split).
-template <int VAR>
+// FUSED: the projection is the sweep's prologue -- the ten input k-steps of B^' ("projection tiles", 12 KiB each: the twelve 16-row blocks
+// of output slots for input slots 32 s .. 32 s + 31, in the SV tiles' piece layout) stream through the SAME LDS-DMA ring in front of the
+// SV tiles, the wave's 64 evaluations x 192 outputs accumulate in 192 registers while the 10-step operand image passes by one k-step at
+// a time (16 registers, the next step's loads issued behind the first MFMAs of the current one), and the converted fp16 fragments never
+// leave the registers: no 6-step image in HBM (3 GB written and read per C5 step), no second launch.  Y = the 10-step images then.
+template <int VAR, bool FUSED>
 __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(const char *__restrict__ Y, const float *__restrict__ raw,
                                                                   const float *__restrict__ nax, const char *__restrict__ svt,
                                                                   const int *__restrict__ evalcell, const int *__restrict__ counters,
                                                                   SvmParams p, float *__restrict__ dec, int8_t *__restrict__ labels,
                                                                   unsigned long long *__restrict__ flag0_words, Dims d,
-                                                                  float *__restrict__ margin, CrParams crp, LrBand lb)
+                                                                  float *__restrict__ margin, CrParams crp, LrBand lb,
+                                                                  const char *__restrict__ ptiles)
 {
     constexpr bool CRP = VAR == SCREEN_CR_POLY;
-    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kLrSvTileBytes + 2 * kS0Waves * kS0WaveEvals * 4];
+    constexpr int kV0 = FUSED ? kHFull : 0;                          // virtual tiles in front of the SV tiles: ring slot of SV tile t = (t + kV0) % 3
+    __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kLrSvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
     const int n_evals = counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
@@ -972,6 +979,7 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
     const int np = d.sv_tile_neg, nt = d.n_sv_tiles;
     float *pos = reinterpret_cast<float *>(lds + kS0Buffers * kLrSvTileBytes) + wave * kS0WaveEvals;
     float *fin = pos + kS0Waves * kS0WaveEvals;
+    float *sdyrow = fin + kS0Waves * kS0WaveEvals;                   // FUSED: |y^ - y32|^2 per evaluation (this wave's row)
     const unsigned lane16 = (unsigned)lane * 16u;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int poff[kS0WavePieces];                                         // (TileDma is sized for the 10-step form: three pieces used)
@@ -983,30 +991,105 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
 #pragma unroll
         for (int q = 0; q < kLrWavePieces; q++) dma_piece(g + poff[q], l + (unsigned)poff[q], lane16);
     };
+    // virtual tile v: the projection tiles (FUSED) in front of the SV tiles; its global image and whether it has a tail piece
+    auto vtile = [&](int v) -> const char * { return (FUSED && v < kV0) ? ptiles + (size_t)v * kLrMatBytes : svt + (size_t)(v - kV0) * kLrSvTileBytes; };
     {
-        stage3(svt, lds0);
-        if (wave_u == 0) dma_piece(svt + kLrMatBytes, lds0 + kLrMatBytes, lane16);
+        stage3(vtile(0), lds0);
+        if (!FUSED && wave_u == 0) dma_piece(svt + kLrMatBytes, lds0 + kLrMatBytes, lane16);
     }
-    if (nt > 1) {
-        const char *g1 = svt + (size_t)kLrSvTileBytes;
-        stage3(g1, lds0 + kLrSvTileBytes);
-        if (wave_u == 0) dma_piece(g1 + kLrMatBytes, lds0 + kLrSvTileBytes + kLrMatBytes, lane16);
+    if (FUSED || nt > 1) {
+        stage3(vtile(1), lds0 + kLrSvTileBytes);
+        if (!FUSED && wave_u == 0) dma_piece(vtile(1) + kLrMatBytes, lds0 + kLrSvTileBytes + kLrMatBytes, lane16);
     }
     half8 a[kLrSteps][4];
-    {
+    if (!FUSED) {
         const char *xt = Y + (size_t)tile32 * kLrMatBytes;
 #pragma unroll
         for (int s = 0; s < kLrSteps; s++)
 #pragma unroll
             for (int m = 0; m < 4; m++)
                 a[s][m] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(xt + (m >> 1) * kLrMatBytes + (s * 2 + (m & 1)) * 1024 + lane * 16));
+#pragma unroll
+        for (int s = 0; s < kLrSteps; s++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) asm volatile("" : "+v"(a[s][m]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        // ---- the projection: D[output slot][evaluation] += B^'[output slot][input slot] X[input slot][evaluation], one input k-step per ring tile ----
+        const char *xt = Y + (size_t)tile32 * kS0MatBytes;           // this wave's two 10-step images
+        auto xload = [&](int sx, half8 (&x)[4]) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                x[m] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(xt + (m >> 1) * kS0MatBytes + (sx * 2 + (m & 1)) * 1024 + lane * 16));
+        };
+        f32x4 accp[2 * kLrSteps][4];                                 // twelve 16-row blocks of outputs x four 16-evaluation blocks
+#pragma unroll
+        for (int rb = 0; rb < 2 * kLrSteps; rb++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) accp[rb][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        half8 xc[4], xn[4];
+        xload(0, xc);
+#pragma unroll
+        for (int m = 0; m < 4; m++) xn[m] = xc[m];
+#pragma unroll
+        for (int m = 0; m < 4; m++) asm volatile("" : "+v"(xc[m]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // projection tiles 0 and 1, step 0 of the operand images
+        __syncthreads();
+#pragma unroll 1
+        for (int v = 0; v < kV0; v++) {
+            const char *cur = lds + (v % kS0Buffers) * kLrSvTileBytes;
+#pragma unroll
+            for (int rb = 0; rb < 2 * kLrSteps; rb++) {
+                const half8 bf = *reinterpret_cast<const half8 *>(cur + rb * 1024 + lane * 16);
+#pragma unroll
+                for (int m = 0; m < 4; m++) accp[rb][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, xc[m], accp[rb][m], 0, 0, 0);
+                if (rb == 0) {
+                    // behind the first MFMAs (which have waited for nothing: everything issued so far has landed): the next step's operand
+                    // fragments and the ring tile two ahead -- a projection tile or one of the first two SV tiles (with its tail piece)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v + 1 < kV0) xload(v + 1, xn);
+                    const int vn = v + 2;
+                    if (vn < kV0 + nt) {
+                        const unsigned ls = lds0 + (vn % kS0Buffers) * kLrSvTileBytes;
+                        stage3(vtile(vn), ls);
+                        if (vn >= kV0 && wave_u == 0) dma_piece(vtile(vn) + kLrMatBytes, ls + kLrMatBytes, lane16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) { asm volatile("" : "+v"(xn[m])); xc[m] = xn[m]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // fp16 fragments of the sweep (screen.hip: k_project for the row order) and |y^ - y32|^2
+        float sdy[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int sp = 0; sp < kLrSteps; sp++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                half8 h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float y0 = accp[2 * sp][m][r], y1 = accp[2 * sp + 1][m][r];
+                    const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+                    h[r] = h0; h[4 + r] = h1;
+                    const float d0 = (float)h0 - y0, d1 = (float)h1 - y1;
+                    sdy[m] = fmaf(d0, d0, sdy[m]);
+                    sdy[m] = fmaf(d1, d1, sdy[m]);
+                }
+                a[sp][m] = h;
+            }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            float sv = sdy[m];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            if (lane < 16) sdyrow[16 * m + lane] = sv;           // (sdyrow is this wave's own row, like pos and fin)
+        }
     }
-#pragma unroll
-    for (int s = 0; s < kLrSteps; s++)
-#pragma unroll
-        for (int m = 0; m < 4; m++) asm volatile("" : "+v"(a[s][m]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     float sum[4][4], part[4][4];
     f32x4 acc0[4], acc1[4];
@@ -1021,11 +1104,11 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
         int fold = 0;
         float cf_prev = 0.0f;
         for (int t = ph ? np : 0; t < t_end; t++) {
-            const char *cur = lds + (t % kS0Buffers) * kLrSvTileBytes;
+            const char *cur = lds + ((t + kV0) % kS0Buffers) * kLrSvTileBytes;
             const int tn = (t + 2) % nt;
-            const TileDma dma = tile_dma(svt + (size_t)tn * kLrSvTileBytes, lds0 + ((t + 2) % kS0Buffers) * kLrSvTileBytes, poff);
+            const TileDma dma = tile_dma(svt + (size_t)tn * kLrSvTileBytes, lds0 + ((t + 2 + kV0) % kS0Buffers) * kLrSvTileBytes, poff);
             if (wave_u == 0) dma_piece(svt + (size_t)tn * kLrSvTileBytes + kLrMatBytes,
-                                       lds0 + ((t + 2) % kS0Buffers) * kLrSvTileBytes + kLrMatBytes, lane16);
+                                       lds0 + ((t + 2 + kV0) % kS0Buffers) * kLrSvTileBytes + kLrMatBytes, lane16);
             const float *tt = reinterpret_cast<const float *>(cur + kLrMatBytes);
             const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];
             half8 bf0, bf1;
@@ -1084,7 +1167,11 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
     if (live) {
         float sc = __builtin_amdgcn_exp2f(nax[e]);
         float4 g, g2 = float4{0.0f, 0.0f, 0.0f, 0.0f};
-        lr_finish_band(raw + kBandFloats * e, lb, g.x, g.y, g.z, g.w);
+        float rw[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) rw[k] = raw[kBandFloats * e + k];
+        if (FUSED) rw[5] = sdyrow[lane];
+        lr_finish_band(rw, lb, g.x, g.y, g.z, g.w);
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
         flagged = screen_tail_vals<VAR, false>((double)pos[lane], (double)fin[lane], 0.0f, e, g, g2, sc, p, crp, nullptr, evalcell, dec, labels, margin);
     }
@@ -1131,17 +1218,17 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
 void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
                           SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                           int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, LrBand lb,
-                          hipStream_t s, int also_counter)
+                          hipStream_t s, int also_counter, const void *ptiles)
 {
     const long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
     lb.poly = variant == SCREEN_CR_POLY;
-    if (variant == SCREEN_CR_POLY)
-        hipLaunchKernelGGL(k_svm_screen_lr<SCREEN_CR_POLY>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,
-                           (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb);
-    else
-        hipLaunchKernelGGL(k_svm_screen_lr<SCREEN_CR_EXP>, dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,
-                           (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb);
+#define HAF_LR_LAUNCH(V, F)                                                                                                           \
+    hipLaunchKernelGGL((k_svm_screen_lr<V, F>), dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,           \
+                       (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb, (const char *)ptiles)
+    if (variant == SCREEN_CR_POLY) { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_POLY, true); else HAF_LR_LAUNCH(SCREEN_CR_POLY, false); }
+    else { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_EXP, true); else HAF_LR_LAUNCH(SCREEN_CR_EXP, false); }
+#undef HAF_LR_LAUNCH
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
     hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, CNT_EVALS);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,

@@ -66,7 +66,7 @@ TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EV
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
               "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS",
-              "HAF_NO_LR")
+              "HAF_NO_LR", "HAF_LR_UNFUSED")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -837,6 +837,24 @@ def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
         assert left["low-rank/general groups"] <= 1.5 * left["full-rank"] + 0.02 * c["n_evals"], left
         assert left["low-rank/negative heights"] <= 0.25 * c["n_evals"], left
         stats["form%d" % v] = left
+        # the projection as the sweep's prologue (the shipped form) against projection and sweep as two launches (k_project): the same
+        # operand bits, the same |y^ - y32|^2, so every decision value and every band (|dec^| / band of the decided cells) is identical
+        monkeypatch.delenv("HAF_NO_FAST_GROUPS", raising=False)
+        grids = {}
+        for unfused in (False, True):
+            if unfused:
+                monkeypatch.setenv("HAF_LR_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("HAF_LR_UNFUSED", raising=False)
+            eng = make_engine(data_dir, model, testing=True, **cfg)
+            eng.score(xyz, capi.default_input(**inp))
+            assert eng.screen_low_rank()["last_used"]
+            grids[unfused] = [(eng.debug(capi.DBG_DECISION, 0, roll), eng.debug(capi.DBG_SCREEN_MARGIN, 0, roll)) for roll in range(cfg["n_rolls"])]
+            eng.close()
+        monkeypatch.delenv("HAF_LR_UNFUSED", raising=False)
+        for (d0, m0), (d1, m1) in zip(grids[False], grids[True]):
+            assert np.array_equal(d0, d1, equal_nan=True) and np.array_equal(m0, m1), "fused and two-launch forms differ"
+            assert (m0 > 0).any()
     STATS["low_rank_undecided"] = stats
 
 

@@ -109,7 +109,7 @@ def main():
         orc = O.Oracle(os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_allfeatures"), path)
         sizes = [(56, 56), (56, 56), (64, 64), (61, 61), (96, 96)] + ([(130, 130), (160, 160), (200, 200)] if a.big else [])
         if a.low_rank:
-            sizes = [(96, 96), (100, 91), (130, 130), (160, 160)] + ([(200, 200), (256, 256)] if a.big else [])
+            sizes = [(96, 96), (100, 100), (130, 130), (160, 160)] + ([(200, 200), (256, 256)] if a.big else [])
             os.environ["HAF_SCREEN_VARIANT"] = str(2 + (mi % 2))
         H, W = sizes[rng.randint(len(sizes))]
         n_rolls, step = [(12, 15), (5, 36), (7, 25), (3, 60), (20, 9)][rng.randint(5)]
@@ -120,7 +120,7 @@ def main():
             orc = O.Oracle(os.path.join(DATA, "Features.txt"), os.path.join(DATA, "range21062012_allfeatures"), path)
             mode, mname = capi.FLAG_PROBABILITY, "probability"
             by_mode.setdefault(mname, 0)
-        eng = T.make_engine(DATA, path, mode, grid_h=H, grid_w=W, n_rolls=n_rolls, roll_step_deg=step, max_points=1 << 17)
+        eng = T.make_engine(DATA, path, mode, grid_h=H, grid_w=W, n_rolls=n_rolls, roll_step_deg=step, max_points=1 << (18 if a.low_rank else 17))
         form = eng.screen_form() if mode == 0 else mname
         n_here = 0
         for _ in range(a.per_model):
@@ -128,7 +128,7 @@ def main():
                 break
             half = 0.005 * H
             xyz = random_cloud(rng, half)
-            if H > 128 and rng.rand() < 0.7:                      # a dense surface under it all, so that most cells are masked
+            if (H > 128 or a.low_rank) and rng.rand() < 0.7:      # a dense surface under it all, so that most cells are masked
                 xyz = np.concatenate([xyz, models.synthetic_cloud(grid=H, k=2, seed=int(rng.randint(1 << 30)))])
             kw = dict(grasp_area_center=tuple(rng.uniform(-0.05, 0.05, 3) * [1, 1, 0.2]),
                       grasp_area_length_x=float(rng.choice([20, 28.9, 32, 44, H, H + 14])),
