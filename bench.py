@@ -479,7 +479,7 @@ def main():
         kernel = {"f16s": "k_svm_screen", "f16x3": "k_svm_rbf_h", "f32": "k_svm_rbf"}[precision]
         lr = precision == "f16s" and bool(r.get("low_rank", {}).get("last_used"))
         if lr:
-            kernel = "k_project+k_svm_screen_lr"
+            kernel = "k_svm_screen_lr"                       # (the projection is its prologue)
         o = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
              "frac": achieved / peak, "traffic": pmc_traffic(args, kernel), "kernel_ms": r["svm_s"] * 1e3,
              "flop_per_launch": flop}
@@ -499,16 +499,16 @@ def main():
         if precision == "f16s" and lr:
             # The HAF attributes are linear functionals of the window spanning `rank` dimensions: the sweep runs on rank + 21 SHAF slots
             # padded to 192 (6 k-steps instead of 10), behind a projection of the 320-slot operand (320 x 192 per evaluation).  `frac`
-            # stays what SURVEY.md 8(d) defines -- ALGORITHMIC flop (646 nSV per evaluation) over the time of BOTH kernels (stage
-            # 'svm' = k_project + k_svm_screen_lr + the two compaction launches) -- the executed flop are fewer
+            # stays what SURVEY.md 8(d) defines -- ALGORITHMIC flop (646 nSV per evaluation) over the time of the kernel, projection
+            # prologue included (stage 'svm' = k_svm_screen_lr + the two compaction launches) -- the executed flop are fewer
             executed = evals_per_launch * 2.0 * (192.0 * nsv + 320.0 * 192.0)
             o.update({"passes": 1, "low_rank": {"rank": r["low_rank"]["rank"], "slots": 192, "executed_over_algorithmic": executed / flop},
                       "executed_tflops": executed / r["svm_s"] / 1e12,
-                      "note": "single fp16 MFMA pass over every evaluation in the LOW-RANK centred-remainder form: the 299 HAF slots are linear "
-                              "functionals of the 15x15 window (fv.cpp:141-199) spanning %d dimensions, so k_project forms y = fp16(B'p) (B: an "
-                              "orthonormal basis of that span + the 21 SHAF slots, 192 columns) and k_svm_screen_lr sweeps the support vectors "
-                              "with K = 192; the guard band carries what the projection drops (the '%%.4g' rounding and the fp32 roundings of "
-                              "the reference's feature arithmetic, bounded per evaluation) and the rounding of y; kernel_ms = both kernels; "
+                      "note": "single fp16 MFMA pass over every evaluation in the LOW-RANK form (centred operands; screening_form says which epilogue): the 299 HAF slots are linear "
+                              "functionals of the 15x15 window (fv.cpp:141-199) spanning %d dimensions, so the kernel's prologue forms y = fp16(B'p) (B: an "
+                              "orthonormal basis of that span + the 21 SHAF slots, 192 columns; 480 MFMAs per 64 evaluations) and its sweep runs over the "
+                              "support vectors with K = 192; the guard band carries what the projection drops (the '%%.4g' rounding and the fp32 roundings of "
+                              "the reference's feature arithmetic, bounded per evaluation) and the rounding of y; "
                               "evaluations inside the band are re-done by the tiers behind, so the labels are libsvm's" % r["low_rank"]["rank"],
                       "refined_per_launch": r["refined"], "refined_share": r["refined"] / max(1.0, evals_per_launch),
                       "refine_ms": r["stage_ms"].get("refine")})

@@ -340,8 +340,10 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             // Low-rank form of the centred-remainder pass (kernels.h: kLrK): whole requests large enough for the thread-per-evaluation
             // feature kernel on grids that went through the parallel integral image (whose pass records negative heights), when the
             // centred-remainder form serves the model; the 10-step images go through k_project, the sweep runs on 6-step images.
-            const bool lr = cr && large && e->lr_available && e->lr_enabled && !fused_pre && (long)H * W > 8192 && !reuse_operands;
+            const bool lr_plain = e->screen_variant == SCREEN_PLAIN && e->lr_plain_available;      // the plain epilogue on the projected (centred) operands
+            const bool lr = (cr || lr_plain) && large && e->lr_available && e->lr_enabled && !fused_pre && (long)H * W > 8192 && !reuse_operands;
             lr_used = lr;
+            if (lr && lr_plain) sp_now = e->screen_lrp;
             if (lr) { sp_now.lr = 1; sp_now.lr_negflags = e->d_inexact.p; sp_now.lr_iiabs = e->d_iiabs.p; }
             if (!reuse_operands)
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_gband.p, d, e->range.lower,
@@ -586,7 +588,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
         // stay with it; when none is left (or the variant is pinned by a test), the three-pass kernel for every evaluation of
         // this call (same labels by construction) -- and, unless pinned, no screening pass for this model from now on.
         while (undecided() > e->flag0_cap && !e->variant_forced && next_variant(e->screen_variant) >= 0) {
-            const bool reuse = e->screen_variant == SCREEN_PLAIN && !t0b_used;     // (tier 0b writes its bands where the first pass's were)
+            const bool reuse = e->screen_variant == SCREEN_PLAIN && !t0b_used && !lr_used;     // (tier 0b writes its bands where the first pass's were; the low-rank form's images are the centred ones)
             t0b_used = false;
             e->screen_variant = next_variant(e->screen_variant);
             HIPCHK(e, hipMemsetAsync(e->d_counters.p + 1, 0, (CNT_COUNT - 1) * sizeof(int), s));

@@ -170,6 +170,9 @@ struct haf_engine {
     bool lr_always = false;
     int lr_rank = 0;                 // dimension of the HAF slots' linear span (158 for the reference's Features.txt)
     DevBuf<char> d_lr_btiles, d_svt_lr;
+    ScreenParams screen_lrp{};       // the feature kernel's constants for the PLAIN epilogue in the low-rank form (centred descriptors, own correction vectors)
+    DevBuf<ScrCorr> d_corr_lrp;
+    bool lr_plain_available = false;
     DevBuf<char> d_lr_btiles_in;     // the projection matrix by input k-step (fused form: the projection is the sweep's prologue)
     bool lr_fused = true;            // testing build: HAF_LR_UNFUSED = k_project + sweep as two launches
     DevBuf<double> d_iiabs;          // per (cloud, roll): sum of |height| (k_integral_totals)
@@ -260,10 +263,10 @@ namespace haf_host {
 // behind it (seed 11 of the bench generator: 5.8 ms for 378 k evaluations against 14.1 ms for 7.9 M)
 constexpr double kVariantCost[SCREEN_VARIANTS] = {1.0, 1.12, 1.10, 1.16};
 constexpr double kUndecidedCost = 8.5;
-// with the low-rank form (kernels.h: kLrK) serving the engine's full-size requests the centred-remainder forms cost less than the plain
-// kernel: measured at C5 (projection + 6-step sweep against the 10-step kernels; the feature kernel's 0.75 ms of noise bounds included)
-// CR_EXP 12.2 + 0.75 against plain 13.8 ms at 4096 SVs, CR_POLY 25.0 + 0.75 against 28.9 ms (plain equivalent) at 8964
-constexpr double kVariantCostLr[SCREEN_VARIANTS] = {1.0, 1.12, 0.94, 0.90};
+// with the low-rank form (kernels.h: kLrK) serving the engine's full-size requests, in units of the TEN-step plain kernel (13.8 ms at C5,
+// 4096 SVs; the feature kernel's 0.8 ms of noise bounds included): plain epilogue 10.3 + 0.8, CR_EXP 11.6 + 0.8, CR_POLY 24.3 + 0.8
+// against 28.9 ms (plain equivalent at 8964 SVs); SUMSQ has no low-rank form
+constexpr double kVariantCostLr[SCREEN_VARIANTS] = {0.80, 1.12, 0.90, 0.87};
 
 constexpr int kStrictSlots = 64;     // evaluations per pass of the strict tier's spread form (a few per request reach it at most)
 
@@ -279,7 +282,11 @@ inline bool lr_typical(const haf_engine *e)
     return e->lr_available && e->lr_enabled && (long)c.grid_h * c.grid_w > 8192 &&
            (long)(c.grid_h - 14) * (c.grid_w - 14) * e->max_rolls >= e->large_evals;
 }
-inline double variant_cost(const haf_engine *e, int v) { return lr_typical(e) ? kVariantCostLr[v] : kVariantCost[v]; }
+inline double variant_cost(const haf_engine *e, int v)
+{
+    if (!lr_typical(e) || (v == SCREEN_PLAIN && !e->lr_plain_available)) return kVariantCost[v];
+    return kVariantCostLr[v];
+}
 enum { MODE_SCREEN = 0, MODE_SPLIT = 1, MODE_F32 = 2 };
 inline int contraction_mode(const haf_config &c)
 {

@@ -655,6 +655,7 @@ int build_tables(haf_engine *e)
                         }
                     }
                     LrBand lb{};
+                    std::vector<double> lr_corr_g, lr_corr_h;            // plain epilogue: the feature kernel's two correction vectors B^ Q~^'b, B^ dQ~'b
                     std::vector<double> Qt((size_t)m.n_sv * KL2, 0.0), Qth((size_t)m.n_sv * KL2, 0.0), dQt((size_t)m.n_sv * KL2, 0.0), Rm((size_t)m.n_sv * K, 0.0);
                     std::vector<char> imgl((size_t)e->n_sv_tiles * kLrSvTileBytes, 0);
                     if (inv_ok) {
@@ -736,6 +737,39 @@ int build_tables(haf_engine *e)
                         { const double x = sigma_upper_bound(Rr.data(), m.n_sv, K); lb.nRabs = x * x * up; }
                         lb.sQb = sigma_upper_bound(Rq.data(), m.n_sv, K) * up;
                         lb.sQtaa = sigma_upper_bound(Ra.data(), m.n_sv, KL2) * up;
+                        // ---- the plain epilogue on the same operands (LrBand: sig_q ...; screen_band.h: lr_finish_band_plain) ----
+                        std::vector<double> gt((size_t)KL2, 0.0), ht((size_t)KL2, 0.0), rhoR((size_t)K, 0.0), Bq((size_t)m.n_sv * KL2), Br((size_t)m.n_sv * K);
+                        for (int n = 0; n < m.n_sv; n++) {
+                            const double bn = b[(size_t)n];
+                            for (int l = 0; l < KL2; l++) {
+                                gt[(size_t)l] += bn * Qth[(size_t)n * KL2 + l];
+                                ht[(size_t)l] += bn * dQt[(size_t)n * KL2 + l];
+                                Bq[(size_t)n * KL2 + l] = bn * Qt[(size_t)n * KL2 + l];
+                            }
+                            for (int l = 0; l < K; l++) { rhoR[(size_t)l] += bn * Rm[(size_t)n * K + l]; Br[(size_t)n * K + l] = bn * Rm[(size_t)n * K + l]; }
+                        }
+                        lb.sig_q = sigma_upper_bound(Qth.data(), m.n_sv, KL2) * up;
+                        lb.sig_dq = sigma_upper_bound(dQt.data(), m.n_sv, KL2) * up;
+                        lb.sig_r = sigma_upper_bound(Rm.data(), m.n_sv, K) * up;
+                        lb.sbq = sigma_upper_bound(Bq.data(), m.n_sv, KL2) * up;
+                        lb.sbr = sigma_upper_bound(Br.data(), m.n_sv, K) * up;
+                        {
+                            double r2 = 0.0, g2 = 0.0, bg2 = 0.0, bh2 = 0.0, ga2 = 0.0;
+                            for (int l = 0; l < K; l++) r2 += rhoR[(size_t)l] * rhoR[(size_t)l];
+                            for (int l = 0; l < KL2; l++) g2 += gt[(size_t)l] * gt[(size_t)l];
+                            lr_corr_g.assign((size_t)K, 0.0); lr_corr_h.assign((size_t)K, 0.0);
+                            for (int sl = 0; sl < K; sl++) {
+                                double tg = 0.0, th = 0.0, ta = 0.0;
+                                for (int a2 = 0; a2 < kc; a2++) {
+                                    const double bv = Bh[(size_t)sl * KL2 + a2];
+                                    tg += bv * gt[(size_t)a2]; th += bv * ht[(size_t)a2]; ta += std::fabs(bv) * std::fabs(gt[(size_t)a2]);
+                                }
+                                lr_corr_g[(size_t)sl] = tg; lr_corr_h[(size_t)sl] = th;
+                                bg2 += tg * tg; bh2 += th * th; ga2 += ta * ta;
+                            }
+                            lb.rho_norm = std::sqrt(r2) * up; lb.gt_norm = std::sqrt(g2) * up;
+                            lb.bg_norm = std::sqrt(bg2) * up; lb.bh_norm = std::sqrt(bh2) * up; lb.gabsB = std::sqrt(ga2) * up;
+                        }
                         lb.sigB = sigma_upper_bound(Bh.data(), K, KL2) * up;
                         lb.sigAbsB = sigma_upper_bound(Bab.data(), K, KL2) * up;
                         for (double *x : {&lb.Ca, &lb.Cq1, &lb.Cqq, &lb.Babs, &lb.qmax, &lb.dqmax, &lb.rmax}) *x *= 1.0 + 1e-9;
@@ -786,6 +820,25 @@ int build_tables(haf_engine *e)
                             e->lr_rank = lr_rank;
                             cp.lr_rho = lr_rho;
                             e->lr_available = true;
+                            // the plain epilogue's instance of the feature kernel's constants: the centred descriptors, its own correction vectors
+                            {
+                                std::vector<ScrCorr> scp((size_t)kS0K * 2);
+                                ScrCorr2 *sp2 = reinterpret_cast<ScrCorr2 *>(scp.data() + kS0K);
+                                for (int sl = 0; sl < kS0K; sl++) {
+                                    scp[(size_t)sl].g = (float)lr_corr_g[(size_t)sl]; scp[(size_t)sl].hd = (float)lr_corr_h[(size_t)sl];
+                                    scp[(size_t)sl].ub = 0.0f; scp[(size_t)sl].pad = 0.0f;
+                                    ScrCorr2 &p2 = sp2[sl >> 1];
+                                    p2.g[sl & 1] = scp[(size_t)sl].g; p2.hd[sl & 1] = scp[(size_t)sl].hd; p2.ub[sl & 1] = 0.0f; p2.pad[sl & 1] = 0.0f;
+                                }
+                                if (hipSuccess != e->d_corr_lrp.alloc(scp.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(low-rank tables)");
+                                HIPCHK(e, hipMemcpy(e->d_corr_lrp.p, scp.data(), scp.size() * sizeof(ScrCorr), hipMemcpyHostToDevice));
+                                e->screen_lrp = cp;
+                                e->screen_lrp.corr = e->d_corr_lrp.p;
+                                e->screen_lrp.corr2 = reinterpret_cast<const ScrCorr2 *>(e->d_corr_lrp.p + kS0K);
+                                const bool finp = std::isfinite(lb.sig_q) && std::isfinite(lb.sig_r) && std::isfinite(lb.sbq) && std::isfinite(lb.sbr) &&
+                                                  std::isfinite(lb.rho_norm) && std::isfinite(lb.bg_norm) && std::isfinite(lb.gabsB);
+                                e->lr_plain_available = finp && !test_env("HAF_NO_LR_PLAIN");
+                            }
                         }
                     }
                 }
@@ -999,6 +1052,7 @@ int build_tables(haf_engine *e)
     e->svm.guard_acc0_s = (float)(guard0_scale * ((2.0 * sweep_tiles + 4.0 + 2.0 + 6.0 + 2.0) * u));
     e->screen.scale = 1.001 * guard0_scale;
     e->screen_cr.scale = 1.001 * guard0_scale;
+    e->screen_lrp.scale = 1.001 * guard0_scale;
     e->lr_band.scale = 1.001 * guard0_scale;
     e->crt1.scale = 1.001 * guard_scale;
     e->crt1.guard_abs = e->svm.guard_abs;

@@ -175,6 +175,14 @@ struct LrBand {
     double mu_norm, mu_norm_t;    // as ScreenParams::cr_mu_norm*
     double eta_abs, scale;
     int poly, pad;
+    // ---- plain epilogue on the same operands (SCREEN_PLAIN in the low-rank form: sum b_n 2^(z_n), one v_exp_f32 and one fma per element;
+    // lr_finish_band_plain): the plain form's band (features.hip: screen_finish) in the projected coordinates, centre = reference operand ----
+    double sig_q, sig_dq, sig_r;  // sigma(Q~^), sigma(dQ~), sigma(R)
+    double sbq, sbr;              // sigma(diag(b) Q~), sigma(diag(b) R): |b (2^z - 1)|_2 <= ln2 2^zmax (sbq |y_e| + sbr |p_perp|)
+    double rho_norm;              // |R'b|: the first-order effect of p_perp on the evaluation-independent part (bounded, not corrected)
+    double gt_norm;               // |Q~^'b| (the rounding of y against it: bounded)
+    double bg_norm, bh_norm;      // |B^ Q~^'b|, |B^ dQ~'b|: the two correction vectors of the feature kernel (ScrCorr::g, ::hd)
+    double gabsB;                 // | |B^| |Q~^'b| |_2: accumulation error of the projection against the first correction vector
 };
 // constants of tier 1's centred-remainder band (k_svm_h_combine_cr): the same bound as screen_finish_cr with the operands'
 // errors those of the hi+lo split (2^-22 relative) and the accumulation that of the PRECISE three-pass form ((kappa + 14) u)

@@ -524,7 +524,14 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
     if (abs_total) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) habs += __shfl_xor(habs, o, 64);
-        if (lane == 0) atomicAdd(&abs_total[br], habs);   // (order of the additions differs from run to run: an upper bound with 1e-4 to spare is all that is read)
+        __syncthreads();                                  // (wsum is free again)
+        if (lane == 0) wsum[wave] = habs;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kIThreads / 64; w++) t += wsum[w];
+            atomicAdd(&abs_total[br], t);                 // one per workgroup (the order of the additions differs from run to run: an upper bound with 1e-4 to spare is all that is read)
+        }
     }
 }
 

@@ -898,8 +898,8 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
                                                 const f32x4 (&old)[4], float cf_old, float (&sum)[4][4],
                                                 const TileDma &dma, unsigned lane16, half8 &b, half8 &b1)
 {
-    constexpr bool CRP = VAR == SCREEN_CR_POLY;
-    static_assert(VAR == SCREEN_CR_EXP || VAR == SCREEN_CR_POLY, "the low-rank form serves the centred-remainder variants");
+    constexpr bool CRP = VAR == SCREEN_CR_POLY, PLN = VAR == SCREEN_PLAIN;
+    static_assert(VAR == SCREEN_CR_EXP || VAR == SCREEN_CR_POLY || VAR == SCREEN_PLAIN, "the low-rank form serves the plain and the centred-remainder variants");
     const char *bl = cur + n * 1024 + lane * 16;
     __builtin_amdgcn_sched_barrier(0);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -920,7 +920,12 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
             if (s == 0 && i < COUNT) { dma_piece(dma.g[FIRST + i], dma.l[FIRST + i], lane16); HAF_SB(); }
             if (!CRP) {
                 if (j < 16) { kq[j] = __builtin_amdgcn_exp2f(old[j >> 2][j & 3]); HAF_SB(); }
-                if (j >= kLrExpLag && j < 16 + kLrExpLag) {
+                if (PLN && j >= kLrExpLag && j < 16 + kLrExpLag) {      // plain epilogue: b 2^z, one fma behind the exp
+                    const int e = j - kLrExpLag;
+                    sum[e >> 2][e & 3] = fmaf(cf_old, kq[e], sum[e >> 2][e & 3]);
+                    HAF_SB();
+                }
+                if (!PLN && j >= kLrExpLag && j < 16 + kLrExpLag) {
                     const int e = j - kLrExpLag;
                     const float em1 = kq[e] - 1.0f;
                     HAF_SB();
@@ -1143,7 +1148,9 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float ck;
-                if (!CRP) {
+                if (VAR == SCREEN_PLAIN) {
+                    ck = cf_prev * acc1[m][r];
+                } else if (!CRP) {
                     ck = cf_prev * fmaf(zz[m][r], -kLn2f, acc1[m][r] - 1.0f);
                 } else {
                     const float z = zz[m][r];
@@ -1171,7 +1178,8 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
 #pragma unroll
         for (int k = 0; k < 6; k++) rw[k] = raw[kBandFloats * e + k];
         if (FUSED) rw[5] = sdyrow[lane];
-        lr_finish_band(rw, lb, g.x, g.y, g.z, g.w);
+        if (VAR == SCREEN_PLAIN) lr_finish_band_plain(rw, lb, g, g2);
+        else lr_finish_band(rw, lb, g.x, g.y, g.z, g.w);
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
         flagged = screen_tail_vals<VAR, false>((double)pos[lane], (double)fin[lane], 0.0f, e, g, g2, sc, p, crp, nullptr, evalcell, dec, labels, margin);
     }
@@ -1227,6 +1235,7 @@ void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const voi
     hipLaunchKernelGGL((k_svm_screen_lr<V, F>), dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,           \
                        (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb, (const char *)ptiles)
     if (variant == SCREEN_CR_POLY) { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_POLY, true); else HAF_LR_LAUNCH(SCREEN_CR_POLY, false); }
+    else if (variant == SCREEN_PLAIN) { if (ptiles) HAF_LR_LAUNCH(SCREEN_PLAIN, true); else HAF_LR_LAUNCH(SCREEN_PLAIN, false); }
     else { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_EXP, true); else HAF_LR_LAUNCH(SCREEN_CR_EXP, false); }
 #undef HAF_LR_LAUNCH
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);

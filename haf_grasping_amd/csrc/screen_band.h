@@ -63,4 +63,56 @@ __device__ __forceinline__ void lr_finish_band(const float *raw, const LrBand &l
     if (!(D < 0.05) || !(a_x < 30.0) || !(zmax < 60.0) || !(c_abs == c_abs)) c_abs_out = __builtin_inff();
 }
 
+// The PLAIN epilogue on the projected operands: the sweep forms D^ = sum_n b_n 2^(z^_n) (dec + rho = A D); with w_n = b_n 2^(z_n),
+// e_n = z^_n - z_n as above, D^ - D = ln2 sum w_n e_n + second order.  Term by term the plain form's band (features.hip: screen_finish):
+//   bilinear part of e_n:  per SV  d_max S  |  through the spectral norms  e2 |w|_2,  e2 = |dy| sigma(Q~^) + |y_e| sigma(dQ~) + |p_perp| sigma(R),
+//                          |w|_2^2 <= max|c_n| S / A (the tail's sqrt_cmax sqrt(S) after the common factor);
+//   accumulation a_n and second order: per unit of S (gB);
+//   centred estimate: w_n = b_n + b_n (2^(z_n) - 1) (reference operand = the centre, p = 0).  First-order error of the first part:
+//     ln2 [dy.g~ + y_e.h~ + sum b_n a_n - p_perp.rho~],  g~ = Q~^'b, h~ = dQ~'b, rho~ = R'b.  What is KNOWN of it -- (p^ - fl32 p').(B^ g~) +
+//     fl32(p').(B^ h~), the feature kernel's `cr` sum -- is subtracted; the rest is bounded: the rounding of y against g~, the projection's
+//     accumulation, p' against p, the fp32 accumulation of the sum itself, |p_perp||rho~| (abs_c); sum b_n a_n stays with gB.
+//     Second part: |sum b_n (2^(z_n) - 1) e_n| <= |b (2^z - 1)|_2 e2 <= ln2 2^zmax (sbq |y_e| + sbr |p_perp|) e2.
+// Output as screen_finish: g = {gA, gB, gC, cm}, g2 = {corr, abs_c}.
+__device__ __forceinline__ void lr_finish_band_plain(const float *raw, const LrBand &lb, float4 &g, float4 &g2)
+{
+    constexpr double kF32Acc = 326.0 * 5.9604644775390625e-08 * 1.01;
+    const double ln2 = 0.69314718056;
+    const double su2 = (double)raw[0], sd2 = (double)raw[1], sx2 = (double)raw[2], cr = (double)raw[3], nu2 = (double)raw[4], sdy2 = (double)raw[5];
+    const double a_x = 0.5 * sx2;
+    const double un_t = sqrt_upper(sx2 * (1.0 + kF32Acc));
+    const double eta_t = kScreenEtaRel * (un_t + lb.mu_norm_t) + lb.eta_abs;
+    const double un1 = sqrt_upper(su2 * (1.0 + kF32Acc));
+    const double dn1 = sqrt_upper(sd2 * (1.0 + kF32Acc)) + 5.97e-8 * un1 + 1e-17;
+    const double eta = kScreenEtaRel * (un1 + lb.mu_norm) + lb.eta_abs;
+    const double un = un1 + eta, dn = dn1 + eta, ph = un1 + dn1;
+    const double D = (kF32Acc + 6.0e-8) * a_x + un_t * eta_t + 0.5 * eta_t * eta_t + 6.0e-7;
+    const double nun = sqrt_upper(nu2 * (1.0 + kF32Acc)) + eta;
+    const double sdy = sqrt_upper(sdy2 * (1.0 + kF32Acc));
+    const double dyn = sdy + lb.acc10 * lb.sigAbsB * ph + lb.sigB * dn;
+    const double yen = lb.sigB * un, yhn = yen + dyn;
+    const double d_max = dyn * lb.qmax + yen * lb.dqmax + nun * lb.rmax;
+    const double acc = lb.acc6 * yhn * lb.qmax;
+    const double e_max = d_max + acc;
+    const double infl = 1.0 + exp2m1_upper(e_max + D);
+    const double e2 = dyn * lb.sig_q + yen * lb.sig_dq + nun * lb.sig_r;
+    const double gB = ln2 * acc + 0.6 * (ln2 * e_max) * (ln2 * e_max);
+    g.x = (float)(ln2 * e2 * infl * lb.scale);
+    g.y = (float)(gB * infl * lb.scale);
+    g.z = (float)(ln2 * d_max * infl * lb.scale);
+    g.w = (float)(exp2m1_upper(D) * lb.scale);
+    const bool bad = !(e_max + D < 0.05) || !(a_x < 30.0);
+    if (bad) g.y = __builtin_inff();
+    const double zmax = yhn * lb.qmax + e_max;
+    const double zf = floor(zmax);
+    const double p2 = (zmax < 60.0) ? ldexp(1.0 + (zmax - zf), (int)zf) : (double)__builtin_inff();
+    const double dev = ln2 * p2 * (lb.sbq * yen + lb.sbr * nun);
+    const double cerr = ln2 * (sdy * lb.gt_norm + lb.acc10 * ph * lb.gabsB + (eta + 6.0e-8 * un1) * (lb.bg_norm + lb.bh_norm) +
+                               4.2e-5 * (dn1 * lb.bg_norm + un1 * lb.bh_norm) + nun * lb.rho_norm);
+    g2.x = (float)(ln2 * cr);
+    g2.y = (float)((e2 * dev * infl + cerr) * lb.scale);
+    if (bad || !(zmax < 60.0) || !(g2.y == g2.y)) g2.y = __builtin_inff();
+    g2.z = 0.0f; g2.w = 0.0f;
+}
+
 }  // namespace haf

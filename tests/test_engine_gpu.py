@@ -66,7 +66,7 @@ TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EV
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
               "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS",
-              "HAF_NO_LR", "HAF_LR_UNFUSED")
+              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -811,9 +811,10 @@ def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
     cfg = dict(n_rolls=4, roll_step_deg=25, grid_h=G, grid_w=G, max_points=2 * G * G)
     inp = dict(grasp_area_length_x=G, grasp_area_length_y=G)
     stats = {}
-    for model, v in ((rnd, 2), (clu, 3)):
+    for model, v in ((rnd, 2), (clu, 3), (rnd, 0)):               # (0: the plain epilogue on the projected operands, tier 0b behind it)
         o = O.Oracle(f, r, model)
         monkeypatch.setenv("HAF_SCREEN_VARIANT", str(v))
+        monkeypatch.setenv("HAF_T0B", "1" if v == 0 else "0")
         left = {}
         for name, cloud, flags, nofast in (("low-rank", xyz, 0, False), ("full-rank", xyz, capi.FLAG_FULL_RANK, False), ("low-rank/general groups", xyz, 0, True),
                                            ("low-rank/negative heights", neg, 0, False)):
@@ -853,8 +854,8 @@ def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
             eng.close()
         monkeypatch.delenv("HAF_LR_UNFUSED", raising=False)
         for (d0, m0), (d1, m1) in zip(grids[False], grids[True]):
-            assert np.array_equal(d0, d1, equal_nan=True) and np.array_equal(m0, m1), "fused and two-launch forms differ"
-            assert (m0 > 0).any()
+            assert np.array_equal(d0, d1, equal_nan=True) and np.array_equal(m0, m1, equal_nan=True), "fused and two-launch forms differ"
+            assert (np.nan_to_num(m0) > 0).any()
     STATS["low_rank_undecided"] = stats
 
 
