@@ -175,7 +175,7 @@ struct haf_engine {
     bool lr_plain_available = false;
     DevBuf<char> d_lr_btiles_in;     // the projection matrix by input k-step (fused form: the projection is the sweep's prologue)
     bool lr_fused = true;            // testing build: HAF_LR_UNFUSED = k_project + sweep as two launches
-    DevBuf<double> d_iiabs;          // per (cloud, roll): sum of |height| (k_integral_totals)
+    DevBuf<unsigned long long> d_iiabs;   // per (cloud, roll): sum of |height| in units of 2^-20 m (k_integral_totals)
     LrBand lr_band{};
     bool last_lr = false;            // the last request's screening pass ran in the low-rank form
     DevBuf<FeatDesc> d_fd_slot_cr;

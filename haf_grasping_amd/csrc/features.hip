@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         if (LR) {
             // raw sums; the part of the slots' linear map that the fp64 roundings of the basis leave outside range(B): lr_rho per unit of the largest corner
             // (no corner of the integral image exceeds the sum of |height| over its grid: prestages.hip, k_integral_totals)
-            const float lr_M = (float)sp.lr_iiabs[evalcell[e_src] / (d.H * d.W)] * 1.0001f;
+            const float lr_M = (float)((double)sp.lr_iiabs[evalcell[e_src] / (d.H * d.W)] * 9.5367431640625e-07) * 1.0001f;
             const float rho = (float)sp.lr_rho * lr_M * 1.000001f;
             nu2 = fmaf(rho, rho, nu2);
             const float sx2 = acc.su2 + sx;                                   // (one more fp32 rounding of |p'|^2: inside kF32Acc's 326)

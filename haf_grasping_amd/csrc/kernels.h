@@ -160,7 +160,7 @@ struct ScreenParams {
     int    lr;
     double lr_rho;                // what the columns of the slots' linear map stick out of range(B) (fp64 roundings of the basis), per unit of the largest window corner
     const int *lr_negflags;       // device, per (cloud, roll): bit 1 = the grid holds a negative height (the wave-level exactness test of the region sums needs a monotone integral image)
-    const double *lr_iiabs;       // device, per (cloud, roll): sum of |height| over the grid >= every |corner| of its integral image
+    const unsigned long long *lr_iiabs;   // device, per (cloud, roll): sum of |height| over the grid in units of 2^-20 m (rounded up) >= every |corner| of its integral image
 };
 // constants of the low-rank band (LrBand: by value to k_svm_screen's low-rank instantiation; everything rounded up at load)
 struct LrBand {
@@ -386,7 +386,7 @@ bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int
                       float r_col, hipStream_t s);
 size_t small_pre_lds(int H, int W);
 void launch_integral(int *hkeys_heights, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s,
-                     double *abs_total = nullptr);   // per (cloud, roll): sum of |height| (parallel form only; low-rank screening form)
+                     unsigned long long *abs_total = nullptr);   // per (cloud, roll): sum of |height| in units of 2^-20 m, rounded up (parallel form only; low-rank screening form)
 void launch_mask_count(const float *ii, const RollGeo *geo, uint8_t *mask, int *rowcount, Dims d, hipStream_t s);
 void launch_scan(const int *rowcount, int *rowoff, int *brcount, int *counters, Dims d, hipStream_t s);
 void launch_compact(const uint8_t *mask, const int *rowcount, const int *rowoff, int *evalcell, Dims d, hipStream_t s);

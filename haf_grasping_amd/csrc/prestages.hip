@@ -470,7 +470,7 @@ __device__ __forceinline__ float final_height(int key)
 // so one column sum per thread (coalesced) and one scan of the band's 512-wide vector instead of sixteen row scans.  Every
 // addition is checked: the totals are then the true values whatever the association.
 __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__restrict__ hk, double *__restrict__ band_tot,
-                                                               int *__restrict__ inexact_flags, double *__restrict__ abs_total, Dims d)
+                                                               int *__restrict__ inexact_flags, unsigned long long *__restrict__ abs_total, Dims d)
 {
     __shared__ double wsum[kIThreads / 64];
     __shared__ double carry;
@@ -482,7 +482,9 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row0 = band * kIBandRows;
     bool inexact = false, negative = false;
-    double habs = 0.0;                                    // sum of |height| over this thread's cells: no corner of the integral image exceeds the grid's total
+    // sum of |height| over this thread's cells, in units of 2^-20 m rounded UP (integers: the total is the same in whatever order the
+    // workgroups add it -- identical calls take identical paths): no corner of the integral image exceeds the grid's total
+    unsigned long long habs = 0ull;
     if (tid == 0) carry = 0.0;
     __syncthreads();
     for (int c0 = 0; c0 < W; c0 += kIThreads) {
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
                 if (row0 + r < H) {
                     const float hh = final_height(kr[r]);
                     negative |= !(hh >= 0.0f);            // (also a NaN height)
-                    habs += (double)fabsf(hh);
+                    habs += (unsigned long long)ceil(fmin((double)fabsf(hh), 1048576.0) * 1048576.0) + ((fabsf(hh) <= 1048576.0f) ? 0ull : (1ull << 62));
                     v = add_checked(v, (double)hh, inexact);
                 }
         }
@@ -524,13 +526,13 @@ __global__ __launch_bounds__(kIThreads) void k_integral_totals(const int *__rest
     if (abs_total) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) habs += __shfl_xor(habs, o, 64);
-        __syncthreads();                                  // (wsum is free again)
-        if (lane == 0) wsum[wave] = habs;
+        __shared__ unsigned long long wabs[kIThreads / 64];
+        if (lane == 0) wabs[wave] = habs;
         __syncthreads();
         if (tid == 0) {
-            double t = 0.0;
-            for (int w = 0; w < kIThreads / 64; w++) t += wsum[w];
-            atomicAdd(&abs_total[br], t);                 // one per workgroup (the order of the additions differs from run to run: an upper bound with 1e-4 to spare is all that is read)
+            unsigned long long t = 0ull;
+            for (int w = 0; w < kIThreads / 64; w++) t += wabs[w];
+            atomicAdd(&abs_total[br], t);                 // one per workgroup (integer sum: order-independent; a height beyond 2^20 m sets bit 62: the bound is then useless, as it must be)
         }
     }
 }
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256) void k_integral_small(int *hk, float *__restri
     }
 }
 
-void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s, double *abs_total)
+void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s, unsigned long long *abs_total)
 {
     if (d.H * d.W <= kISmallCells) {
         const int pitch = ((d.W + 15) / 16) * 16 + 1;
@@ -683,7 +685,7 @@ void launch_integral(int *hk, double *rowsum, float *ii, int *inexact_flags, int
     // scratch of the sequential fallback
     const int n_bands = (d.H + kIBandRows - 1) / kIBandRows;
     (void)hipMemsetAsync(inexact_flags, 0, (size_t)d.B * d.R * sizeof(int), s);
-    if (abs_total) (void)hipMemsetAsync(abs_total, 0, (size_t)d.B * d.R * sizeof(double), s);
+    if (abs_total) (void)hipMemsetAsync(abs_total, 0, (size_t)d.B * d.R * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(k_integral_totals, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, inexact_flags, abs_total, d);
     hipLaunchKernelGGL(k_integral_band, dim3(n_bands, d.B * d.R), dim3(kIThreads), 0, s, hk, rowsum, ii, inexact_flags, d);
     // sequential order for the grids whose parallel sums were not exact (practically never; the kernels exit at once otherwise)
