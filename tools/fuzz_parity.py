@@ -110,7 +110,8 @@ def main():
         sizes = [(56, 56), (56, 56), (64, 64), (61, 61), (96, 96)] + ([(130, 130), (160, 160), (200, 200)] if a.big else [])
         if a.low_rank:
             sizes = [(96, 96), (100, 100), (130, 130), (160, 160)] + ([(200, 200), (256, 256)] if a.big else [])
-            os.environ["HAF_SCREEN_VARIANT"] = str(2 + (mi % 2))
+            os.environ["HAF_SCREEN_VARIANT"] = str((2, 3, 0)[mi % 3])       # both centred-remainder epilogues and the plain one (tier 0b behind it)
+            os.environ["HAF_T0B"] = "1" if mi % 3 == 2 else "0"
         H, W = sizes[rng.randint(len(sizes))]
         n_rolls, step = [(12, 15), (5, 36), (7, 25), (3, 60), (20, 9)][rng.randint(5)]
         mode, mname = mode_list[mi % 3] if mi % 2 else mode_list[2]           # two thirds of the models through the default path
