@@ -443,7 +443,8 @@ int build_tables(haf_engine *e)
             int lr_cols = 0, lr_rank = 0;
             double lr_rho = 0.0;
             bool lr_basis = false;
-            if (!test_env("HAF_NO_LR") && !test_env("HAF_CR_NO_CENTRE")) {
+            // (only for engines whose grid can carry a request the form applies to: engine_request.cpp; a 56 x 56 engine skips the seconds of table work)
+            if (!test_env("HAF_NO_LR") && !test_env("HAF_CR_NO_CENTRE") && (long)e->cfg.grid_h * e->cfg.grid_w > 8192) {
                 std::vector<int> lin((size_t)kS0K, 0), pass((size_t)kS0K, 0);
                 std::vector<long double> Ms((size_t)225 * kS0K, 0.0L);         // column j of the map = Ms[j * kS0K ...]
                 static const long double sgn[4] = {1.0L, -1.0L, -1.0L, 1.0L};
