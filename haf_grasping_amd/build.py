@@ -25,7 +25,7 @@ SOURCES = ["prestages.hip", "features.hip", "contraction.hip", "screen.hip", "re
           ENGINE_SOURCES + ["parsers.cpp", "multi.cpp"]
 # per-file extra flags (screen.hip: see its header)
 EXTRA = {"screen.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["kernels.h", "device_common.h", "feature_device.h", "parsers.h", "decq.h", "engine_internal.h", "engine_state.h"] + TESTING_ONLY + [ os.path.join("..", "..", "include", "hafgrasp.h"),
+HEADERS = ["kernels.h", "device_common.h", "feature_device.h", "screen_band.h", "parsers.h", "decq.h", "engine_internal.h", "engine_state.h"] + TESTING_ONLY + [ os.path.join("..", "..", "include", "hafgrasp.h"),
            os.path.join("..", "cli", "haf_grasp_cli.cpp"), os.path.join("..", "..", "ros_shim", "shim_core.h")]
 # -ffp-contract=off: the bit-exact stages spell out every rounding; nothing may be fused behind their back
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
