@@ -178,6 +178,7 @@ def main():
             n_here += 1
             evals += int(want["n_evals"])
             by_mode[mname] = by_mode.get(mname, 0) + 1
+            print("    [%6.1f s] case %d: %d evaluations" % (time.time() - t0, done, int(want["n_evals"])), flush=True)   # (a sign of life: a big grid against a big model keeps the oracle busy for minutes)
         by_model[what.split(" nsv")[0]] = by_model.get(what.split(" nsv")[0], 0) + n_here
         by_form[form] = by_form.get(form, 0) + n_here
         eng.close()
