@@ -920,9 +920,14 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
             if (s == 0 && i < COUNT) { dma_piece(dma.g[FIRST + i], dma.l[FIRST + i], lane16); HAF_SB(); }
             if (!CRP) {
                 if (j < 16) { kq[j] = __builtin_amdgcn_exp2f(old[j >> 2][j & 3]); HAF_SB(); }
-                if (PLN && j >= kLrExpLag && j < 16 + kLrExpLag) {      // plain epilogue: b 2^z, one fma behind the exp
-                    const int e = j - kLrExpLag;
-                    sum[e >> 2][e & 3] = fmaf(cf_old, kq[e], sum[e >> 2][e & 3]);
+                if (PLN && j >= 16) {
+                    // plain epilogue: b 2^z, one fma per element -- TWO of them behind each of the last eight MFMAs, the sixteen exps behind the
+                    // first sixteen: every MFMA then shares the issue port with 8 cycles of vector work, exactly half its own 16 (with the fma
+                    // four MFMAs behind its exp the middle twelve carried 12 cycles and the last four none)
+                    const int e0 = 2 * (j - 16), e1 = e0 + 1;
+                    sum[e0 >> 2][e0 & 3] = fmaf(cf_old, kq[e0], sum[e0 >> 2][e0 & 3]);
+                    HAF_SB();
+                    sum[e1 >> 2][e1 & 3] = fmaf(cf_old, kq[e1], sum[e1 >> 2][e1 & 3]);
                     HAF_SB();
                 }
                 if (!PLN && j >= kLrExpLag && j < 16 + kLrExpLag) {
