@@ -309,14 +309,17 @@ __global__ __launch_bounds__(kS0Waves * 64, 2) void k_svm_screen(const char *__r
                                                                unsigned long long *__restrict__ flag0_words, Dims d,
                                                                float *__restrict__ margin, CrParams crp,
                                                                const int *__restrict__ idx_list, int count_slot,
-                                                               float4 *__restrict__ part_out, int forced_parts)
+                                                               float4 *__restrict__ part_out, int forced_parts, int in_cap)
 {
     // LIST mode (idx_list != nullptr; round 4, "tier 0b"): the operand images, bands and common factors are indexed by list slot
     // (the feature kernel's list mode wrote them), slot j holds evaluation idx_list[j], counters[count_slot] says how many
     constexpr bool SUMSQ = VAR == SCREEN_SUMSQ, CRE = VAR == SCREEN_CR_EXP, CRP = VAR == SCREEN_CR_POLY;
     // the ONLY LDS object: 3 SV tile images + per wave one row of positive-group sums and one row of final sums
     __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kS0SvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
-    const int n_evals = counters[count_slot];
+    // (list mode: the counter holds how many evaluations the previous pass left undecided, which may EXCEED what its list holds --
+    // the host finds out after the request and redoes the decision stage; until then no consumer may walk past the list's end: the
+    // entries beyond it are stale flag words and foreign memory, and evaluation ids read from there were written through)
+    const int n_evals = min(counters[count_slot], in_cap);
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -509,9 +512,9 @@ __global__ __launch_bounds__(kS0BlockEvals) void k_screen_combine(const float4 *
                                                                   const int *__restrict__ counters, SvmParams p, float *__restrict__ dec,
                                                                   int8_t *__restrict__ labels, unsigned long long *__restrict__ flag0_words,
                                                                   Dims d, float *__restrict__ margin, CrParams crp,
-                                                                  const int *__restrict__ idx_list, int count_slot, int forced_parts)
+                                                                  const int *__restrict__ idx_list, int count_slot, int forced_parts, int in_cap)
 {
-    const int n_evals = counters[count_slot];
+    const int n_evals = min(counters[count_slot], in_cap);
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
     const long e = base + threadIdx.x;
@@ -538,16 +541,16 @@ __global__ __launch_bounds__(kS0BlockEvals) void k_screen_combine(const float4 *
 // the list's capacity (the host then falls back to the three-pass kernel for everything).
 constexpr int kCompactWords = 256;
 
-__device__ __forceinline__ int screen_words(const int *counters, int count_slot)
+__device__ __forceinline__ int screen_words(const int *counters, int count_slot, int in_cap)
 {
-    return (counters[count_slot] + kS0BlockEvals - 1) / kS0BlockEvals * (kS0BlockEvals / 64);
+    return (min(counters[count_slot], in_cap) + kS0BlockEvals - 1) / kS0BlockEvals * (kS0BlockEvals / 64);
 }
 
 __global__ __launch_bounds__(kCompactWords) void k_screen_count(const unsigned long long *__restrict__ words,
-                                                                int *__restrict__ wgcount, const int *__restrict__ counters, int count_slot)
+                                                                int *__restrict__ wgcount, const int *__restrict__ counters, int count_slot, int in_cap)
 {
     __shared__ int red[kCompactWords / 64];
-    const int n_words = screen_words(counters, count_slot);
+    const int n_words = screen_words(counters, count_slot, in_cap);
     const int w = blockIdx.x * kCompactWords + threadIdx.x;
     int c = (w < n_words) ? __popcll(words[w]) : 0;
 #pragma unroll
@@ -560,11 +563,11 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_count(const unsigned l
 __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned long long *__restrict__ words,
                                                                   const int *__restrict__ wgcount, int n_wg,
                                                                   int *__restrict__ list, int cap, int *__restrict__ counters, int also_counter,
-                                                                  const int *__restrict__ idx_list, int count_slot, int out_slot)
+                                                                  const int *__restrict__ idx_list, int count_slot, int out_slot, int in_cap)
 {
     __shared__ int part[kCompactWords];
     __shared__ int s_base;
-    const int n_words = screen_words(counters, count_slot);
+    const int n_words = screen_words(counters, count_slot, in_cap);
     const int t = threadIdx.x;
     // slots taken by the preceding workgroups (the last workgroup also publishes the total)
     int before = 0;
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned
     }
     const int w = blockIdx.x * kCompactWords + t;
     unsigned long long m = (w < n_words) ? words[w] : 0ull;
-    const int cnt = __popcll(m);
+    const int cnt = __popcll(m);                                      // (the flag words of a partly filled block hold no bits beyond the live count: screen_tail)
     part[t] = cnt;
     __syncthreads();
     for (int o = 1; o < kCompactWords; o <<= 1) {
@@ -1199,6 +1202,8 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
 {
     long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
+    // list mode: what the INPUT list holds (it is the same size as the output list; whole requests: everything the launch covers)
+    const int in_cap = idx_list ? (int)std::min<long>(flag0_cap, max_evals) : 0x7fffffff;
     // parts: 0 = the engine's rule (requests of up to kS0PartBlocks workgroups are split over SV ranges, as many as the live count asks
     // for), 1 = never, > 1 = that many (tests); the buffer holds kS0MaxParts x kS0PartBlocks x 256 partial sums (screen_part_bytes())
     const bool split = part_buf && parts != 1 && blocks <= kS0PartBlocks && (parts > 1 || d.n_sv_tiles >= 4 * kS0MinPartTiles);
@@ -1206,13 +1211,13 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
     if (split) {                                                                                                                  \
         hipLaunchKernelGGL((k_svm_screen<V, true>), dim3((unsigned)blocks, kS0MaxParts), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax, \
                            (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot,      \
-                           (float4 *)part_buf, parts);                                                                            \
+                           (float4 *)part_buf, parts, in_cap);                                                                    \
         hipLaunchKernelGGL(k_screen_combine<V>, dim3((unsigned)blocks), dim3(kS0BlockEvals), 0, s, (const float4 *)part_buf, gband, nax,   \
-                           evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot, parts);           \
+                           evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot, parts, in_cap);   \
     } else {                                                                                                                      \
         hipLaunchKernelGGL((k_svm_screen<V, false>), dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)X0, gband, nax,     \
                            (const char *)svt0, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, idx_list, count_slot,      \
-                           (float4 *)nullptr, 0);                                                                                 \
+                           (float4 *)nullptr, 0, in_cap);                                                                         \
     }
     switch (variant) {
         case SCREEN_SUMSQ: HAF_SCREEN_LAUNCH(SCREEN_SUMSQ); break;
@@ -1223,9 +1228,9 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
 #undef HAF_SCREEN_LAUNCH
     // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
-    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, count_slot);
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, count_slot, in_cap);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw, also_counter, idx_list, count_slot, out_slot);
+                       counters_rw, also_counter, idx_list, count_slot, out_slot, in_cap);
 }
 
 void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
@@ -1244,9 +1249,9 @@ void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const voi
     else { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_EXP, true); else HAF_LR_LAUNCH(SCREEN_CR_EXP, false); }
 #undef HAF_LR_LAUNCH
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
-    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, CNT_EVALS);
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, CNT_EVALS, 0x7fffffff);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw, also_counter, (const int *)nullptr, CNT_EVALS, CNT_FLAGGED0);
+                       counters_rw, also_counter, (const int *)nullptr, CNT_EVALS, CNT_FLAGGED0, 0x7fffffff);
 }
 
 size_t screen_part_bytes() { return (size_t)kS0MaxParts * kS0PartBlocks * kS0BlockEvals * sizeof(float4); }

@@ -788,6 +788,34 @@ def test_sv_range_split_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
     eng.close()
 
 
+def test_tier_0b_behind_a_first_pass_that_overflows_its_list(data_dir, golden_dir, monkeypatch):
+    """Round 4 (found by fuzz campaign 48 as a GPU memory fault): a pinned plain first pass on a model it cannot serve -- the committed
+    surrogate: nine tenths of the evaluations inside the band -- leaves more undecided than its list holds.  The host notices after the
+    request and redoes the decision stage; until then the second pass and the compaction behind it must stop at the list's END, not at
+    the counter: beyond it lie stale flag words and foreign memory, and evaluation ids read from there were written through by the
+    tiers behind.  Ten-step form on the reference's grid and low-rank form on a 128 x 128 grid: every stage and label the oracle's."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    monkeypatch.setenv("HAF_SCREEN_VARIANT", "0")
+    monkeypatch.setenv("HAF_T0B", "1")
+    f, r = _files(data_dir)
+    model = os.path.join(golden_dir, "surrogate.model")
+    o = O.Oracle(f, r, model)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    cfg, inp = dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0))
+    eng = make_engine(data_dir, model, testing=True)
+    compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+    eng.close()
+    monkeypatch.setenv("HAF_LARGE_EVALS", "1")
+    G = 128
+    cloud = models.synthetic_cloud(grid=G, k=2, seed=9)
+    cfg = dict(n_rolls=3, roll_step_deg=60, grid_h=G, grid_w=G, max_points=2 * G * G)
+    inp = dict(grasp_area_length_x=G + 14, grasp_area_length_y=G)
+    eng = make_engine(data_dir, model, testing=True, **cfg)
+    compare_full(eng, o, cloud, cfg, inp, check_dec=False)
+    assert eng.screen_low_rank()["rank"] == 158
+    eng.close()
+
+
 def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
     """Round 4: the 299 HAF slots are linear functionals of the 15 x 15 window (fv.cpp:141-199) spanning 158 dimensions, so whole requests
     on large grids are swept on a projected operand (k_project: y = fp16(B'p); k_svm_screen_lr: 6 k-steps instead of 10) and the band
