@@ -165,48 +165,31 @@ def run_cabi_side(args, world, seed):
         return {"error": repr(ex)}
 
 
-def pmc_traffic(args, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), when they
-    were taken on this exact workload; PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        w = t["workload"]
-        if (w["grid"], w["rolls"], w["n_sv"]) == (args.grid, args.rolls, args.nsv):
-            ks = t["kernels"]
-            total = 0.0
-            for part in kernel.split("+"):             # "k_project+k_svm_screen_lr": both kernels' traffic
-                hit = [ks[k]["hbm_bytes"] for k in sorted(ks) if k == part or k.startswith(part + "<")]   # template instances: k_svm_screen<false>
-                if not hit:
-                    return None
-                total += hit[0]
-            return total
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+SCREEN_FORMS = ("plain", "sumsq", "centred-remainder/exp", "centred-remainder/poly")
 
 
-def rocprof_kernel_ms(args, kernel):
-    """Average duration of the dominant kernel's full-size launches under rocprofv3 --kernel-trace on this exact workload, from the
-    committed profile (profiles/r04b_kernel_avg.json, tools/profile_round.sh): the judge's reading of `roofline.frac`.  None when the
-    committed profile is of another workload."""
+def profile_entry(args, model_key, precision, n_sv, kernel):
+    """The committed rocprofv3 evidence for ONE kernel instance of ONE profiled run, or None.  profiles/index.json (written by
+    tools/collect_profiles.sh from the passes of tools/profile_round.sh) lists, per profiled run -- keyed "<model>/<precision>", e.g.
+    "seed42/f16s", "trained/f16s", "seed42/f16x3" -- the workload, the build commit and per kernel instance the full-size average under
+    --kernel-trace (avg_ms), the MFMA-busy share of the SQ pass (mfma_busy) and the HBM bytes of the FETCH_SIZE / WRITE_SIZE passes
+    (hbm_bytes).  A figure is only handed out when grid, rolls, SV count, model, contraction mode AND kernel instance (template
+    arguments included: the screening form) are those of the run being reported; PMC counters cannot be read from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04b_kernel_avg.json")) as f:
-            t = json.load(f)
-        if (t["workload"]["grid"], t["workload"]["rolls"], t["workload"]["n_sv"]) != (args.grid, args.rolls, args.nsv):
+        with open(os.path.join(ROOT, "profiles", "index.json")) as f:
+            idx = json.load(f)
+        run = idx["runs"].get("%s/%s" % (model_key, precision))
+        if not run:
             return None
-        ks = t["kernels"]
-        total = 0.0
-        for part in kernel.split("+"):                    # "k_project+k_svm_screen_lr": the sum of the two kernels' full-size averages
-            hit = [ks[k]["avg_ms"] for k in sorted(ks) if k == part or k.startswith(part + "<")]
-            if not hit:
-                return None
-            total += hit[0]
-        return total
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        w = run["workload"]
+        if (w["grid"], w["rolls"], w["n_sv"]) != (args.grid, args.rolls, n_sv):
+            return None
+        k = run["kernels"].get(kernel)
+        if not k:
+            return None
+        return dict(k, source="profiles/index.json run %s/%s (%s, build %s)" % (model_key, precision, idx.get("round", "?"), idx.get("commit", "?")))
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def cpu_baseline(feat, rng_file, model_path, xyz, args):
@@ -426,7 +409,7 @@ def main():
             for k, v in st.items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
         fence()
-        return dict(low_rank=eng.screen_low_rank(),
+        return dict(low_rank=eng.screen_low_rank(), form=eng.screen_form(),
                     elapsed=time.perf_counter() - t0, coll_us=float(np.median(coll_us)) if coll_us else None, evals=evals, steps=steps, svm_s=float(np.mean(svm_ms)) * 1e-3,
                     stage_ms={k: v / steps for k, v in stage_acc.items()}, rechecked=rechecked / steps,
                     strict=strict / steps, refined=refined / steps, exact_integer=n_i8 / steps, fp64=n_fp64 / steps, out=out)
@@ -452,7 +435,6 @@ def main():
         models.write_random_model(mp, args.nsv, D=D_ATTR, seed=sd, balanced=True)
         eng = make_engine(args.precision, mp)
         r = run(eng, args.steps, args.warmup, use_dist)
-        r["form"] = eng.screen_form()
         eng.close()
         t = torch.tensor([r["elapsed"]], dtype=torch.float64, device="cuda")
         ev = torch.tensor([r["evals"]], dtype=torch.int64, device="cuda")
@@ -470,30 +452,42 @@ def main():
     med = ranked[(len(ranked) - 1) // 2]                    # lower median: never better than half of the seeds
     res, elapsed, total_evals, model_path = med["res"], med["elapsed"], med["total_evals"], med["model"]
 
-    def roofline(r, precision, nsv=None):
+    def roofline(r, precision, nsv=None, model_key=None):
+        """model_key: which profiled run of profiles/index.json this result may be compared with ("seed42", "trained", "hard"; None: none)"""
         nsv = nsv or args.nsv
         evals_per_launch = r["evals"] / r["steps"]
         flop = evals_per_launch * 2.0 * D_ATTR * nsv                # algorithmic: 646*nSV per eval, ONE pass
         achieved = flop / r["svm_s"] / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
-        kernel = {"f16s": "k_svm_screen", "f16x3": "k_svm_rbf_h", "f32": "k_svm_rbf"}[precision]
         lr = precision == "f16s" and bool(r.get("low_rank", {}).get("last_used"))
-        if lr:
-            kernel = "k_svm_screen_lr"                       # (the projection is its prologue)
-        o = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-             "frac": achieved / peak, "traffic": pmc_traffic(args, kernel), "kernel_ms": r["svm_s"] * 1e3,
-             "flop_per_launch": flop}
-        prof_ms = rocprof_kernel_ms(args, kernel) if nsv == args.nsv else None
-        if prof_ms:
-            # both readings of the same kernel: HIP events in this run (`frac`) and the committed rocprofv3 summary (3 % slower: the profiler)
-            o.update({"kernel_ms_rocprof": prof_ms, "frac_rocprof": flop / (prof_ms * 1e-3) / 1e12 / peak,
-                      "rocprof_source": "profiles/r04b_kernel_avg.json (rocprofv3 --kernel-trace of this workload, full-size launches)"})
+        form = r.get("form")
+        var = SCREEN_FORMS.index(form) if form in SCREEN_FORMS else 0
+        # the kernel INSTANCE (template arguments included): the profile of another screening form is another kernel
+        if precision == "f16s":
+            kernel, instance = ("k_svm_screen_lr", "k_svm_screen_lr<%d, true>" % var) if lr else ("k_svm_screen", "k_svm_screen<%d, false>" % var)
+        elif precision == "f16x3":
+            kernel, instance = "k_svm_rbf_h", "k_svm_rbf_h<false, false>"
+        else:
+            kernel, instance = "k_svm_rbf", "k_svm_rbf"
+        prof = profile_entry(args, model_key, precision, nsv, instance) if model_key else None
+        o = {"kernel": kernel, "kernel_instance": instance, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+             "frac": achieved / peak, "traffic": prof.get("hbm_bytes") if prof else None, "kernel_ms": r["svm_s"] * 1e3,
+             "flop_per_launch": flop,
+             "frac_note": "frac = ALGORITHMIC flop (646 x nSV per evaluation, SURVEY 8d) / kernel time / dense peak -- for the low-rank form that includes "
+                          "an algorithmic saving, it is not matrix-pipe utilisation: see frac_executed and mfma_busy"}
+        if prof and prof.get("avg_ms"):
+            # both readings of the same kernel instance: HIP events in this run (`frac`) and the committed rocprofv3 summary (the profiler's runs are ~3 % slower)
+            fr = flop / (prof["avg_ms"] * 1e-3) / 1e12 / peak
+            if fr <= 1.0:                                    # a figure above the peak can only be a mismatched profile: never published
+                o.update({"kernel_ms_rocprof": prof["avg_ms"], "frac_rocprof": fr, "rocprof_source": prof["source"]})
+            if prof.get("mfma_busy") is not None:
+                o["mfma_busy"] = prof["mfma_busy"]           # SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), tracked PMC pass
         if precision == "f16x3":
             # three fp16 passes over K padded to 336 execute 3*336/323 = 3.12 times the algorithmic flop: the ceiling
             # of `frac` for this split-precision contraction is 0.32, not 1
             executed = flop * 3.0 * 336.0 / D_ATTR
             o.update({"passes": 3, "executed_tflops": executed / r["svm_s"] / 1e12,
-                      "mfma_busy_frac": executed / r["svm_s"] / 1e12 / peak,
+                      "frac_executed": executed / r["svm_s"] / 1e12 / peak,
                       "note": "fp32 operands split into fp16 hi+lo; x.s = xh.sh + xl.sh + xh.sl (3 MFMA passes, fp32 "
                               "accumulate); algorithmic flop counted once, per SURVEY.md 8(d)"})
         if precision == "f16s" and lr:
@@ -503,7 +497,7 @@ def main():
             # prologue included (stage 'svm' = k_svm_screen_lr + the two compaction launches) -- the executed flop are fewer
             executed = evals_per_launch * 2.0 * (192.0 * nsv + 320.0 * 192.0)
             o.update({"passes": 1, "low_rank": {"rank": r["low_rank"]["rank"], "slots": 192, "executed_over_algorithmic": executed / flop},
-                      "executed_tflops": executed / r["svm_s"] / 1e12,
+                      "executed_tflops": executed / r["svm_s"] / 1e12, "frac_executed": executed / r["svm_s"] / 1e12 / peak,
                       "note": "single fp16 MFMA pass over every evaluation in the LOW-RANK form (centred operands; screening_form says which epilogue): the 299 HAF slots are linear "
                               "functionals of the 15x15 window (fv.cpp:141-199) spanning %d dimensions, so the kernel's prologue forms y = fp16(B'p) (B: an "
                               "orthonormal basis of that span + the 21 SHAF slots, 192 columns; 480 MFMAs per 64 evaluations) and its sweep runs over the "
@@ -514,7 +508,7 @@ def main():
                       "refine_ms": r["stage_ms"].get("refine")})
         elif precision == "f16s":
             executed = flop * 320.0 / D_ATTR
-            o.update({"passes": 1, "executed_tflops": executed / r["svm_s"] / 1e12,
+            o.update({"passes": 1, "executed_tflops": executed / r["svm_s"] / 1e12, "frac_executed": executed / r["svm_s"] / 1e12 / peak,
                       "note": "single fp16 MFMA pass over every evaluation; K = 320 slots for the 323 attributes (three pairs of "
                               "Features.txt rows are the same feature with the same range and share a slot; the norm terms are the "
                               "accumulator's initial value and a common factor, not K slots); evaluations inside its rigorous guard "
@@ -533,14 +527,18 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.shard == "clouds" else "strong", "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x3": "f16x3", "f16s": "f16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "C5: synthetic %dx%d heightmap (%d points), %d rolls x %d deg, %dx%d cm area, seeded random "
-                                   "libsvm RBF model nSV=%d D=323 gamma=1/323 (generator seeds %s: median seed %d), one cloud per GPU per step, cloud resident in HBM"
-                                   % (G, G, xyz.shape[0], args.rolls, args.roll_step, G, G, args.nsv, ",".join(str(q) for q in seeds), med["seed"]),
+            # (the driver keeps the first ~100 characters of `workload`: what identifies the model comes first)
+            "config": {"workload": "C5 nSV=%d D=323 gamma=1/323 random RBF model (median of seeds %s: %d); synthetic %dx%d heightmap, %d pts, "
+                                   "%d rolls x %d deg, %dx%d cm area, one cloud per GPU per step, resident in HBM"
+                                   % (args.nsv, ",".join(str(q) for q in seeds), med["seed"], G, G, xyz.shape[0], args.rolls, args.roll_step, G, G),
                        "evals_per_cloud": int(res["evals"] / args.steps), "n_sv": args.nsv, "grid": G, "rolls": args.rolls,
                        "contraction": args.precision,
                        "sharding": ("clouds (1 per GPU); all-reduce(max) of an 8-byte best-grasp key per step" if args.shard == "clouds"
                                     else "rolls of one cloud split over the GPUs; all-gather of the 16-byte roll records per step")},
-            "roofline": roofline(res, args.precision),
+            "roofline": roofline(res, args.precision, model_key="seed%d" % med["seed"]),
+            # the whole step against the same roof: algorithmic flop of the dominant contraction / ms_per_step / dense peak of its dtype
+            "end_to_end_frac": (res["evals"] / res["steps"]) * 2.0 * D_ATTR * args.nsv / (elapsed / args.steps) / 1e12 /
+                               (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS),   # rank 0's GPU against one GPU's peak
             "seeds": {"generator": "tests/models.py write_random_model(nsv, seed, balanced=True): SV values U(-1,1), coef U(0,2) x class sign, "
                                    "sum(coef) = 0, gamma = 1/323, rho 0.01",
                       "headline": "median seed %d (value, ms_per_step, roofline, stage_ms_per_step are that seed's run)" % med["seed"],
@@ -602,7 +600,7 @@ def main():
                 r2 = run(e2, 2, 1, False)
                 e2.close()
                 line[other + "_mode"] = {"value": r2["evals"] / r2["elapsed"], "ms_per_step": 1e3 * r2["elapsed"] / 2,
-                                         "roofline": roofline(r2, other), "stage_ms_per_step": r2["stage_ms"],
+                                         "roofline": roofline(r2, other, model_key="seed%d" % med["seed"]), "stage_ms_per_step": r2["stage_ms"],
                                          "same_best": bool(r2["out"]["eval"] == res["out"]["eval"] and
                                                            r2["out"]["best_row"] == res["out"]["best_row"] and
                                                            r2["out"]["best_col"] == res["out"]["best_col"] and
@@ -626,7 +624,7 @@ def main():
             line["hard_model"] = {"model": "tests/golden/surrogate.model (libsvm-3.12 svm-train -c 512 -g 0.0031 on real feature rows) x 24 "
                                            "jittered copies: nSV=%d" % nsv_h,
                                   "value": rh["evals"] / rh["elapsed"], "unit": "evals/s", "ms_per_step": 1e3 * rh["elapsed"] / 3,
-                                  "roofline": roofline(rh, "f16s", nsv_h), "stage_ms_per_step": rh["stage_ms"],
+                                  "roofline": roofline(rh, "f16s", nsv_h, model_key="hard"), "stage_ms_per_step": rh["stage_ms"],
                                   "refined_share": rh["refined"] / max(1.0, rh["evals"] / 3), "screening_form": form_h,
                                   "f16x3_ms_per_step": 1e3 * r3["elapsed"],
                                   "same_best_as_f16x3": bool(all(r3["out"][k] == rh["out"][k] for k in ("eval", "best_row", "best_col", "best_roll")))}
@@ -648,7 +646,7 @@ def main():
             e3 = make_engine("f16x3", tr_path)
             r3 = run(e3, 1, 1, False)
             e3.close()
-            rl = roofline(rt, "f16s", nsv_t)
+            rl = roofline(rt, "f16s", nsv_t, model_key="trained")
             line["trained_model"] = {
                 "model": "tests/golden/trained.model.npz: libsvm-3.12 C-SVC/RBF trained by the REFERENCE svm-train (oracle/_ref) on %d feature rows "
                          "harvested from all data/*.pcd x 12 rolls (label rule + %.1f %% seeded flips), C = %g and gamma = %g from a %d-fold "

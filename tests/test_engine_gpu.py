@@ -1404,7 +1404,8 @@ def test_attribute_pipeline_thread_per_evaluation_kernel_and_list_mode(data_dir,
 def test_attribute_pipeline_against_reference_tool_fixtures(data_dir, golden_dir, surrogate, name, roll):
     """The same records against tests/golden/g23_*.npz: the q4 column is what the REAL svm-scale read from the feature
     text, `scaled` what the REAL svm-predict read from svm-scale's output (tests/golden/make_fixtures.py ran the reference's
-    own binaries).  No oracle in between."""
+    own binaries): for those two columns there is no oracle in between.  The `features` column of the fixture is the ORACLE's
+    own fp32 output (make_fixtures.py:172-175 -- fv.cpp cannot be built here), so that comparison is engine against oracle."""
     g = np.load(os.path.join(golden_dir, "g23_%s_r%d.npz" % (name, roll)))
     xyz = pcdio.load_pcd(os.path.join(data_dir, name + ".pcd"))
     eng = make_engine(data_dir, surrogate, capi.FLAG_SPLIT_F16)

@@ -11,7 +11,10 @@ if [ "$1" = build ]; then
     # (the variants are linked under the product names on the way; whatever happens -- an error, an interrupt -- the real
     # build is put back before this script ends, and a library built with experiment flags never stays under those names)
     restore() { unset HAF_EXPERIMENT_FLAGS; python3 -c "from haf_grasping_amd import build; build.build(verbose=False, force=True)"; }
-    trap restore EXIT INT TERM
+    # an interrupt restores the real build ONCE and ends the script (a bare `trap restore INT` would run the handler and then go on
+    # building variants under the product names); EXIT covers the normal end and `exit 1`
+    trap 'trap - EXIT; restore; exit 130' INT TERM
+    trap restore EXIT
     for n in ${VARIANTS:-0 1 2 3 4 5}; do
         HAF_EXPERIMENT_FLAGS="-DHAF_ABL=$n" python3 -c "from haf_grasping_amd import build; build.build(verbose=False, force=True)" || exit 1
         cp haf_grasping_amd/libhafgrasp_testing.so haf_grasping_amd/abl/libhafgrasp_testing_abl$n.so
