@@ -186,15 +186,17 @@ def check_no_spills(lib=None, verbose=False):
     return report
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return LIB
+def _compile_and_link(out_lib, out_testing, obj_dir, extra_flags=(), verbose=False):
+    """Compiles every translation unit into obj_dir and links the two libraries under the given names (checked for the v_exp_f32
+    hazard and for spills before they get those names)."""
     hipcc = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
+    os.makedirs(obj_dir, exist_ok=True)
 
     def compile_one(src, suffix="", defs=()):
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + suffix + ".o")
         # HAF_EXPERIMENT_FLAGS: extra compiler flags for ablation builds (tools/ablate_h.sh); never set for a build that is kept
-        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + os.environ.get("HAF_EXPERIMENT_FLAGS", "").split() + list(defs) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + os.environ.get("HAF_EXPERIMENT_FLAGS", "").split() + list(extra_flags) + list(defs) + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -214,9 +216,9 @@ def build(force=False, verbose=False):
     # mistake it for an up-to-date one.
     staged = []
     try:
-        for out in (LIB, LIB_TESTING):
+        for out in (out_lib, out_testing):
             tmp = out + ".unchecked"
-            if out == LIB:
+            if out == out_lib:
                 members = [objs[s] for s in SOURCES]
             else:
                 members = [testing_objs.get(s, objs[s]) for s in SOURCES] + [testing_objs[s] for s in TESTING_ONLY]
@@ -225,7 +227,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             staged.append((tmp, out))
-        for out in (LIB, LIB_TESTING):
+        for out in (out_lib, out_testing):
             if os.path.exists(out):
                 os.remove(out)                  # whatever happens below, a stale library must not survive a failed build
         check_exp_hazard(staged[0][0], verbose=verbose)
@@ -236,6 +238,25 @@ def build(force=False, verbose=False):
         for tmp, _ in staged:
             if os.path.exists(tmp):
                 os.remove(tmp)
+
+
+def build_variant(name, flags, verbose=False):
+    """An experiment build NEXT TO the product: haf_grasping_amd/variants/libhafgrasp_<name>.so and libhafgrasp_testing_<name>.so from
+    the same sources with extra compiler flags (e.g. -DHAF_LR_WGS=3), objects under csrc/_variants/<name>/.  The product's names
+    are never touched; load a variant with HAF_LIB / HAF_TESTLIB (capi.py).  Same ISA checks as the product build."""
+    vdir = os.path.join(HERE, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, "libhafgrasp_%s.so" % name)
+    out_t = os.path.join(vdir, "libhafgrasp_testing_%s.so" % name)
+    _compile_and_link(out, out_t, os.path.join(CSRC, "_variants", name), extra_flags=list(flags), verbose=verbose)
+    return out, out_t
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    hipcc = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
+    _compile_and_link(LIB, LIB_TESTING, CSRC, verbose=verbose)
     # ROS-free command line front end (C++ host code over the C-ABI)
     cli = os.path.join(HERE, "haf_grasp_cli")
     cmd = [hipcc, "-O2", "-std=c++17", "-I" + os.path.join(HERE, "..", "ros_shim"), "-I" + os.path.join(HERE, "..", "include"),
@@ -248,4 +269,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python -m haf_grasping_amd.build --variant NAME -DFLAG ...
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 for n in ${1:-0 5}; do
     O=$GRAFT_REPO_ROOT/gpurun_out/ablf_$n
     rm -rf $O; mkdir -p $O
-    HAF_NO_CALIBRATE=1 HAF_TESTLIB=$GRAFT_REPO_ROOT/haf_grasping_amd/abl/libhafgrasp_testing_abl$n.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 tools/seed_sweep.py --seeds 42 --no-ab --steps 1 > $O/run.log 2>&1
+    HAF_NO_CALIBRATE=1 HAF_TESTLIB=$GRAFT_REPO_ROOT/haf_grasping_amd/variants/libhafgrasp_testing_abl$n.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 tools/seed_sweep.py --seeds 42 --no-ab --steps 1 > $O/run.log 2>&1
     python3 - $O $n <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/kt/**/*kernel_stats.csv", recursive=True)[0]
