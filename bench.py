@@ -70,10 +70,11 @@ def parse():
     return ap.parse_args()
 
 
-def spawn_ranks(args):
+def spawn_ranks(args, script=None, argv=None):
     """`python bench.py --gpus N` without a launcher: start one rank process per GPU ourselves (what torch.distributed.run
     would do), BEFORE anything in this process touches a GPU -- this parent never imports torch -- and wait for them.
-    Rank 0's JSON line goes straight to our stdout.  Any rank failing fails the run."""
+    Rank 0's JSON line goes straight to our stdout.  Any rank failing fails the run.  (script / argv: the rank program and its
+    arguments -- this file and our own by default; tests/test_distributed_cpu.py drives the same plumbing with a gloo stub.)"""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -83,7 +84,7 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv)), env=env))
     # poll ALL ranks: when one dies the others would sit in a collective until its timeout -- stop them at once
     rc, alive = 0, set(range(len(procs)))
     while alive:
@@ -323,6 +324,34 @@ def latency_small(feat, rng_file, device, flags, trained_model=None, headline_mo
     return c2
 
 
+def reduce_over_ranks(dist, torch, device, world, elapsed_s, evals, step_ms, coll_us, kernel_ms):
+    """The contract's reductions for one timed run -- MAX of the elapsed time over the ranks, SUM of the evaluations -- and an
+    all-gather of every rank's own (ms per step, collective us, kernel ms), so that a multi-GPU run explains itself.
+    -> (elapsed_max_s, total_evals, per_rank [[step_ms, coll_us, kernel_ms] per rank])"""
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    ev = torch.tensor([evals], dtype=torch.int64, device=device)
+    mine = torch.tensor([step_ms, coll_us or 0.0, kernel_ms], dtype=torch.float64, device=device)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    per_rank = [[float(v) for v in q.tolist()] for q in allr]
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(ev, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(ev.item()), per_rank
+
+
+def ranks_block(world, per_rank, shard, use_dist, dist=None, rccl_version=None, fallback=None):
+    """The `ranks` object of the JSON line: how the ranks were launched, what the communicator saw, every rank's own timings."""
+    return {"world_size": world, "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+            ("bench.py (self-spawned ranks)" if world > 1 else "single process"),
+            "per_rank_ms_per_step": [q[0] for q in per_rank] if per_rank else [fallback[0]],
+            "per_rank_collective_us": [q[1] for q in per_rank] if per_rank else None,
+            "per_rank_kernel_ms": [q[2] for q in per_rank] if per_rank else [fallback[1]],
+            "collective": ("one all-gather of the 16-byte roll records per step" if shard == "rolls" else
+                           "one 8-byte all-reduce(max) per step") + " (host wall-clock incl. its synchronisation, median over the steps of the median seed)",
+            "rccl_world_size": dist.get_world_size() if use_dist else 1,
+            "rccl_version": rccl_version}
+
+
 def main():
     args = parse()
     if args.cabi_child:
@@ -436,18 +465,11 @@ def main():
         eng = make_engine(args.precision, mp)
         r = run(eng, args.steps, args.warmup, use_dist)
         eng.close()
-        t = torch.tensor([r["elapsed"]], dtype=torch.float64, device="cuda")
-        ev = torch.tensor([r["evals"]], dtype=torch.int64, device="cuda")
-        per_rank = None
+        per_rank, el, tot = None, r["elapsed"], r["evals"]
         if use_dist:
-            # every rank's own step time and collective time (so that a multi-GPU run explains itself), then the reductions of the contract
-            mine = torch.tensor([1e3 * r["elapsed"] / args.steps, r["coll_us"] or 0.0, r["svm_s"] * 1e3], dtype=torch.float64, device="cuda")
-            allr = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)
-            per_rank = [[float(v) for v in q.tolist()] for q in allr]
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dist.all_reduce(ev, op=dist.ReduceOp.SUM)
-        runs.append(dict(seed=sd, model=mp, res=r, elapsed=float(t.item()), total_evals=int(ev.item()), per_rank=per_rank))
+            el, tot, per_rank = reduce_over_ranks(dist, torch, "cuda", world, r["elapsed"], r["evals"], 1e3 * r["elapsed"] / args.steps,
+                                                  r["coll_us"], r["svm_s"] * 1e3)
+        runs.append(dict(seed=sd, model=mp, res=r, elapsed=el, total_evals=tot, per_rank=per_rank))
     ranked = sorted(runs, key=lambda q: q["total_evals"] / q["elapsed"])
     med = ranked[(len(ranked) - 1) // 2]                    # lower median: never better than half of the seeds
     res, elapsed, total_evals, model_path = med["res"], med["elapsed"], med["total_evals"], med["model"]
@@ -677,15 +699,9 @@ def main():
             line["grasp_latency"] = latency_small(feat, rng_file, local_rank,
                                                {"f32": capi.FLAG_FP32_MFMA, "f16x3": capi.FLAG_SPLIT_F16, "f16s": 0}[args.precision], tr_lat,
                                                model_path if args.nsv >= 1024 else None)
-        line["ranks"] = {"world_size": world, "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
-                         ("bench.py (self-spawned ranks)" if world > 1 else "single process"),
-                         "per_rank_ms_per_step": [q[0] for q in med["per_rank"]] if med["per_rank"] else [1e3 * elapsed / args.steps],
-                         "per_rank_collective_us": [q[1] for q in med["per_rank"]] if med["per_rank"] else None,
-                         "per_rank_kernel_ms": [q[2] for q in med["per_rank"]] if med["per_rank"] else [res["svm_s"] * 1e3],
-                         "collective": ("one all-gather of the 16-byte roll records per step" if args.shard == "rolls" else
-                                        "one 8-byte all-reduce(max) per step") + " (host wall-clock incl. its synchronisation, median over the steps of the median seed)",
-                         "rccl_world_size": dist.get_world_size() if use_dist else 1,
-                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if use_dist else None}
+        line["ranks"] = ranks_block(world, med["per_rank"], args.shard, use_dist, dist,
+                                    ".".join(str(v) for v in torch.cuda.nccl.version()) if use_dist else None,
+                                    fallback=(1e3 * elapsed / args.steps, res["svm_s"] * 1e3))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -186,7 +186,7 @@ def check_no_spills(lib=None, verbose=False):
     return report
 
 
-def _compile_and_link(out_lib, out_testing, obj_dir, extra_flags=(), verbose=False):
+def _compile_and_link(out_lib, out_testing, obj_dir, extra_flags=(), verbose=False, checks=True):
     """Compiles every translation unit into obj_dir and links the two libraries under the given names (checked for the v_exp_f32
     hazard and for spills before they get those names)."""
     hipcc = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
@@ -230,8 +230,9 @@ def _compile_and_link(out_lib, out_testing, obj_dir, extra_flags=(), verbose=Fal
         for out in (out_lib, out_testing):
             if os.path.exists(out):
                 os.remove(out)                  # whatever happens below, a stale library must not survive a failed build
-        check_exp_hazard(staged[0][0], verbose=verbose)
-        check_no_spills(staged[0][0], verbose=verbose)
+        if checks:
+            check_exp_hazard(staged[0][0], verbose=verbose)
+            check_no_spills(staged[0][0], verbose=verbose)
         for tmp, out in staged:
             os.replace(tmp, out)
     finally:
@@ -240,15 +241,16 @@ def _compile_and_link(out_lib, out_testing, obj_dir, extra_flags=(), verbose=Fal
                 os.remove(tmp)
 
 
-def build_variant(name, flags, verbose=False):
+def build_variant(name, flags, verbose=False, checks=True):
     """An experiment build NEXT TO the product: haf_grasping_amd/variants/libhafgrasp_<name>.so and libhafgrasp_testing_<name>.so from
     the same sources with extra compiler flags (e.g. -DHAF_LR_WGS=3), objects under csrc/_variants/<name>/.  The product's names
-    are never touched; load a variant with HAF_LIB / HAF_TESTLIB (capi.py).  Same ISA checks as the product build."""
+    are never touched; load a variant with HAF_LIB / HAF_TESTLIB (capi.py).  Same ISA checks as the product build unless checks=False
+    (--no-checks: TIMING-ONLY ablation variants whose results are garbage by construction; never for a build whose results are used)."""
     vdir = os.path.join(HERE, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, "libhafgrasp_%s.so" % name)
     out_t = os.path.join(vdir, "libhafgrasp_testing_%s.so" % name)
-    _compile_and_link(out, out_t, os.path.join(CSRC, "_variants", name), extra_flags=list(flags), verbose=verbose)
+    _compile_and_link(out, out_t, os.path.join(CSRC, "_variants", name), extra_flags=list(flags), verbose=verbose, checks=checks)
     return out, out_t
 
 
@@ -270,6 +272,7 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python -m haf_grasping_amd.build --variant NAME -DFLAG ...
-        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+        rest = [a for a in sys.argv[3:] if a != "--no-checks"]
+        print(build_variant(sys.argv[2], rest, verbose=True, checks="--no-checks" not in sys.argv))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -891,6 +891,11 @@ void launch_project(const void *X0, const void *btiles, void *Y, float *raw, con
 #ifndef HAF_LR_EXPLAG
 #define HAF_LR_EXPLAG 4
 #endif
+// HAF_LR_ABL (experiment builds only, haf_grasping_amd/build.py: build_variant; results are garbage, only the kernel's time means anything):
+// bit 0 no in-loop LDS-DMA, 1 no epilogue VALU, 2 no B-fragment reads, 3 no tile barrier / wait, 4 no projection MFMAs
+#ifndef HAF_LR_ABL
+#define HAF_LR_ABL 0
+#endif
 constexpr int kLrExpLag = HAF_LR_EXPLAG;        // MFMAs between an element's v_exp_f32 and its first consumer (>= 2: ten instructions)
 constexpr bool kLrTwoLevel = HAF_LR_WGS < 3;   // three workgroups per CU need the sixteen registers of the second summation level (its band term is relative to S_psi: small either way)
 // One column block (16 SVs) of the 6-step sweep: 24 MFMAs; the epilogue of the PREVIOUS block's 16 elements rides between them --
@@ -908,11 +913,13 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const float ba2 = CRP ? cf_old * kPsiA2 : 0.0f, ba3 = CRP ? cf_old * kPsiA3 : 0.0f, ba4 = CRP ? cf_old * kPsiA4 : 0.0f;
     if (n == 0) b = *reinterpret_cast<const half8 *>(bl);
+    if (HAF_LR_ABL & 2) asm volatile("" :: "v"(old[0]), "v"(old[1]), "v"(old[2]), "v"(old[3]));
     float kq[16];                                                    // exp2 results in flight (CR_EXP): at most five live at a time
 #define HAF_SB() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int s = 0; s < kLrSteps; s++) {
-        if (s + 1 < kLrSteps) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
+        if (HAF_LR_ABL & 4) b1 = b;
+        else if (s + 1 < kLrSteps) b1 = *reinterpret_cast<const half8 *>(bl + (s + 1) * 2048);
         else if (n == 0) b1 = *reinterpret_cast<const half8 *>(bl + 1024);
         HAF_SB();
 #pragma unroll
@@ -920,7 +927,8 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
             const int j = 4 * s + i;
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][i], b, s == 0 ? z4 : acc[i], 0, 0, 0);
             HAF_SB();
-            if (s == 0 && i < COUNT) { dma_piece(dma.g[FIRST + i], dma.l[FIRST + i], lane16); HAF_SB(); }
+            if (s == 0 && i < COUNT && !(HAF_LR_ABL & 1)) { dma_piece(dma.g[FIRST + i], dma.l[FIRST + i], lane16); HAF_SB(); }
+            if (HAF_LR_ABL & 2) continue;
             if (!CRP) {
                 if (j < 16) { kq[j] = __builtin_amdgcn_exp2f(old[j >> 2][j & 3]); HAF_SB(); }
                 if (PLN && j >= 16) {
@@ -1055,8 +1063,12 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
 #pragma unroll
             for (int rb = 0; rb < 2 * kLrSteps; rb++) {
                 const half8 bf = *reinterpret_cast<const half8 *>(cur + rb * 1024 + lane * 16);
+                if (!(HAF_LR_ABL & 16)) {
 #pragma unroll
                 for (int m = 0; m < 4; m++) accp[rb][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, xc[m], accp[rb][m], 0, 0, 0);
+                } else if (rb < 4) {
+                    accp[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, xc[rb], accp[rb][0], 0, 0, 0);
+                }
                 if (rb == 0) {
                     // behind the first MFMAs (which have waited for nothing: everything issued so far has landed): the next step's operand
                     // fragments and the ring tile two ahead -- a projection tile or one of the first two SV tiles (with its tail piece)
@@ -1120,7 +1132,7 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
             const char *cur = lds + ((t + kV0) % kS0Buffers) * kLrSvTileBytes;
             const int tn = (t + 2) % nt;
             const TileDma dma = tile_dma(svt + (size_t)tn * kLrSvTileBytes, lds0 + ((t + 2 + kV0) % kS0Buffers) * kLrSvTileBytes, poff);
-            if (wave_u == 0) dma_piece(svt + (size_t)tn * kLrSvTileBytes + kLrMatBytes,
+            if (wave_u == 0 && !(HAF_LR_ABL & 1)) dma_piece(svt + (size_t)tn * kLrSvTileBytes + kLrMatBytes,
                                        lds0 + ((t + 2 + kV0) % kS0Buffers) * kLrSvTileBytes + kLrMatBytes, lane16);
             const float *tt = reinterpret_cast<const float *>(cur + kLrMatBytes);
             const float cf0 = tt[32 + (lane & 15)], cf1 = tt[48 + (lane & 15)];
@@ -1135,8 +1147,10 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
 #pragma unroll
                     for (int r = 0; r < 4; r++) { part[m][r] += sum[m][r]; sum[m][r] = 0.0f; }
             }
+            if (!(HAF_LR_ABL & 8)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            }
             asm volatile("" ::: "memory");
         }
         float *dst = ph ? fin : pos;

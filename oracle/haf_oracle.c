@@ -874,6 +874,10 @@ static void effective_ranges(const hafo_range *rg, const double *q4, long rows, 
     *fmin_o = fmin; *fmax_o = fmax; *max_index_o = max_index;
 }
 
+/* test hook (haf_oracle.h): the roll loop of hafo_run starts here instead of at 0 */
+static int g_roll_first = 0;
+void hafo_set_roll_first(int roll) { g_roll_first = roll < 0 ? 0 : roll; }
+
 int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg, const hafo_model *m,
              const float *xyz, size_t n, size_t stride, const hafo_input *in, hafo_output *out, hafo_debug *dbg)
 {
@@ -895,7 +899,7 @@ int hafo_run(const hafo_cfg *cfg, const hafo_features *ft, const hafo_range *rg,
     int rolls_done = 0;
     float M_last[16]; mat4_identity(M_last);
 
-    for (int roll = 0; roll < cfg->n_rolls; roll++) {              /* 345 */
+    for (int roll = g_roll_first; roll < cfg->n_rolls; roll++) {   /* 345 (the reference always starts at 0: g_roll_first is a test hook) */
         if (in->show_only_best && o_top >= cfg->graspval_top) break;   /* 362-365 */
         float M[16];
         hafo_transform(cfg, in, roll, 0, M);

@@ -126,6 +126,10 @@ enum { HAFO_V_EIGEN_TREE = 1,         /* 4x4 products: (a0b0 + a1b1) + (a2b2 + a
        HAFO_V_INTEGRAL_COLFIRST = 16  /* summed-area table by running column sums               server.cpp:595      */ };
 void hafo_set_variant(int flags);
 int hafo_get_variant(void);
+/* Test hook: hafo_run scores rolls [first, cfg->n_rolls) only (the reference's loop, server.cpp:345, always starts at 0; its rolls
+ * are independent, 376-385).  For tests that compare ONE complete roll of a large request with the engine without paying for the
+ * rolls in front of it; the debug arrays stay indexed by the absolute roll.  0 = the reference's behaviour. */
+void hafo_set_roll_first(int first);
 
 void hafo_transform(const hafo_cfg *cfg, const hafo_input *in, int roll,
                     int use_double_atan2, float M[16]);

@@ -101,6 +101,7 @@ def lib():
         L.hafo_run.argtypes = [C.POINTER(Cfg), C.POINTER(Features), C.POINTER(Range), C.POINTER(Model), C.c_void_p,
                                C.c_size_t, C.c_size_t, C.POINTER(Input), C.POINTER(Output), C.POINTER(Debug)]
         L.hafo_set_variant.argtypes = [C.c_int]
+        L.hafo_set_roll_first.argtypes = [C.c_int]
         L.hafo_get_variant.restype = C.c_int
         L.hafo_dump_feature_file.restype = C.c_long
         L.hafo_dump_feature_file.argtypes = [C.POINTER(Cfg), C.POINTER(Features), C.c_void_p, C.c_size_t, C.c_size_t,
@@ -207,7 +208,8 @@ class Oracle:
         lab = lib().hafo_probability(self.m, float(dec), pr)
         return (lab, pr[0], pr[1]) if self.m.contents.has_prob else None
 
-    def run(self, xyz, cfg, inp, debug=True):
+    def run(self, xyz, cfg, inp, debug=True, roll_first=0):
+        """hafo_run; roll_first > 0 (test hook): only rolls [roll_first, cfg.n_rolls) are scored, arrays stay indexed by absolute roll"""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)
         assert xyz.ndim == 2 and xyz.shape[1] >= 3
         out = Output()
@@ -225,8 +227,12 @@ class Oracle:
             dbg = Debug(*[_p(arrays[k]) if k in arrays else None
                           for k in ("heights", "integral", "mask", "labels", "dec", "graspseval", "roll_best", "M", "sabs",
                                     "prob", "graspsgrid")])
-        rc = lib().hafo_run(C.byref(cfg), self.ft, self.rg, self.m, _p(xyz), xyz.shape[0], xyz.shape[1],
-                            C.byref(inp), C.byref(out), C.byref(dbg) if dbg else None)
+        lib().hafo_set_roll_first(int(roll_first))
+        try:
+            rc = lib().hafo_run(C.byref(cfg), self.ft, self.rg, self.m, _p(xyz), xyz.shape[0], xyz.shape[1],
+                                C.byref(inp), C.byref(out), C.byref(dbg) if dbg else None)
+        finally:
+            lib().hafo_set_roll_first(0)
         if rc != 0:
             raise RuntimeError("hafo_run failed: %d" % rc)
         res = dict(eval=out.eval, gp1=tuple(out.gp1), gp2=tuple(out.gp2), avg=tuple(out.avg), av=tuple(out.av),

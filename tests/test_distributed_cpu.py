@@ -95,6 +95,51 @@ def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpus():
     assert p.stdout.strip() == ""                              # no JSON line from a failed run
 
 
+def _spawn(world, extra):
+    """bench.spawn_ranks in a child of its own (it must never share a process with torch), driving tests/stub_rank.py"""
+    import subprocess
+    import sys
+    code = ("import sys, argparse; sys.path.insert(0, %r); import bench; "
+            "raise SystemExit(bench.spawn_ranks(argparse.Namespace(gpus=%d), script=%r, argv=%r))"
+            % (ROOT, world, os.path.join(ROOT, "tests", "stub_rank.py"), ["--gpus", str(world)] + extra))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=420, env=env)
+
+
+def test_self_spawned_ranks_world8_on_gloo():
+    """no 8-GPU run has happened on this pool, so the first one must not fail on plumbing.  bench.py's own launcher
+    (spawn_ranks) starts EIGHT rank processes of a stub that does what bench.py's ranks do around the timed region -- rendezvous from
+    the launcher's environment, the per-step election collective, the contract's reductions (bench.reduce_over_ranks), rank 0's ONE
+    JSON line with the `ranks` block (bench.ranks_block) -- on gloo: rank 0's line is the only stdout, every per-rank field has eight
+    entries in rank order, the elapsed time is the MAX over the ranks and the evaluations their SUM."""
+    import json
+    p = _spawn(8, ["--steps", "3"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    # (the gloo library itself reports its connections on stdout, "[Gloo] Rank r is connected to ..."; RCCL does not)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
+    assert len(lines) == 1, p.stdout                                   # rank 0's line and nothing else
+    d = json.loads(lines[0])
+    rk = d["ranks"]
+    assert d["n_gpus"] == 8 and rk["world_size"] == 8 and rk["rccl_world_size"] == 8 and rk["launched_by"] == "bench.py (self-spawned ranks)"
+    assert len(rk["per_rank_ms_per_step"]) == len(rk["per_rank_collective_us"]) == len(rk["per_rank_kernel_ms"]) == 8
+    assert rk["per_rank_kernel_ms"] == [7.0 + r for r in range(8)]                      # all-gathered in rank order
+    np.testing.assert_allclose(rk["per_rank_ms_per_step"], [10.0 * (1.0 + 0.01 * r) for r in range(8)], rtol=1e-12)
+    np.testing.assert_allclose(d["ms_per_step"], 10.7, rtol=1e-12)                      # MAX over the ranks
+    np.testing.assert_allclose(d["value"], 8 * 3000 / (0.0107 * 3), rtol=1e-12)         # SUM of the evaluations / that time
+    assert all(c > 0 for c in rk["per_rank_collective_us"])
+
+
+def test_self_spawned_ranks_propagate_a_failing_rank():
+    """One of eight ranks dies with exit code 7 before the first collective: the launcher returns 7, names the rank, stops the other
+    seven at once (they would otherwise wait for the rendezvous until its timeout) and prints no JSON line."""
+    import time
+    t0 = time.time()
+    p = _spawn(8, ["--fail-rank", "5", "--fail-code", "7"])
+    assert p.returncode == 7, (p.returncode, p.stderr[-1000:])
+    assert "rank 5 exited with 7; stopping the other ranks" in p.stderr
+    assert p.stdout.strip() == "" and time.time() - t0 < 120
+
+
 def test_multi_gpu_partition_without_a_device(data_dir=None):
     """the argument and partition logic of haf_create_multi (csrc/multi.cpp) runs here, on the CPU, through
     haf_multi_plan -- the function create_multi itself uses: 36 rolls over 8 GPUs are 5,5,5,5,4,4,4,4 contiguous ranges

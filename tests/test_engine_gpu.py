@@ -1599,6 +1599,57 @@ def test_bench_configuration_against_the_oracle_where_screening_was_closest(data
     eng.close()
 
 
+@pytest.mark.parametrize("spec,roll", [(("rand", 4096, 42), 0), (("trained", None), 7)], ids=["rand4096-42-roll0", "trained-roll7"])
+def test_one_complete_roll_of_the_bench_workload_against_the_oracle(data_dir, tmp_path, trained_model, spec, roll):
+    """parity at the bench's OWN size was a sample of ~2 900 cells per model plus cross-mode equality.  Here one
+    COMPLETE roll of the C5 request bench.py times -- 512 x 512 grid, 36 rolls of 5 degrees, 524 288 points; the median-seed random
+    model (nSV 4096, seed 42) roll 0, and the trained 8964-SV model on a ROLLED grid (roll 7 = 35 degrees) -- is compared with the
+    oracle cell for cell: height grid, integral image and mask bit for bit, the label of every one of its ~248 000 evaluations
+    (libsvm's fp64 order: svm.cpp:2478-2532), the 29-tap vote grid and the roll record (server.cpp:803-973).  The engine runs the whole
+    36-roll request in its default mode, product library, exactly as the bench does (low-rank form of the screening pass + the tiers
+    behind it); the oracle scores the one roll on all host cores (HAFO_THREADS; rows are independent, arithmetic untouched)."""
+    path, _ = _bench_model(tmp_path, spec, trained_model)
+    f, r = _files(data_dir)
+    G = 512
+    xyz = models.synthetic_cloud(grid=G, k=2, seed=0)
+    eng = make_engine(data_dir, path, 0, grid_h=G, grid_w=G, n_rolls=36, roll_step_deg=5, max_points=1 << 20)
+    inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=G)
+    rec = eng.score_rolls([xyz], [inp], 0, 36)[0]
+    cnt = eng.last_counts()
+    assert eng.screen_low_rank()["last_used"] and 0 < cnt["n_refined"] < 0.1 * cnt["n_evals"]     # the bench's path: low-rank screening + tiers
+    got = dict(heights=eng.debug(capi.DBG_HEIGHTS, 0, roll), integral=eng.debug(capi.DBG_INTEGRAL, 0, roll), mask=eng.debug(capi.DBG_MASK, 0, roll),
+               labels=eng.debug(capi.DBG_LABELS, 0, roll), vote=eng.roll_grid(0, roll)[0])
+    form = eng.screen_form()
+    eng.close()
+    cores = len(os.sched_getaffinity(0))
+    old = os.environ.get("HAFO_THREADS")
+    os.environ["HAFO_THREADS"] = str(cores)
+    import time
+    t0 = time.perf_counter()
+    try:
+        o = O.Oracle(f, r, path)
+        want = o.run(xyz, O.make_cfg(H=G, W=G, n_rolls=roll + 1, roll_step_deg=5), O.make_input(length_x=G, length_y=G), roll_first=roll)
+    finally:
+        if old is None:
+            os.environ.pop("HAFO_THREADS", None)
+        else:
+            os.environ["HAFO_THREADS"] = old
+    dt = time.perf_counter() - t0
+    assert want["rolls_done"] == 1 and want["n_evals"] == int(rec["n_evals"][roll]) > 240000
+    assert (got["heights"].view(np.uint32) == want["heights"][roll].view(np.uint32)).all()
+    assert (got["integral"].view(np.uint32) == want["integral"][roll].view(np.uint32)).all()
+    assert (got["mask"] == want["mask"][roll]).all()
+    n_diff = int((got["labels"] != want["labels"][roll]).sum())
+    assert n_diff == 0, ("labels differ from libsvm's", n_diff)
+    assert (got["vote"] == want["graspseval"][roll]).all()
+    br, bc, bv = (int(v) for v in want["roll_best"][roll])
+    assert (int(rec["row"][roll]), int(rec["col"][roll]), int(rec["vote"][roll])) == (br, bc, bv)
+    lab = want["labels"][roll][want["mask"][roll] == 1]
+    STATS["full_roll_%s_r%d" % ("_".join(str(t) for t in spec), roll)] = {
+        "evaluations": int(want["n_evals"]), "oracle_seconds": dt, "oracle_cores": cores, "labels_differing": n_diff, "form": form,
+        "positive_labels": int((lab == lab.max()).sum()), "record": [br, bc, bv]}
+
+
 def test_integral_image_falls_back_to_the_sequential_order_when_sums_are_inexact(data_dir, surrogate, orc):
     """Beyond ~70 x 70 cells the integral image is built by parallel scans whose every fp64 addition is checked for exactness;
     exact sums are order independent, so the result equals cv::integral's sequential order bit for bit (calc_intimage,
