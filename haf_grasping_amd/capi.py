@@ -154,6 +154,10 @@ def _bind(path, testing):
         L.haf_test_f16_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.haf_test_screen_state.argtypes = [E, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.haf_test_set_screen_inactive.argtypes = [E]
+        L.haf_test_check_canaries.argtypes = [C.c_char_p, C.c_int]
+        L.haf_test_canary_buffers.argtypes = []
+        L.haf_test_poke_flag0_list.argtypes = [E, C.c_int, C.c_int, C.c_int]
+        L.haf_test_overflow_stats.argtypes = [E, C.c_void_p]
     return L
 
 
@@ -185,6 +189,15 @@ def testlib():
     if _testlib is None:
         _testlib = _bind(TESTLIB_PATH, testing=True)
     return _testlib
+
+
+def check_canaries():
+    """Testing build: the guard zones in front of and behind EVERY device buffer of every engine of this process (csrc/engine_state.h:
+    DevBuf).  -> (number of damaged buffers, report naming them by the source line that allocated them, buffers registered)"""
+    L = testlib()
+    msg = C.create_string_buffer(4096)
+    bad = L.haf_test_check_canaries(msg, 4096)
+    return bad, msg.value.decode(errors="replace"), L.haf_test_canary_buffers()
 
 
 def default_config(**kw):
@@ -291,6 +304,12 @@ class Engine:
         a, r, b, c = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._L.haf_last_tiers(self._h, C.byref(a), C.byref(r), C.byref(b), C.byref(c)))
         return dict(n_evals=a.value, n_refined=r.value, n_rechecked=b.value, n_strict=c.value)
+
+    def overflow_stats(self):
+        """Testing build: how often this engine's requests met a list smaller than what it had to hold."""
+        out = (C.c_longlong * 2)()
+        self._check(self._L.haf_test_overflow_stats(self._h, out))
+        return dict(screening_list_overflows=int(out[0]), extra_windows=int(out[1]))
 
     def last_exact_tiers(self):
         a, b = C.c_int64(), C.c_int64()

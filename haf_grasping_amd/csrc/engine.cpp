@@ -314,7 +314,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
     // the tests that scale a guard band or force a tier mean the tiers themselves, also on a tiny request
     if (test_env("HAF_NO_DIRECT") || test_env("HAF_GUARD_REL") || test_env("HAF_GUARD0_REL") || test_env("HAF_GUARD2_REL") ||
         test_env("HAF_LARGE_EVALS") || test_env("HAF_NO_FAST_GROUPS") || test_env("HAF_SCREEN_NO_CENTRE") || test_env("HAF_FLAG_WINDOW") ||
-        test_env("HAF_HOST_EXP_ALL") || test_env("HAF_NO_I8") || test_env("HAF_GUARD_I8_REL"))
+        test_env("HAF_HOST_EXP_ALL") || test_env("HAF_NO_I8") || test_env("HAF_GUARD_I8_REL") || test_env("HAF_FLAG0_CAP"))
         e->direct_work = 0;
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     if (const char *v = test_env("HAF_REPROBE_EVERY")) e->reprobe_every = std::max(1, atoi(v));

@@ -490,7 +490,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             // then the vote again.  Slower, same labels.
             int done_fp64 = e->flag_cap;                  // entries of its list the fp64 tier has seen (window 0)
             if (more_i8) {
-                for (int off = e->flag_cap; off < flagged; off += e->flag_cap) i8_window(off);
+                for (int off = e->flag_cap; off < flagged; off += e->flag_cap) { i8_window(off); e->stat_extra_windows++; }
                 // the fp64 tier's list has grown behind its first window: all of it again from the start (its results and the
                 // strict tier's list are rebuilt; both are idempotent)
                 HIPCHK(e, hipMemsetAsync(e->d_counters.p + CNT_FLAGGED2, 0, sizeof(int), s));
@@ -499,7 +499,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                 done_fp64 = 0;
             }
             const int n_fp64 = i8 ? e->h_counters[CNT_FLAGGEDI] : flagged;
-            for (int off = done_fp64; off < n_fp64; off += e->flag_cap) fp64_window(off);
+            for (int off = done_fp64; off < n_fp64; off += e->flag_cap) { fp64_window(off); e->stat_extra_windows++; }
             launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
                            e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
             rc = vote();
@@ -587,6 +587,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
         // More undecided evaluations than the refinement list holds: this pass's labels are incomplete.  Remedy: the next form, and
         // stay with it; when none is left (or the variant is pinned by a test), the three-pass kernel for every evaluation of
         // this call (same labels by construction) -- and, unless pinned, no screening pass for this model from now on.
+        if (undecided() > e->flag0_cap) e->stat_flag0_overflows++;
         while (undecided() > e->flag0_cap && !e->variant_forced && next_variant(e->screen_variant) >= 0) {
             const bool reuse = e->screen_variant == SCREEN_PLAIN && !t0b_used && !lr_used;     // (tier 0b writes its bands where the first pass's were; the low-rank form's images are the centred ones)
             t0b_used = false;
@@ -650,6 +651,14 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
     // (the tier lists hold every evaluation of a request: list_cap >= last_evals >= last_flagged >= last_flagged2)
     if (e->last_flagged > e->list_cap || e->last_flagged2 > e->list_cap || e->last_flaggedi > e->list_cap) return fail(e, HAF_E_INTERNAL, "recheck list counters exceed the number of evaluations");
     e->last_i8 = i8_used;
+#ifdef HAF_TESTING
+    // testing build, HAF_CANARY_CHECK set (tests/conftest.py): the guard zones around every device buffer after EVERY request
+    if (test_env("HAF_CANARY_CHECK")) {
+        std::string rep;
+        const int bad = canary_check(&rep);
+        if (bad != 0) return fail(e, HAF_E_INTERNAL, "device buffer guard zones damaged (" + std::to_string(bad) + "): " + rep);
+    }
+#endif
     for (int i = 0; i < B * R; i++) {
         records[i].vote = e->h_rec[i].vote;
         records[i].row = e->h_rec[i].row;

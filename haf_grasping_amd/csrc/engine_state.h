@@ -62,9 +62,45 @@ Mat4 roll_transform(const haf_config &cfg, const haf_grasp_input &in, const Norm
 void fill_roll_geo(const haf_config &cfg, const haf_grasp_input &in, const NormalisedInput &n, int roll, RollGeo &g, float *m0 = nullptr);
 bool invert(const Mat4 &m, Mat4 &inv);
 
+// Testing build: every device buffer lies between two guard zones filled with kCanaryByte -- kCanaryGuard bytes in front, and from
+// the buffer's last byte to the next multiple of kCanaryGuard plus kCanaryGuard behind -- and is registered with the source line that
+// allocated it (engine_testing.cpp: canary_check).  A kernel that writes one element past a list, an operand image or a flag-word
+// array changes a guard byte; read as a list entry the pattern is a NEGATIVE evaluation id (0xA5A5A5A5), which no consumer may follow.
+// The tests check the zones after every request (HAF_CANARY_CHECK=1 in tests/conftest.py; haf_test_check_canaries).  The product
+// library allocates exactly what is asked for.
+#ifdef HAF_TESTING
+constexpr size_t kCanaryGuard = 256;
+constexpr int kCanaryByte = 0xA5;
+void canary_register(void *user, size_t bytes, const char *file, int line);
+void canary_unregister(void *user);
+int canary_check(std::string *report);          // number of buffers with a damaged guard zone (engine_testing.cpp)
+#endif
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+#ifdef HAF_TESTING
+    hipError_t alloc(size_t count, const char *file = __builtin_FILE(), int line = __builtin_LINE())
+    {
+        n = count;
+        if (!count) return hipSuccess;
+        const size_t bytes = count * sizeof(T), padded = (bytes + kCanaryGuard - 1) / kCanaryGuard * kCanaryGuard;
+        char *raw = nullptr;
+        hipError_t rc = hipMalloc((void **)&raw, kCanaryGuard + padded + kCanaryGuard);
+        if (rc != hipSuccess) return rc;
+        rc = hipMemset(raw, kCanaryByte, kCanaryGuard);
+        if (rc == hipSuccess) rc = hipMemset(raw + kCanaryGuard + bytes, kCanaryByte, padded - bytes + kCanaryGuard);
+        if (rc != hipSuccess) { (void)hipFree(raw); return rc; }
+        p = reinterpret_cast<T *>(raw + kCanaryGuard);
+        canary_register(p, bytes, file, line);
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) { canary_unregister(p); (void)hipFree(reinterpret_cast<char *>(p) - kCanaryGuard); }
+        p = nullptr; n = 0;
+    }
+#else
     hipError_t alloc(size_t count)
     {
         n = count;
@@ -72,6 +108,7 @@ template <typename T> struct DevBuf {
         return hipMalloc((void **)&p, count * sizeof(T));
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+#endif
 };
 
 }  // namespace haf_host
@@ -240,6 +277,9 @@ struct haf_engine {
 
     std::vector<std::pair<const char *, size_t>> host_regs;   // haf_register_host_cloud: page-locked caller buffers
 
+    // how often a request met a list smaller than what it had to hold (the overflow campaigns read them: haf_test_overflow_stats)
+    long stat_flag0_overflows = 0;  // the screening passes left more undecided than their list holds: decision stage redone
+    long stat_extra_windows = 0;    // windows of the exact tiers' lists beyond the first
     // last call
     int last_B = 0, last_R = 0, last_roll_first = 0;
     int last_evals = 0, last_flagged = 0, last_flagged2 = 0, last_flagged0 = 0, last_inexact = 0;

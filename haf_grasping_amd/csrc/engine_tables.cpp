@@ -1093,6 +1093,12 @@ int alloc_buffers(haf_engine *e)
     // screening pass: up to half of the evaluations may go on to the three-pass kernel; a model that sends more is served by
     // the three-pass kernel alone from then on (haf_score_rolls)
     e->flag0_cap = mode == MODE_SCREEN ? (int)std::min<long>(std::max<long>(4096, (e->max_evals / 2 + 255) / 256 * 256), 1L << 23) : 0;
+    // testing build, the overflow campaigns (tools/fuzz_parity.py --overflow): a screening list far smaller than a request, so that every
+    // producer of it runs into its capacity and every consumer meets a counter beyond it (the engine's answer to such an overflow: the
+    // next form, then the three-pass kernel for everything).  The windows of the exact tiers shrink with HAF_FLAG_WINDOW above.  The
+    // TIER lists (list_cap) are not shrunk: they hold one entry per evaluation of the largest request, no producer can overrun them,
+    // and their window-by-window consumers rely on exactly that (a counter never exceeds the list).
+    if (const char *v = test_env("HAF_FLAG0_CAP")) e->flag0_cap = mode == MODE_SCREEN ? (int)std::min<long>(e->list_cap, std::max(256, atoi(v) / 256 * 256)) : 0;
     bool ok = true;
     e->in_hdr_cap = (B * sizeof(CloudDev) + 15) / 16 * 16 + (B * R * sizeof(RollGeo) + 15) / 16 * 16;
     ok &= hipSuccess == e->d_in.alloc(e->in_hdr_cap + (size_t)c.max_points * 3 * sizeof(float));

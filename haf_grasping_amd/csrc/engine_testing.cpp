@@ -5,7 +5,93 @@
 #error "engine_testing.cpp belongs to the testing build (-DHAF_TESTING)"
 #endif
 
+// ---- guard zones around every device buffer (engine_state.h: DevBuf) ----
+namespace haf_host {
+namespace {
+struct CanaryRec { char *user; size_t bytes; const char *file; int line; };
+std::mutex g_canary_mu;
+std::vector<CanaryRec> g_canary;
+}
+void canary_register(void *user, size_t bytes, const char *file, int line)
+{
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    g_canary.push_back(CanaryRec{static_cast<char *>(user), bytes, file, line});
+}
+void canary_unregister(void *user)
+{
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    for (size_t i = 0; i < g_canary.size(); i++)
+        if (g_canary[i].user == user) { g_canary[i] = g_canary.back(); g_canary.pop_back(); return; }
+}
+// Copies both zones of every registered buffer back and compares them with the pattern; the report names each damaged buffer by the
+// source line that allocated it, the side, the first damaged byte's offset from the buffer's end (or start) and the 4 bytes found there.
+// Synchronises the device first: every kernel of the requests so far has finished.
+int canary_check(std::string *report)
+{
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    if (hipDeviceSynchronize() != hipSuccess) { if (report) *report += "hipDeviceSynchronize failed; "; return -1; }
+    int bad = 0;
+    std::vector<unsigned char> h;
+    for (const CanaryRec &r : g_canary) {
+        const size_t padded = (r.bytes + kCanaryGuard - 1) / kCanaryGuard * kCanaryGuard, back = padded - r.bytes + kCanaryGuard;
+        bool hit = false;
+        for (int side = 0; side < 2; side++) {
+            const size_t len = side ? back : kCanaryGuard;
+            const char *src = side ? r.user + r.bytes : r.user - kCanaryGuard;
+            h.resize(len);
+            if (hipMemcpy(h.data(), src, len, hipMemcpyDeviceToHost) != hipSuccess) { if (report) *report += "hipMemcpy of a guard zone failed; "; return -1; }
+            for (size_t i = 0; i < len; i++)
+                if (h[i] != (unsigned char)kCanaryByte) {
+                    hit = true;
+                    if (report) {
+                        char buf[256];
+                        const size_t w = i / 4 * 4;
+                        unsigned word = 0;
+                        memcpy(&word, h.data() + w, std::min<size_t>(4, len - w));
+                        snprintf(buf, sizeof buf, "%s:%d (%zu bytes): %s guard damaged at %s%zu, word there 0x%08x; ", r.file, r.line, r.bytes,
+                                 side ? "back" : "front", side ? "end+" : "start-", side ? i : kCanaryGuard - i, word);
+                        *report += buf;
+                    }
+                    break;
+                }
+        }
+        bad += hit ? 1 : 0;
+    }
+    return bad;
+}
+}  // namespace haf_host
+
 extern "C" {
+
+// number of device buffers whose guard zones were written (0 = intact, < 0: HIP failure); msg (cap bytes) names them.  Covers every
+// engine of the process.
+int haf_test_check_canaries(char *msg, int cap)
+{
+    std::string rep;
+    const int bad = canary_check(&rep);
+    if (msg && cap > 0) { strncpy(msg, rep.c_str(), (size_t)cap - 1); msg[cap - 1] = 0; }
+    return bad;
+}
+// how many buffers are registered (the test checks that the hook sees the engine's buffers at all)
+int haf_test_canary_buffers()
+{
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    return (int)g_canary.size();
+}
+int haf_test_overflow_stats(haf_engine *e, long long *out2)
+{
+    if (!e || !out2) return HAF_E_ARG;
+    out2[0] = e->stat_flag0_overflows; out2[1] = e->stat_extra_windows;
+    return HAF_OK;
+}
+// writes `count` ints of value `v` at int offset `at` relative to the END of the d_flag0_list buffer (at >= 0) of this engine -- the
+// canary test's own "bug": what a producer that ignores its capacity does
+int haf_test_poke_flag0_list(haf_engine *e, int at, int count, int v)
+{
+    if (!e || !e->d_flag0_list.p) return HAF_E_ARG;
+    std::vector<int> h((size_t)count, v);
+    return hipMemcpy(e->d_flag0_list.p + e->d_flag0_list.n + at, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
 
 // ---- the hooks below exist in libhafgrasp_testing.so only (-DHAF_TESTING); the product library does not export them ----
 // host-only hooks: parsers, per-roll geometry and the cross-roll rule/pose, none of which touches a device

@@ -177,6 +177,8 @@ __device__ __forceinline__ ScrDescK constant_ptr(const ScrDesc *p) { return (Scr
 // the attribute -- the "%.4g" rounding |q4 - v| (formed in fp32: its cast costs another u |q4|) plus the fp32 roundings of the
 // products and of their sum (<= 3.1 u sum|w_k R_k|), valid when the region sums themselves are exact (k_features_serial checks that
 // per wave), times |scr_mul| (ScrDesc::pad, rounded up; 0 for a SHAF slot, which is passed through as it is).
+// u = 2^-24: 3 u (1 + 1e-3) and 4 u (1 + 1e-3), rounded up (the fp32 roundings of the bound's own three operations included)
+constexpr float kNbRound = 1.80e-7f, kNbRound3 = 2.40e-7f;
 template <int NB>
 __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2)
 {
@@ -210,13 +212,16 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         const double q4 = hafq::decq4_float_scr(v, st);
         ud[q] = fma(q4, sd[q].scr_mul, sd[q].scr_add);
         if (NB) {
-            // the products' rounding errors EXACTLY (fma), the sum's and the cast's bounded: u |v| + u |q4| <= 1.3e-7 |v| (|q4 - v| <= 5e-4 |v|)
-            const float e0 = fmaf(sd[q].w[0], R0, -r0), e1 = fmaf(sd[q].w[1], R1, -r1);
+            // round 5: the fp32 roundings BOUNDED instead of measured -- two products (u |r_k| each), their sum (u |v|) and the cast of q4
+            // (u |q4| <= 1.0005 u |v|), |v| <= (1 + u)(|r0| + |r1|): at most kNbRound (|r0| + |r1|), a thousandth of the "%.4g" term beside
+            // it (|q4 - v| ~ 1e-4 |v|).  Six vector instructions per slot instead of eleven.
             float ar = 0.0f;                               // NB == 2: a wave that did not pass the exactness test as a whole (features.hip)
             if (NB == 2)
                 ar = fabsf(sd[q].w[0]) * region_round_bound(c[q][0], c[q][1], c[q][2], c[q][3], s10, s20, R0) +
                      fabsf(sd[q].w[1]) * region_round_bound(c[q][4], c[q][5], c[q][6], c[q][7], s11, s21, R1);
-            const float nbq = sd[q].pad * (fabsf((float)q4 - v) + fabsf(e0 + e1) * 1.000001f + 1.3e-7f * fabsf(v) + ar);
+            float nbq = fmaf(kNbRound, fabsf(r0) + fabsf(r1), fabsf((float)q4 - v));
+            if (NB == 2) nbq += ar;
+            nbq *= sd[q].pad;
             nu2 = fmaf(nbq, nbq, nu2);
             // (the sum is tied to the sequence of the volatile LDS reads: left to float, the temporaries of eight slots stay alive until
             // the sums are finally formed -- 45 registers, two waves of occupancy)
@@ -279,9 +284,9 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
         const double q4 = hafq::decq4_float_scr(v, st);
         ud[q] = fma(q4, sd[q].scr_mul, sd[q].scr_add);
         if (NB) {
-            // (HAF slots only -- pad[0] = 0 for SHAF: exact product errors, the partial sum r0 + r1 and the total rounded once each)
-            const float ee = fmaf(sd[q].w[0], Rk[0], -r[0]) + fmaf(sd[q].w[1], Rk[1], -r[1]) + fmaf(sd[q].w[2], Rk[2], -r[2]);
-            const float nbq = sd[q].pad[0] * (fabsf((float)q4 - v) + fabsf(ee) * 1.000001f + 6.1e-8f * fabsf(r[0] + r[1]) + 1.3e-7f * fabsf(v) + ar);
+            // (HAF slots only -- pad[0] = 0 for SHAF: three products, the partial sum r0 + r1, the total and the cast of q4 rounded once each:
+            // at most 4 u (|r0| + |r1| + |r2|) <= kNbRound3 of it)
+            const float nbq = sd[q].pad[0] * (fmaf(kNbRound3, (fabsf(r[0]) + fabsf(r[1])) + fabsf(r[2]), fabsf((float)q4 - v)) + ar);
             nu2 = fmaf(nbq, nbq, nu2);
             asm volatile("" : "+v"(nu2));
         }

@@ -310,8 +310,8 @@ __device__ __forceinline__ void i8_store(float *X, long e, int g, const unsigned
 // workgroups for C5).  Small requests use k_features below.
 // LR (screening form only; kernels.h: kLrK, ScreenParams::lr): the wave also sums nu2 >= |p' - p_lin|^2 over the HAF slots and the
 // kernel leaves the RAW sums {su2, sd2, sx2, L, nu2} where the finished band would go (k_project adds |y^ - y32|^2, the sweep's tail
-// finishes the band: screen_band.h).  Per slot the bound is the "%.4g" rounding as it happened, the products' rounding errors exactly
-// and the sums' roundings (feature_device.h: screen_quad / screen_pair3 / screen_attribute_lr), plus, for a region whose sum is not
+// finishes the band: screen_band.h).  Per slot the bound is the "%.4g" rounding as it happened plus the fp32 roundings of the products
+// and their sum, bounded (round 5; the fast paths measured them until then) (feature_device.h: screen_quad / screen_pair3 / screen_attribute_lr), plus, for a region whose sum is not
 // provably EXACT in the reference's own order ((a - b) - c) + d (fv.cpp:161-162), the three roundings of that order.  Three paths,
 // wave-uniform: (A) a run of 64 neighbours whose windows pass the exactness test AS A WHOLE -- no negative height in the grid (integral
 // image monotone), bottom row of the band <= 2 x its top row in each of the lane's 15 columns (a - b exact by Sterbenz), the window's

@@ -66,7 +66,7 @@ TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EV
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
               "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS",
-              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN")
+              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN", "HAF_CANARY_CHECK", "HAF_FLAG0_CAP")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -814,6 +814,59 @@ def test_tier_0b_behind_a_first_pass_that_overflows_its_list(data_dir, golden_di
     compare_full(eng, o, cloud, cfg, inp, check_dec=False)
     assert eng.screen_low_rank()["rank"] == 158
     eng.close()
+
+
+def test_guard_zones_around_every_device_buffer(data_dir, golden_dir, tmp_path, monkeypatch):
+    """Round 5 (the list-overflow bug of round 4 lived through a round with every test green).  In the testing build every
+    device buffer -- lists, operand images, flag words, tables -- lies between two guard zones of a fixed pattern (csrc/engine_state.h:
+    DevBuf) and, with HAF_CANARY_CHECK set, the engine checks all of them after EVERY request and fails the request when one is damaged.
+    Here: (1) the hook sees the engine's buffers; (2) requests in the regimes where lists overflow -- a pinned first pass on a model it
+    cannot serve (round 4's case), screening lists of 256 entries, exact-tier windows of 64, bands scaled up so that the lists behind them
+    fill -- leave every zone intact and match the oracle stage by stage (the tier lists hold an entry per evaluation and cannot
+    overflow: their capacity is not a knob); (3) a write one element past a list's end, which is
+    what a producer that ignores its capacity does, IS reported, by the allocating source line."""
+    f, r = _files(data_dir)
+    model = os.path.join(golden_dir, "surrogate.model")
+    o = O.Oracle(f, r, model)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    cfg, inp = dict(n_rolls=12), dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0))
+    monkeypatch.setenv("HAF_CANARY_CHECK", "1")
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    regimes = [dict(HAF_SCREEN_VARIANT="0", HAF_T0B="1"),                                    # round 4's case: the counter exceeds the list
+               dict(HAF_SCREEN_VARIANT="0", HAF_T0B="1", HAF_FLAG0_CAP="256"),
+               dict(HAF_SCREEN_VARIANT="2", HAF_T0B="0", HAF_FLAG0_CAP="256", HAF_FLAG_WINDOW="64"),
+               dict(HAF_SCREEN_VARIANT="3", HAF_T1_SKIP="1", HAF_FLAG0_CAP="512"),
+               dict(HAF_SCREEN_VARIANT="1", HAF_T1_SKIP="0", HAF_FLAG_WINDOW="64", HAF_GUARD_REL="4000"),
+               dict(HAF_FLAG_WINDOW="64", HAF_GUARD0_REL="50"),
+               dict(HAF_FLAG0_CAP="256", HAF_FLAG_WINDOW="64", HAF_GUARD0_REL="50", HAF_GUARD_REL="4000")]
+    outcomes = []
+    crumbs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "canary_regimes.log")          # (which regime a GPU fault, should one ever come, belongs to)
+    os.makedirs(os.path.dirname(crumbs), exist_ok=True)
+    for reg in regimes:
+        with open(crumbs, "a") as fh:
+            fh.write("regime %r\n" % (reg,))
+        with monkeypatch.context() as mp:
+            for k, v in reg.items():
+                mp.setenv(k, v)
+            eng = make_engine(data_dir, model, testing=True)
+            compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+            outcomes.append(eng.overflow_stats())
+            bad, rep, n_buf = capi.check_canaries()
+            assert bad == 0, (reg, rep)
+            assert n_buf >= 40                                                                 # every DevBuf of the engine is registered
+            eng.close()
+    assert sum(x["screening_list_overflows"] for x in outcomes) >= 3 and sum(x["extra_windows"] for x in outcomes) >= 3, outcomes
+    # (3) the detector detects: one int behind the end of the screening list
+    eng = make_engine(data_dir, model, testing=True)
+    assert capi.check_canaries()[0] == 0
+    assert eng._L.haf_test_poke_flag0_list(eng._h, 0, 1, 12345) == 0
+    bad, rep, _ = capi.check_canaries()
+    assert bad == 1 and "engine_tables.cpp" in rep and "back guard damaged at end+0" in rep and "0x00003039" in rep, rep
+    with pytest.raises(capi.HafError, match="guard zones damaged"):
+        eng.score(xyz, capi.default_input(**inp))                                            # ... and a request on such an engine fails loudly
+    eng.close()
+    assert capi.check_canaries()[0] == 0                                                       # (released buffers leave the registry)
+    STATS["canary_regimes"] = dict(regimes=len(regimes), outcomes=outcomes, buffers=n_buf)
 
 
 def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):

@@ -89,11 +89,23 @@ def main():
                     help="round 4: grids of more than 8192 cells, every request through the thread-per-evaluation feature kernel (testing build: "
                          "HAF_LARGE_EVALS=1) and the default-mode models pinned to one of the two centred-remainder forms, so that the screening "
                          "pass runs in its LOW-RANK form (k_project + k_svm_screen_lr); the summary counts the requests it served")
+    ap.add_argument("--overflow", action="store_true",
+                    help="round 5: the regimes in which device lists overflow.  Testing build with the guard zones of csrc/engine_state.h checked after "
+                         "every request (HAF_CANARY_CHECK); per model one screening form pinned (HAF_SCREEN_VARIANT 0..3, HAF_T0B, HAF_T1_SKIP) and "
+                         "the capacities shrunk at random -- HAF_FLAG0_CAP (screening lists), HAF_FLAG_WINDOW (windows of the exact tiers) -- with the bands "
+                         "scaled up (HAF_GUARD0_REL / HAF_GUARD_REL) so that the lists behind them fill.  (The tier lists hold one entry per evaluation "
+                         "and cannot overflow: not a knob.)  The summary counts the overflows seen")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"))
     a = ap.parse_args()
     if a.low_rank:
         os.environ["HAF_LARGE_EVALS"] = "1"
         os.environ["HAF_NO_DIRECT"] = "1"
+    OVERFLOW_KNOBS = ("HAF_SCREEN_VARIANT", "HAF_T0B", "HAF_T1_SKIP", "HAF_FLAG0_CAP", "HAF_FLAG_WINDOW", "HAF_GUARD0_REL", "HAF_GUARD_REL",
+                      "HAF_LARGE_EVALS")
+    if a.overflow:
+        os.environ["HAF_CANARY_CHECK"] = "1"
+        os.environ["HAF_NO_DIRECT"] = "1"
+    ov = dict(requests=0, screening_list_overflows=0, windows_walked=0, by_variant={}, canary_checks=0)
     rng = np.random.RandomState(a.seed)
     tmp = tempfile.mkdtemp(prefix="haf_fuzz_")
     t0 = time.time()
@@ -115,6 +127,25 @@ def main():
         H, W = sizes[rng.randint(len(sizes))]
         n_rolls, step = [(12, 15), (5, 36), (7, 25), (3, 60), (20, 9)][rng.randint(5)]
         mode, mname = mode_list[mi % 3] if mi % 2 else mode_list[2]           # two thirds of the models through the default path
+        knobs = {}
+        if a.overflow:
+            for k in OVERFLOW_KNOBS:
+                os.environ.pop(k, None)
+            if mi % 4:
+                mode, mname = mode_list[2]                                    # three quarters through the default path: its lists are the subject
+            v = int(rng.randint(4))
+            knobs["HAF_SCREEN_VARIANT"] = str(v)
+            knobs["HAF_T0B"] = str(int(rng.randint(2)))
+            knobs["HAF_T1_SKIP"] = str(int(rng.randint(2)))
+            knobs["HAF_FLAG0_CAP"] = str(int(rng.choice([256, 256, 512, 1024, 4096])))
+            knobs["HAF_FLAG_WINDOW"] = str(int(rng.choice([64, 64, 128, 512])))
+            if rng.rand() < 0.6:
+                knobs["HAF_GUARD0_REL"] = "%g" % rng.choice([5.0, 50.0, 1e4])
+            if rng.rand() < 0.5:
+                knobs["HAF_GUARD_REL"] = "%g" % rng.choice([100.0, 4000.0])
+            if H * W > 8192 and rng.rand() < 0.5:
+                knobs["HAF_LARGE_EVALS"] = "1"                                # the thread-per-evaluation feature kernel and the low-rank form
+            os.environ.update(knobs)
         prob = a.probability and mi % 3 == 0
         if prob:
             path = models.write_probability_model(os.path.join(tmp, "p%d.model" % mi), path, "%g" % rng.uniform(-30, 30), "%g" % rng.uniform(-2, 2))
@@ -139,6 +170,9 @@ def main():
             if rng.rand() < 0.5:
                 kw["approach_vector"] = tuple(rng.standard_normal(3) * [0.3, 0.3, 1.0] + [0, 0, 1.0])
             try:
+                if a.overflow:
+                    ov["requests"] += 1
+                    ov["by_variant"][knobs["HAF_SCREEN_VARIANT"]] = ov["by_variant"].get(knobs["HAF_SCREEN_VARIANT"], 0) + 1
                 if prob:
                     got, want = T.compare_probability(eng, orc, xyz, dict(n_rolls=n_rolls, roll_step_deg=step, grid_h=H, grid_w=W), kw)
                     done += 1
@@ -170,8 +204,16 @@ def main():
                     dec_stats[mname]["max_abs_err"] = max(dec_stats[mname]["max_abs_err"], float(err.max()))
                     dec_stats[mname]["values"] += int(msk.sum())
                     dec_stats[mname]["outside_in_range_bound"] += int((err > bound).sum())
+                if a.overflow:
+                    bad, rep, _ = capi.check_canaries()
+                    ov["canary_checks"] += 1
+                    assert bad == 0, ("guard zones", rep)
+            except capi.HafError as ex:
+                failure = dict(case=done, model=what, grid=[H, W], rolls=[n_rolls, step], mode=mname, request=repr(kw), knobs=knobs,
+                               points=int(xyz.shape[0]), error=repr(ex)[:2000])
+                break
             except AssertionError as ex:
-                failure = dict(case=done, model=what, grid=[H, W], rolls=[n_rolls, step], mode=mname, request=repr(kw),
+                failure = dict(case=done, model=what, grid=[H, W], rolls=[n_rolls, step], mode=mname, request=repr(kw), knobs=knobs,
                                points=int(xyz.shape[0]), error=repr(ex)[:2000])
                 break
             done += 1
@@ -179,6 +221,10 @@ def main():
             evals += int(want["n_evals"])
             by_mode[mname] = by_mode.get(mname, 0) + 1
             print("    [%6.1f s] case %d: %d evaluations" % (time.time() - t0, done, int(want["n_evals"])), flush=True)   # (a sign of life: a big grid against a big model keeps the oracle busy for minutes)
+        if a.overflow:
+            st = eng.overflow_stats()
+            ov["screening_list_overflows"] += st["screening_list_overflows"]
+            ov["windows_walked"] += st["extra_windows"]
         by_model[what.split(" nsv")[0]] = by_model.get(what.split(" nsv")[0], 0) + n_here
         by_form[form] = by_form.get(form, 0) + n_here
         eng.close()
@@ -186,7 +232,7 @@ def main():
               % (time.time() - t0, done, evals, what, H, W, n_rolls, step, mname, form), flush=True)
     summary = dict(seed=a.seed, cases=done, evaluations_compared=evals, seconds=round(time.time() - t0, 1), by_mode=by_mode,
                    by_model=by_model, by_screening_form=by_form,
-                   low_rank=dict(requests=lr_cases, evaluations=lr_evals, left_undecided=lr_left), mismatches=0 if failure is None else 1, failure=failure, decision_values=dec_stats,
+                   low_rank=dict(requests=lr_cases, evaluations=lr_evals, left_undecided=lr_left), overflow=ov if a.overflow else None, mismatches=0 if failure is None else 1, failure=failure, decision_values=dec_stats,
                    compared="heights, integral image, mask, labels, vote grid, per-roll winners, overall grasp (bit-exact / "
                             "identical), grasp points (1e-4 m); decision values recorded against S = sum |coef| K")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
