@@ -158,6 +158,7 @@ def _bind(path, testing):
         L.haf_test_canary_buffers.argtypes = []
         L.haf_test_poke_flag0_list.argtypes = [E, C.c_int, C.c_int, C.c_int]
         L.haf_test_overflow_stats.argtypes = [E, C.c_void_p]
+        L.haf_test_fetch_list.argtypes = [E, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     return L
 
 
@@ -304,6 +305,14 @@ class Engine:
         a, r, b, c = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._L.haf_last_tiers(self._h, C.byref(a), C.byref(r), C.byref(b), C.byref(c)))
         return dict(n_evals=a.value, n_refined=r.value, n_rechecked=b.value, n_strict=c.value)
+
+    def fetch_list(self, which, cap=1 << 22):
+        """Testing build: a device list of the last request as it lies in memory (0 evaluation cells, 1 exact tiers' input, 2 exact-integer
+        tier's hand-over, 3 strict tier's, 4 screening pass's)."""
+        buf = np.empty(cap, dtype=np.int32)
+        n = C.c_int()
+        self._check(self._L.haf_test_fetch_list(self._h, which, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return buf[:min(n.value, cap)].copy()
 
     def overflow_stats(self):
         """Testing build: how often this engine's requests met a list smaller than what it had to hold."""

@@ -75,7 +75,7 @@ void haf_destroy(haf_engine *e)
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release(); e->d_flag0b_list.release(); e->d_screen_part.release();
     e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
-    e->d_lr_btiles.release(); e->d_svt_lr.release(); e->d_lr_btiles_in.release(); e->d_corr_lrp.release(); e->d_iiabs.release();
+    e->d_brslot.release(); e->d_tier_words.release(); e->d_lr_btiles.release(); e->d_svt_lr.release(); e->d_lr_btiles_in.release(); e->d_corr_lrp.release(); e->d_iiabs.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);

@@ -195,6 +195,9 @@ struct haf_engine {
     DevBuf<float> d_ii;
     DevBuf<uint8_t> d_mask;
     DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_evalcell, d_flag_list, d_flag2_list;
+    DevBuf<unsigned long long> d_tier_words;   // exact tiers: one "undecided" bit per entry of a window, for the ordered hand-over lists
+    DevBuf<unsigned long long> d_brslot;   // k_small_pre: per (cloud, roll) {request epoch, evaluations} in one word (ordered evaluation list)
+    unsigned pre_epoch = 0;
     struct View { int *p = nullptr; } d_counters;      // inside d_out
     DevBuf<float> d_X, d_ax, d_dec, d_svt;
     DevBuf<char> d_svt_h;            // split-fp16 SV tile images

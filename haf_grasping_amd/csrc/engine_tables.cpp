@@ -1124,6 +1124,8 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_rowcount.alloc(B * R * H);
     ok &= hipSuccess == e->d_rowoff.alloc(2 * (B * R * H + 1));      // whole-chunk and left-over starts (k_scan)
     ok &= hipSuccess == e->d_brcount.alloc(B * R);
+    ok &= hipSuccess == e->d_brslot.alloc(B * R);
+    if (ok) ok &= hipSuccess == hipMemset(e->d_brslot.p, 0, B * R * sizeof(unsigned long long));       // epoch 0: no request yet
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->list_cap);
     if (mode == MODE_SCREEN) {
@@ -1150,6 +1152,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_labels.alloc(e->cells_cap);
     ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->list_cap);
     ok &= hipSuccess == e->d_part64.alloc((size_t)e->flag_cap * kRecheckPartRows);
+    ok &= hipSuccess == e->d_tier_words.alloc(((size_t)e->flag_cap + 63) / 64 + 4);
     // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->list_cap);

@@ -78,6 +78,26 @@ int haf_test_canary_buffers()
     std::lock_guard<std::mutex> lk(g_canary_mu);
     return (int)g_canary.size();
 }
+// the device lists of the last request as they lie in memory: 0 the evaluation list (cell ids), 1 the exact tiers' input list, 2 the
+// exact-integer tier's hand-over list, 3 the strict tier's list, 4 the screening pass's list.  *n = entries the list holds.
+int haf_test_fetch_list(haf_engine *e, int which, int *out, int cap, int *n)
+{
+    if (!e || !out || !n || cap < 0) return HAF_E_ARG;
+    const int *src = nullptr;
+    int cnt = 0;
+    switch (which) {
+        case 0: src = e->d_evalcell.p; cnt = e->last_evals; break;
+        case 1: src = e->d_flag_list.p; cnt = std::min(e->last_flagged, e->list_cap); break;
+        case 2: src = e->d_flagi_list.p; cnt = e->last_i8 ? std::min(e->last_flaggedi, e->list_cap) : 0; break;
+        case 3: src = e->d_flag2_list.p; cnt = std::min(e->last_flagged2, e->list_cap); break;
+        case 4: src = e->d_flag0_list.p; cnt = std::min(e->last_flagged0, e->flag0_cap); break;
+        default: return HAF_E_ARG;
+    }
+    *n = cnt;
+    if (!src || cnt <= 0) { *n = 0; return HAF_OK; }
+    if (hipDeviceSynchronize() != hipSuccess) return HAF_E_DEVICE;
+    return hipMemcpy(out, src, (size_t)std::min(cnt, cap) * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? HAF_OK : HAF_E_DEVICE;
+}
 int haf_test_overflow_stats(haf_engine *e, long long *out2)
 {
     if (!e || !out2) return HAF_E_ARG;

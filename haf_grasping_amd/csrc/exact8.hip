@@ -18,7 +18,7 @@
 // i.e. |dec_q - dec| <= (exp(gamma * that) - 1) * S -- about 2e-7 S on the bench models (q_s = 26), 20x inside the three-pass band; what
 // is still closer to zero than that goes on to the fp64 MFMA tier (k_recheck_mfma) exactly as before.  Same task structure as
 // that tier: a workgroup = 4 waves x 16 evaluations, one of kMSplit ranges of SV tiles, partial sums added in a fixed order.
-#include "kernels.h"
+#include "device_common.h"
 
 namespace haf {
 
@@ -219,10 +219,16 @@ __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ 
 __global__ __launch_bounds__(256) void k_recheck_i8_combine(const double *__restrict__ part64, const int *__restrict__ evalcell, I8Params p,
                                                             const int *__restrict__ flag_list, int flag_cap, int list_off,
                                                             int *__restrict__ counters, int cslot, double *__restrict__ dec_exact,
-                                                            int8_t *__restrict__ labels, int *__restrict__ flagi_list, int flagi_cap)
+                                                            int8_t *__restrict__ labels, int *__restrict__ flagi_list, int flagi_cap,
+                                                            unsigned long long *__restrict__ words)
 {
     const int n_flag = window_count8(counters[cslot], list_off, flag_cap);
-    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
+    const int lane = threadIdx.x & 63;
+    // (wave-uniform trip count: every lane takes part in the ballot of its 64 entries; words != nullptr: ordered hand-over, device_common.h)
+    for (int base = blockIdx.x * 256 + (threadIdx.x & ~63); base < n_flag; base += gridDim.x * 256) {
+        const int sl = base + lane;
+        bool undecided = false;
+        if (sl < n_flag) {
         double P = 0.0, S = 0.0;
 #pragma unroll
         for (int h = 0; h < kI8Split; h++) {
@@ -243,18 +249,32 @@ __global__ __launch_bounds__(256) void k_recheck_i8_combine(const double *__rest
         }
         dec_exact[sl] = dv;
         labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
-        if (!decided) {
+        undecided = !decided;
+        if (!decided && !words) {
             const int s2 = atomicAdd(&counters[CNT_FLAGGEDI], 1);
             if (s2 < flagi_cap) flagi_list[s2] = e;
         }
+        }
+        if (words) {
+            const unsigned long long bal = __ballot(undecided);
+            if (lane == 0) words[base >> 6] = bal;
+        }
     }
+}
+
+__global__ __launch_bounds__(kListCompactThreads) void k_i8_handover(const unsigned long long *__restrict__ words, const int *__restrict__ flag_list,
+                                                                     int flag_cap, int list_off, int *__restrict__ counters, int cslot,
+                                                                     int *__restrict__ flagi_list, int flagi_cap)
+{
+    __shared__ int s_scan[kListCompactThreads];
+    list_compact_body(words, window_count8(counters[cslot], list_off, flag_cap), flag_list, flagi_list, flagi_cap, counters, CNT_FLAGGEDI, s_scan);
 }
 
 // One window [list_off, list_off + window_cap) of the list counted by counters[CNT_FLAGGED]: digit image (the feature kernel), the
 // int8 contraction, combine.  ximg holds kI8GroupBytes per 16 slots of a window, part64 the fp64 tier's [2 kMSplit + 1][window_cap].
 void launch_recheck_i8(const float *ii, const int *evalcell, const FeatDesc *fd, const void *sv_i8, I8Params p, double lower, double upper,
                        const int *flag_list, int window_cap, int list_off, int *counters, void *ximg, double *part64, double *dec_exact,
-                       int8_t *labels, int *flagi_list, int flagi_cap, Dims d, hipStream_t s)
+                       int8_t *labels, int *flagi_list, int flagi_cap, Dims d, hipStream_t s, unsigned long long *words)
 {
     const int groups = (window_cap + kI8Evals - 1) / kI8Evals;
     if (groups <= 0) return;
@@ -268,7 +288,10 @@ void launch_recheck_i8(const float *ii, const int *evalcell, const FeatDesc *fd,
                        window_cap, list_off, counters, CNT_FLAGGED, part64);
     const int blocks = groups < 2048 ? groups : 2048;
     hipLaunchKernelGGL(k_recheck_i8_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, window_cap, list_off, counters,
-                       CNT_FLAGGED, dec_exact, labels, flagi_list, flagi_cap);
+                       CNT_FLAGGED, dec_exact, labels, flagi_list, flagi_cap, words);
+    // (flag_list already points at the window's first entry)
+    if (words) hipLaunchKernelGGL(k_i8_handover, dim3(1), dim3(kListCompactThreads), 0, s, words, flag_list, window_cap, list_off, counters, CNT_FLAGGED,
+                                  flagi_list, flagi_cap);
 }
 
 }  // namespace haf

@@ -180,7 +180,7 @@ __device__ __forceinline__ ScrDescK constant_ptr(const ScrDesc *p) { return (Scr
 // u = 2^-24: 3 u (1 + 1e-3) and 4 u (1 + 1e-3), rounded up (the fp32 roundings of the bound's own three operations included)
 constexpr float kNbRound = 1.80e-7f, kNbRound3 = 2.40e-7f;
 template <int NB>
-__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2)
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2, float &rmin)
 {
     float c[4][8];
     unsigned adr[4][8];                               // all descriptor words first: a volatile asm pins what follows it
@@ -221,6 +221,11 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
                      fabsf(sd[q].w[1]) * region_round_bound(c[q][4], c[q][5], c[q][6], c[q][7], s11, s21, R1);
             float nbq = fmaf(kNbRound, fabsf(r0) + fabsf(r1), fabsf((float)q4 - v));
             if (NB == 2) nbq += ar;
+            // path A (NB == 1, the wave passed the exactness test as a whole): that test takes R >= 0 from the monotone integral image, which
+            // holds for the TRUE sums; the fp32-rounded corners can leave a near-empty region at -1..-3 ulp(d), and then (a - b) - c may have
+            // rounded.  The smallest computed R of the evaluation rides along (one v_min3 per slot); a negative one voids the
+            // evaluation's screening pass (features.hip)
+            if (NB == 1) rmin = fminf(fminf(R0, R1), rmin);
             nbq *= sd[q].pad;
             nu2 = fmaf(nbq, nbq, nu2);
             // (the sum is tied to the sequence of the volatile LDS reads: left to float, the temporaries of eight slots stay alive until
@@ -229,7 +234,7 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         }
     }
 }
-__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f; screen_quad<0>(band, sd, st, ud, dummy); }
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f, dmin = 0.0f; screen_quad<0>(band, sd, st, ud, dummy, dmin); }
 
 // Two attribute slots of any other group, from the band: three regions each, the HAF sum or the SHAF rule (feature_value).
 // A slot of a dropped or absent attribute has scr_mul = scr_add = 0: its u' is 0 (NaN if its feature value left the decimal
@@ -240,7 +245,7 @@ __device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (S
 // (NQ slots per call: two in the plain form; ONE with the low-rank form's noise bound, whose temporaries would otherwise cost the
 // kernel 48 registers -- a wave of occupancy -- for the four groups of 40 that take this path)
 template <int NB, int NQ>
-__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud, float &nu2)
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud, float &nu2, float &rmin)
 {
     float c[NQ][12];
     unsigned adr[NQ][12];
@@ -288,11 +293,12 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
             // at most 4 u (|r0| + |r1| + |r2|) <= kNbRound3 of it)
             const float nbq = sd[q].pad[0] * (fmaf(kNbRound3, (fabsf(r[0]) + fabsf(r[1])) + fabsf(r[2]), fabsf((float)q4 - v)) + ar);
             nu2 = fmaf(nbq, nbq, nu2);
+            if (NB == 1 && !sd[q].shaf) rmin = fminf(fminf(Rk[0], Rk[1]), fminf(Rk[2], rmin));   // (as in screen_quad; a SHAF slot is passed through, not bounded)
             asm volatile("" : "+v"(nu2));
         }
     }
 }
-__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f; screen_pair3<0, 2>(band, sd, st, ud, dummy); }
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f, dmin = 0.0f; screen_pair3<0, 2>(band, sd, st, ud, dummy, dmin); }
 
 // the decimal tables (95 doubles) in LDS: call from every thread of the workgroup before any divergent return
 __device__ __forceinline__ hafq::PtrTabs load_decimal_tables(double *lds_tab)

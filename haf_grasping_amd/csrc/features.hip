@@ -411,23 +411,24 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         float sx = 0.0f;
         const bool lr_nb = LR && fastwave && lr_exact;    // wave-uniform: every region sum of the wave is exact
         float nu2 = 0.0f;
+        float rmin = 0.0f;                                // path A: the smallest computed region sum of this evaluation (feature_device.h: screen_quad)
         for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
             double ud[8];
             if (lr_nb) {
                 if ((sp.fast_groups >> g) & 1) {
-                    screen_quad<1>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2);
-                    screen_quad<1>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2);
+                    screen_quad<1>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2, rmin);
+                    screen_quad<1>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2, rmin);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) screen_pair3<1, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2);
+                    for (int q = 0; q < 8; q++) screen_pair3<1, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2, rmin);
                 }
             } else if (LR && fastwave) {                  // a wave with regions that may round: bounded region by region
                 if ((sp.fast_groups >> g) & 1) {
-                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2);
-                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2);
+                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2, rmin);
+                    screen_quad<2>(band, constant_ptr(sp.sd) + g * 8 + 4, st, ud + 4, nu2, rmin);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) screen_pair3<2, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2);
+                    for (int q = 0; q < 8; q++) screen_pair3<2, 1>(band, constant_ptr(sp.sd3) + g * 8 + q, st, ud + q, nu2, rmin);
                 }
             } else if (fastwave && ((sp.fast_groups >> g) & 1)) {   // wave-uniform
                 screen_quad(band, constant_ptr(sp.sd) + g * 8, st, ud);
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             const float lr_M = (float)((double)sp.lr_iiabs[evalcell[e_src] / (d.H * d.W)] * 9.5367431640625e-07) * 1.0001f;
             const float rho = (float)sp.lr_rho * lr_M * 1.000001f;
             nu2 = fmaf(rho, rho, nu2);
+            if (rmin < 0.0f) nu2 = __builtin_inff();                              // (path A met a negative computed region sum: never trusted, next tier)
             const float sx2 = acc.su2 + sx;                                   // (one more fp32 rounding of |p'|^2: inside kF32Acc's 326)
             band[0] = acc.su2; band[1] = acc.sd2; band[2] = sx2; band[3] = acc.cr; band[4] = nu2; band[5] = 0.0f; band[6] = 0.0f; band[7] = 0.0f;
             nax = -0.5f * sx2;

@@ -343,7 +343,8 @@ struct I8Params {
 };
 void launch_recheck_i8(const float *ii, const int *evalcell, const FeatDesc *fd, const void *sv_i8, I8Params p, double lower, double upper,
                        const int *flag_list, int window_cap, int list_off, int *counters, void *ximg, double *part64, double *dec_exact,
-                       int8_t *labels, int *flagi_list, int flagi_cap, Dims d, hipStream_t s);
+                       int8_t *labels, int *flagi_list, int flagi_cap, Dims d, hipStream_t s,
+                       unsigned long long *words = nullptr);   // != nullptr: one ballot word per 64 entries of a window -> ORDERED hand-over (device_common.h)
 
 // fp64 model image for the rechecks: attribute-major [kM64Rows][n_sv_pad]; rows 0..323 attributes (model order of SVs),
 // row 324 |s|^2, row 325 coef
@@ -383,7 +384,7 @@ bool launch_bin(const CloudDev *clouds, const CloudDev *clouds_host, int max_n, 
 // small grids: a1 (tail) + a2 + a3 + a4 in one launch, one workgroup per (cloud, roll); false when the grid does not fit LDS
 bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int *hkeys, float *ii, uint8_t *mask, int *rowcount,
                       int *brcount, int8_t *labels, int *evalcell, int *counters, int *flag_list, bool direct, Dims d, float r_row,
-                      float r_col, hipStream_t s);
+                      float r_col, hipStream_t s, unsigned long long *brslot = nullptr, unsigned epoch = 0);
 size_t small_pre_lds(int H, int W);
 void launch_integral(int *hkeys_heights, double *rowsum, float *ii, int *inexact_flags, int *counters, Dims d, hipStream_t s,
                      unsigned long long *abs_total = nullptr);   // per (cloud, roll): sum of |height| in units of 2^-20 m, rounded up (parallel form only; low-rank screening form)
@@ -443,7 +444,8 @@ void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *f
                          double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s,
                          AttrRecord *dbg = nullptr,    // dbg: attribute records of a request that went straight to this tier
                          bool have_x64 = false,        // the attribute image is in place already (launch_features XMODE_F64)
-                         int counter_slot = CNT_FLAGGED);   // the counter of flag_list (CNT_FLAGGEDI behind the exact-integer tier)
+                         int counter_slot = CNT_FLAGGED,    // the counter of flag_list (CNT_FLAGGEDI behind the exact-integer tier)
+                         unsigned long long *words = nullptr);   // as launch_recheck_i8: ordered hand-over to the strict tier's list
 constexpr int kRecheckPartRows = 2 * 8 + 1;       // part64: [2 * kMSplit + 1][flag_cap] doubles (partial sums + |x|^2)
 void launch_vote(const int8_t *labels, const float *heights, const int *brcount, short *ev16, unsigned long long *topkey,
                  int *rowmax, RollRecordDev *rec, Dims d, hipStream_t s);

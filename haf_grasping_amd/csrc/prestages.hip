@@ -861,10 +861,12 @@ __global__ __launch_bounds__(kSmallPreThreads) void k_small_pre(const CloudDev *
                                                                 int *__restrict__ rowcount, int *__restrict__ brcount,
                                                                 int8_t *__restrict__ labels, int *__restrict__ evalcell,
                                                                 int *__restrict__ counters, int *__restrict__ flag_list, int direct,
-                                                                Dims d, float r_row, float r_col, int key_empty)
+                                                                Dims d, float r_row, float r_col, int key_empty,
+                                                                unsigned long long *__restrict__ brslot, unsigned epoch)
 {
     extern __shared__ double s_rs[];                      // [H][pitch] fp64 row sums | [H*W] keys -> heights | [(H+1)*(W+1)] II | [H] counts
     __shared__ int s_base;
+    __shared__ int s_red[kSmallPreThreads / 64];
     const int br = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = d.H, W = d.W, W1 = W + 1, HW = H * W;
     const int pitch = small_pre_pitch(W);
@@ -946,10 +948,40 @@ __global__ __launch_bounds__(kSmallPreThreads) void k_small_pre(const CloudDev *
         int run = 0;
         for (int i = 0; i < H; i++) { const int c = s_cnt[i]; s_cnt[i] = run; run += c; }
         brcount[br] = run;
-        s_base = run ? atomicAdd(&counters[CNT_EVALS], run) : 0;
+        // Where this (cloud, roll)'s evaluations go in the list.  Round 5: the evaluations of (cloud, roll) 0, 1, 2 ... follow each other
+        // in THAT order, run after run (until then a segment was reserved with the atomicAdd's return value: whichever workgroup came
+        // first; labels never depended on it, the contents of list windows and the debug lists did).  Every workgroup publishes its
+        // count together with the request's epoch in ONE 64-bit word -- no fence, no zeroing between requests -- and sums the words of the
+        // workgroups in front of it (below).  Grids of up to 256 workgroups only: those are all resident at once, so nobody waits for a
+        // workgroup that cannot start; larger grids keep the reservation by arrival.
+        const bool ordered = brslot != nullptr && gridDim.x <= 256;
+        if (ordered) __hip_atomic_store(&brslot[br], ((unsigned long long)epoch << 32) | (unsigned)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int arrived = run ? atomicAdd(&counters[CNT_EVALS], run) : 0;
+        s_base = ordered ? -1 : arrived;
         if (direct && run) atomicAdd(&counters[CNT_FLAGGED], run);
     }
     __syncthreads();
+    if (s_base < 0) {                                      // (uniform: ordered)
+        int part = 0;
+        for (int t = tid; t < br; t += kSmallPreThreads) {
+            unsigned long long v;
+            do {
+                v = __hip_atomic_load(&brslot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+            } while ((unsigned)(v >> 32) != epoch);
+            part += (int)(unsigned)(v & 0xffffffffull);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        if (tid == 0) {
+            int b = 0;
+            for (int w = 0; w < kSmallPreThreads / 64; w++) b += s_red[w];
+            s_base = b;
+        }
+        __syncthreads();
+    }
     const int base = s_base;
     for (int i = wave; i < H; i += kSmallPreThreads / 64) {   // (each lane re-reads the mask bytes it wrote itself)
         int done = s_cnt[i];
@@ -970,7 +1002,7 @@ __global__ __launch_bounds__(kSmallPreThreads) void k_small_pre(const CloudDev *
 // true when the fused form ran (then nothing else of a1 tail / a2 / a3 / a4 has to be launched, and the labels are initialised)
 bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int *hkeys, float *ii, uint8_t *mask, int *rowcount,
                       int *brcount, int8_t *labels, int *evalcell, int *counters, int *flag_list, bool direct, Dims d, float r_row,
-                      float r_col, hipStream_t s)
+                      float r_col, hipStream_t s, unsigned long long *brslot, unsigned epoch)
 {
     const size_t lds = small_pre_lds(d.H, d.W);
     if (lds > 64 * 1024) return false;                    // (the default dynamic-LDS limit: grids up to ~58 x 58)
@@ -980,14 +1012,14 @@ bool launch_small_pre(const CloudDev *clouds, const RollGeo *geo, int max_n, int
     key_empty ^= 0x7FFFFFFF;                              // ordered key of -1.0f (499-501): an empty cell
     if (max_n <= kSmallPreMaxPoints) {
         hipLaunchKernelGGL(k_small_pre<true>, dim3(d.B * d.R), dim3(kSmallPreThreads), lds, s, clouds, geo, hkeys, ii, mask, rowcount, brcount,
-                           labels, evalcell, counters, flag_list, direct ? 1 : 0, d, r_row, r_col, key_empty);
+                           labels, evalcell, counters, flag_list, direct ? 1 : 0, d, r_row, r_col, key_empty, brslot, epoch);
     } else {
         // a large cloud: many workgroups bin it (k_bin_lds: LDS-private grids, one global atomicMax per touched cell), then the rest
         launch_fill_i32(hkeys, key_empty, (size_t)d.B * d.R * d.H * d.W, s);
         dim3 grid((max_n + kBinChunk - 1) / kBinChunk, d.B * d.R);
         hipLaunchKernelGGL(k_bin_lds, grid, dim3(256), (size_t)d.H * d.W * sizeof(int), s, clouds, geo, hkeys, d, r_row, r_col, key_empty);
         hipLaunchKernelGGL(k_small_pre<false>, dim3(d.B * d.R), dim3(kSmallPreThreads), lds, s, clouds, geo, hkeys, ii, mask, rowcount, brcount,
-                           labels, evalcell, counters, flag_list, direct ? 1 : 0, d, r_row, r_col, key_empty);
+                           labels, evalcell, counters, flag_list, direct ? 1 : 0, d, r_row, r_col, key_empty, brslot, epoch);
     }
     return true;
 }

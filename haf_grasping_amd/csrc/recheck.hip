@@ -337,13 +337,18 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
                                                          ExactParams p, const int *__restrict__ flag_list, int flag_cap,
                                                          int list_off, int *__restrict__ counters, double *__restrict__ dec_exact,
                                                          int8_t *__restrict__ labels, int *__restrict__ flag2_list, int flag2_cap,
-                                                         int cslot)
+                                                         int cslot, unsigned long long *__restrict__ words)
 {
     const int n_flag = window_count(counters[cslot], list_off, flag_cap);
     int splits;
     size_t pitch;
     recheck_split(n_flag, flag_cap, p.n_sv_pad / 16, splits, pitch);
-    for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_flag; sl += gridDim.x * 256) {
+    const int lane = threadIdx.x & 63;
+    // (wave-uniform trip count; words != nullptr: ordered hand-over to the strict tier's list, device_common.h)
+    for (int base = blockIdx.x * 256 + (threadIdx.x & ~63); base < n_flag; base += gridDim.x * 256) {
+        const int sl = base + lane;
+        bool undecided = false;
+        if (sl < n_flag) {
         double P = 0.0, S = 0.0;
         for (int h = 0; h < splits; h++) {
             P += part64[(size_t)(2 * h) * pitch + sl];
@@ -354,11 +359,25 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
         const int e = flag_list[sl];
         labels[evalcell[e]] = (int8_t)(dv > 0.0 ? p.gv0 : p.gv1);
         const double T = p.as_max1 + p.gamma2 * part64[(size_t)(2 * splits) * pitch + sl];
-        if (!(fabs(dv) > p.guard2 * T * S)) {
+        undecided = !(fabs(dv) > p.guard2 * T * S);
+        if (undecided && !words) {
             int s2 = atomicAdd(&counters[CNT_FLAGGED2], 1);
             if (s2 < flag2_cap) flag2_list[s2] = e;
         }
+        }
+        if (words) {
+            const unsigned long long bal = __ballot(undecided);
+            if (lane == 0) words[base >> 6] = bal;
+        }
     }
+}
+
+__global__ __launch_bounds__(kListCompactThreads) void k_strict_handover(const unsigned long long *__restrict__ words, const int *__restrict__ flag_list,
+                                                                         int flag_cap, int list_off, int *__restrict__ counters, int cslot,
+                                                                         int *__restrict__ flag2_list, int flag2_cap)
+{
+    __shared__ int s_scan[kListCompactThreads];
+    list_compact_body(words, window_count(counters[cslot], list_off, flag_cap), flag_list, flag2_list, flag2_cap, counters, CNT_FLAGGED2, s_scan);
 }
 
 // flag_list and dec_exact are the WHOLE lists (one entry per flagged evaluation, sized for every evaluation of a request);
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(256) void k_recheck_combine(const double *__restric
 void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *fd, const double *sv64, ExactParams p,
                          const int *flag_list, int window_cap, int list_off, int *counters, double *x64, double *part64,
                          double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, Dims d, hipStream_t s, AttrRecord *dbg,
-                         bool have_x64, int counter_slot)
+                         bool have_x64, int counter_slot, unsigned long long *words)
 {
     int groups = (window_cap + kMEvals - 1) / kMEvals;
     int blocks = groups < 2048 ? groups : 2048;
@@ -382,7 +401,9 @@ void launch_recheck_mfma(const float *ii, const int *evalcell, const FeatDesc *f
     hipLaunchKernelGGL(k_recheck_mfma, dim3((unsigned)(tasks < 4096 ? tasks : 4096)), dim3(256), 0, s, x64, evalcell, sv64, p,
                        flag_list, window_cap, list_off, counters, part64, d, counter_slot);
     hipLaunchKernelGGL(k_recheck_combine, dim3(blocks), dim3(256), 0, s, part64, evalcell, p, flag_list, window_cap, list_off, counters,
-                       dec_exact, labels, flag2_list, flag2_cap, counter_slot);
+                       dec_exact, labels, flag2_list, flag2_cap, counter_slot, words);
+    if (words) hipLaunchKernelGGL(k_strict_handover, dim3(1), dim3(kListCompactThreads), 0, s, words, flag_list, window_cap, list_off, counters,
+                                  counter_slot, flag2_list, flag2_cap);
 }
 
 }  // namespace haf

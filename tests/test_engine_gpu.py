@@ -299,6 +299,48 @@ def test_identical_calls_give_identical_decision_values(data_dir, surrogate, mod
     eng.close()
 
 
+def test_identical_calls_give_identical_device_lists(data_dir, surrogate, tmp_path, monkeypatch):
+    """Round 5.  The evaluation list of a small request and the hand-over lists of the exact tiers were filled by
+    arrival (atomicAdd): labels never depended on the order, but the contents of list windows and every debug list changed from run to
+    run.  Now (cloud, roll) r's evaluations follow (cloud, roll) r - 1's (k_small_pre: counts published per workgroup, summed by the ones
+    behind) and an undecided entry keeps its place in the next tier's list (one ballot word per 64 entries + a one-workgroup compaction):
+    the same request five times -- C3 through the fused pre-stage, and a 96 x 96 request against a 517-SV model through the screening
+    pass, the exact-integer tier and the fp64 tier with 64-entry windows -- must leave the SAME lists in device memory, entry for entry,
+    and the evaluation list must be the row-major masked cells of roll 0, then roll 1, ..."""
+    xyz = capi.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    cases = [(surrogate, dict(n_rolls=20, roll_step_deg=9, max_points=1 << 18), dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0)), xyz, {})]
+    path = models.write_random_model(str(tmp_path / "r517.model"), 517, seed=77, gamma=1.0 / 323, balanced=True, rho=0.01)
+    G = 96
+    cases.append((path, dict(n_rolls=5, roll_step_deg=36, grid_h=G, grid_w=G, max_points=2 * G * G),
+                  dict(grasp_area_length_x=G, grasp_area_length_y=G), models.synthetic_cloud(grid=G, k=2, seed=4),
+                  dict(HAF_FLAG_WINDOW="64", HAF_GUARD0_REL="30", HAF_GUARD_I8_REL="2000")))
+    seen = {}
+    for ci, (model, cfg, inp, cloud, env) in enumerate(cases):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            eng = make_engine(data_dir, model, testing=True, **cfg)
+            ref = None
+            for call in range(5):
+                eng.score(cloud, capi.default_input(**inp))
+                cur = [eng.fetch_list(w) for w in range(5)]
+                if ref is None:
+                    ref = cur
+                    # the evaluation list: per roll the masked cells in row-major order (calc_featurevectors, server.cpp:637-643), roll after roll
+                    H, W = cfg.get("grid_h", 56), cfg.get("grid_w", 56)
+                    want = np.concatenate([np.flatnonzero(eng.debug(capi.DBG_MASK, 0, r).reshape(-1)) + r * H * W for r in range(cfg["n_rolls"])])
+                    if ci == 0:
+                        assert (np.sort(cur[0]) == np.sort(want)).all() and (cur[0] == want).all(), "evaluation list is not roll after roll, row-major"
+                    continue
+                for w in range(5):
+                    assert cur[w].shape == ref[w].shape and (cur[w] == ref[w]).all(), (ci, call, w, cur[w].shape, ref[w].shape)
+            seen[ci] = [int(x.size) for x in ref]
+            eng.close()
+    assert seen[0][0] > 30000 and seen[1][1] > 64 and seen[1][2] > 0, seen        # the lists in question were not empty
+    STATS["ordered_lists"] = seen
+
+
 def test_batch_of_eight_equals_single_and_shards_compose(data_dir, surrogate):
     """C4: pcd1..8 in one batch call == eight single calls; roll shards + haf_finalize == the unsharded call."""
     names = ["pcd%d" % i for i in range(1, 9)]
