@@ -145,6 +145,7 @@ def _bind(path, testing):
                                            C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.haf_test_model.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.haf_test_model_kernel.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.haf_test_roll_geo.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
         L.haf_test_finalize.argtypes = [C.POINTER(Config), C.POINTER(GraspInput), C.c_void_p, C.POINTER(GraspOutput)]

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
                                                             const int *__restrict__ counters, SvmParams p,
                                                             float *__restrict__ dec, int8_t *__restrict__ labels,
                                                             int *__restrict__ flag_list, int flag_cap,
-                                                            int *__restrict__ counters_rw, Dims d)
+                                                            int *__restrict__ counters_rw, Dims d, unsigned char *__restrict__ t1flags)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats];   // the ONLY LDS object: two SV tile images
     const int n_evals = counters[CNT_EVALS];
@@ -143,7 +143,9 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
                 labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);      // svm.cpp:2516-2531
                 // guard band: the fp32 error of the sum is at most (guard_acc + guard_dot*(|a_x| + max|a_s|)) * sum|coef|K
                 // (DESIGN.md §2); inside it the evaluation goes to the fp64 tiers.  Also catches NaN.
-                if (!(fabsf(dv) > (p.guard_acc + p.guard_dot * (p.as_max + fabsf(axr[r]))) * pabs[r] + p.guard_abs)) {
+                const bool undecided = !(fabsf(dv) > (p.guard_acc + p.guard_dot * (p.as_max + fabsf(axr[r]))) * pabs[r] + p.guard_abs);
+                if (t1flags) t1flags[e] = undecided ? 1 : 0;          // ordered hand-over (k_t1_handover, below)
+                else if (undecided) {
                     int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                     if (slot < flag_cap) flag_list[slot] = (int)e;
                 }
@@ -152,14 +154,31 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
     }
 }
 
+// Ordered hand-over of tier 1 (round 5; device_common.h: list_compact_bytes): the contraction kernels leave one byte per entry of their
+// iteration space -- "undecided" -- and ONE workgroup appends those entries' evaluations to the exact tiers' list in that order.
+__global__ __launch_bounds__(kListCompactThreads) void k_t1_handover(const unsigned char *__restrict__ flags, const int *__restrict__ counters,
+                                                                     int count_slot, int in_cap, const int *__restrict__ idx_list,
+                                                                     int *__restrict__ flag_list, int flag_cap, int *__restrict__ counters_rw)
+{
+    __shared__ int s_scan[kListCompactThreads];
+    list_compact_bytes(flags, min(counters[count_slot], in_cap), idx_list, flag_list, flag_cap, counters_rw, CNT_FLAGGED, s_scan);
+}
+static void launch_t1_handover(const unsigned char *flags, const int *counters, int count_slot, int in_cap, const int *idx_list, int *flag_list,
+                               int flag_cap, int *counters_rw, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_t1_handover, dim3(1), dim3(kListCompactThreads), 0, s, flags, counters, count_slot, in_cap, idx_list, flag_list, flag_cap,
+                       counters_rw);
+}
+
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters, SvmParams p,
                 float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
-                hipStream_t s)
+                hipStream_t s, unsigned char *t1flags)
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_svm_rbf, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, X, ax, svt, evalcell, counters, p,
-                       dec, labels, flag_list, flag_cap, counters_rw, d);
+                       dec, labels, flag_list, flag_cap, counters_rw, d, t1flags);
+    if (t1flags) launch_t1_handover(t1flags, counters, CNT_EVALS, 0x7fffffff, nullptr, flag_list, flag_cap, counters_rw, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                                                               int *__restrict__ flag_list, int flag_cap,
                                                               int *__restrict__ counters_rw, Dims d,
                                                               const int *__restrict__ idx_list, int list_counter, int list_cap,
-                                                              double *__restrict__ part_out, long part_stride)
+                                                              double *__restrict__ part_out, long part_stride, unsigned char *__restrict__ t1flags)
 {
     // the ONLY LDS object: 3 SV tile images + per wave one row of a_x (fp32) and one row of positive-group sums (fp64)
     __shared__ __attribute__((aligned(16))) char lds[kHBuffers * kHSvTileBytes + 3 * 8 * kTile * 4];
@@ -582,7 +601,9 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__rest
                     labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
                     const float gdot = PRECISE ? p.guard_dot_p : p.guard_dot;
                     const float gacc = PRECISE ? p.guard_acc_l : p.guard_acc;
-                    if (!(fabsf(dv) > (gacc + gdot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs)) {
+                    const bool undecided = !(fabsf(dv) > (gacc + gdot * (p.as_max + fabsf(axs[row]))) * sabs + p.guard_abs);
+                    if (t1flags) t1flags[es] = undecided ? 1 : 0;
+                    else if (undecided) {
                         int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
                         if (slot < flag_cap) flag_list[slot] = e;
                     }
@@ -598,7 +619,7 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const double *__restrict_
                                                        const int *__restrict__ counters, SvmParams p, float *__restrict__ dec,
                                                        int8_t *__restrict__ labels, int *__restrict__ flag_list, int flag_cap,
                                                        int *__restrict__ counters_rw, const int *__restrict__ idx_list,
-                                                       int list_counter, int list_cap)
+                                                       int list_counter, int list_cap, unsigned char *__restrict__ t1flags)
 {
     const int n_evals = min(counters[list_counter], list_cap);
     parts = h_list_parts(n_evals, parts, part_stride);
@@ -614,7 +635,9 @@ __global__ __launch_bounds__(256) void k_svm_h_combine(const double *__restrict_
         const float sabs = (float)(P - N);              // sum |coef| K
         dec[e] = dv;
         labels[evalcell[e]] = (int8_t)(dv > 0.0f ? p.gv0 : p.gv1);
-        if (!(fabsf(dv) > (p.guard_acc_l + p.guard_dot_p * (p.as_max + fabsf(ax[es]))) * sabs + p.guard_abs)) {
+        const bool undecided = !(fabsf(dv) > (p.guard_acc_l + p.guard_dot_p * (p.as_max + fabsf(ax[es]))) * sabs + p.guard_abs);
+        if (t1flags) t1flags[es] = undecided ? 1 : 0;
+        else if (undecided) {
             int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
             if (slot < flag_cap) flag_list[slot] = e;
         }
@@ -629,7 +652,8 @@ __global__ __launch_bounds__(256) void k_svm_h_combine_cr(const double *__restri
                                                           const int *__restrict__ evalcell, const int *__restrict__ counters, CrT1Params c,
                                                           float *__restrict__ dec, int8_t *__restrict__ labels,
                                                           int *__restrict__ flag_list, int flag_cap, int *__restrict__ counters_rw,
-                                                          const int *__restrict__ idx_list, int list_counter, int list_cap)
+                                                          const int *__restrict__ idx_list, int list_counter, int list_cap,
+                                                          unsigned char *__restrict__ t1flags)
 {
     const int n_evals = min(counters[list_counter], list_cap);
     parts = h_list_parts(n_evals, parts, part_stride);
@@ -671,7 +695,9 @@ __global__ __launch_bounds__(256) void k_svm_h_combine_cr(const double *__restri
                            (double)c.guard_abs;
         dec[e] = dv;
         labels[evalcell[e]] = (int8_t)(dv > 0.0f ? c.gv0 : c.gv1);
-        if (!(fabs(dvd) > err) || !(D < 0.05)) {
+        const bool undecided = !(fabs(dvd) > err) || !(D < 0.05);
+        if (t1flags) t1flags[es] = undecided ? 1 : 0;
+        else if (undecided) {
             int slot = atomicAdd(&counters_rw[CNT_FLAGGED], 1);
             if (slot < flag_cap) flag_list[slot] = e;
         }
@@ -681,7 +707,7 @@ __global__ __launch_bounds__(256) void k_svm_h_combine_cr(const double *__restri
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters, SvmParams p,
                   float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d, long max_evals,
                   const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride, hipStream_t s,
-                  const CrT1Params *cr, const double *Lbuf)
+                  const CrT1Params *cr, const double *Lbuf, unsigned char *t1flags)
 {
     long blocks = (max_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
     if (blocks <= 0) return;
@@ -693,9 +719,10 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
         const int parts = list_parts;
         hipLaunchKernelGGL((k_svm_rbf_h<true, true>), dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
                            (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
-                           list_counter, list_cap, part_out, part_stride);
+                           list_counter, list_cap, part_out, part_stride, t1flags);
         hipLaunchKernelGGL(k_svm_h_combine_cr, dim3(1024), dim3(256), 0, s, part_out, part_stride, parts, ax, Lbuf, evalcell, counters, *cr, dec,
-                           labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap);
+                           labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap, t1flags);
+        if (t1flags) launch_t1_handover(t1flags, counters, list_counter, list_cap, idx_list, flag_list, flag_cap, counters_rw, s);
         return;
     }
     if (idx_list) {
@@ -703,14 +730,16 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
         double *po = parts > 1 ? part_out : nullptr;
         hipLaunchKernelGGL(k_svm_rbf_h<true>, dim3((unsigned)blocks, (unsigned)parts), dim3(kSvmThreads), 0, s, (const char *)Xh, ax,
                            (const char *)svt_h, evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list,
-                           list_counter, list_cap, po, part_stride);
+                           list_counter, list_cap, po, part_stride, t1flags);
         if (po)
             hipLaunchKernelGGL(k_svm_h_combine, dim3(1024), dim3(256), 0, s, po, part_stride, parts, ax, evalcell, counters, p, dec,
-                               labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap);
+                               labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap, t1flags);
+        if (t1flags) launch_t1_handover(t1flags, counters, list_counter, list_cap, idx_list, flag_list, flag_cap, counters_rw, s);
     } else {
         hipLaunchKernelGGL(k_svm_rbf_h<false>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
                            evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap,
-                           (double *)nullptr, 0L);
+                           (double *)nullptr, 0L, t1flags);
+        if (t1flags) launch_t1_handover(t1flags, counters, CNT_EVALS, 0x7fffffff, nullptr, flag_list, flag_cap, counters_rw, s);
     }
 }
 

@@ -75,7 +75,7 @@ void haf_destroy(haf_engine *e)
     e->d_sd.release(); e->d_corr.release(); e->d_sd3.release(); e->d_fd_slot.release(); e->d_part1.release();
     e->d_svt_h_cr.release(); e->d_t1_tab.release(); e->d_t1_L.release(); e->d_flag0b_list.release(); e->d_screen_part.release();
     e->d_svt0_cr.release(); e->d_fd_slot_cr.release(); e->d_sd_cr.release(); e->d_sd3_cr.release(); e->d_corr_cr.release();
-    e->d_brslot.release(); e->d_tier_words.release(); e->d_lr_btiles.release(); e->d_svt_lr.release(); e->d_lr_btiles_in.release(); e->d_corr_lrp.release(); e->d_iiabs.release();
+    e->d_brslot.release(); e->d_tier_words.release(); e->d_t1_flags.release(); e->d_lr_btiles.release(); e->d_svt_lr.release(); e->d_lr_btiles_in.release(); e->d_corr_lrp.release(); e->d_iiabs.release();
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -247,6 +247,15 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
     if (!load_features(e->feature_file, e->features, e->error)) return bail(HAF_E_IO);
     if (!load_range(e->range_file, e->range, e->error)) return bail(HAF_E_IO);
     if (!load_model(e->model_file, e->model, e->error)) return bail(HAF_E_IO);
+    // libsvm's other vector kernels (linear, polynomial, sigmoid): svm-predict serves them, so the drop-in does -- through the tier that
+    // IS libsvm's arithmetic (k_recheck: every evaluation in the library's own order, then the C library's tanh near zero).  The fast tiers
+    // are built for the RBF kernel (the reference's model is an easy.py product); their tables are not built for such a model.
+    e->generic_kernel = e->model.kernel_type != HAF_KERNEL_RBF;
+    if (e->generic_kernel) {
+        e->cfg.flags &= ~(uint32_t)HAF_FLAG_FP32_MFMA;
+        e->cfg.flags |= HAF_FLAG_SPLIT_F16;                // (no screening tables, no calibration; the request path never looks at the contraction mode)
+        e->direct_work = 0;
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { e->error = "no HIP device available: this engine has no CPU fallback"; return bail(HAF_E_DEVICE); }

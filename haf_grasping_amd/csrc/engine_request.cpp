@@ -5,6 +5,32 @@
 
 namespace haf_host {
 
+// One kernel value K(x, s_n) on the HOST exactly as svm-predict forms it (Kernel::k_function, svm.cpp:318-371) with the C library's
+// exp / tanh: x = the device's attributes (stride 16 doubles: one column of the fp64 image), s_n in model order.  -ffp-contract=off.
+static double host_kernel_value(const SvmModel &m, const double *xg, int n, int kx)
+{
+    double acc = 0.0;
+    if (m.kernel_type == HAF_KERNEL_RBF) {
+        for (int k = 0; k < kx; k++) {                           // svm.cpp:333-347: index order, a missing entry is 0
+            const double sv = k < m.dim ? m.sv[(size_t)n * m.dim + k] : 0.0;
+            const double dd = xg[(size_t)k * 16] - sv;
+            acc += dd * dd;
+        }
+        return std::exp(-m.gamma * acc);                         // svm.cpp:364: glibc's exp
+    }
+    for (int k = 0; k < kx; k++) {                               // Kernel::dot, svm.cpp:299-316 (a zero on either side adds +-0)
+        const double sv = k < m.dim ? m.sv[(size_t)n * m.dim + k] : 0.0;
+        acc += xg[(size_t)k * 16] * sv;
+    }
+    if (m.kernel_type == HAF_KERNEL_POLY) {                      // powi, svm.cpp:26-36
+        double tmp = m.gamma * acc + m.coef0, ret = 1.0;
+        for (int t = m.degree; t > 0; t /= 2) { if (t % 2 == 1) ret *= tmp; tmp = tmp * tmp; }
+        return ret;
+    }
+    if (m.kernel_type == HAF_KERNEL_SIGMOID) return std::tanh(m.gamma * acc + m.coef0);   // svm.cpp:367: glibc's tanh
+    return acc;                                                  // LINEAR
+}
+
 // The strict tier (k_recheck) restates libsvm's summation order operation for operation, but its exp() is the device's, not
 // glibc's.  Both are within an ulp of the true value, so the two sums differ by at most 2^-52 sum|coef|; a strict-tier decision
 // value closer to zero than host_exp_thr (256 x that) is therefore evaluated once more HERE, on the host, with the C library's
@@ -38,13 +64,8 @@ static int host_resolve_strict(haf_engine *e, const Dims &d, hipStream_t s, bool
         const double *xg = x64.data() + (size_t)(i >> 4) * kKP * 16 + (i & 15);
         double sum = 0.0;
         for (int n = 0; n < m.n_sv; n++) {                       // svm.cpp:2509-2512: both classes' terms in model order
-            double d2 = 0.0;
-            for (int k = 0; k < kx; k++) {                       // svm.cpp:333-347: index order, a missing entry is 0
-                const double sv = k < m.dim ? m.sv[(size_t)n * m.dim + k] : 0.0;
-                const double dd = xg[(size_t)k * 16] - sv;
-                d2 += dd * dd;
-            }
-            sum += m.coef[(size_t)n] * std::exp(-m.gamma * d2);  // svm.cpp:364: glibc's exp
+            const double kv = host_kernel_value(m, xg, n, kx);
+            sum += m.coef[(size_t)n] * kv;
         }
         const double dv = sum - m.rho;                           // 2513
         const int8_t lab = (int8_t)(dv > 0.0 ? e->gv0 : e->gv1);
@@ -122,15 +143,7 @@ static int host_resolve_probability(haf_engine *e, const Dims &d, hipStream_t s)
         for (int i = 0; i < nw; i++) {
             const double *xg = x64.data() + (size_t)(i >> 4) * kKP * 16 + (i & 15);
             double sum = 0.0;
-            for (int nn = 0; nn < m.n_sv; nn++) {                    // svm.cpp:2509-2512
-                double d2 = 0.0;
-                for (int k = 0; k < kx; k++) {
-                    const double sv = k < m.dim ? m.sv[(size_t)nn * m.dim + k] : 0.0;
-                    const double dd = xg[(size_t)k * 16] - sv;
-                    d2 += dd * dd;
-                }
-                sum += m.coef[(size_t)nn] * std::exp(-m.gamma * d2);
-            }
+            for (int nn = 0; nn < m.n_sv; nn++) sum += m.coef[(size_t)nn] * host_kernel_value(m, xg, nn, kx);   // svm.cpp:2509-2512
             const double dv = sum - m.rho;
             double p[2];
             const int idx = host_probability(dv, e->prob.A, e->prob.B, p);
@@ -282,7 +295,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
     // A request whose whole SVM work is tiny goes straight to the fp64 MFMA tier (every evaluation enters its list): same
     // labels by construction -- the tier decides outside its own band and hands the rest to the strict tier -- and three
     // launches instead of a feature kernel, a contraction kernel and the rechecks behind them.
-    const bool direct = !e->prob_mode && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= e->direct_work;
+    const bool direct = !e->prob_mode && !e->generic_kernel && e->direct_work > 0 && evals_sel * (long)e->n_sv_pad <= e->direct_work;
     const bool short_request = evals_sel * (long)e->n_sv_pad <= (1L << 26) && total_n <= (1L << 20);
     // A small engine with a small model behind one of the fast contractions: what that contraction flags goes through the SAME one-launch
     // kernel in list mode (exact attributes + fp64 MFMA decision, tier 2's arithmetic) instead of tier 2a's three launches and tier 2's
@@ -325,7 +338,14 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
         t0b_used = false;
         mark(e, HAF_ST_FEATURES);
         const bool large = evals_sel >= e->large_evals;      // enough evaluations to fill the chip with one thread each
-        if (direct) {
+        if (e->generic_kernel) {
+            // a model whose kernel is not RBF: every evaluation on the strict tier's list, libsvm's own arithmetic for all of them
+            launch_prob_list(e->d_counters.p, CNT_FLAGGED2, e->d_flag2_list.p, e->list_cap, s);
+            launch_recheck(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p, e->list_cap,
+                           e->d_counters.p, CNT_FLAGGED2, e->d_dec_exact2.p, e->d_labels.p, d, s);
+            mark(e, HAF_ST_SVM);
+            mark(e, HAF_ST_REFINE);
+        } else if (direct) {
             // tiny request: exact attributes, fp64 MFMA decision and label of EVERY evaluation in one launch (k_small_direct: tier 2's
             // arithmetic); every evaluation counts as rechecked (k_small_pre / k_prob_list have put them on that tier's list)
             launch_small_direct(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_sv64.p, e->exact, d, std::min<long>(evals_cap, e->list_cap),
@@ -409,21 +429,21 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                             e->flag0_cap, false, list_cap, e->d_attr.p, nullptr, s);
             launch_svm_h(e->d_X1.p, e->d_ax1.p, t1cr ? e->d_svt_h_cr.p : e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                          e->d_flag_list.p, e->list_cap, e->d_counters.p, d, list_cap, t1_list, t1_counter, e->flag0_cap,
-                         e->d_part1.p, e->part1_stride, s, t1cr ? &e->crt1 : nullptr, t1cr ? e->d_t1_L.p : nullptr);
+                         e->d_part1.p, e->part1_stride, s, t1cr ? &e->crt1 : nullptr, t1cr ? e->d_t1_L.p : nullptr, e->d_t1_flags.p);
             }
         } else if (mode == MODE_SPLIT) {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_SPLIT, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, nullptr, s);
             mark(e, HAF_ST_SVM);
             launch_svm_h(e->d_X.p, e->d_ax.p, e->d_svt_h.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                         e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s);
+                         e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, nullptr, 0, 0, nullptr, 0, s, nullptr, nullptr, e->d_t1_flags.p);
             mark(e, HAF_ST_REFINE);
         } else {
             launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X.p, e->d_ax.p, d, e->range.lower,
                             e->range.upper, e->svm.neg_gamma2, evals_cap, XMODE_F32, e->screen, nullptr, 0, 0, large, evals_sel, e->d_attr.p, nullptr, s);
             mark(e, HAF_ST_SVM);
             launch_svm(e->d_X.p, e->d_ax.p, e->d_svt.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
-                       e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, s);
+                       e->d_flag_list.p, e->list_cap, e->d_counters.p, d, evals_cap, s, e->d_t1_flags.p);
             mark(e, HAF_ST_REFINE);
         }
         mark(e, HAF_ST_RECHECK);
@@ -455,7 +475,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                               off, e->d_counters.p, e->d_x64.p, e->d_part64.p, e->d_dec_exact.p, e->d_labels.p, e->d_flagi_list.p, e->list_cap, d, s,
                               e->d_tier_words.p);
         };
-        if (!direct) {
+        if (!direct && !e->generic_kernel) {
             if (i8) i8_window(0);
             fp64_window(0);
         }
@@ -508,6 +528,8 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             rc = vote();
             if (rc != HAF_OK) return rc;
             strict_ran = e->h_counters[CNT_FLAGGED2] > 0;
+        } else if (e->generic_kernel) {
+            strict_ran = true;                            // (it has run, on everything; what is left is the C library's tanh near zero)
         } else if (e->h_counters[CNT_FLAGGED2] > 0) {
             // (the host knows the list's length here: the spread form of the tier, recheck.hip)
             launch_recheck_known(e->d_ii.p, e->d_evalcell.p, e->d_fd.p, e->d_sv64.p, e->d_coef64.p, e->exact, e->d_flag2_list.p,

@@ -141,6 +141,7 @@ struct haf_engine {
     int list_cap = 0;
     int flag_cap = 0;
     int flag0_cap = 0;      // screening pass: evaluations that go on to the three-pass kernel
+    bool generic_kernel = false; // the model's kernel is not RBF: every evaluation through the libsvm-order tier (engine.cpp, engine_request.cpp)
     bool screen_active = true;   // default mode only: cleared once more than 60 % of a call's evaluations fell inside the band of every
                                  // form of the screening pass -- for such a model the single pass is wasted work.  Not for good: every
                                  // reprobe_every-th full-size request afterwards tries the pass again (the judgement may have come from
@@ -195,6 +196,7 @@ struct haf_engine {
     DevBuf<float> d_ii;
     DevBuf<uint8_t> d_mask;
     DevBuf<int> d_rowcount, d_rowoff, d_brcount, d_evalcell, d_flag_list, d_flag2_list;
+    DevBuf<unsigned char> d_t1_flags;          // tier 1: one "undecided" byte per entry (list slot, or evaluation in the all-evaluations modes)
     DevBuf<unsigned long long> d_tier_words;   // exact tiers: one "undecided" bit per entry of a window, for the ordered hand-over lists
     DevBuf<unsigned long long> d_brslot;   // k_small_pre: per (cloud, roll) {request epoch, evaluations} in one word (ordered evaluation list)
     unsigned pre_epoch = 0;

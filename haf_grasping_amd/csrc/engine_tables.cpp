@@ -931,7 +931,7 @@ int build_tables(haf_engine *e)
     HIPCHK(e, hipMemcpy(e->d_sv64.p, sv64.data(), sv64.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->d_coef64.p, coef64.data(), coef64.size() * sizeof(double), hipMemcpyHostToDevice));
     // ---- tier 2a: support vectors as four int8 digit planes in the B-operand layout of v_mfma_i32_16x16x64_i8 (kernels.h) ----
-    e->i8_active = !(c.flags & HAF_FLAG_PROBABILITY) && !test_env("HAF_NO_I8") && e->kx <= 64 * kI8Steps;
+    e->i8_active = !(c.flags & HAF_FLAG_PROBABILITY) && !test_env("HAF_NO_I8") && e->kx <= 64 * kI8Steps && !e->generic_kernel;
     if (e->i8_active) {
         const int n_tiles16 = e->n_sv_pad / 16;
         std::vector<char> img((size_t)n_tiles16 * kI8SvTileBytes, 0);
@@ -1075,6 +1075,7 @@ int build_tables(haf_engine *e)
     e->exact.lower = e->range.lower; e->exact.upper = e->range.upper;
     e->exact.n_sv = m.n_sv; e->exact.n_sv_pad = e->n_sv_pad; e->exact.kx = e->kx;
     e->exact.gv0 = e->gv0; e->exact.gv1 = e->gv1;
+    e->exact.kernel_type = m.kernel_type; e->exact.degree = m.degree; e->exact.coef0 = m.coef0;
     return HAF_OK;
 }
 
@@ -1153,6 +1154,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->list_cap);
     ok &= hipSuccess == e->d_part64.alloc((size_t)e->flag_cap * kRecheckPartRows);
     ok &= hipSuccess == e->d_tier_words.alloc(((size_t)e->flag_cap + 63) / 64 + 4);
+    ok &= hipSuccess == e->d_t1_flags.alloc((size_t)e->max_evals_pad + 64);      // (a default-mode engine can fall back to three passes for every evaluation)
     // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->list_cap);

@@ -155,6 +155,15 @@ int haf_test_model(const char *path, double *gamma, double *rho, int *n_sv, int 
     return HAF_OK;
 }
 
+int haf_test_model_kernel(const char *path, int *kernel_type, int *degree, double *coef0, double *gamma)
+{
+    SvmModel m;
+    std::string err;
+    if (!load_model(path, m, err)) return HAF_E_IO;
+    *kernel_type = m.kernel_type; *degree = m.degree; *coef0 = m.coef0; *gamma = m.gamma;
+    return HAF_OK;
+}
+
 // out: 12 transform floats, then sa, ca, cx1, cy1, cx2, cy2, cx3, cy3, cx4, cy4; full 4x4 (generate_grid form) in m16
 int haf_test_roll_geo(const haf_config *cfg, const haf_grasp_input *in, int roll, float *out22, float *m16, float *m16_pose)
 {

@@ -305,6 +305,8 @@ struct ExactParams {
     double gamma2;                // gamma * log2(e)
     int n_sv, n_sv_pad, kx;       // kx = rows of the fp64 k-major SV image
     int gv0, gv1;
+    int kernel_type, degree;      // libsvm's kernel_type (parsers.h: HAF_KERNEL_*; 2 = RBF) -- the strict tier serves all four vector kernels
+    double coef0;
 };
 
 // counters[] slots in device memory
@@ -421,12 +423,14 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
 size_t screen_part_bytes();                               // the counter that receives the length of the compacted list
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters,
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
-                long max_evals, hipStream_t s);
+                long max_evals, hipStream_t s,
+                unsigned char *t1flags = nullptr);   // != nullptr: one byte per entry -> ORDERED hand-over to the exact tiers' list (contraction.hip: k_t1_handover)
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                   long max_evals, const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride,
                   hipStream_t s,
-                  const CrT1Params *cr = nullptr, const double *Lbuf = nullptr);   // list mode only: the centred-remainder form (svt_h = its images)
+                  const CrT1Params *cr = nullptr, const double *Lbuf = nullptr,    // list mode only: the centred-remainder form (svt_h = its images)
+                  unsigned char *t1flags = nullptr);   // as launch_svm
 // tiny requests: exact attributes + fp64 MFMA decision + label in one launch (tier 2's arithmetic for every evaluation)
 void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,
                          long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s,

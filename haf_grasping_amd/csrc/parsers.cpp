@@ -137,10 +137,17 @@ bool load_model(const std::string &path, SvmModel &m, std::string &err)
         if (key == "svm_type") {
             if (!token(val) || (val != "c_svc" && val != "nu_svc")) { err = "model: svm_type '" + val + "' is not a classifier the server path uses"; return false; }
         } else if (key == "kernel_type") {
-            if (!token(val) || val != "rbf") { err = "model: only kernel_type rbf is supported (got '" + val + "')"; return false; }
+            // (round 5: svm-predict serves any of libsvm's four vector kernels; the reference's own model is RBF, which is the one the
+            // fast tiers are built for -- the others go through the libsvm-order tier for every evaluation, engine_request.cpp)
+            if (!token(val)) { err = "model: kernel_type without a value"; return false; }
+            if (val == "linear") m.kernel_type = HAF_KERNEL_LINEAR;
+            else if (val == "polynomial") m.kernel_type = HAF_KERNEL_POLY;
+            else if (val == "rbf") m.kernel_type = HAF_KERNEL_RBF;
+            else if (val == "sigmoid") m.kernel_type = HAF_KERNEL_SIGMOID;
+            else { err = "model: kernel_type '" + val + "' has no attribute vectors to score (linear, polynomial, rbf, sigmoid are served)"; return false; }
         } else if (key == "gamma") { if (!number(m.gamma)) { err = "model: bad gamma"; return false; } }
-        else if (key == "degree") { int d; if (!integer(d)) { err = "model: bad degree"; return false; } }
-        else if (key == "coef0") { double d; if (!number(d)) { err = "model: bad coef0"; return false; } }
+        else if (key == "degree") { if (!integer(m.degree) || m.degree < 0 || m.degree > 64) { err = "model: bad degree"; return false; } }
+        else if (key == "coef0") { if (!number(m.coef0)) { err = "model: bad coef0"; return false; } }
         else if (key == "nr_class") { if (!integer(nr_class) || nr_class != 2) { err = "model: nr_class must be 2"; return false; } }
         else if (key == "total_sv") { if (!integer(m.n_sv) || m.n_sv <= 0 || m.n_sv > kMaxSupportVectors) { err = "model: bad total_sv (must be in [1, " + std::to_string(kMaxSupportVectors) + "])"; return false; } }
         else if (key == "rho") { if (nr_class != 2 || !number(m.rho)) { err = "model: bad rho"; return false; } }

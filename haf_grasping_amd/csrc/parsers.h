@@ -29,7 +29,11 @@ struct RangeTable {
 bool load_range(const std::string &path, RangeTable &rt, std::string &err);
 
 // libsvm text model, the subset the server exercises: 2-class C-SVC / nu-SVC with RBF kernel (svm.cpp:2714-2927)
+enum { HAF_KERNEL_LINEAR = 0, HAF_KERNEL_POLY = 1, HAF_KERNEL_RBF = 2, HAF_KERNEL_SIGMOID = 3 };   // libsvm's kernel_type indices (svm.h)
 struct SvmModel {
+    int kernel_type = HAF_KERNEL_RBF;      // Kernel::k_function, svm.cpp:318-371 (precomputed kernels have no attribute vectors: refused)
+    int degree = 0;                        // polynomial
+    double coef0 = 0;                      // polynomial, sigmoid
     double gamma = 0, rho = 0;
     int n_sv = 0, dim = 0;                 // dim = largest attribute index
     int n_sv_class[2] = {0, 0};

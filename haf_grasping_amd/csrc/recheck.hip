@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
 #pragma unroll
                 for (int ev = 0; ev < kRB; ev++) sum[ev] = 0.0;
                 const double *col = sv64 + n;
+                const double c = coef64[n];
+                if (p.kernel_type == 2) {                                          // RBF (wave-uniform)
                 for (int k = 0; k < p.kx; k++) {
                     const double s = col[(size_t)k * p.n_sv_pad];
 #pragma unroll
@@ -63,9 +65,36 @@ __global__ __launch_bounds__(256) void k_recheck(const float *__restrict__ ii, c
                         sum[ev] = __dadd_rn(sum[ev], __dmul_rn(dd, dd));          // svm.cpp:333-334, 342, 347
                     }
                 }
-                const double c = coef64[n];
 #pragma unroll
                 for (int ev = 0; ev < kRB; ev++) terms[ev][tid] = __dmul_rn(c, exp(__dmul_rn(-p.gamma, sum[ev])));
+                } else {
+                    // round 5: libsvm's other vector kernels (Kernel::k_function, svm.cpp:318-371), for models the fast tiers are not built
+                    // for.  Kernel::dot (299-316): the products of the attributes both vectors carry, in index order; a zero on either side
+                    // adds +-0, which leaves the sum as it is.  powi: svm.cpp:26-36.
+                    for (int k = 0; k < p.kx; k++) {
+                        const double s = col[(size_t)k * p.n_sv_pad];
+#pragma unroll
+                        for (int ev = 0; ev < kRB; ev++) sum[ev] = __dadd_rn(sum[ev], __dmul_rn(xs[ev][k], s));
+                    }
+#pragma unroll
+                    for (int ev = 0; ev < kRB; ev++) {
+                        double kv = sum[ev];                                       // LINEAR
+                        if (p.kernel_type != 0) {
+                            const double arg = __dadd_rn(__dmul_rn(p.gamma, sum[ev]), p.coef0);
+                            if (p.kernel_type == 1) {                              // POLY: powi(gamma * dot + coef0, degree)
+                                double tmp = arg, ret = 1.0;
+                                for (int t = p.degree; t > 0; t /= 2) {
+                                    if (t % 2 == 1) ret = __dmul_rn(ret, tmp);
+                                    tmp = __dmul_rn(tmp, tmp);
+                                }
+                                kv = ret;
+                            } else {
+                                kv = tanh(arg);                                    // SIGMOID (last bit: the host's tanh decides near zero, engine_request.cpp)
+                            }
+                        }
+                        terms[ev][tid] = __dmul_rn(c, kv);
+                    }
+                }
             }
             __syncthreads();
             if (tid < kRB) {

@@ -192,9 +192,9 @@ hafo_model *hafo_model_load(const char *path)
             if (fscanf(fp, "%80s", cmd) != 1) { ok = 0; break; }
             for (int i = 0; k_kernel_types[i]; i++) if (!strcmp(cmd, k_kernel_types[i])) m->kernel_type = i;
             if (m->kernel_type < 0) ok = 0;
-        } else if (!strcmp(cmd, "degree")) { int d; ok = fscanf(fp, "%d", &d) == 1; }
+        } else if (!strcmp(cmd, "degree")) ok = fscanf(fp, "%d", &m->degree) == 1;
         else if (!strcmp(cmd, "gamma")) ok = fscanf(fp, "%lf", &m->gamma) == 1;
-        else if (!strcmp(cmd, "coef0")) { double d; ok = fscanf(fp, "%lf", &d) == 1; }
+        else if (!strcmp(cmd, "coef0")) ok = fscanf(fp, "%lf", &m->coef0) == 1;
         else if (!strcmp(cmd, "nr_class")) ok = fscanf(fp, "%d", &m->nr_class) == 1;
         else if (!strcmp(cmd, "total_sv")) ok = fscanf(fp, "%d", &m->l) == 1;
         else if (!strcmp(cmd, "rho")) {
@@ -214,8 +214,9 @@ hafo_model *hafo_model_load(const char *path)
             break;
         } else ok = 0;                                                        /* svm.cpp:2841-2852 */
     }
-    /* only the path the server exercises: 2-class C-SVC/nu-SVC with RBF kernel */
-    if (!ok || !have_sv || m->nr_class != 2 || m->kernel_type != 2 || m->svm_type > 1 || m->l <= 0) {
+    /* what svm-predict serves on the server's path: a 2-class C-SVC / nu-SVC with any of libsvm's four vector kernels (round 5; the
+       reference's own model is RBF); precomputed kernels have no attribute vectors */
+    if (!ok || !have_sv || m->nr_class != 2 || m->kernel_type > 3 || m->svm_type > 1 || m->l <= 0) {
         fclose(fp); free(m); return NULL;
     }
     m->has_prob = have_a && have_b;
@@ -583,8 +584,18 @@ void hafo_scale_row(const hafo_range *rg, const unsigned char *skip, const doubl
 }
 
 /* ------------------------------------------------------------------ */
-/* a8: RBF decision (svm.cpp:325-365, 2478-2532)                       */
+/* a8: decision function (Kernel::k_function svm.cpp:318-371, svm_predict_values 2478-2532) */
 /* ------------------------------------------------------------------ */
+static double powi_(double base, int times)           /* svm.cpp:26-36 */
+{
+    double tmp = base, ret = 1.0;
+    for (int t = times; t > 0; t /= 2) {
+        if (t % 2 == 1) ret *= tmp;
+        tmp = tmp * tmp;
+    }
+    return ret;
+}
+
 static double decision_nx2(const hafo_model *m, const double *xs, int nx, double *sabs_out)
 {
     const int D = m->D;
@@ -592,15 +603,27 @@ static double decision_nx2(const hafo_model *m, const double *xs, int nx, double
     double dec = 0, sabs = 0;
     for (int i = 0; i < m->l; i++) {
         const double *sv = m->sv + (size_t)i * D;
-        double sum = 0;
-        for (int k = 0; k < K; k++) {          /* dense form of the sparse merge: missing attribute = 0 */
-            double xv = k < nx ? xs[k] : 0.0, yv = k < D ? sv[k] : 0.0;
-            double d = xv - yv;
-            sum += d * d;
+        double sum = 0, kv;
+        if (m->kernel_type == 2) {             /* RBF, 325-365 */
+            for (int k = 0; k < K; k++) {      /* dense form of the sparse merge: missing attribute = 0 */
+                double xv = k < nx ? xs[k] : 0.0, yv = k < D ? sv[k] : 0.0;
+                double d = xv - yv;
+                sum += d * d;
+            }
+            kv = exp(-m->gamma * sum);
+        } else {
+            /* Kernel::dot (299-316): products of the attributes BOTH vectors carry, in index order.  A text row omits zeros
+               (svm-scale.c:348, svm.cpp:2677), so "carried" = non-zero here; a product with a zero adds +-0 and changes nothing */
+            for (int k = 0; k < K; k++) {
+                double xv = k < nx ? xs[k] : 0.0, yv = k < D ? sv[k] : 0.0;
+                if (xv != 0.0 && yv != 0.0) sum += xv * yv;
+            }
+            if (m->kernel_type == 0) kv = sum;                                          /* LINEAR 321-322 */
+            else if (m->kernel_type == 1) kv = powi_(m->gamma * sum + m->coef0, m->degree);   /* POLY 323-324 */
+            else kv = tanh(m->gamma * sum + m->coef0);                                  /* SIGMOID 366-367 */
         }
-        double kv = exp(-m->gamma * sum);
         dec += m->coef[i] * kv;                     /* 2509-2512 */
-        sabs += fabs(m->coef[i]) * kv;              /* not part of the reference: error scale for the tests */
+        sabs += fabs(m->coef[i] * kv);              /* not part of the reference: error scale for the tests (|coef| K for the RBF kernel) */
     }
     dec -= m->rho;                                  /* 2513 */
     if (sabs_out) *sabs_out = sabs;

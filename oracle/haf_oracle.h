@@ -51,7 +51,7 @@ typedef struct {
 } hafo_range;
 
 typedef struct {
-    int    svm_type, kernel_type; /* indices into libsvm's tables; 0 = c_svc, 2 = rbf */
+    int    svm_type, kernel_type; /* indices into libsvm's tables; 0 = c_svc, 1 = nu_svc; kernels 0 linear, 1 polynomial, 2 rbf, 3 sigmoid */
     double gamma, rho;
     int    nr_class, l;
     int    nSV[2], label[2];
@@ -60,6 +60,8 @@ typedef struct {
     double *sv;               /* dense [l][D], attribute k at column k-1 */
     int    has_prob;          /* probA and probB both present (svm.cpp:2811-2824): svm_check_probability_model, 3098-3104 */
     double probA, probB;      /* the pair (0,1) sigmoid of a 2-class model */
+    int    degree;            /* polynomial kernel (svm.cpp:2742-2743); 0 in files that do not carry it */
+    double coef0;             /* polynomial / sigmoid kernel (2746-2747) */
 } hafo_model;
 
 hafo_features *hafo_features_load(const char *path);

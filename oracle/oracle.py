@@ -55,7 +55,7 @@ class Model(C.Structure):
     _fields_ = [("svm_type", C.c_int), ("kernel_type", C.c_int), ("gamma", C.c_double), ("rho", C.c_double),
                 ("nr_class", C.c_int), ("l", C.c_int), ("nSV", C.c_int * 2), ("label", C.c_int * 2),
                 ("D", C.c_int), ("coef", C.POINTER(C.c_double)), ("sv", C.POINTER(C.c_double)),
-                ("has_prob", C.c_int), ("probA", C.c_double), ("probB", C.c_double)]
+                ("has_prob", C.c_int), ("probA", C.c_double), ("probB", C.c_double), ("degree", C.c_int), ("coef0", C.c_double)]
 
 
 def lib():

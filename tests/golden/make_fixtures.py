@@ -73,7 +73,8 @@ def parse_sparse(path, D):
     return np.array(labels), np.array(rows).reshape(len(rows), D)
 
 
-def make_surrogate():
+def make_surrogate(train_model=True):
+    """train_model=False: only (re)writes the 700 training rows to TMP/train.txt (make_gk trains its own models on them)."""
     os.makedirs(TMP, exist_ok=True)
     orc = O.Oracle(FEATURES, RANGE, None)
     cfg = O.make_cfg()
@@ -114,6 +115,8 @@ def make_surrogate():
         for i in sorted(idx):
             f.write(lines[i] + "\n")
     model = os.path.join(HERE, "surrogate.model")
+    if not train_model:
+        return model
     run([os.path.join(REF, "svm-train"), "-c", "512", "-g", "0.0031", "-q", train, model])
     with open(model) as f:
         head = [next(f) for _ in range(9)]
@@ -202,6 +205,46 @@ def make_g3t(model):
         print("g3t", name, len(dec), "rows; +1:", int((labels > 0).sum()), "min |dec| %.3g" % np.abs(dec).min())
     np.savez_compressed(os.path.join(HERE, "g3_trained.npz"), **{n + "_dec": d for n, d in zip(names, decs)},
                         **{n + "_labels": l for n, l in zip(names, labs)})
+
+
+KERNEL_MODELS = [("linear", ["-t", "0", "-c", "1"]),
+                 ("poly", ["-t", "1", "-d", "3", "-g", "0.0031", "-r", "1", "-c", "8"]),
+                 ("sigmoid", ["-t", "3", "-g", "0.0031", "-r", "-0.5", "-c", "64"]),
+                 ("nu_rbf", ["-s", "1", "-n", "0.25", "-g", "0.0031"])]
+
+
+def make_gk():
+    """Round 5: libsvm's OTHER vector kernels and nu-SVC (svm-predict serves them: Kernel::k_function svm.cpp:318-371).  The reference
+    svm-train on the surrogate's own 700 training rows (TMP/train.txt, written by make_surrogate) with -t 0 / 1 / 3 and -s 1; the model
+    texts go into kernel_models.npz byte for byte (compressed), and for the rows of the four g23 fixtures the fp64 decision values of
+    the REAL svm_predict_values (libsvm_ref.so) and the labels of the REAL svm-predict into gk_kernels.npz."""
+    train = os.path.join(TMP, "train.txt")
+    if not os.path.exists(train):
+        make_surrogate(train_model=False)
+    texts, out = {}, {}
+    for kname, args in KERNEL_MODELS:
+        model = os.path.join(TMP, "k_%s.model" % kname)
+        run([os.path.join(REF, "svm-train")] + args + ["-q", train, model])
+        with open(model, "rb") as f:
+            texts[kname] = np.frombuffer(f.read(), dtype=np.uint8)
+        with open(model) as f:
+            head = [next(f) for _ in range(10)]
+        print("gk", kname, " | ".join(h.strip() for h in head if not h.startswith("SV"))[:200], os.path.getsize(model), "bytes")
+        for name in ["g23_pcd2_r0", "g23_pcd2_r5", "g23_pcd3_r2", "g23_plastic_mug2_r7"]:
+            g = np.load(os.path.join(HERE, name + ".npz"))
+            fpath = os.path.join(TMP, name + ".scaled.txt")
+            with open(fpath, "w") as f:
+                for row in g["scaled"]:
+                    f.write("0 " + " ".join("%d:%r" % (k + 1, float(v)) for k, v in enumerate(row) if v != 0.0) + "\n")
+            run([os.path.join(REF, "svm-predict"), fpath, model, fpath + ".out"], stdout=subprocess.DEVNULL)
+            labels = np.loadtxt(fpath + ".out").reshape(-1)
+            dec, lab2 = ref_decisions(model, fpath)
+            assert (labels == lab2).all() and len(dec) == len(g["scaled"])
+            out["%s_%s_dec" % (kname, name)] = dec
+            out["%s_%s_labels" % (kname, name)] = labels.astype(np.int8)
+            print("   ", name, len(dec), "rows; +1:", int((labels > 0).sum()), "min |dec| %.3g" % np.abs(dec).min())
+    np.savez_compressed(os.path.join(HERE, "kernel_models.npz"), **texts)
+    np.savez_compressed(os.path.join(HERE, "gk_kernels.npz"), **out)
 
 
 def make_g5():
@@ -371,6 +414,8 @@ if __name__ == "__main__":
     if "g23" in what:
         os.makedirs(TMP, exist_ok=True)
         make_g23(model)
+    if "gk" in what:
+        make_gk()
     if "g5" in what:
         os.makedirs(TMP, exist_ok=True)
         make_g5()

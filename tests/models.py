@@ -1,4 +1,6 @@
 """Seeded synthetic libsvm-3.12 text models and synthetic clouds (test / bench inputs; data only)."""
+import os
+
 import numpy as np
 
 
@@ -164,3 +166,16 @@ def unpack_trained_model(npz_path, model_path):
             f.write((over[r] if r in over else "%.16g" % coef[r]) + " " +
                     "".join(fmt % (k, float(v)) for k, v in zip(indices[a:b].tolist(), vals[a:b].tolist())) + "\n")
     return model_path
+
+
+KERNEL_MODELS = ("linear", "poly", "sigmoid", "nu_rbf")
+
+
+def unpack_kernel_model(golden_dir, name, model_path):
+    """tests/golden/kernel_models.npz: the model texts the REFERENCE svm-train wrote for libsvm's other vector kernels and nu-SVC
+    (tests/golden/make_fixtures.py: make_gk), byte for byte."""
+    z = np.load(os.path.join(golden_dir, "kernel_models.npz"))
+    with open(model_path, "wb") as f:
+        f.write(z[name].tobytes())
+    return model_path
+

@@ -181,6 +181,28 @@ def test_parsers_match_oracle(data_dir, golden_dir):
     assert (coef == om["coef"]).all() and (sv == om["sv"]).all()
 
 
+def test_model_parser_reads_every_vector_kernel(golden_dir, tmp_path):
+    """Round 5: svm_load_model's header (svm.cpp:2714-2860) for libsvm's four vector kernels and both classifier types -- the model
+    texts the reference svm-train wrote (kernel_models.npz) -- and the two things that are refused: a precomputed kernel (no attribute
+    vectors to score) and a regression / one-class type (not a classifier svm-predict's label path serves)."""
+    import models
+    L = capi.testlib()
+    want = {"linear": (0, 0, 0.0, 0.0), "poly": (1, 3, 1.0, 0.0031), "sigmoid": (3, 0, -0.5, 0.0031), "nu_rbf": (2, 0, 0.0, 0.0031)}
+    for kname, (kt, deg, c0, gam) in want.items():
+        path = models.unpack_kernel_model(golden_dir, kname, str(tmp_path / (kname + ".model")))
+        k, d, c, g = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        assert L.haf_test_model_kernel(path.encode(), C.byref(k), C.byref(d), C.byref(c), C.byref(g)) == 0, kname
+        assert (k.value, d.value, c.value, g.value) == (kt, deg, c0, gam), (kname, k.value, d.value, c.value, g.value)
+        om = O.lib().hafo_model_load(path.encode())
+        assert om and (om.contents.kernel_type, om.contents.degree, om.contents.coef0) == (kt, deg, c0)
+    text = open(str(tmp_path / "linear.model")).read()
+    for bad in (text.replace("kernel_type linear", "kernel_type precomputed"), text.replace("svm_type c_svc", "svm_type epsilon_svr")):
+        p = tmp_path / "bad.model"
+        p.write_text(bad)
+        k, d, c, g = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        assert L.haf_test_model_kernel(str(p).encode(), C.byref(k), C.byref(d), C.byref(c), C.byref(g)) == capi.HAF_E_IO
+
+
 def test_feature_file_trailing_line_quirks(tmp_path):
     """fv.cpp:60-82: a final EMPTY line adds a phantom all-zero feature; a last line WITHOUT newline is dropped."""
     L = capi.testlib()
