@@ -395,7 +395,20 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
             const int *t1_list = e->d_flag0_list.p;
             int t1_counter = CNT_FLAGGED0;
             bool t1_run = !straight;
-            if (t0b) {
+            const bool skip1 = e->t1_skip;
+            // round 5: behind a LOW-RANK first pass with the plain epilogue tier 0b is the low-rank sweep itself with the centred-remainder
+            // epilogue in its GATHER form -- the first pass's operand images and raw sums by evaluation id, no second feature kernel
+            const bool t0b_gather = t0b && lr && lr_plain && e->lr_fused && !test_env("HAF_T0B_NO_GATHER");
+            if (t0b_gather) {
+                launch_svm_screen_lr(reinterpret_cast<char *>(e->d_X.p), e->d_gband.p, e->d_ax.p, e->d_svt_lr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p,
+                                     e->d_labels.p, e->d_flag0_words.p, e->d_flag0_wgcount.p, skip1 ? e->d_flag_list.p : e->d_flag0b_list.p, e->flag0_cap,
+                                     e->d_counters.p, d, list_cap, e->d_margin.p, SCREEN_CR_EXP, e->crp, e->lr_band, s, skip1 ? CNT_FLAGGED : -1,
+                                     e->d_lr_btiles_in.p, e->d_flag0_list.p, CNT_FLAGGED0, CNT_FLAGGED0B);
+                t1_list = e->d_flag0b_list.p;
+                t1_counter = CNT_FLAGGED0B;
+                t1_run = !skip1;
+                t0b_used = true;
+            } else if (t0b) {
                 // tier 0b: the centred-remainder form on the LIST of the first pass (its own operand images: translated attributes,
                 // centred support vectors; band, common factor and images indexed by list slot)
                 ScreenParams sp_b = e->screen_cr;
@@ -406,7 +419,6 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                 launch_features(e->d_ii.p, e->d_evalcell.p, e->d_counters.p, e->d_fd.p, e->d_X1.p, e->d_gband.p, d, e->range.lower,
                                 e->range.upper, e->svm.neg_gamma2, list_cap, XMODE_SCREEN, sp_b, e->d_flag0_list.p, CNT_FLAGGED0, e->flag0_cap,
                                 false, list_cap, nullptr, e->d_ax.p, s);
-                const bool skip1 = e->t1_skip;
                 launch_svm_screen(e->d_X1.p, e->d_gband.p, e->d_ax.p, e->d_svt0_cr.p, e->d_evalcell.p, e->d_counters.p, e->svm, e->d_dec.p, e->d_labels.p,
                                   e->d_flag0_words.p, e->d_flag0_wgcount.p, skip1 ? e->d_flag_list.p : e->d_flag0b_list.p, e->flag0_cap, e->d_counters.p, d,
                                   list_cap, e->d_margin.p, SCREEN_CR_EXP, e->crp, s, skip1 ? CNT_FLAGGED : -1, e->d_flag0_list.p, CNT_FLAGGED0, CNT_FLAGGED0B,

@@ -827,9 +827,12 @@ int build_tables(haf_engine *e)
                                 ScrCorr2 *sp2 = reinterpret_cast<ScrCorr2 *>(scp.data() + kS0K);
                                 for (int sl = 0; sl < kS0K; sl++) {
                                     scp[(size_t)sl].g = (float)lr_corr_g[(size_t)sl]; scp[(size_t)sl].hd = (float)lr_corr_h[(size_t)sl];
-                                    scp[(size_t)sl].ub = 0.0f; scp[(size_t)sl].pad = 0.0f;
+                                    // round 5: the feature kernel's fifth sum (unused by this form's band) carries L = ln2 p.g of the
+                                    // centred-remainder form -- the very constants and the very fp32 sum of screen_cr's `cr` -- so that
+                                    // tier 0b can run on this pass's images and raw sums (k_svm_screen_lr<CR_EXP, ., GATHER>: raw[6])
+                                    scp[(size_t)sl].ub = scc[(size_t)sl].hd; scp[(size_t)sl].pad = 0.0f;
                                     ScrCorr2 &p2 = sp2[sl >> 1];
-                                    p2.g[sl & 1] = scp[(size_t)sl].g; p2.hd[sl & 1] = scp[(size_t)sl].hd; p2.ub[sl & 1] = 0.0f; p2.pad[sl & 1] = 0.0f;
+                                    p2.g[sl & 1] = scp[(size_t)sl].g; p2.hd[sl & 1] = scp[(size_t)sl].hd; p2.ub[sl & 1] = scp[(size_t)sl].ub; p2.pad[sl & 1] = 0.0f;
                                 }
                                 if (hipSuccess != e->d_corr_lrp.alloc(scp.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(low-rank tables)");
                                 HIPCHK(e, hipMemcpy(e->d_corr_lrp.p, scp.data(), scp.size() * sizeof(ScrCorr), hipMemcpyHostToDevice));

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
             nu2 = fmaf(rho, rho, nu2);
             if (rmin < 0.0f) nu2 = __builtin_inff();                              // (path A met a negative computed region sum: never trusted, next tier)
             const float sx2 = acc.su2 + sx;                                   // (one more fp32 rounding of |p'|^2: inside kF32Acc's 326)
-            band[0] = acc.su2; band[1] = acc.sd2; band[2] = sx2; band[3] = acc.cr; band[4] = nu2; band[5] = 0.0f; band[6] = 0.0f; band[7] = 0.0f;
+            band[0] = acc.su2; band[1] = acc.sd2; band[2] = sx2; band[3] = acc.cr; band[4] = nu2; band[5] = 0.0f; band[6] = acc.ub; band[7] = 0.0f;   // ([6]: L of the centred-remainder form when this pass runs the plain epilogue, else 0: engine_tables.cpp)
             nax = -0.5f * sx2;
         } else {
             screen_finish((double)acc.su2, (double)acc.sd2, (double)acc.su2 + (double)sx, (double)acc.cr, (double)acc.ub, sp, band, nax);

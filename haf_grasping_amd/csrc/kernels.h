@@ -412,7 +412,11 @@ void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const voi
                           SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                           int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, LrBand lb,
                           hipStream_t s, int also_counter = -1,
-                          const void *ptiles = nullptr);   // != nullptr: the FUSED form -- Y holds the 10-step images, ptiles the projection tiles by input k-step (no launch_project)
+                          const void *ptiles = nullptr,
+                          // round 5, GATHER form ("tier 0b" behind a low-rank first pass): the centred-remainder/exp epilogue on the LIST idx_list
+                          // (counters[count_slot] entries, at most flag0_cap) straight from the first pass's images and raw sums; the
+                          // compacted output list's length goes to counters[out_slot]
+                          const int *idx_list = nullptr, int count_slot = CNT_EVALS, int out_slot = CNT_FLAGGED0);   // != nullptr: the FUSED form -- Y holds the 10-step images, ptiles the projection tiles by input k-step (no launch_project)
 void launch_svm_screen(const void *X0, const float *gband, const float *nax, const void *svt0, const int *evalcell, const int *counters,
                        SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                        int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, hipStream_t s,

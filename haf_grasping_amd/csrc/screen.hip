@@ -979,19 +979,27 @@ __device__ __forceinline__ void screen_block_lr(const char *cur, int n, int lane
 // SV tiles, the wave's 64 evaluations x 192 outputs accumulate in 192 registers while the 10-step operand image passes by one k-step at
 // a time (16 registers, the next step's loads issued behind the first MFMAs of the current one), and the converted fp16 fragments never
 // leave the registers: no 6-step image in HBM (3 GB written and read per C5 step), no second launch.  Y = the 10-step images then.
-template <int VAR, bool FUSED>
+// GATHER (round 5, "tier 0b" behind a low-rank first pass with the plain epilogue): the kernel serves a LIST -- slot j is evaluation
+// idx_list[j], counters[count_slot] of them, never more than in_cap -- straight from what the first pass left in memory: the wave's 64
+// operand images are gathered from the 10-step images by evaluation id (a lane's 16 bytes of a k-step lie where the feature kernel put
+// them: screen.hip header), the raw sums and the common factor are read by evaluation id in the tail (the linear term L of the
+// centred-remainder form rides in raw[6] since round 5: features.hip), flag words and the compaction behind them go by slot.  No
+// second feature kernel, no second set of operand images (0.30 of tier 0b's 0.68 ms at C5).
+template <int VAR, bool FUSED, bool GATHER>
 __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(const char *__restrict__ Y, const float *__restrict__ raw,
                                                                   const float *__restrict__ nax, const char *__restrict__ svt,
                                                                   const int *__restrict__ evalcell, const int *__restrict__ counters,
                                                                   SvmParams p, float *__restrict__ dec, int8_t *__restrict__ labels,
                                                                   unsigned long long *__restrict__ flag0_words, Dims d,
                                                                   float *__restrict__ margin, CrParams crp, LrBand lb,
-                                                                  const char *__restrict__ ptiles)
+                                                                  const char *__restrict__ ptiles,
+                                                                  const int *__restrict__ idx_list, int count_slot, int in_cap)
 {
+    static_assert(!GATHER || FUSED, "the gather form reads the 10-step images");
     constexpr bool CRP = VAR == SCREEN_CR_POLY;
     constexpr int kV0 = FUSED ? kHFull : 0;                          // virtual tiles in front of the SV tiles: ring slot of SV tile t = (t + kV0) % 3
     __shared__ __attribute__((aligned(16))) char lds[kS0Buffers * kLrSvTileBytes + 3 * kS0Waves * kS0WaveEvals * 4];
-    const int n_evals = counters[CNT_EVALS];
+    const int n_evals = GATHER ? min(counters[count_slot], in_cap) : counters[CNT_EVALS];
     const long base = (long)blockIdx.x * kS0BlockEvals;
     if (base >= n_evals) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1039,10 +1047,22 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
     } else {
         // ---- the projection: D[output slot][evaluation] += B^'[output slot][input slot] X[input slot][evaluation], one input k-step per ring tile ----
         const char *xt = Y + (size_t)tile32 * kS0MatBytes;           // this wave's two 10-step images
+        // GATHER: row block m of this wave holds the evaluations of list slots base + 64 wave + 16 m + (lane & 15); a lane's fragment of
+        // k-step sx of evaluation e lies at image e / 32, piece (sx, (e / 16) % 2), lane 16 (lane / 16) + e % 16 (slots beyond the list: evaluation 0)
+        const char *xg[4];
+        if (GATHER) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const long sl = base + wave * kS0WaveEvals + 16 * m + (lane & 15);
+                const int eg = sl < n_evals ? idx_list[sl] : 0;
+                xg[m] = Y + (size_t)(eg >> 5) * kS0MatBytes + ((eg >> 4) & 1) * 1024 + ((lane >> 4) * 16 + (eg & 15)) * 16;
+            }
+        }
         auto xload = [&](int sx, half8 (&x)[4]) {
 #pragma unroll
             for (int m = 0; m < 4; m++)
-                x[m] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(xt + (m >> 1) * kS0MatBytes + (sx * 2 + (m & 1)) * 1024 + lane * 16));
+                x[m] = GATHER ? *reinterpret_cast<const half8 *>(xg[m] + sx * 2048)
+                              : __builtin_nontemporal_load(reinterpret_cast<const half8 *>(xt + (m >> 1) * kS0MatBytes + (sx * 2 + (m & 1)) * 1024 + lane * 16));
         };
         f32x4 accp[2 * kLrSteps][4];                                 // twelve 16-row blocks of outputs x four 16-evaluation blocks
 #pragma unroll
@@ -1194,16 +1214,18 @@ __global__ __launch_bounds__(kS0Waves * 64, HAF_LR_WGS) void k_svm_screen_lr(con
     bool flagged = false;
     if (!kLrTwoLevel) p.guard_acc0 = p.guard_acc0_s;                  // single-level coefficient sum: (2 tiles + 14) u instead of (34 + tiles / 8) u
     if (live) {
-        float sc = __builtin_amdgcn_exp2f(nax[e]);
+        const long es = GATHER ? (long)idx_list[e] : e;                  // the evaluation this slot holds
+        float sc = __builtin_amdgcn_exp2f(nax[es]);
         float4 g, g2 = float4{0.0f, 0.0f, 0.0f, 0.0f};
         float rw[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) rw[k] = raw[kBandFloats * e + k];
+        for (int k = 0; k < 6; k++) rw[k] = raw[kBandFloats * es + k];
+        if (GATHER) rw[3] = raw[kBandFloats * es + 6];                   // L = ln2 p.g of the centred-remainder form (the first pass's raw[3] is ITS correction sum)
         if (FUSED) rw[5] = sdyrow[lane];
         if (VAR == SCREEN_PLAIN) lr_finish_band_plain(rw, lb, g, g2);
         else lr_finish_band(rw, lb, g.x, g.y, g.z, g.w);
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc));
-        flagged = screen_tail_vals<VAR, false>((double)pos[lane], (double)fin[lane], 0.0f, e, g, g2, sc, p, crp, nullptr, evalcell, dec, labels, margin);
+        flagged = screen_tail_vals<VAR, false>((double)pos[lane], (double)fin[lane], 0.0f, e, g, g2, sc, p, crp, GATHER ? idx_list : nullptr, evalcell, dec, labels, margin);
     }
     const unsigned long long bal = __ballot(flagged);
     if (lane == 0) flag0_words[(base >> 6) + wave] = bal;
@@ -1250,22 +1272,27 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
 void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
                           SvmParams p, float *dec, int8_t *labels, unsigned long long *flag0_words, int *wgcount, int *flag0_list,
                           int flag0_cap, int *counters_rw, Dims d, long max_evals, float *margin, int variant, CrParams cr, LrBand lb,
-                          hipStream_t s, int also_counter, const void *ptiles)
+                          hipStream_t s, int also_counter, const void *ptiles, const int *idx_list, int count_slot, int out_slot)
 {
     const long blocks = (max_evals + kS0BlockEvals - 1) / kS0BlockEvals;
     if (blocks <= 0) return;
     lb.poly = variant == SCREEN_CR_POLY;
-#define HAF_LR_LAUNCH(V, F)                                                                                                           \
-    hipLaunchKernelGGL((k_svm_screen_lr<V, F>), dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,           \
-                       (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb, (const char *)ptiles)
-    if (variant == SCREEN_CR_POLY) { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_POLY, true); else HAF_LR_LAUNCH(SCREEN_CR_POLY, false); }
-    else if (variant == SCREEN_PLAIN) { if (ptiles) HAF_LR_LAUNCH(SCREEN_PLAIN, true); else HAF_LR_LAUNCH(SCREEN_PLAIN, false); }
-    else { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_EXP, true); else HAF_LR_LAUNCH(SCREEN_CR_EXP, false); }
+    // gather form (idx_list != nullptr; CR_EXP on the fused kernel only): what the INPUT list holds, as in launch_svm_screen
+    const int in_cap = idx_list ? (int)std::min<long>(flag0_cap, max_evals) : 0x7fffffff;
+#define HAF_LR_LAUNCH(V, F, G)                                                                                                        \
+    hipLaunchKernelGGL((k_svm_screen_lr<V, F, G>), dim3((unsigned)blocks), dim3(kS0Waves * 64), 0, s, (const char *)Y, raw, nax,        \
+                       (const char *)svt_lr, evalcell, counters, p, dec, labels, flag0_words, d, margin, cr, lb, (const char *)ptiles,  \
+                       idx_list, count_slot, in_cap)
+    if (idx_list) { HAF_LR_LAUNCH(SCREEN_CR_EXP, true, true); }
+    else if (variant == SCREEN_CR_POLY) { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_POLY, true, false); else HAF_LR_LAUNCH(SCREEN_CR_POLY, false, false); }
+    else if (variant == SCREEN_PLAIN) { if (ptiles) HAF_LR_LAUNCH(SCREEN_PLAIN, true, false); else HAF_LR_LAUNCH(SCREEN_PLAIN, false, false); }
+    else { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_EXP, true, false); else HAF_LR_LAUNCH(SCREEN_CR_EXP, false, false); }
 #undef HAF_LR_LAUNCH
     const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
-    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, CNT_EVALS, 0x7fffffff);
+    const int cs = idx_list ? count_slot : CNT_EVALS;
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, cs, in_cap);
     hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw, also_counter, (const int *)nullptr, CNT_EVALS, CNT_FLAGGED0, 0x7fffffff);
+                       counters_rw, also_counter, idx_list, cs, idx_list ? out_slot : CNT_FLAGGED0, in_cap);
 }
 
 size_t screen_part_bytes() { return (size_t)kS0MaxParts * kS0PartBlocks * kS0BlockEvals * sizeof(float4); }

@@ -66,7 +66,7 @@ TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EV
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
               "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS",
-              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN", "HAF_CANARY_CHECK", "HAF_FLAG0_CAP")
+              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN", "HAF_CANARY_CHECK", "HAF_FLAG0_CAP", "HAF_T0B_NO_GATHER")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -989,6 +989,7 @@ def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
         # the projection as the sweep's prologue (the shipped form) against projection and sweep as two launches (k_project): the same
         # operand bits, the same |y^ - y32|^2, so every decision value and every band (|dec^| / band of the decided cells) is identical
         monkeypatch.delenv("HAF_NO_FAST_GROUPS", raising=False)
+        monkeypatch.setenv("HAF_T0B_NO_GATHER", "1")     # (the gather form of tier 0b exists on the fused kernel only: compare like with like)
         grids = {}
         for unfused in (False, True):
             if unfused:
@@ -1001,10 +1002,46 @@ def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
             grids[unfused] = [(eng.debug(capi.DBG_DECISION, 0, roll), eng.debug(capi.DBG_SCREEN_MARGIN, 0, roll)) for roll in range(cfg["n_rolls"])]
             eng.close()
         monkeypatch.delenv("HAF_LR_UNFUSED", raising=False)
+        monkeypatch.delenv("HAF_T0B_NO_GATHER", raising=False)
         for (d0, m0), (d1, m1) in zip(grids[False], grids[True]):
             assert np.array_equal(d0, d1, equal_nan=True) and np.array_equal(m0, m1, equal_nan=True), "fused and two-launch forms differ"
             assert (np.nan_to_num(m0) > 0).any()
     STATS["low_rank_undecided"] = stats
+
+
+def test_tier_0b_gathers_from_the_low_rank_first_pass(data_dir, tmp_path, monkeypatch):
+    """Round 5: behind a low-rank first pass with the plain epilogue, tier 0b is the low-rank sweep with the centred-remainder epilogue in
+    its GATHER form (k_svm_screen_lr<CR_EXP, FUSED, GATHER>): operand images and raw sums of the first pass by evaluation id (L = ln2 p.g
+    rides in raw[6]), no second feature kernel.  A rolled 128 x 128 grid with negative heights and a balanced 517-SV random model
+    (a plain first pass leaves a few per cent), the form pinned: every stage and label the oracle's in the gather form AND in the
+    list-image form it replaces (HAF_T0B_NO_GATHER), tier 0b really ran, and the projected form's band leaves at most a fifth more
+    undecided than the full-rank one's (within 10 % per evaluation)."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    monkeypatch.setenv("HAF_LARGE_EVALS", "1")
+    monkeypatch.setenv("HAF_SCREEN_VARIANT", "0")
+    monkeypatch.setenv("HAF_T0B", "1")
+    monkeypatch.setenv("HAF_CANARY_CHECK", "1")
+    path = models.write_random_model(str(tmp_path / "r517.model"), 517, seed=5, gamma=1.0 / 323, balanced=True, rho=0.01)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, path)
+    G = 128
+    cloud = models.synthetic_cloud(grid=G, k=2, seed=11)
+    cloud[::7, 2] -= 0.3                                                     # some heights below zero: the per-region exactness path
+    cfg = dict(n_rolls=4, roll_step_deg=35, grid_h=G, grid_w=G, max_points=2 * G * G)
+    inp = dict(grasp_area_length_x=G + 14, grasp_area_length_y=G)
+    left = {}
+    for mode in ("gather", "images"):
+        with monkeypatch.context() as mp:
+            if mode == "images":
+                mp.setenv("HAF_T0B_NO_GATHER", "1")
+            eng = make_engine(data_dir, path, testing=True, **cfg)
+            compare_full(eng, o, cloud, cfg, inp, check_dec=False)
+            assert eng.screen_low_rank()["last_used"] and eng.screen_form() == "plain"
+            c = eng.last_counts()
+            left[mode] = (c["n_refined"], c["n_rechecked"])
+            eng.close()
+    assert 0 < left["gather"][0] <= 1.2 * left["images"][0] + 16, left
+    STATS["tier0b_gather_vs_images_left"] = left
 
 
 @pytest.mark.parametrize("t0b,skip", [(0, 0), (1, 0), (1, 1), (0, 1)])
