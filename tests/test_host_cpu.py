@@ -336,7 +336,7 @@ def test_create_reports_file_errors_before_touching_a_device(data_dir, golden_di
     r = os.path.join(data_dir, "range21062012_allfeatures")
     m = os.path.join(golden_dir, "surrogate.model")
     bad_kernel = tmp_path / "lin.model"
-    bad_kernel.write_text(open(m).read().replace("kernel_type rbf", "kernel_type linear", 1))
+    bad_kernel.write_text(open(m).read().replace("kernel_type rbf", "kernel_type precomputed", 1))     # (round 5: the four vector kernels are served)
     three = tmp_path / "three.model"
     three.write_text(open(m).read().replace("nr_class 2", "nr_class 3", 1))
     trunc = tmp_path / "trunc.model"
@@ -347,7 +347,7 @@ def test_create_reports_file_errors_before_touching_a_device(data_dir, golden_di
              ((f, str(tmp_path / "nope"), m), "cannot open range file"),
              ((f, str(norange), m), "no x section"),
              ((f, r, str(tmp_path / "nope.model")), "cannot open model file"),
-             ((f, r, str(bad_kernel)), "kernel_type rbf"),
+             ((f, r, str(bad_kernel)), "no attribute vectors"),
              ((f, r, str(three)), "nr_class must be 2"),
              ((f, r, str(trunc)), "fewer SV lines")]
     for args, msg in cases:
