@@ -486,7 +486,7 @@ def main():
         var = SCREEN_FORMS.index(form) if form in SCREEN_FORMS else 0
         # the kernel INSTANCE (template arguments included): the profile of another screening form is another kernel
         if precision == "f16s":
-            kernel, instance = ("k_svm_screen_lr", "k_svm_screen_lr<%d, true>" % var) if lr else ("k_svm_screen", "k_svm_screen<%d, false>" % var)
+            kernel, instance = ("k_svm_screen_lr", "k_svm_screen_lr<%d, true, false>" % var) if lr else ("k_svm_screen", "k_svm_screen<%d, false>" % var)
         elif precision == "f16x3":
             kernel, instance = "k_svm_rbf_h", "k_svm_rbf_h<false, false>"
         else:

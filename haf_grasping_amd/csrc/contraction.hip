@@ -154,20 +154,101 @@ __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf(const float *__restr
     }
 }
 
-// Ordered hand-over of tier 1 (round 5; device_common.h: list_compact_bytes): the contraction kernels leave one byte per entry of their
-// iteration space -- "undecided" -- and ONE workgroup appends those entries' evaluations to the exact tiers' list in that order.
-__global__ __launch_bounds__(kListCompactThreads) void k_t1_handover(const unsigned char *__restrict__ flags, const int *__restrict__ counters,
-                                                                     int count_slot, int in_cap, const int *__restrict__ idx_list,
-                                                                     int *__restrict__ flag_list, int flag_cap, int *__restrict__ counters_rw)
+// Ordered hand-over of tier 1 (round 5): the contraction kernels leave one byte per entry of their iteration space -- "undecided" -- and
+// two launches append those entries' evaluations to the exact tiers' list in that order: k_t1_count (a workgroup per 4096 entries:
+// 16 bytes per thread) and k_t1_compact (the workgroups in front of mine summed, an ordered scan inside, the total published by the
+// last one).  The list's counter is zero when tier 1 starts (a request's counters are zeroed; a screening pass that writes the tier
+// list itself means tier 1 does not run), so the total IS the counter.  The grid is sized for the capacity; workgroups beyond the live
+// count leave at once.  (A first version did this with ONE workgroup: 5.6 ms for the 7.9 M entries of the all-evaluations modes.)
+constexpr int kT1Chunk = 4096;
+__device__ __forceinline__ int t1_flags16(const unsigned char *flags, long b, long n)
 {
-    __shared__ int s_scan[kListCompactThreads];
-    list_compact_bytes(flags, min(counters[count_slot], in_cap), idx_list, flag_list, flag_cap, counters_rw, CNT_FLAGGED, s_scan);
+    if (b + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(flags + b);       // (flags are 0 / 1; b is a multiple of 16)
+        return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    int c = 0;
+    for (long q = b; q < n; q++) c += flags[q] ? 1 : 0;
+    return c;
 }
-static void launch_t1_handover(const unsigned char *flags, const int *counters, int count_slot, int in_cap, const int *idx_list, int *flag_list,
-                               int flag_cap, int *counters_rw, hipStream_t s)
+__global__ __launch_bounds__(256) void k_t1_count(const unsigned char *__restrict__ flags, const int *__restrict__ counters, int count_slot,
+                                                  int in_cap, int *__restrict__ blkcount)
 {
-    hipLaunchKernelGGL(k_t1_handover, dim3(1), dim3(kListCompactThreads), 0, s, flags, counters, count_slot, in_cap, idx_list, flag_list, flag_cap,
-                       counters_rw);
+    __shared__ int red[4];
+    const long n = min(counters[count_slot], in_cap);
+    const long b = (long)blockIdx.x * kT1Chunk + threadIdx.x * 16;
+    int c = (b < n) ? t1_flags16(flags, b, n) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcount[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void k_t1_compact(const unsigned char *__restrict__ flags, const int *__restrict__ counters, int count_slot,
+                                                    int in_cap, const int *__restrict__ blkcount, const int *__restrict__ idx_list,
+                                                    int *__restrict__ flag_list, int flag_cap, int *__restrict__ counters_rw)
+{
+    __shared__ int part[256];
+    __shared__ int s_base;
+    const long n = min(counters[count_slot], in_cap);
+    const int n_blk = (int)((n + kT1Chunk - 1) / kT1Chunk);
+    if ((int)blockIdx.x >= n_blk && blockIdx.x != 0) return;
+    const int t = threadIdx.x;
+    int before = 0, total = 0;
+    const bool last = (int)blockIdx.x == max(n_blk - 1, 0);
+    const int upto = last ? n_blk : (int)blockIdx.x;
+    for (int j = t; j < upto; j += 256) {
+        const int c = blkcount[j];
+        total += c;
+        if (j < (int)blockIdx.x) before += c;
+    }
+    part[t] = before;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) part[t] += part[t + o];
+        __syncthreads();
+    }
+    if (t == 0) s_base = part[0];
+    __syncthreads();
+    if (last) {
+        part[t] = total;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) part[t] += part[t + o];
+            __syncthreads();
+        }
+        if (t == 0) counters_rw[CNT_FLAGGED] = part[0];
+        __syncthreads();
+    }
+    const long b = (long)blockIdx.x * kT1Chunk + t * 16;
+    const int mine = (b < n) ? t1_flags16(flags, b, n) : 0;
+    part[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int slot = s_base + part[t] - mine;
+    if (mine) {
+        const long e1 = min(b + 16, n);
+        for (long q = b; q < e1; q++)
+            if (flags[q]) {
+                if (slot < flag_cap) flag_list[slot] = idx_list ? idx_list[q] : (int)q;
+                slot++;
+            }
+    }
+}
+// the flag buffer's layout (engine_tables.cpp sizes it with t1_flag_bytes): [max_entries bytes, rounded up to 64][one int per 4096 entries]
+static int *t1_blkcount(unsigned char *flags, long max_entries) { return reinterpret_cast<int *>(flags + (((size_t)max_entries + 63) / 64) * 64); }
+static void launch_t1_handover(const unsigned char *flags, const int *counters, int count_slot, int in_cap, const int *idx_list, int *flag_list,
+                               int flag_cap, int *counters_rw, hipStream_t s, long max_entries, int *blkcount)
+{
+    const int n_blk = (int)((max_entries + kT1Chunk - 1) / kT1Chunk);
+    if (n_blk <= 0) return;
+    hipLaunchKernelGGL(k_t1_count, dim3(n_blk), dim3(256), 0, s, flags, counters, count_slot, in_cap, blkcount);
+    hipLaunchKernelGGL(k_t1_compact, dim3(n_blk), dim3(256), 0, s, flags, counters, count_slot, in_cap, blkcount, idx_list, flag_list, flag_cap, counters_rw);
 }
 
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters, SvmParams p,
@@ -178,7 +259,7 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_svm_rbf, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, X, ax, svt, evalcell, counters, p,
                        dec, labels, flag_list, flag_cap, counters_rw, d, t1flags);
-    if (t1flags) launch_t1_handover(t1flags, counters, CNT_EVALS, 0x7fffffff, nullptr, flag_list, flag_cap, counters_rw, s);
+    if (t1flags) launch_t1_handover(t1flags, counters, CNT_EVALS, 0x7fffffff, nullptr, flag_list, flag_cap, counters_rw, s, max_evals, t1_blkcount(t1flags, max_evals));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -722,7 +803,7 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
                            list_counter, list_cap, part_out, part_stride, t1flags);
         hipLaunchKernelGGL(k_svm_h_combine_cr, dim3(1024), dim3(256), 0, s, part_out, part_stride, parts, ax, Lbuf, evalcell, counters, *cr, dec,
                            labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap, t1flags);
-        if (t1flags) launch_t1_handover(t1flags, counters, list_counter, list_cap, idx_list, flag_list, flag_cap, counters_rw, s);
+        if (t1flags) launch_t1_handover(t1flags, counters, list_counter, list_cap, idx_list, flag_list, flag_cap, counters_rw, s, max_evals, t1_blkcount(t1flags, max_evals));
         return;
     }
     if (idx_list) {
@@ -734,13 +815,15 @@ void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int 
         if (po)
             hipLaunchKernelGGL(k_svm_h_combine, dim3(1024), dim3(256), 0, s, po, part_stride, parts, ax, evalcell, counters, p, dec,
                                labels, flag_list, flag_cap, counters_rw, idx_list, list_counter, list_cap, t1flags);
-        if (t1flags) launch_t1_handover(t1flags, counters, list_counter, list_cap, idx_list, flag_list, flag_cap, counters_rw, s);
+        if (t1flags) launch_t1_handover(t1flags, counters, list_counter, list_cap, idx_list, flag_list, flag_cap, counters_rw, s, max_evals, t1_blkcount(t1flags, max_evals));
     } else {
         hipLaunchKernelGGL(k_svm_rbf_h<false>, dim3((unsigned)blocks), dim3(kSvmThreads), 0, s, (const char *)Xh, ax, (const char *)svt_h,
                            evalcell, counters, p, dec, labels, flag_list, flag_cap, counters_rw, d, idx_list, list_counter, list_cap,
                            (double *)nullptr, 0L, t1flags);
-        if (t1flags) launch_t1_handover(t1flags, counters, CNT_EVALS, 0x7fffffff, nullptr, flag_list, flag_cap, counters_rw, s);
+        if (t1flags) launch_t1_handover(t1flags, counters, CNT_EVALS, 0x7fffffff, nullptr, flag_list, flag_cap, counters_rw, s, max_evals, t1_blkcount(t1flags, max_evals));
     }
 }
+
+size_t t1_flag_bytes(long max_entries) { return (((size_t)max_entries + 63) / 64) * 64 + ((size_t)max_entries / kT1Chunk + 2) * sizeof(int); }
 
 }  // namespace haf

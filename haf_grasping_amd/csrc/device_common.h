@@ -65,44 +65,6 @@ __device__ __forceinline__ void list_compact_body(const unsigned long long *__re
     if (t == 0) counters[out_slot] = base0 + total;
 }
 
-// The same from one BYTE per entry (tier 1: the contraction kernels finish entries in the order of their tiles, several per lane): src ==
-// nullptr means the entry's own index.
-__device__ __forceinline__ void list_compact_bytes(const unsigned char *__restrict__ flags, int n_entries, const int *__restrict__ src,
-                                                   int *__restrict__ dst, int dst_cap, int *__restrict__ counters, int out_slot, int *s_scan)
-{
-    const int t = threadIdx.x;
-    const int chunk = ((n_entries + kListCompactThreads - 1) / kListCompactThreads + 15) & ~15;      // 16-byte pieces
-    const long b0 = min((long)t * chunk, (long)n_entries), b1 = min(b0 + chunk, (long)n_entries);
-    int mine = 0;
-    for (long b = b0; b < b1; b += 16) {
-        if (b + 16 <= b1) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(flags + b);                               // (flags are 0 / 1: b0 is a multiple of 16)
-            mine += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-        } else {
-            for (long q = b; q < b1; q++) mine += flags[q] ? 1 : 0;
-        }
-    }
-    s_scan[t] = mine;
-    __syncthreads();
-    for (int o = 1; o < kListCompactThreads; o <<= 1) {
-        const int v = (t >= o) ? s_scan[t - o] : 0;
-        __syncthreads();
-        s_scan[t] += v;
-        __syncthreads();
-    }
-    const int base0 = counters[out_slot];
-    int slot = base0 + s_scan[t] - mine;
-    const int total = s_scan[kListCompactThreads - 1];
-    if (mine)
-        for (long b = b0; b < b1; b++)
-            if (flags[b]) {
-                if (slot < dst_cap) dst[slot] = src ? src[b] : (int)b;
-                slot++;
-            }
-    __syncthreads();
-    if (t == 0) counters[out_slot] = base0 + total;
-}
-
 // Upper bound of sqrt(x) to 1e-9 relative without a transcendental instruction (the guard band is never checked bit for
 // bit by a test, so nothing in it may hang on the v_exp/v_rsq result hazard described in screen.hip): 1/sqrt(x) by the
 // exponent-halving bit trick and four Newton steps r <- r (1.5 - 0.5 x r^2), which only multiply and add.

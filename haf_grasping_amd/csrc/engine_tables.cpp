@@ -1157,7 +1157,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_dec_exact.alloc((size_t)e->list_cap);
     ok &= hipSuccess == e->d_part64.alloc((size_t)e->flag_cap * kRecheckPartRows);
     ok &= hipSuccess == e->d_tier_words.alloc(((size_t)e->flag_cap + 63) / 64 + 4);
-    ok &= hipSuccess == e->d_t1_flags.alloc((size_t)e->max_evals_pad + 64);      // (a default-mode engine can fall back to three passes for every evaluation)
+    ok &= hipSuccess == e->d_t1_flags.alloc(t1_flag_bytes(e->max_evals_pad));    // (a default-mode engine can fall back to three passes for every evaluation)
     // k_recheck_mfma reads whole workgroups of 64 evaluations (4 groups of 16): round the image up accordingly
     ok &= hipSuccess == e->d_x64.alloc(((size_t)e->flag_cap + 63) / 64 * 64 * kKP);
     ok &= hipSuccess == e->d_flag2_list.alloc((size_t)e->list_cap);

@@ -429,6 +429,7 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s,
                 unsigned char *t1flags = nullptr);   // != nullptr: one byte per entry -> ORDERED hand-over to the exact tiers' list (contraction.hip: k_t1_handover)
+size_t t1_flag_bytes(long max_entries);                   // size of the t1flags buffer for launches of up to max_entries entries (flags + per-block counts)
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                   long max_evals, const int *idx_list, int list_counter, int list_cap, double *part_out, long part_stride,
