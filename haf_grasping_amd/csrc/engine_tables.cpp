@@ -1129,7 +1129,7 @@ int alloc_buffers(haf_engine *e)
     ok &= hipSuccess == e->d_rowoff.alloc(2 * (B * R * H + 1));      // whole-chunk and left-over starts (k_scan)
     ok &= hipSuccess == e->d_brcount.alloc(B * R);
     ok &= hipSuccess == e->d_brslot.alloc(B * R);
-    if (ok) ok &= hipSuccess == hipMemset(e->d_brslot.p, 0, B * R * sizeof(unsigned long long));       // epoch 0: no request yet
+    if (ok) ok &= hipSuccess == hipMemsetAsync(e->d_brslot.p, 0, B * R * sizeof(unsigned long long), e->stream);   // epoch 0: no request yet (on the engine's stream: in front of its first kernel)
     ok &= hipSuccess == e->d_evalcell.alloc((size_t)e->max_evals_pad);
     ok &= hipSuccess == e->d_flag_list.alloc((size_t)e->list_cap);
     if (mode == MODE_SCREEN) {
