@@ -231,7 +231,7 @@ int build_tables(haf_engine *e)
             std::vector<FeatDesc> fds((size_t)kS0K);
             memset(fds.data(), 0, fds.size() * sizeof(FeatDesc));
             for (auto &x : fds) x.skip = 1;                          // unused slots evaluate to exactly 0
-            double ea2 = 0.0;
+            double ea2 = 0.0, ea2_f32 = 0.0;
             sp.fast_groups = 0;
             sp.extra_groups = 0;
             for (int f = 0; f < n_attr; f++) {
@@ -243,6 +243,10 @@ int build_tables(haf_engine *e)
                 const double ef = 2.0 * (std::fabs(d.scr_mul) * 1.0e-15 * (1e4 + 2.0 * std::fabs(d.fmin)) +
                                          4.5e-16 * std::fabs(sp.c * e->range.lower));
                 ea2 += ef * ef;
+                // round 5: the scaling runs in fp32 -- fl32(q4), fl32(scr_mul), fl32(scr_add) and the fma's rounding: at most
+                // 3 u (|q4 scr_mul| + |scr_add|) <= 3 u (|u'| + 2 |scr_add|) per attribute; the |u'| part is in kScreenEtaRel
+                const double e32 = 3.6e-7 * std::fabs(d.scr_add);
+                ea2_f32 += e32 * e32;
             }
             for (int g = 0; g < kS0Groups; g++) {
                 bool fast = true;
@@ -256,7 +260,7 @@ int build_tables(haf_engine *e)
                         sdesc.w[k] = d.w[k];
                         for (int j = 0; j < 4; j++) sdesc.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
-                    sdesc.scr_mul = d.scr_mul; sdesc.scr_add = d.scr_add;
+                    sdesc.scr_mul = (float)d.scr_mul; sdesc.scr_add = (float)d.scr_add;
                     sdesc.extra = (float)extra[(size_t)sl];
                     // low-rank form: |scr_mul| rounded up for a slot that is a linear functional of the window (HAF), 0 for a SHAF slot
                     const float mul_up = d.shaf ? 0.0f : std::nextafterf((float)std::fabs(d.scr_mul), INFINITY);
@@ -267,7 +271,7 @@ int build_tables(haf_engine *e)
                         for (int j = 0; j < 4; j++) s3.off[k * 4 + j] = ((d.off[k][j] / ld) * kBandPitch + d.off[k][j] % ld) * 4;
                     }
                     s3.shaf = d.shaf;
-                    s3.scr_mul = d.scr_mul; s3.scr_add = d.scr_add;
+                    s3.scr_mul = (float)d.scr_mul; s3.scr_add = (float)d.scr_add;
                     s3.extra = (float)extra[(size_t)sl];
                     s3.pad[0] = mul_up;
                     fds[(size_t)sl] = d;
@@ -280,7 +284,7 @@ int build_tables(haf_engine *e)
             if (test_env("HAF_NO_FAST_GROUPS")) sp.fast_groups = 0;        // A/B runs and the generic-path test
             // a degenerate target range or bounds beyond the decimal path's error budget: serve the model without screening
             if (!(e->range.upper > e->range.lower) || std::fabs(e->range.lower) > 1e3 || std::fabs(e->range.upper) > 1e3) e->screen_active = false;
-            sp.eta_abs = std::max(std::sqrt(ea2) * 1.01, 1e-12 * 18.0 * sp.c);
+            sp.eta_abs = std::max(std::sqrt(ea2 + ea2_f32) * 1.01, 1e-12 * 18.0 * sp.c);
             sd_keep = sd; sd3_keep = sd3; fds_keep = fds; ea2_keep = ea2;
             HIPCHK(e, hipMemcpy(e->d_fd.p, fd2.data(), fd2.size() * sizeof(FeatDesc), hipMemcpyHostToDevice));
             if (hipSuccess != e->d_sd.alloc(sd.size())) return fail(e, HAF_E_DEVICE, "hipMalloc(screening descriptors)");
@@ -525,9 +529,11 @@ int build_tables(haf_engine *e)
                 const double add = d0.scr_mul != 0.0 ? (double)((long double)sp.c * (long double)e->range.lower - (long double)d0.fmin * (long double)d0.scr_mul -
                                                                (long double)mu[(size_t)sl]) : 0.0;
                 if (d0.scr_mul == 0.0) mu[(size_t)sl] = 0.0;          // a slot whose attribute svm-scale drops stays 0
-                sdc[(size_t)sl].scr_add = add; sd3c[(size_t)sl].scr_add = add; fdsc[(size_t)sl].scr_add = add;
+                sdc[(size_t)sl].scr_add = (float)add; sd3c[(size_t)sl].scr_add = (float)add; fdsc[(size_t)sl].scr_add = add;
                 const double ef = 4.5e-16 * std::fabs(mu[(size_t)sl]);
                 ea2c += ef * ef;
+                const double e32 = 3.6e-7 * std::fabs(add) * (1.0 + extra[(size_t)sl]);       // (the fp32 scaling of THIS instance's constants; per slot, its attributes counted)
+                ea2c += e32 * e32;
             }
             cp.eta_abs = std::max(std::sqrt(ea2c) * 1.01, 1e-12 * 18.0 * sp.c);
             // centred support vectors: Q (fp64), Q^ = fp16(Q), b_n = c_n 2^(-|q_n|^2/2) with |q_n|^2 over ALL attributes of the model
@@ -1093,6 +1099,10 @@ int alloc_buffers(haf_engine *e)
     e->list_cap = (int)e->max_evals_pad;             // (< 2^31: cells are 32-bit ids, checked in haf_create)
     e->flag_cap = (int)std::min<long>(std::max<long>(4096, e->max_evals / 4), 1L << 22);
     if (const char *v = test_env("HAF_FLAG_WINDOW")) e->flag_cap = std::max(64, atoi(v));     // tests: many small windows
+    // a whole number of 64-entry blocks: the exact tiers' feature kernels finish whole blocks, padding entries included, and a FULL window
+    // whose length was not a multiple of 64 had them write up to 63 doubles past the last row of d_part64 (found by the guard zones of
+    // the testing build, round 5: every request of the GPU suite under HAF_CANARY_CHECK)
+    e->flag_cap = std::max(64, e->flag_cap / 64 * 64);
     const int mode = contraction_mode(c);
     // screening pass: up to half of the evaluations may go on to the three-pass kernel; a model that sends more is served by
     // the three-pass kernel alone from then on (haf_score_rolls)

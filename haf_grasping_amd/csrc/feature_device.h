@@ -103,12 +103,14 @@ __device__ __forceinline__ double attribute_value_rec(const Src &src, const Feat
 // omission and the min/max shortcuts).  screen_finish() carries that difference through the guard band; evaluations the
 // screening pass cannot decide get the exact attributes in the three-pass tier.  An fp32 feature outside the decimal
 // path's range comes back NaN and poisons the norms: that evaluation is never trusted.
-constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6);
+// (round 5: + 3 u for the fp32 scaling -- fl32(q4), the product's and the sum's rounding inside the fma are one, the constants' own roundings --
+// relative to |u'|; the part relative to |scr_add| is in eta_abs)
+constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6) + 1.8e-7;
 template <class Src>
-__device__ __forceinline__ double screen_attribute(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st)
+__device__ __forceinline__ float screen_attribute(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st)
 {
     const float v = feature_value(src, f);
-    return fma(hafq::decq4_float_scr(v, st), f.scr_mul, f.scr_add);
+    return fmaf((float)hafq::decq4_float_scr(v, st), (float)f.scr_mul, (float)f.scr_add);     // (the same floats ScrDesc holds: engine_tables.cpp)
 }
 
 // The same with the low-rank form's noise bound (kernels.h: kLrK; features.hip: k_features_serial, LR) for a lane of a wave that is
@@ -130,7 +132,7 @@ __device__ __forceinline__ float region_round_bound(float a, float b, float c, f
     return (e1 && e2) ? 0.0f : 6.1e-8f * (fabsf(s1) + fabsf(s2) + fabsf(R));
 }
 template <class Src>
-__device__ __forceinline__ double screen_attribute_lr(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st, float &nb)
+__device__ __forceinline__ float screen_attribute_lr(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st, float &nb)
 {
     if (f.shaf) { nb = 0.0f; return screen_attribute(src, f, st); }
     float rv = 0.0f, ee = 0.0f, esum = 0.0f;
@@ -148,9 +150,9 @@ __device__ __forceinline__ double screen_attribute_lr(const Src &src, const Feat
             if (!first) esum = fmaf(6.1e-8f, fabsf(rv), esum);           // (0 + p is exact; every later addition rounds its result once)
             first = false;
         }
-    const double q4 = hafq::decq4_float_scr(rv, st);
-    nb = f.pad2 * (fabsf((float)q4 - rv) + fabsf(ee) * 1.000001f + esum + 6.1e-8f * fabsf(rv));
-    return fma(q4, f.scr_mul, f.scr_add);
+    const float q4f = (float)hafq::decq4_float_scr(rv, st);
+    nb = f.pad2 * (fabsf(q4f - rv) + fabsf(ee) * 1.000001f + esum + 6.1e-8f * fabsf(rv));
+    return fmaf(q4f, (float)f.scr_mul, (float)f.scr_add);
 }
 
 // ---- the fast form of the screening feature pass ------------------------------------------------------------------
@@ -180,7 +182,7 @@ __device__ __forceinline__ ScrDescK constant_ptr(const ScrDesc *p) { return (Scr
 // u = 2^-24: 3 u (1 + 1e-3) and 4 u (1 + 1e-3), rounded up (the fp32 roundings of the bound's own three operations included)
 constexpr float kNbRound = 1.80e-7f, kNbRound3 = 2.40e-7f;
 template <int NB>
-__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud, float &nu2, float &rmin)
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, float *ud, float &nu2, float &rmin)
 {
     float c[4][8];
     unsigned adr[4][8];                               // all descriptor words first: a volatile asm pins what follows it
@@ -209,8 +211,8 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         const float r0 = __fmul_rn(sd[q].w[0], R0);
         const float r1 = __fmul_rn(sd[q].w[1], R1);
         const float v = __fadd_rn(r0, r1);      // 0.0f + r0 first (fv.cpp:164) only turns a -0 into +0: same decimal, same u'
-        const double q4 = hafq::decq4_float_scr(v, st);
-        ud[q] = fma(q4, sd[q].scr_mul, sd[q].scr_add);
+        const float q4f = (float)hafq::decq4_float_scr(v, st);
+        ud[q] = fmaf(q4f, sd[q].scr_mul, sd[q].scr_add);
         if (NB) {
             // round 5: the fp32 roundings BOUNDED instead of measured -- two products (u |r_k| each), their sum (u |v|) and the cast of q4
             // (u |q4| <= 1.0005 u |v|), |v| <= (1 + u)(|r0| + |r1|): at most kNbRound (|r0| + |r1|), a thousandth of the "%.4g" term beside
@@ -219,7 +221,7 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
             if (NB == 2)
                 ar = fabsf(sd[q].w[0]) * region_round_bound(c[q][0], c[q][1], c[q][2], c[q][3], s10, s20, R0) +
                      fabsf(sd[q].w[1]) * region_round_bound(c[q][4], c[q][5], c[q][6], c[q][7], s11, s21, R1);
-            float nbq = fmaf(kNbRound, fabsf(r0) + fabsf(r1), fabsf((float)q4 - v));
+            float nbq = fmaf(kNbRound, fabsf(r0) + fabsf(r1), fabsf(q4f - v));
             if (NB == 2) nbq += ar;
             // path A (NB == 1, the wave passed the exactness test as a whole): that test takes R >= 0 from the monotone integral image, which
             // holds for the TRUE sums; the fp32-rounded corners can leave a near-empty region at -1..-3 ulp(d), and then (a - b) - c may have
@@ -234,7 +236,7 @@ __device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const ha
         }
     }
 }
-__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f, dmin = 0.0f; screen_quad<0>(band, sd, st, ud, dummy, dmin); }
+__device__ __forceinline__ void screen_quad(unsigned band, ScrDescK sd, const hafq::ScrTabs &st, float *ud) { float dummy = 0.0f, dmin = 0.0f; screen_quad<0>(band, sd, st, ud, dummy, dmin); }
 
 // Two attribute slots of any other group, from the band: three regions each, the HAF sum or the SHAF rule (feature_value).
 // A slot of a dropped or absent attribute has scr_mul = scr_add = 0: its u' is 0 (NaN if its feature value left the decimal
@@ -245,7 +247,7 @@ __device__ __forceinline__ ScrDesc3K constant_ptr(const ScrDesc3 *p) { return (S
 // (NQ slots per call: two in the plain form; ONE with the low-rank form's noise bound, whose temporaries would otherwise cost the
 // kernel 48 registers -- a wave of occupancy -- for the four groups of 40 that take this path)
 template <int NB, int NQ>
-__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud, float &nu2, float &rmin)
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, float *ud, float &nu2, float &rmin)
 {
     float c[NQ][12];
     unsigned adr[NQ][12];
@@ -286,19 +288,19 @@ __device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const 
         } else {
             v = __fadd_rn(__fadd_rn(r[0], r[1]), r[2]);
         }
-        const double q4 = hafq::decq4_float_scr(v, st);
-        ud[q] = fma(q4, sd[q].scr_mul, sd[q].scr_add);
+        const float q4f = (float)hafq::decq4_float_scr(v, st);
+        ud[q] = fmaf(q4f, sd[q].scr_mul, sd[q].scr_add);
         if (NB) {
             // (HAF slots only -- pad[0] = 0 for SHAF: three products, the partial sum r0 + r1, the total and the cast of q4 rounded once each:
             // at most 4 u (|r0| + |r1| + |r2|) <= kNbRound3 of it)
-            const float nbq = sd[q].pad[0] * (fmaf(kNbRound3, (fabsf(r[0]) + fabsf(r[1])) + fabsf(r[2]), fabsf((float)q4 - v)) + ar);
+            const float nbq = sd[q].pad[0] * (fmaf(kNbRound3, (fabsf(r[0]) + fabsf(r[1])) + fabsf(r[2]), fabsf(q4f - v)) + ar);
             nu2 = fmaf(nbq, nbq, nu2);
             if (NB == 1 && !sd[q].shaf) rmin = fminf(fminf(Rk[0], Rk[1]), fminf(Rk[2], rmin));   // (as in screen_quad; a SHAF slot is passed through, not bounded)
             asm volatile("" : "+v"(nu2));
         }
     }
 }
-__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, double *ud) { float dummy = 0.0f, dmin = 0.0f; screen_pair3<0, 2>(band, sd, st, ud, dummy, dmin); }
+__device__ __forceinline__ void screen_pair3(unsigned band, ScrDesc3K sd, const hafq::ScrTabs &st, float *ud) { float dummy = 0.0f, dmin = 0.0f; screen_pair3<0, 2>(band, sd, st, ud, dummy, dmin); }
 
 // the decimal tables (95 doubles) in LDS: call from every thread of the workgroup before any divergent return
 __device__ __forceinline__ hafq::PtrTabs load_decimal_tables(double *lds_tab)

@@ -46,9 +46,9 @@ __device__ __forceinline__ void store_group_h(char *xtile, int r, int g, half8 h
 // ub = u'.ubar for |u' - ubar|.  (u^ - u' is exact in fp32, so the first dot product does not cancel.)
 struct ScreenSums { float su2, sd2, cr, ub; };
 template <class Corr>
-__device__ __forceinline__ _Float16 screen_operand(double ud, ScreenSums &a, const Corr &k)
+__device__ __forceinline__ _Float16 screen_operand(float ud, ScreenSums &a, const Corr &k)
 {
-    const float f = (float)ud;                       // fl32(u'): |f - u'| <= 2^-24 |u'|
+    const float f = ud;                              // u' IS an fp32 number since round 5 (feature_device.h: the scaling runs in fp32)
     _Float16 h = (_Float16)f;                        // subnormal results stay: the matrix core multiplies them as they are
 #ifdef HAF_FLUSH_F16_SUBNORMALS                      // (checked at haf_create: probe_f16_subnormal_mfma, screen.hip)
     if (fabsf((float)h) < kF16MinNormal) h = (_Float16)0.0f;
@@ -73,9 +73,9 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 struct ScreenSums2 { f32x2 su2, sd2, cr, ub; };
 typedef const ScrCorr2 __attribute__((address_space(4))) *ScrCorr2K;
 __device__ __forceinline__ ScrCorr2K constant_ptr(const ScrCorr2 *p) { return (ScrCorr2K)(unsigned long long)p; }
-__device__ __forceinline__ half2v screen_operand2(double u0, double u1, ScreenSums2 &a, ScrCorr2K k)
+__device__ __forceinline__ half2v screen_operand2(float u0, float u1, ScreenSums2 &a, ScrCorr2K k)
 {
-    const f32x2 f = {(float)u0, (float)u1};
+    const f32x2 f = {u0, u1};
     half2v h = __builtin_convertvector(f, half2v);   // RN (v_cvt_pk_f16_f32)
 #ifdef HAF_FLUSH_F16_SUBNORMALS
     if (fabsf((float)h[0]) < kF16MinNormal) h[0] = (_Float16)0.0f;
@@ -97,14 +97,14 @@ __device__ __forceinline__ ScreenSums screen_sums(const ScreenSums2 &a)
 
 // attributes that share a slot beyond the first count once more in |u|^2 (the common factor), not in the operand: sx gets
 // extra * u'^2 for the slots of group g that have any (wave-uniform; three slots of the reference's feature file)
-__device__ __forceinline__ void screen_extra_norm(const ScreenParams &sp, int g, const double *ud, float &sx)
+__device__ __forceinline__ void screen_extra_norm(const ScreenParams &sp, int g, const float *ud, float &sx)
 {
     if (!((sp.extra_groups >> g) & 1)) return;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const float ex = constant_ptr(sp.sd)[g * 8 + q].extra;
         if (ex != 0.0f) {
-            const float f = (float)ud[q];
+            const float f = ud[q];
             sx = fmaf(ex * f, f, sx);
         }
     }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
         float nu2 = 0.0f;
         float rmin = 0.0f;                                // path A: the smallest computed region sum of this evaluation (feature_device.h: screen_quad)
         for (int g = 0; g < kS0Groups; g++) {             // 40 groups of 8 SLOTS (kernels.h)
-            double ud[8];
+            float ud[8];
             if (lr_nb) {
                 if ((sp.fast_groups >> g) & 1) {
                     screen_quad<1>(band, constant_ptr(sp.sd) + g * 8, st, ud, nu2, rmin);
@@ -441,14 +441,14 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
                 for (int q = 0; q < 8; q++) {
                     const FeatDesc &F = fd[g * 8 + q];
                     float nbq = 0.0f;
-                    ud[q] = F.skip ? 0.0 : screen_attribute_lr(SrcBuf<true>{iir, w0}, F, st, nbq);
+                    ud[q] = F.skip ? 0.0f : screen_attribute_lr(SrcBuf<true>{iir, w0}, F, st, nbq);
                     nu2 = fmaf(nbq, nbq, nu2);
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const FeatDesc &F = fd[g * 8 + q];               // screening form: fd = one descriptor per SLOT (an unused slot has skip = 1)
-                    ud[q] = F.skip ? 0.0 : screen_attribute(SrcBuf<true>{iir, w0}, F, st);
+                    ud[q] = F.skip ? 0.0f : screen_attribute(SrcBuf<true>{iir, w0}, F, st);
                 }
             }
             half8 hi;
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     for (int g = gl; g < n_groups; g += kFeatWaves) {
         half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
         double udv[8];
+        float udf[8];
         unsigned long long dig[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -605,9 +606,10 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
                 }
             }
             udv[q] = xd;
-            const float xf = (float)xd;
+            const float xf = (float)xd;                                // (screening form: xd IS an fp32 number)
+            udf[q] = xf;
             if (MODE == XMODE_SCREEN) {
-                hi[q] = screen_operand(xd, acc, constant_ptr(sp.corr)[f]);
+                hi[q] = screen_operand(xf, acc, constant_ptr(sp.corr)[f]);
             } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
         }
         if (MODE == XMODE_SPLIT) store_group_h(xtile, r, g, hi, lo);
         if (MODE == XMODE_SCREEN) {
-            screen_extra_norm(sp, g, udv, sx);
+            screen_extra_norm(sp, g, udf, sx);
             store_group_img(xtile, r, g, hi);
         }
         if (MODE == XMODE_I8) i8_store(X, e, g, dig);
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
-                hi[q] = screen_operand(xd, acc, sp.corr[f]);           // (per quarter wave: a 16-byte vector load)
+                hi[q] = screen_operand(xf, acc, sp.corr[f]);           // (per quarter wave: a 16-byte vector load; xd IS an fp32 number here)
             } else if (MODE == XMODE_SPLIT) {
                 const _Float16 h = (_Float16)xf;                       // RN
                 const _Float16 l = (_Float16)(xf - (float)h);          // exact difference, then RN

@@ -207,10 +207,13 @@ struct ScrDesc {
     int    off[8];                // BYTE offsets of the corners of regions 0 and 1 (A-B-C+D each) from the window origin, in
                                   // the LDS band of a wave (kBandPitch floats per row, features.hip: screen_quad)
     float  w[2];                  // region weights (0: region inactive, its corners point at the window origin)
-    double scr_mul;               // c * (upper - lower) * RN(1/(fmax - fmin))   (0 for an attribute svm-scale drops)
-    double scr_add;               // c * lower - fmin * scr_mul                   (0 likewise):  u' = fma(q4, scr_mul, scr_add)
+    // round 5: the scaling runs in fp32 -- u' = fmaf(fl32(q4), scr_mul, scr_add) -- with the fp64 constants of FeatDesc rounded once
+    // (what that costs, 3 u (|u'| + |scr_add|) per slot, is part of eta: kScreenEtaRel, ScreenParams::eta_abs)
+    float  scr_mul;               // fl32(c * (upper - lower) * RN(1/(fmax - fmin)))   (0 for an attribute svm-scale drops)
+    float  scr_add;               // fl32(c * lower - fmin * scr_mul [- centre])        (0 likewise)
     float  extra;                 // attributes sharing this slot beyond the first (0 almost everywhere): |u|^2 counts u'^2 that often more
     float  pad;                   // low-rank form: |scr_mul| rounded up (0 for a slot that is not a linear functional of the window: passed through)
+    float  rsv[2];
 };
 static_assert(sizeof(ScrDesc) == 64, "ScrDesc is one 64-byte scalar load");
 // per-slot constants of the centred band (ScreenParams): one 16-byte scalar load
@@ -221,9 +224,9 @@ struct ScrDesc3 {
     int    off[12];               // band BYTE offsets of the corners of regions 0..2
     float  w[3];
     int    shaf;                  // fv.cpp:187-191 instead of the weighted sum
-    double scr_mul, scr_add;
+    float  scr_mul, scr_add;      // as in ScrDesc
     float  extra;                 // as in ScrDesc
-    float  pad[3];                // pad[0]: as ScrDesc::pad
+    float  pad[5];                // pad[0]: as ScrDesc::pad
 };
 static_assert(sizeof(ScrDesc3) == 96, "ScrDesc3 layout");
 constexpr int kBandPitch = 80;     // floats per row of a wave's integral-image band in LDS: 64 + 14 columns, padded
