@@ -513,6 +513,45 @@ __global__ __launch_bounds__(256) void k_features_serial(const float *__restrict
 // never one long serial chain of 324 attributes.
 constexpr int kFeatEvals = 64;
 constexpr int kWinPitch = 225;        // floats per staged window (15 x 15); odd, so the 64 lanes of a read hit 32 banks twice over
+// The 15 x 15 integral-image windows of a workgroup's NEV evaluations go to LDS (s_win[evaluation * kWinPitch + row * 15 + col], origin
+// of evaluation v in s_w0[v], 0xffffffff = none: zeros).  Sixteen lanes take one window row.  Every load of a thread is in flight before
+// the first is stored: as a loop this compiled to load -> s_waitcnt vmcnt(0) -> ds_write per step, NEV * 240 / THREADS serial L2
+// latencies in front of every block of evaluations (round 5: 30 of them in k_features<., 8>, ~20 us of C3's 49 us feature launch).
+template <int NEV, int THREADS>
+__device__ __forceinline__ void stage_windows(const rsrc_t iir, const unsigned *s_w0, float *s_win, int row_floats)
+{
+    // per step only a compile-time LDS offset and a wave-uniform row offset (the load's SGPR operand) change: a thread keeps its
+    // evaluation(s) -- with per-step vector addresses the thirty of them were all computed up front, 38 VGPRs
+    constexpr int kRows16 = THREADS / 16;                            // window rows one step of the workgroup covers
+    static_assert((NEV & (NEV - 1)) == 0 && THREADS % 16 == 0 && (kRows16 % NEV == 0 || NEV % kRows16 == 0), "a row per 16 lanes");
+    constexpr int kEvs = kRows16 >= NEV ? 1 : NEV / kRows16;         // evaluations a thread alternates between
+    constexpr int kRowStep = kRows16 >= NEV ? kRows16 / NEV : 1;     // rows it advances per visit of the same evaluation
+    constexpr int kSteps = kEvs * ((15 + kRowStep - 1) / kRowStep);
+    const int s0 = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const int wev0 = kEvs == 1 ? (s0 & (NEV - 1)) : s0, x0 = kEvs == 1 ? s0 / NEV : 0;
+    int voff[kEvs];
+    bool ok[kEvs];
+#pragma unroll
+    for (int m = 0; m < kEvs; m++) {
+        const unsigned o = s_w0[wev0 + kRows16 * m];
+        ok[m] = o != 0xffffffffu && col < 15;
+        voff[m] = ok[m] ? (int)(o + (unsigned)(x0 * row_floats + col) * 4u) : 0;
+    }
+    float *dst = s_win + wev0 * kWinPitch + x0 * 15 + col;
+    float v[kSteps];
+#pragma unroll
+    for (int k = 0; k < kSteps; k++) {
+        const int m = k % kEvs, x = (k / kEvs) * kRowStep;
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, voff[m], x * row_floats * 4, 0));
+        v[k] = ok[m] ? t : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kSteps; k++) {
+        const int m = k % kEvs, x = (k / kEvs) * kRowStep;
+        if (col < 15 && x0 + x < 15) dst[m * kRows16 * kWinPitch + x * 15] = v[k];
+    }
+}
+
 // kFeatWaves = 8 or 16 waves per workgroup, each taking the attribute groups w, w + kFeatWaves, ...: 16 halves the serial
 // chain of a thread (a few thousand evaluations, the refinement list), 8 keeps more evaluations resident when there are
 // enough of them to fill the chip.
@@ -571,13 +610,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     // wave group -- the vector L1 was what bounded this kernel.  Staged, a window row is one or two accesses, once.
     if (gl == 0) s_w0[ev] = live ? w0 : 0xffffffffu;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kFeatEvals * 15 * 16; idx += kFeatWaves * 64) {
-        const int col = idx & 15, seg = idx >> 4, wev = seg & (kFeatEvals - 1), x = seg >> 6;      // 16 lanes = one window row
-        const unsigned o = s_w0[wev];
-        if (col < 15)
-            s_win[wev * kWinPitch + x * 15 + col] =
-                (o != 0xffffffffu) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, (int)(o + (unsigned)(x * (d.W + 1) + col) * 4u), 0, 0)) : 0.0f;
-    }
+    stage_windows<kFeatEvals, kFeatWaves * 64>(iir, s_w0, s_win, d.W + 1);
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0;
@@ -730,13 +763,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;   // the evaluation this slot holds
     if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e_src], d.H, d.W) : 0xffffffffu;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kSmEvals * 15 * 16; idx += kSmWaves * 64) {
-        const int col = idx & 15, seg = idx >> 4, wev = seg & (kSmEvals - 1), x = seg >> 4;       // 16 lanes = one window row
-        const unsigned o = s_w0[wev];
-        if (col < 15)
-            s_win[wev * kWinPitch + x * 15 + col] =
-                (o != 0xffffffffu) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, (int)(o + (unsigned)(x * (d.W + 1) + col) * 4u), 0, 0)) : 0.0f;
-    }
+    stage_windows<kSmEvals, kSmWaves * 64>(iir, s_w0, s_win, d.W + 1);
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     double xx = 0.0;
@@ -849,13 +876,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
     const rsrc_t iir = make_ii_rsrc(ii, d);
     if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e_src], d.H, d.W) : 0xffffffffu;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kSmEvals * 15 * 16; idx += kSmWaves * 64) {
-        const int col = idx & 15, seg = idx >> 4, wev = seg & (kSmEvals - 1), x = seg >> 4;       // 16 lanes = one window row
-        const unsigned o = s_w0[wev];
-        if (col < 15)
-            s_win[wev * kWinPitch + x * 15 + col] =
-                (o != 0xffffffffu) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(iir, (int)(o + (unsigned)(x * (d.W + 1) + col) * 4u), 0, 0)) : 0.0f;
-    }
+    stage_windows<kSmEvals, kSmWaves * 64>(iir, s_w0, s_win, d.W + 1);
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     const int g = slot;

@@ -619,6 +619,62 @@ __global__ __launch_bounds__(kCompactWords) void k_screen_compact(const unsigned
     }
 }
 
+// Small requests -- at most kListCompactThreads flag words, 65 536 evaluations: the reference's own grids -- count, scan and ordered
+// write in ONE workgroup, a word per thread (round 5: the two launches above were 4.5 + 6.7 us and a gap of C3's 0.26 ms).  Same list.
+__global__ __launch_bounds__(kListCompactThreads) void k_screen_compact_small(const unsigned long long *__restrict__ words, int *__restrict__ list,
+                                                                              int cap, int *__restrict__ counters, int also_counter,
+                                                                              const int *__restrict__ idx_list, int count_slot, int out_slot, int in_cap)
+{
+    __shared__ int s_wave[kListCompactThreads / 64];
+    const int n_words = screen_words(counters, count_slot, in_cap);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long m = (t < n_words) ? words[t] : 0ull;
+    const int cnt = __popcll(m);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kListCompactThreads / 64; k++) {
+        const int c = s_wave[k];
+        if (k < wave) before += c;
+        total += c;
+    }
+    int slot = before + incl - cnt;
+    while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (slot < cap) list[slot] = idx_list ? idx_list[t * 64 + b] : t * 64 + b;
+        slot++;
+    }
+    if (t == 0) {
+        counters[out_slot] = total;
+        if (also_counter >= 0) counters[also_counter] = min(total, cap);
+    }
+}
+
+// the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones) -> the ordered list
+static void launch_screen_compaction(const unsigned long long *flag0_words, int *wgcount, long blocks, int *flag0_list, int flag0_cap,
+                                     int *counters_rw, int also_counter, const int *idx_list, int count_slot, int out_slot, int in_cap,
+                                     hipStream_t s)
+{
+    const long words = blocks * (kS0BlockEvals / 64);
+    if (words <= kListCompactThreads) {
+        hipLaunchKernelGGL(k_screen_compact_small, dim3(1), dim3(kListCompactThreads), 0, s, flag0_words, flag0_list, flag0_cap, counters_rw,
+                           also_counter, idx_list, count_slot, out_slot, in_cap);
+        return;
+    }
+    const int n_wg = (int)((words + kCompactWords - 1) / kCompactWords);
+    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters_rw, count_slot, in_cap);
+    hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
+                       counters_rw, also_counter, idx_list, count_slot, out_slot, in_cap);
+}
+
 // Does the matrix core take fp16 subnormal A operands at their value?  The screening feature kernel stores u^ = fp16(u') without
 // flushing small magnitudes (two vector instructions per attribute saved) and counts |u^ - u'| from the stored value; that is
 // only right if the MFMA multiplies what is stored.  haf_create runs this once per process and refuses a device that flushes
@@ -1262,11 +1318,7 @@ void launch_svm_screen(const void *X0, const float *gband, const float *nax, con
         default: HAF_SCREEN_LAUNCH(SCREEN_PLAIN); break;
     }
 #undef HAF_SCREEN_LAUNCH
-    // the flag words of every workgroup that can hold evaluations (the kernels clip to the live ones)
-    const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
-    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, count_slot, in_cap);
-    hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw, also_counter, idx_list, count_slot, out_slot, in_cap);
+    launch_screen_compaction(flag0_words, wgcount, blocks, flag0_list, flag0_cap, counters_rw, also_counter, idx_list, count_slot, out_slot, in_cap, s);
 }
 
 void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const void *svt_lr, const int *evalcell, const int *counters,
@@ -1288,11 +1340,9 @@ void launch_svm_screen_lr(const void *Y, float *raw, const float *nax, const voi
     else if (variant == SCREEN_PLAIN) { if (ptiles) HAF_LR_LAUNCH(SCREEN_PLAIN, true, false); else HAF_LR_LAUNCH(SCREEN_PLAIN, false, false); }
     else { if (ptiles) HAF_LR_LAUNCH(SCREEN_CR_EXP, true, false); else HAF_LR_LAUNCH(SCREEN_CR_EXP, false, false); }
 #undef HAF_LR_LAUNCH
-    const int n_wg = (int)((blocks * (kS0BlockEvals / 64) + kCompactWords - 1) / kCompactWords);
     const int cs = idx_list ? count_slot : CNT_EVALS;
-    hipLaunchKernelGGL(k_screen_count, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, counters, cs, in_cap);
-    hipLaunchKernelGGL(k_screen_compact, dim3(n_wg), dim3(kCompactWords), 0, s, flag0_words, wgcount, n_wg, flag0_list, flag0_cap,
-                       counters_rw, also_counter, idx_list, cs, idx_list ? out_slot : CNT_FLAGGED0, in_cap);
+    launch_screen_compaction(flag0_words, wgcount, blocks, flag0_list, flag0_cap, counters_rw, also_counter, idx_list, cs,
+                             idx_list ? out_slot : CNT_FLAGGED0, in_cap, s);
 }
 
 size_t screen_part_bytes() { return (size_t)kS0MaxParts * kS0PartBlocks * kS0BlockEvals * sizeof(float4); }

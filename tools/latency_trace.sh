@@ -4,7 +4,12 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/lat_${1:-C2}
 rm -rf $O; mkdir -p $O
-mkdir -p $O; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/latency_breakdown.py --only ${1:-C2} > $O/kt.log 2>&1
+# C3T / C3R: the C3 request against the trained 8 964-SV model / the seeded 4096-SV one (tools/c3_big_model.py)
+case "${1:-C2}" in
+  C3T) timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/c3_big_model.py trained --requests 6 > $O/kt.log 2>&1 ;;
+  C3R) timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/c3_big_model.py rand4096 --requests 6 > $O/kt.log 2>&1 ;;
+  *) timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 tools/latency_breakdown.py --only ${1:-C2} > $O/kt.log 2>&1 ;;
+esac
 python3 - ${1:-C2} <<'PY'
 import csv,glob,os,sys
 fs=glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "lat_%s/kt/**/*kernel_trace.csv" % (sys.argv[1] if len(sys.argv) > 1 else "C2")), recursive=True)
