@@ -240,6 +240,62 @@ __global__ __launch_bounds__(256) void k_t1_compact(const unsigned char *__restr
             }
     }
 }
+// Lists of at most 65 536 entries (a small request's: the reference's own grids) in ONE workgroup, 64 flags per thread: the two launches
+// above are 5 + 8 us of a C3 request against a big model.  Same list.
+__global__ __launch_bounds__(kListCompactThreads) void k_t1_handover_small(const unsigned char *__restrict__ flags, const int *__restrict__ counters,
+                                                                           int count_slot, int in_cap, const int *__restrict__ idx_list,
+                                                                           int *__restrict__ flag_list, int flag_cap, int *__restrict__ counters_rw)
+{
+    __shared__ int s_wave[kListCompactThreads / 64];
+    const int n = min(min(counters[count_slot], in_cap), kListCompactThreads * 64);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = t * 64;
+    // the thread's 64 flags in sixteen registers (the buffer is a whole number of 64-byte blocks; bytes from n on are stale: masked)
+    unsigned w[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (b + 16 * q < n) v = *reinterpret_cast<const uint4 *>(flags + b + 16 * q);
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int keep = n - (b + 4 * k);                                    // entries of this word below n
+        if (keep < 4) w[k] = keep <= 0 ? 0u : (w[k] & ((1u << (8 * keep)) - 1u));
+        mine += __popc(w[k]);                                                // (flags are 0 / 1)
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kListCompactThreads / 64; k++) {
+        const int c = s_wave[k];
+        if (k < wave) before += c;
+        total += c;
+    }
+    int slot = before + incl - mine;
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            unsigned m = w[k];
+            while (m) {
+                const int j = (__ffs((int)m) - 1) >> 3;
+                m &= ~(0xffu << (8 * j));
+                const int q = b + 4 * k + j;
+                if (slot < flag_cap) flag_list[slot] = idx_list ? idx_list[q] : q;
+                slot++;
+            }
+        }
+    }
+    if (t == 0) counters_rw[CNT_FLAGGED] = total;
+}
 // the flag buffer's layout (engine_tables.cpp sizes it with t1_flag_bytes): [max_entries bytes, rounded up to 64][one int per 4096 entries]
 static int *t1_blkcount(unsigned char *flags, long max_entries) { return reinterpret_cast<int *>(flags + (((size_t)max_entries + 63) / 64) * 64); }
 static void launch_t1_handover(const unsigned char *flags, const int *counters, int count_slot, int in_cap, const int *idx_list, int *flag_list,
@@ -247,6 +303,11 @@ static void launch_t1_handover(const unsigned char *flags, const int *counters, 
 {
     const int n_blk = (int)((max_entries + kT1Chunk - 1) / kT1Chunk);
     if (n_blk <= 0) return;
+    if (max_entries <= (long)kListCompactThreads * 64) {
+        hipLaunchKernelGGL(k_t1_handover_small, dim3(1), dim3(kListCompactThreads), 0, s, flags, counters, count_slot, in_cap, idx_list, flag_list,
+                           flag_cap, counters_rw);
+        return;
+    }
     hipLaunchKernelGGL(k_t1_count, dim3(n_blk), dim3(256), 0, s, flags, counters, count_slot, in_cap, blkcount);
     hipLaunchKernelGGL(k_t1_compact, dim3(n_blk), dim3(256), 0, s, flags, counters, count_slot, in_cap, blkcount, idx_list, flag_list, flag_cap, counters_rw);
 }
@@ -315,16 +376,20 @@ __device__ __forceinline__ f32x4 h_fma4s(float s, f32x4 v, f32x4 c)        // fm
 constexpr float kPsiA2h = 0.240226506959101f, kPsiA3h = 0.0555041086648216f, kPsiA4h = 0.00961812910762848f, kPsiA5h = 0.00133335581464284f;
 // List mode: the number of SV tile ranges a list of n evaluations is cut into.  gridDim.y = kHListParts for the long lists of a
 // bench-sized request; a request that cannot fill the chip anyway (the host launches gridDim.y = kHListPartsShort then) takes as many
-// ranges as put ~512 workgroups on the chip -- from the LIVE length, on the device.  More than kHListParts ranges use a quarter of the
-// part buffer's stride (the buffer holds 2 x kHListParts x part_stride sums): only for lists that a quarter stride holds.
-constexpr int kHListPartsShort = 16;
+// ranges as put one workgroup on every CU (the kernel's 132 KiB of LDS: one per CU, 256 of them) -- from the LIVE length, on the
+// device.  The part buffer holds 2 x kHListParts x part_stride sums: P > kHListParts ranges use the stride part_stride kHListParts / P,
+// for lists that stride holds.  (Round 5: up to 32 ranges and 256 / blocks of them, not 16 and 512 / blocks -- C3 against the
+// 8 964-SV model, 1 964 entries: 128 workgroups of 18 tiles on half of the CUs.)
+constexpr int kHListPartsShort = 32;
 __device__ __forceinline__ int h_list_parts(int n_evals, int max_parts, long part_stride)
 {
-    if (max_parts <= kHListParts || n_evals > part_stride / (kHListPartsShort / kHListParts)) return min(max_parts, kHListParts);
+    if (max_parts <= kHListParts) return max_parts;
     const int blocks = (n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
-    return min(max_parts, max(kHListParts, blocks > 0 ? 512 / blocks : max_parts));
+    int want = min(max_parts, max(kHListParts, blocks > 0 ? 256 / blocks : max_parts));
+    while (want > kHListParts && (long)n_evals * want > part_stride * kHListParts) want--;
+    return want;
 }
-__device__ __forceinline__ long h_list_stride(long part_stride, int parts) { return parts > kHListParts ? part_stride / (kHListPartsShort / kHListParts) : part_stride; }
+__device__ __forceinline__ long h_list_stride(long part_stride, int parts) { return parts > kHListParts ? part_stride * kHListParts / parts : part_stride; }
 
 template <bool PRECISE, bool CRP = false>
 __global__ __launch_bounds__(kSvmThreads, 2) void k_svm_rbf_h(const char *__restrict__ X, const float *__restrict__ ax,

@@ -35,23 +35,79 @@ template <bool UNI>
 struct SrcBuf {
     rsrc_t r;
     unsigned w0b;
-    __device__ __forceinline__ float corner(const FeatDesc &f, int k, int j) const { return ii_load<UNI>(r, w0b, f.off[k][j]); }
+    template <class FD>
+    __device__ __forceinline__ float corner(const FD &f, int k, int j) const { return ii_load<UNI>(r, w0b, f.off[k][j]); }
 };
 struct SrcWin {
     const float *win;             // this lane's window, row pitch 15
-    __device__ __forceinline__ float corner(const FeatDesc &f, int k, int j) const { return win[f.offw[k][j]]; }
+    template <class FD>
+    __device__ __forceinline__ float corner(const FD &f, int k, int j) const { return win[f.offw[k][j]]; }
 };
 
-template <class Src>
-__device__ __forceinline__ float region_sum(const Src &src, const FeatDesc &f, int k)
+// LDS forms of a descriptor for the workgroups whose lanes take DIFFERENT attributes (k_features_small, k_small_direct: the attribute
+// index differs between the quarters of a wave, so the descriptor words are vector loads).  Read from global memory where they are
+// needed they were seven dependent round trips per attribute -- corner offsets, weight, the next region's, the scaling constants --
+// and those round trips, not the arithmetic, were the kernels' time (round 5: k_small_direct 35 us for 4 072 evaluations).  The
+// workgroup copies what its mode reads once; window offsets fit a byte (15 x 15 - 1 = 224).  Same members, same values.
+struct FeatDescX {                // exact attributes (attribute_value_rec): 64 bytes
+    unsigned char offw[3][4];
+    unsigned char active, shaf, skip, pad;
+    float w[3];
+    float pad1;
+    double fmin, fmax, range, inv_range;
+};
+struct FeatDescS {                // screening attributes (screen_attribute): 48 bytes
+    unsigned char offw[3][4];
+    unsigned char active, shaf, skip, pad;
+    float w[3];
+    float scr_extra;
+    double scr_mul, scr_add;
+};
+template <int THREADS>
+__device__ __forceinline__ void stage_descriptors(const FeatDesc *__restrict__ fd, int n, FeatDescX *s_fd)
+{
+    for (int f = threadIdx.x; f < n; f += THREADS) {
+        const FeatDesc &F = fd[f];
+        FeatDescX L;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) L.offw[k][j] = (unsigned char)F.offw[k][j];
+            L.w[k] = F.w[k];
+        }
+        L.active = (unsigned char)F.active; L.shaf = F.shaf ? 1 : 0; L.skip = F.skip ? 1 : 0; L.pad = 0; L.pad1 = 0.0f;
+        L.fmin = F.fmin; L.fmax = F.fmax; L.range = F.range; L.inv_range = F.inv_range;
+        s_fd[f] = L;
+    }
+}
+template <int THREADS>
+__device__ __forceinline__ void stage_descriptors(const FeatDesc *__restrict__ fd, int n, FeatDescS *s_fd)
+{
+    for (int f = threadIdx.x; f < n; f += THREADS) {
+        const FeatDesc &F = fd[f];
+        FeatDescS L;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) L.offw[k][j] = (unsigned char)F.offw[k][j];
+            L.w[k] = F.w[k];
+        }
+        L.active = (unsigned char)F.active; L.shaf = F.shaf ? 1 : 0; L.skip = F.skip ? 1 : 0; L.pad = 0;
+        L.scr_extra = F.scr_extra; L.scr_mul = F.scr_mul; L.scr_add = F.scr_add;
+        s_fd[f] = L;
+    }
+}
+
+template <class Src, class FD>
+__device__ __forceinline__ float region_sum(const Src &src, const FD &f, int k)
 {
     float s = __fsub_rn(src.corner(f, k, 0), src.corner(f, k, 1));
     s = __fsub_rn(s, src.corner(f, k, 2));
     return __fadd_rn(s, src.corner(f, k, 3));                            // fv.cpp:161-162 / 183-184
 }
 
-template <class Src>
-__device__ __forceinline__ float feature_value(const Src &src, const FeatDesc &f)
+template <class Src, class FD>
+__device__ __forceinline__ float feature_value(const Src &src, const FD &f)
 {
     if (!f.shaf) {
         float rv = 0.0f;
@@ -72,8 +128,8 @@ __device__ __forceinline__ float feature_value(const Src &src, const FeatDesc &f
 }
 
 // fp32 feature -> attribute value svm-predict would parse (both decimal text round trips emulated exactly)
-template <class Src, class Tabs>
-__device__ __forceinline__ double attribute_value(const Src &src, const FeatDesc &f, double lower, double upper, const Tabs &tb)
+template <class Src, class FD, class Tabs>
+__device__ __forceinline__ double attribute_value(const Src &src, const FD &f, double lower, double upper, const Tabs &tb)
 {
     float v = feature_value(src, f);
     double q4 = hafq::decq4_float(v, tb);
@@ -83,8 +139,8 @@ __device__ __forceinline__ double attribute_value(const Src &src, const FeatDesc
 // The same, leaving the three stages of the attribute behind for haf_debug_fetch_attr (HAF_FLAG_KEEP_DEBUG): rec == nullptr in
 // every production call.  An attribute svm-scale drops (f.skip) is 0 for the contraction; its feature and "%.4g" value are
 // still what fv.cpp writes into the text file, so the record keeps them.
-template <class Src, class Tabs>
-__device__ __forceinline__ double attribute_value_rec(const Src &src, const FeatDesc &f, double lower, double upper, const Tabs &tb,
+template <class Src, class FD, class Tabs>
+__device__ __forceinline__ double attribute_value_rec(const Src &src, const FD &f, double lower, double upper, const Tabs &tb,
                                                       AttrRecord *rec)
 {
     if (f.skip && !rec) return 0.0;
@@ -106,8 +162,8 @@ __device__ __forceinline__ double attribute_value_rec(const Src &src, const Feat
 // (round 5: + 3 u for the fp32 scaling -- fl32(q4), the product's and the sum's rounding inside the fma are one, the constants' own roundings --
 // relative to |u'|; the part relative to |scr_add| is in eta_abs)
 constexpr double kScreenEtaRel = 5.0e-6 * (1.0 + 1e-6) + 1.8e-7;
-template <class Src>
-__device__ __forceinline__ float screen_attribute(const Src &src, const FeatDesc &f, const hafq::ScrTabs &st)
+template <class Src, class FD>
+__device__ __forceinline__ float screen_attribute(const Src &src, const FD &f, const hafq::ScrTabs &st)
 {
     const float v = feature_value(src, f);
     return fmaf((float)hafq::decq4_float_scr(v, st), (float)f.scr_mul, (float)f.scr_add);     // (the same floats ScrDesc holds: engine_tables.cpp)

@@ -270,6 +270,7 @@ __device__ __forceinline__ void store_band(float *dst, const float *band)
 
 // ---- XMODE_I8: the int8 digit image of the exact-integer tier (exact8.hip; kernels.h "tier 2a") ----
 constexpr int kI8SmallList = 16384;                    // lists up to this length: k_features_small, beyond: k_features<.., 16>
+constexpr int kSplitSmallList = 8192;                  // the same rule for tier 1's lists (XMODE_SPLIT in list mode): 512 workgroups of 16 fill the chip once
 // fixed point with kI8Q fractional bits, round to nearest (the scaling by 2^kI8Q is exact): |x - X 2^-kI8Q| <= 2^-(kI8Q+1); balanced
 // base-128 digits, d in [-64, 63], X = ((d0 128 + d1) 128 + d2) 128 + d3; attribute q of this thread's group goes to byte q of the
 // four digit planes.  xx: sum of X^2 (exact in int64: < 324 * 2^54); ovf: an attribute beyond the fixed-point range (or NaN).
@@ -581,6 +582,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const double *t1_tab = (MODE == XMODE_SPLIT) ? sp.cr_t1_tab : nullptr;
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     if (MODE == XMODE_I8 && n_evals <= kI8SmallList) return;           // short lists are k_features_small's (see there)
+    if (MODE == XMODE_SPLIT && idx_list && n_evals <= kSplitSmallList) return;
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     hafq::ScrTabs st{};
     if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
     else tb = load_decimal_tables(s_tab);
-    const int ev = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int ev = threadIdx.x & 63, gl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in an SGPR: descriptor words by scalar loads -- as a VGPR expression they were ~17 vector loads and as many waits per slot)
     // grid-stride over blocks of 64 evaluations: a list launch is sized for a few thousand workgroups, not for the list's
     // capacity (tens of thousands of workgroups that would only find out that there is nothing for them)
     for (long blk = blockIdx.x; blk * kFeatEvals < n_pad; blk += gridDim.x) {
@@ -733,18 +735,28 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     __shared__ float red4[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals], red5[(MODE == XMODE_SCREEN) ? kSmSlots : 1][kSmEvals];
     __shared__ float s_win[kSmEvals * kWinPitch];
     __shared__ unsigned s_w0[kSmEvals];
+    __shared__ double red_l[(MODE == XMODE_SPLIT) ? kSmSlots : 1][kSmEvals];   // centred-remainder form of tier 1: see k_features
+    const double *t1_tab = (MODE == XMODE_SPLIT) ? sp.cr_t1_tab : nullptr;
     // (list mode: slot j holds evaluation idx_list[j] of the window [list_off, list_off + list_cap) of the list counted by list_counter)
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     // XMODE_I8: lists are of unknown length at launch; both feature kernels are launched and the list's length decides on the
     // device which of them works -- this one (a third of the serial chain per thread: latency) up to kI8SmallList entries, the
     // 64-evaluation workgroups of k_features (half the time per evaluation at 100 k entries: 2.9 against 5.5 ns) beyond
     if (MODE == XMODE_I8 && n_evals > kI8SmallList) return;
+    // XMODE_SPLIT in list mode (tier 1; round 5): the same rule with kSplitSmallList -- C3 against the 8 964-SV model leaves tier 1 a list of
+    // ~4 000 entries, 72 workgroups of k_features<., 16> on 256 CUs: 54 us
+    if (MODE == XMODE_SPLIT && idx_list && n_evals > kSplitSmallList) return;
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kSmEvals >= n_pad) return;
     // (list mode is launched for the list's CAPACITY -- at C5 123 k workgroups for a list of a few hundred entries, 90 us of empty
     // workgroups -- so its grid is capped and the workgroups stride over the blocks of 16 evaluations)
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
     __shared__ unsigned long long s_scr[MODE == XMODE_SCREEN ? hafq::kScrTabWords : 1];
+    // the descriptors this mode reads, once per workgroup (feature_device.h: FeatDescX / FeatDescS)
+    __shared__ FeatDescX s_fdx[MODE == XMODE_SCREEN ? 1 : kKP];
+    __shared__ FeatDescS s_fds[MODE == XMODE_SCREEN ? kS0K : 1];
+    if (MODE == XMODE_SCREEN) stage_descriptors<kSmWaves * 64>(fd, kS0K, s_fds);
+    else stage_descriptors<kSmWaves * 64>(fd, min(d.nf, kKP), s_fdx);
     hafq::PtrTabs tb{};
     hafq::ScrTabs st{};
     if (MODE == XMODE_SCREEN) st = load_screen_tables(s_scr);
@@ -775,18 +787,23 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     long long xx_ll = 0;                                   // XMODE_I8: sum of the squared fixed-point attributes of this group (exact)
     int ovf = 0;
     unsigned long long dig[4] = {0, 0, 0, 0};             // XMODE_I8: the four digit planes of this thread's 8 attributes
+    double lsum = 0.0;
     if (has_group) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int f = g * 8 + q;
             double xd = 0.0;
             if (MODE == XMODE_SCREEN) {
-                const FeatDesc &F = fd[f];                               // screening form: fd = one descriptor per SLOT (an unused slot has skip = 1)
+                const FeatDescS &F = s_fds[f];                           // screening form: fd = one descriptor per SLOT (an unused slot has skip = 1)
                 if (live && !F.skip) xd = screen_attribute(src, F, st);
                 const float ex = F.scr_extra;                            // (per quarter wave here: the group differs between them)
                 if (ex != 0.0f) { const float ff = (float)xd; sx = fmaf(ex * ff, ff, sx); }
-            } else if (live && f < d.nf) {
-                xd = attribute_value_rec(src, fd[f], lower, upper, tb, (dbg) ? dbg + (size_t)e_src * kKP + f : nullptr);
+            } else if (live && f < d.nf && f < kKP) {
+                xd = attribute_value_rec(src, s_fdx[f], lower, upper, tb, (dbg) ? dbg + (size_t)e_src * kKP + f : nullptr);
+                if (MODE == XMODE_SPLIT && t1_tab && f < kKP) {
+                    xd -= t1_tab[f];
+                    lsum = fma(xd, t1_tab[kKP + f], lsum);
+                }
             }
             const float xf = (float)xd;
             if (MODE == XMODE_SCREEN) {
@@ -812,6 +829,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
         if (MODE == XMODE_I8) i8_store(X, e, g, dig);
     }
     if (MODE == XMODE_I8) { red_ll[slot][ev] = xx_ll; red_ovf[slot][ev] = ovf; }
+    if (MODE == XMODE_SPLIT) red_l[slot][ev] = lsum;
     red[slot][ev] = (MODE == XMODE_SCREEN) ? (double)acc.su2 : xx;
     if (MODE == XMODE_SCREEN) { red2[slot][ev] = (double)acc.sd2; red3[slot][ev] = (double)sx; red4[slot][ev] = acc.cr; red5[slot][ev] = acc.ub; }
     __syncthreads();
@@ -835,6 +853,12 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
             reinterpret_cast<double *>(ax)[e] = any ? -1.0 : ldexp((double)s2, -2 * kI8Q);
         } else if (MODE != XMODE_F64) {
             ax[e] = neg_gamma2 * (float)t;                             // -gamma*log2(e)*|x|^2, folded into the exp2 argument
+            if (MODE == XMODE_SPLIT && t1_tab) {
+                double l = 0.0;
+#pragma unroll
+                for (int k = 0; k < kSmSlots; k++) l += red_l[k][ev];    // fixed order
+                sp.cr_t1_L[e] = l;
+            }
         }
     }
     __syncthreads();                                                   // the next block reuses s_w0, s_win and the reduction arrays
@@ -850,6 +874,13 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
 // the same hand-over to the strict tier for |dec| <= guard2 * T * S.  Replaces three launches and the 10 MB round trip of the
 // attribute image for such a request.
 constexpr int kSdMSteps = kKP / 4;                // 81 k-steps of 4
+// (round 5, measured and dropped: EIGHT evaluations per workgroup and four attributes per thread -- kSdEvals = 8 below still compiles --
+// halves the attribute chain and doubles the workgroups, but every workgroup streams the whole fp64 model through its MFMA phase, whose
+// sixteen rows are then half empty: 34.5 us either way at C3, 48 -> 70 us for C4's 6 476 evaluations.)
+constexpr int kSdEvals = 16;
+constexpr int kSdSlots = kSmWaves * 64 / kSdEvals;     // 48
+constexpr int kSdAttrs = 128 / kSdEvals;               // attributes per thread: 8
+static_assert(kSdSlots * kSdAttrs >= kKP && (kSdEvals == 8 || kSdEvals == 16), "slots cover the attributes");
 __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                                 const FeatDesc *__restrict__ fd, const double *__restrict__ sv64,
                                                                 ExactParams p, Dims d, double *__restrict__ dec_exact,
@@ -860,57 +891,67 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
     // (list mode, idx_list != nullptr: the window [list_off, list_off + list_cap) of a tier's list instead of every evaluation --
     // the exact stage of a SMALL request behind the three-pass kernel in one launch; slot j holds evaluation idx_list[j], its
     // decision value goes to dec_exact[j]; idx_list and dec_exact already point at entry list_off)
-    __shared__ double s_x[kKP * 16];                  // [attribute][evaluation]: the A operand of the fp64 MFMA, k-major
-    __shared__ double s_part[kSmWaves][16][2];        // per wave: sum coef*K and sum |coef|*K of its SV tiles, per evaluation
-    __shared__ double s_xx[16];
-    __shared__ float s_win[kSmEvals * kWinPitch];
-    __shared__ unsigned s_w0[kSmEvals];
+    __shared__ double s_x[kKP * kSdEvals];            // [attribute][evaluation]: the A operand of the fp64 MFMA, k-major
+    __shared__ double s_part[kSmWaves][kSdEvals][2];  // per wave: sum coef*K and sum |coef|*K of its SV tiles, per evaluation
+    __shared__ double s_xx[kSdEvals];
+    __shared__ float s_win[kSdEvals * kWinPitch];
+    __shared__ unsigned s_w0[kSdEvals];
     __shared__ double s_tab[hafq::kTabDoubles];
+    __shared__ FeatDescX s_fd[kKP];                   // the descriptors, once per workgroup (feature_device.h)
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
-    if ((long)blockIdx.x * kSmEvals >= n_evals) return;
+    if ((long)blockIdx.x * kSdEvals >= n_evals) return;
+    stage_descriptors<kSmWaves * 64>(fd, min(d.nf, kKP), s_fd);
     const hafq::PtrTabs tb = load_decimal_tables(s_tab);
-    const int ev = threadIdx.x & 15, slot = threadIdx.x >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long e = (long)blockIdx.x * kSmEvals + ev;
+    const int ev = threadIdx.x & (kSdEvals - 1), slot = threadIdx.x / kSdEvals, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * kSdEvals + ev;
     const bool live = e < n_evals;
     const int e_src = live ? (idx_list ? idx_list[e] : (int)e) : 0;    // the evaluation this slot holds
     const rsrc_t iir = make_ii_rsrc(ii, d);
     if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e_src], d.H, d.W) : 0xffffffffu;
     __syncthreads();
-    stage_windows<kSmEvals, kSmWaves * 64>(iir, s_w0, s_win, d.W + 1);
+    stage_windows<kSdEvals, kSmWaves * 64>(iir, s_w0, s_win, d.W + 1);
     __syncthreads();
     const SrcWin src{s_win + ev * kWinPitch};
     const int g = slot;
-    if (g < (kKP + 7) / 8) {
+    if (g < (kKP + kSdAttrs - 1) / kSdAttrs) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int f = g * 8 + q;
+        for (int q = 0; q < kSdAttrs; q++) {
+            const int f = g * kSdAttrs + q;
             double xd = 0.0;
-            if (live && f < d.nf) xd = attribute_value_rec(src, fd[f], p.lower, p.upper, tb, dbg ? dbg + (size_t)e_src * kKP + f : nullptr);
-            if (f < kKP) s_x[f * 16 + ev] = xd;
+            if (live && f < d.nf && f < kKP) xd = attribute_value_rec(src, s_fd[f], p.lower, p.upper, tb, dbg ? dbg + (size_t)e_src * kKP + f : nullptr);
+            if (f < kKP) s_x[f * kSdEvals + ev] = xd;
         }
     }
     __syncthreads();
-    if (threadIdx.x < 16) {                           // |x|^2, attributes in index order (as k_recheck_mfma's per-lane sums would not be: fixed here)
+    if (threadIdx.x < kSdEvals) {                     // |x|^2, attributes in index order (as k_recheck_mfma's per-lane sums would not be: fixed here)
         double xx = 0.0;
-        for (int k = 0; k < kKP; k++) xx = fma(s_x[k * 16 + threadIdx.x], s_x[k * 16 + threadIdx.x], xx);
+        static_assert(kKP % 12 == 0, "unroll");
+#pragma unroll 1
+        for (int k0 = 0; k0 < kKP; k0 += 12) {        // (twelve LDS reads in flight, then the chain in index order: read -> wait -> fma per step was 324 LDS latencies)
+            double v[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) v[j] = s_x[(k0 + j) * kSdEvals + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 12; j++) xx = fma(v[j], v[j], xx);
+        }
         s_xx[threadIdx.x] = xx;
     }
     __syncthreads();
-    // ---- fp64 MFMA over this wave's SV tiles: A[row = lane&15][k = 4s + (lane>>4)] from LDS, B[k][col = lane&15] from the model ----
+    // ---- fp64 MFMA over this wave's SV tiles: A[row = lane&15][k = 4s + (lane>>4)] from LDS (row & 7: the evaluation), B[k][col = lane&15] from the model ----
     const int n_tiles = p.n_sv_pad / 16;
     double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
     for (int t = wave; t < n_tiles; t += kSmWaves) {
         const double *Bg = sv64 + (size_t)t * 16 + (lane & 15);
         f64x4 acc = {0, 0, 0, 0};
-#pragma unroll 9
+#pragma unroll 27
         for (int s = 0; s < kSdMSteps; s++) {
             const int k = 4 * s + (lane >> 4);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_x[k * 16 + (lane & 15)], Bg[(size_t)k * p.n_sv_pad], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_x[k * kSdEvals + (lane & (kSdEvals - 1))], Bg[(size_t)k * p.n_sv_pad], acc, 0, 0, 0);
         }
         const double ss = Bg[(size_t)kKP * p.n_sv_pad];
         const double cf = Bg[(size_t)(kKP + 1) * p.n_sv_pad];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < kSdEvals / 4; r++) {                               // (kSdEvals = 8: rows 8-15, registers 2 and 3, repeat rows 0-7)
             const int row = (lane >> 4) + 4 * r;                               // f64 C/D layout: row = (lane>>4) + 4*reg
             const double d2 = fma(-2.0, acc[r], s_xx[row] + ss);
             const double kv = exp(-p.gamma * d2);
@@ -919,7 +960,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < kSdEvals / 4; r++) {
         double v = part[r], w = pabs[r];
         v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
         v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
@@ -928,7 +969,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
         if ((lane & 15) == 0) { s_part[wave][(lane >> 4) + 4 * r][0] = v; s_part[wave][(lane >> 4) + 4 * r][1] = w; }
     }
     __syncthreads();
-    if (threadIdx.x < 16 && live) {
+    if (threadIdx.x < kSdEvals && live) {
         double P = 0.0, S = 0.0;
 #pragma unroll
         for (int w = 0; w < kSmWaves; w++) { P += s_part[w][threadIdx.x][0]; S += s_part[w][threadIdx.x][1]; }   // fixed order
@@ -947,7 +988,7 @@ void launch_small_direct(const float *ii, const int *evalcell, int *counters, co
                          long max_evals, double *dec_exact, int8_t *labels, int *flag2_list, int flag2_cap, AttrRecord *dbg, hipStream_t s,
                          const int *idx_list, int list_counter, int list_off)
 {
-    const long nb = (max_evals + kSmEvals - 1) / kSmEvals;
+    const long nb = (max_evals + kSdEvals - 1) / kSdEvals;
     if (nb <= 0) return;
     if (idx_list) { idx_list += list_off; dec_exact += list_off; }
     hipLaunchKernelGGL(k_small_direct, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, fd, sv64, p, d, dec_exact, labels,
@@ -987,6 +1028,13 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
     }
     // small requests -- and every list of the fp64 tier, which is short unless the model is ill-conditioned: a third of the
     // serial chain per thread (C3's ~8 000 flagged evaluations: 27 us against 56 us with the 64-evaluation workgroups)
+    if (MODE == XMODE_SPLIT && idx_list) {                             // tier 1's list: its length decides on the device (kSplitSmallList)
+        const long cap_small = std::min<long>(max_evals, kSplitSmallList);
+        long nb = ((cap_small + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
+        hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
+                           lower, upper, neg_gamma2, sp, dbg, ax2, idx_list, list_counter, list_cap, list_off);
+        if (max_evals <= kSplitSmallList) return;
+    }
     if ((!idx_list && sel_evals <= kSmallEvals) || (idx_list && MODE == XMODE_F64)) {
         long nb = ((max_evals + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
         if (idx_list && nb > 2048) nb = 2048;                          // grid-stride inside the kernel

@@ -83,13 +83,23 @@ __global__ __launch_bounds__(256) void k_bin_lds(const CloudDev *__restrict__ cl
     const int first = blockIdx.x * kBinChunk;
     if (first >= c.n) return;
     const int HW = d.H * d.W;
+    const int last = min(c.n, first + kBinChunk);
+    // the thread's kBinChunk / 256 points are loaded up front, behind them the private grid is cleared (as a loop: a chain of eight global-load latencies)
+    static_assert(kBinChunk % 256 == 0, "points per thread");
+    float xs[kBinChunk / 256], ys[kBinChunk / 256], zs[kBinChunk / 256];
+#pragma unroll
+    for (int j = 0; j < kBinChunk / 256; j++) {
+        const int i = first + threadIdx.x + 256 * j;
+        const float *p = c.xyz + (size_t)(i < last ? i : first) * c.stride;
+        xs[j] = p[0]; ys[j] = p[1]; zs[j] = p[2];
+    }
     for (int k = threadIdx.x; k < HW; k += 256) cells[k] = key_empty;
     __syncthreads();
     const RollGeo &g = geo[br];
-    const int last = min(c.n, first + kBinChunk);
-    for (int i = first + threadIdx.x; i < last; i += 256) {
-        const float *p = c.xyz + (size_t)i * c.stride;
-        const float x = p[0], y = p[1], z = p[2];
+#pragma unroll
+    for (int j = 0; j < kBinChunk / 256; j++) {
+        if (first + (int)threadIdx.x + 256 * j >= last) continue;
+        const float x = xs[j], y = ys[j], z = zs[j];
         // pcl::transformPointCloud (488): fp32, left to right, unfused
         float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[0], x), __fmul_rn(g.m[1], y)), __fmul_rn(g.m[2], z)), g.m[3]);
         float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g.m[4], x), __fmul_rn(g.m[5], y)), __fmul_rn(g.m[6], z)), g.m[7]);
@@ -102,9 +112,17 @@ __global__ __launch_bounds__(256) void k_bin_lds(const CloudDev *__restrict__ cl
     }
     __syncthreads();
     int *out = hkeys + (size_t)br * HW;
-    for (int k = threadIdx.x; k < HW; k += 256) {
-        const int v = cells[k];
-        if (v > key_empty && v > out[k]) atomicMax(&out[k], v);    // stale read is safe: the cell only grows
+    // (eight cells per thread and step, their global reads in flight together: one read -> compare -> atomic per step was a chain of
+    // HW / 256 L2 latencies, 13 of them on the reference's grid -- most of this kernel's 17.6 us at C3)
+    for (int k0 = threadIdx.x; k0 < HW; k0 += 256 * 8) {
+        int v[8], o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (k0 + 256 * j < HW) ? cells[k0 + 256 * j] : key_empty;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = out[min(k0 + 256 * j, HW - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (v[j] > key_empty && v[j] > o[j]) atomicMax(&out[k0 + 256 * j], v[j]);    // stale read is safe: the cell only grows
     }
 }
 

@@ -240,7 +240,10 @@ __device__ __forceinline__ void recheck_split(int n_flag, int flag_cap, int n_ti
     // (only while the coarse split leaves half of the CUs without a task: from ~1 500 entries on the tier is bound by the fp64 matrix
     // rate -- 1 574 entries x 4096 SVs are 54 us at its peak -- and finer tasks only reload the A operands: 118 -> 131 us measured)
     const bool fine = (long)n_flag * 4 <= (long)flag_cap && n_tiles >= 16 * kMSplit && flag_cap >= 4 && n_flag <= 1024;
-    splits = fine ? 4 * kMSplit : kMSplit;
+    // (round 5: as many ranges as give every CU ONE task -- the kernel's 290 registers leave a CU one workgroup, and 9 groups x 32
+    // ranges were 288 tasks for 256 CUs: two rounds, 125 us for C3's 557 entries against the 8 964-SV model)
+    const int n_groups = (n_flag + kMEvals - 1) / kMEvals;
+    splits = fine ? max(kMSplit, min(4 * kMSplit, 256 / max(n_groups, 1))) : kMSplit;
     pitch = fine ? (size_t)(flag_cap / 4) : (size_t)flag_cap;
 }
 

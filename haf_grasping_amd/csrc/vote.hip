@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_vote_small(const int8_t *__restrict__ l
                                                     const int *__restrict__ brcount, short *__restrict__ ev16,
                                                     RollRecordDev *__restrict__ rec, Dims d)
 {
-    extern __shared__ short s_ev[];                       // [H*W] votes, then [H*W] labels as bytes
+    extern __shared__ __attribute__((aligned(16))) short s_ev[];   // [H*W] votes, then [H*W] labels as bytes
     __shared__ unsigned long long red[256];
     __shared__ int s_top, s_row, s_col;
     const int br = blockIdx.x, t = threadIdx.x;
@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) void k_vote_small(const int8_t *__restrict__ l
     int8_t *s_g = reinterpret_cast<int8_t *>(s_ev + HW);
     const int8_t *g = labels + (size_t)br * HW;
     short *ev = ev16 + (size_t)br * HW;
-    for (int k = t; k < HW; k += 256) s_g[k] = g[k];
+    if ((HW & 15) == 0) {                                 // sixteen labels per load (byte by byte this loop was HW / 256 dependent round trips)
+        for (int k = t; k < HW / 16; k += 256) reinterpret_cast<uint4 *>(s_g)[k] = reinterpret_cast<const uint4 *>(g)[k];
+    } else {
+        for (int k = t; k < HW; k += 256) s_g[k] = g[k];
+    }
     __syncthreads();
     unsigned long long best = 0;
     for (int idx = t; idx < HW; idx += 256) {

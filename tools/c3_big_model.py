@@ -25,6 +25,6 @@ for name, m in (("trained", tr), ("rand4096", rnd)):
         ts = []
         for _ in range(nreq):
             t0 = time.perf_counter(); out = eng.score(xyz, inp); ts.append(time.perf_counter() - t0)
-        print(name, "profile" if flags else "plain", "median %.3f ms" % (1e3 * np.median(ts)), eng.screen_form(), eng.last_tiers() if hasattr(eng, "last_tiers") else "", flush=True)
+        print(name, "profile" if flags else "plain", "median %.3f ms" % (1e3 * np.median(ts)), eng.screen_form(), eng.last_counts(), eng.last_exact_tiers(), flush=True)
         if flags: print("   ", {k: round(v, 3) for k, v in eng.stage_ms().items()})
         eng.close()
