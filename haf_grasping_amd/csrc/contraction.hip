@@ -376,16 +376,16 @@ __device__ __forceinline__ f32x4 h_fma4s(float s, f32x4 v, f32x4 c)        // fm
 constexpr float kPsiA2h = 0.240226506959101f, kPsiA3h = 0.0555041086648216f, kPsiA4h = 0.00961812910762848f, kPsiA5h = 0.00133335581464284f;
 // List mode: the number of SV tile ranges a list of n evaluations is cut into.  gridDim.y = kHListParts for the long lists of a
 // bench-sized request; a request that cannot fill the chip anyway (the host launches gridDim.y = kHListPartsShort then) takes as many
-// ranges as put one workgroup on every CU (the kernel's 132 KiB of LDS: one per CU, 256 of them) -- from the LIVE length, on the
-// device.  The part buffer holds 2 x kHListParts x part_stride sums: P > kHListParts ranges use the stride part_stride kHListParts / P,
-// for lists that stride holds.  (Round 5: up to 32 ranges and 256 / blocks of them, not 16 and 512 / blocks -- C3 against the
-// 8 964-SV model, 1 964 entries: 128 workgroups of 18 tiles on half of the CUs.)
-constexpr int kHListPartsShort = 32;
+// ranges as put ~512 workgroups on the chip -- from the LIVE length, on the device.  The part buffer holds 2 x kHListParts x part_stride
+// sums: P > kHListParts ranges use the stride part_stride kHListParts / P, for lists that stride holds.
+// (Round 5 tried 32 ranges and one workgroup per CU -- 256 / blocks -- for C3 against the 8 964-SV model, 1 964 entries: 78 us against
+// 69 with 16 ranges.  A workgroup's prologue -- 336 KB of hi / lo operand fragments -- is paid per range and costs more than nine tiles.)
+constexpr int kHListPartsShort = 16;
 __device__ __forceinline__ int h_list_parts(int n_evals, int max_parts, long part_stride)
 {
     if (max_parts <= kHListParts) return max_parts;
     const int blocks = (n_evals + kSvmBlockEvals - 1) / kSvmBlockEvals;
-    int want = min(max_parts, max(kHListParts, blocks > 0 ? 256 / blocks : max_parts));
+    int want = min(max_parts, max(kHListParts, blocks > 0 ? 512 / blocks : max_parts));
     while (want > kHListParts && (long)n_evals * want > part_stride * kHListParts) want--;
     return want;
 }

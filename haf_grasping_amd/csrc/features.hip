@@ -873,6 +873,14 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
 // except for the order in which the partial sums of the SV tiles are added -- eleven waves instead of eight ranges, fixed -- and
 // the same hand-over to the strict tier for |dec| <= guard2 * T * S.  Replaces three launches and the 10 MB round trip of the
 // attribute image for such a request.
+// -DHAF_PHASE_CLOCK (variant builds only: python -m haf_grasping_amd.build --variant phase -DHAF_PHASE_CLOCK; tools/phase_clock.py):
+// workgroup 0 of k_small_direct leaves the 100 MHz wall clock at its phase boundaries
+#ifdef HAF_PHASE_CLOCK
+__device__ unsigned long long g_phase_clock[16];
+#define HAF_PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clock[i] = wall_clock64(); } while (0)
+#else
+#define HAF_PHASE(i) do { } while (0)
+#endif
 constexpr int kSdMSteps = kKP / 4;                // 81 k-steps of 4
 // (round 5, measured and dropped: EIGHT evaluations per workgroup and four attributes per thread -- kSdEvals = 8 below still compiles --
 // halves the attribute chain and doubles the workgroups, but every workgroup streams the whole fp64 model through its MFMA phase, whose
@@ -900,8 +908,10 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
     __shared__ FeatDescX s_fd[kKP];                   // the descriptors, once per workgroup (feature_device.h)
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     if ((long)blockIdx.x * kSdEvals >= n_evals) return;
+    HAF_PHASE(0);
     stage_descriptors<kSmWaves * 64>(fd, min(d.nf, kKP), s_fd);
     const hafq::PtrTabs tb = load_decimal_tables(s_tab);
+    HAF_PHASE(1);
     const int ev = threadIdx.x & (kSdEvals - 1), slot = threadIdx.x / kSdEvals, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long e = (long)blockIdx.x * kSdEvals + ev;
     const bool live = e < n_evals;
@@ -909,8 +919,10 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
     const rsrc_t iir = make_ii_rsrc(ii, d);
     if (slot == 0) s_w0[ev] = live ? window_origin(evalcell[e_src], d.H, d.W) : 0xffffffffu;
     __syncthreads();
+    HAF_PHASE(2);
     stage_windows<kSdEvals, kSmWaves * 64>(iir, s_w0, s_win, d.W + 1);
     __syncthreads();
+    HAF_PHASE(3);
     const SrcWin src{s_win + ev * kWinPitch};
     const int g = slot;
     if (g < (kKP + kSdAttrs - 1) / kSdAttrs) {
@@ -923,26 +935,34 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
         }
     }
     __syncthreads();
-    if (threadIdx.x < kSdEvals) {                     // |x|^2, attributes in index order (as k_recheck_mfma's per-lane sums would not be: fixed here)
+    HAF_PHASE(4);
+    if (threadIdx.x < 4 * kSdEvals) {                 // |x|^2: four index ranges per evaluation, each in index order, then (s0 + s1) + (s2 + s3): fixed
+        static_assert(kKP % 4 == 0 && (kKP / 4) % 9 == 0 && 4 * kSdEvals <= 64, "one wave, whole batches");
+        const int xe = threadIdx.x & (kSdEvals - 1), k_lo = (threadIdx.x / kSdEvals) * (kKP / 4);
         double xx = 0.0;
-        static_assert(kKP % 12 == 0, "unroll");
 #pragma unroll 1
-        for (int k0 = 0; k0 < kKP; k0 += 12) {        // (twelve LDS reads in flight, then the chain in index order: read -> wait -> fma per step was 324 LDS latencies)
-            double v[12];
+        for (int k0 = k_lo; k0 < k_lo + kKP / 4; k0 += 9) {   // (nine LDS reads in flight, then the chain: read -> wait -> fma per step was 324 LDS latencies)
+            double v[9];
 #pragma unroll
-            for (int j = 0; j < 12; j++) v[j] = s_x[(k0 + j) * kSdEvals + threadIdx.x];
+            for (int j = 0; j < 9; j++) v[j] = s_x[(k0 + j) * kSdEvals + xe];
 #pragma unroll
-            for (int j = 0; j < 12; j++) xx = fma(v[j], v[j], xx);
+            for (int j = 0; j < 9; j++) xx = fma(v[j], v[j], xx);
         }
-        s_xx[threadIdx.x] = xx;
+        xx += __shfl_xor(xx, kSdEvals, 64);
+        xx += __shfl_xor(xx, 2 * kSdEvals, 64);
+        if (threadIdx.x < kSdEvals) s_xx[threadIdx.x] = xx;
     }
     __syncthreads();
+    HAF_PHASE(5);
     // ---- fp64 MFMA over this wave's SV tiles: A[row = lane&15][k = 4s + (lane>>4)] from LDS (row & 7: the evaluation), B[k][col = lane&15] from the model ----
     const int n_tiles = p.n_sv_pad / 16;
     double part[4] = {0, 0, 0, 0}, pabs[4] = {0, 0, 0, 0};
     for (int t = wave; t < n_tiles; t += kSmWaves) {
         const double *Bg = sv64 + (size_t)t * 16 + (lane & 15);
         f64x4 acc = {0, 0, 0, 0};
+        // (the B operand comes from L2 as the loop asks for it, six loads in flight.  Round 5 tried three batches of 27 loads, each in
+        // flight before its first MFMA: the phase went from 8.3 to 6.7 us for wave 0 and the barrier behind it from 4.1 to 7.2 -- all
+        // 255 workgroups stream the whole fp64 model here, 117 MB in ~10 us: L2 bandwidth, not latency -- at 108 instead of 76 VGPRs)
 #pragma unroll 27
         for (int s = 0; s < kSdMSteps; s++) {
             const int k = 4 * s + (lane >> 4);
@@ -959,6 +979,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
             pabs[r] = fma(fabs(cf), kv, pabs[r]);
         }
     }
+    HAF_PHASE(6);
 #pragma unroll
     for (int r = 0; r < kSdEvals / 4; r++) {
         double v = part[r], w = pabs[r];
@@ -969,6 +990,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
         if ((lane & 15) == 0) { s_part[wave][(lane >> 4) + 4 * r][0] = v; s_part[wave][(lane >> 4) + 4 * r][1] = w; }
     }
     __syncthreads();
+    HAF_PHASE(7);
     if (threadIdx.x < kSdEvals && live) {
         double P = 0.0, S = 0.0;
 #pragma unroll
@@ -982,6 +1004,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_small_direct(const float *__r
             if (s2 < flag2_cap) flag2_list[s2] = e_src;
         }
     }
+    HAF_PHASE(8);
 }
 
 void launch_small_direct(const float *ii, const int *evalcell, int *counters, const FeatDesc *fd, const double *sv64, ExactParams p, Dims d,
@@ -1082,3 +1105,13 @@ void launch_features(const float *ii, const int *evalcell, const int *counters, 
 }
 
 }  // namespace haf
+
+#ifdef HAF_PHASE_CLOCK
+extern "C" int haf_phase_clock(unsigned long long *out, int n)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(haf::g_phase_clock), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 16; i++) out[i] = h[i];
+    return 0;
+}
+#endif
