@@ -97,6 +97,19 @@ __device__ __forceinline__ void i8_tile_epilogue(const i32x4 (&acc)[5], const do
     }
 }
 
+// SV ranges of a group of evaluations and the row pitch of part64, as recheck_split of the fp64 tier (recheck.hip): kI8Split ranges on
+// one row per slot of the window -- or, for a list of at most 1 024 entries that fills at most a quarter of the window, up to four times
+// as many on a quarter of the pitch, as many as give the chip's 512 workgroup slots one task each (round 5: C3 against a 4 096-SV model
+// leaves this tier 31 entries -- one group, eight tasks of 32 tiles, 47 us).  Both kernels derive the same numbers from the same counter.
+// (|xq|^2, which the feature kernel writes, stays at row 2 kI8Split of the FULL pitch: 64 rows of a quarter pitch end exactly there.)
+__device__ __forceinline__ void i8_split(int n_flag, int flag_cap, int n_tiles, int &splits, size_t &pitch)
+{
+    const bool fine = (long)n_flag * 4 <= (long)flag_cap && n_tiles >= 16 * kI8Split && flag_cap >= 4 && n_flag <= 1024;
+    const int n_groups = (n_flag + kI8Evals - 1) / kI8Evals;
+    splits = fine ? max(kI8Split, min(4 * kI8Split, 512 / max(n_groups, 1))) : kI8Split;
+    pitch = fine ? (size_t)(flag_cap / 4) : (size_t)flag_cap;
+}
+
 __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ ximg, const char *__restrict__ svimg, I8Params p,
                                                        int flag_cap, int list_off, const int *__restrict__ counters, int cslot,
                                                        double *__restrict__ part64)
@@ -106,10 +119,13 @@ __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ 
     const int n_groups = (n_flag + kI8Evals - 1) / kI8Evals;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_tiles = p.n_sv_pad / 16;
-    const int tiles_per_part = (n_tiles + kI8Split - 1) / kI8Split;
+    int splits;
+    size_t pitch;
+    i8_split(n_flag, flag_cap, n_tiles, splits, pitch);
+    const int tiles_per_part = (n_tiles + splits - 1) / splits;
     const double *xnorm = part64 + (size_t)(2 * kI8Split) * flag_cap;      // |xq|^2 per slot, written by the feature kernel
-    for (int task = blockIdx.x; task < n_groups * kI8Split; task += gridDim.x) {
-        const int g = task / kI8Split, h = task - g * kI8Split;
+    for (int task = blockIdx.x; task < n_groups * splits; task += gridDim.x) {
+        const int g = task / splits, h = task - g * splits;
         const int t_begin = h * tiles_per_part, t_end = min(n_tiles, t_begin + tiles_per_part);
         const int grp = g * kI8Waves + wave;                         // this wave's 16 slots
         // ---- A operand: the digit image of 16 evaluations, [digit][k-step][lane][16 int8]: 1 KiB per wave load ----
@@ -206,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void k_recheck_i8(const char *__restrict__ 
             for (int r = 0; r < 4; r++) {
                 const int sl = grp * 16 + 4 * (lane >> 4) + r;
                 if (sl < n_flag) {
-                    part64[(size_t)(2 * h) * flag_cap + sl] = part[r];
-                    part64[(size_t)(2 * h + 1) * flag_cap + sl] = pabs[r];
+                    part64[(size_t)(2 * h) * pitch + sl] = part[r];
+                    part64[(size_t)(2 * h + 1) * pitch + sl] = pabs[r];
                 }
             }
         }
@@ -224,16 +240,18 @@ __global__ __launch_bounds__(256) void k_recheck_i8_combine(const double *__rest
 {
     const int n_flag = window_count8(counters[cslot], list_off, flag_cap);
     const int lane = threadIdx.x & 63;
+    int splits;
+    size_t pitch;
+    i8_split(n_flag, flag_cap, p.n_sv_pad / 16, splits, pitch);
     // (wave-uniform trip count: every lane takes part in the ballot of its 64 entries; words != nullptr: ordered hand-over, device_common.h)
     for (int base = blockIdx.x * 256 + (threadIdx.x & ~63); base < n_flag; base += gridDim.x * 256) {
         const int sl = base + lane;
         bool undecided = false;
         if (sl < n_flag) {
         double P = 0.0, S = 0.0;
-#pragma unroll
-        for (int h = 0; h < kI8Split; h++) {
-            P += part64[(size_t)(2 * h) * flag_cap + sl];
-            S += part64[(size_t)(2 * h + 1) * flag_cap + sl];
+        for (int h = 0; h < splits; h++) {
+            P += part64[(size_t)(2 * h) * pitch + sl];
+            S += part64[(size_t)(2 * h + 1) * pitch + sl];
         }
         const double dv = P - p.rho;
         const double xq2 = part64[(size_t)(2 * kI8Split) * flag_cap + sl];
@@ -283,7 +301,7 @@ void launch_recheck_i8(const float *ii, const int *evalcell, const FeatDesc *fd,
     launch_features(ii, evalcell, counters, fd, reinterpret_cast<float *>(ximg), reinterpret_cast<float *>(part64 + (size_t)(2 * kI8Split) * window_cap),
                     d, lower, upper, 0.0f, window_cap, XMODE_I8, ScreenParams{}, flag_list, CNT_FLAGGED, window_cap, false, window_cap, nullptr,
                     nullptr, s, list_off);
-    const long tasks = (long)groups * kI8Split;
+    const long tasks = (long)groups * 4 * kI8Split;                     // (the kernel strides over the tasks the list really has)
     hipLaunchKernelGGL(k_recheck_i8, dim3((unsigned)(tasks < 8192 ? tasks : 8192)), dim3(256), 0, s, (const char *)ximg, (const char *)sv_i8, p,
                        window_cap, list_off, counters, CNT_FLAGGED, part64);
     const int blocks = groups < 2048 ? groups : 2048;

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features(const float *__res
     const double *t1_tab = (MODE == XMODE_SPLIT) ? sp.cr_t1_tab : nullptr;
     const int n_evals = idx_list ? window_count(counters[list_counter], list_off, list_cap) : counters[CNT_EVALS];
     if (MODE == XMODE_I8 && n_evals <= kI8SmallList) return;           // short lists are k_features_small's (see there)
-    if (MODE == XMODE_SPLIT && idx_list && n_evals <= kSplitSmallList) return;
+    if ((MODE == XMODE_SPLIT || MODE == XMODE_SCREEN) && idx_list && n_evals <= kSplitSmallList) return;   // (tier 1's and tier 0b's lists)
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kFeatEvals >= n_pad) return;
     __shared__ double s_tab[MODE == XMODE_SCREEN ? 1 : hafq::kTabDoubles];
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kSmWaves * 64) void k_features_small(const float *_
     if (MODE == XMODE_I8 && n_evals > kI8SmallList) return;
     // XMODE_SPLIT in list mode (tier 1; round 5): the same rule with kSplitSmallList -- C3 against the 8 964-SV model leaves tier 1 a list of
     // ~4 000 entries, 72 workgroups of k_features<., 16> on 256 CUs: 54 us
-    if (MODE == XMODE_SPLIT && idx_list && n_evals > kSplitSmallList) return;
+    if ((MODE == XMODE_SPLIT || MODE == XMODE_SCREEN) && idx_list && n_evals > kSplitSmallList) return;    // (the same for tier 0b's list: C3 against a 4 096-SV model, k_features<2, 16> 34 us)
     const long n_pad = ((long)n_evals + kBlock - 1) / kBlock * kBlock;
     if ((long)blockIdx.x * kSmEvals >= n_pad) return;
     // (list mode is launched for the list's CAPACITY -- at C5 123 k workgroups for a list of a few hundred entries, 90 us of empty
@@ -1051,7 +1051,7 @@ static void launch_features_mode(const float *ii, const int *evalcell, const int
     }
     // small requests -- and every list of the fp64 tier, which is short unless the model is ill-conditioned: a third of the
     // serial chain per thread (C3's ~8 000 flagged evaluations: 27 us against 56 us with the 64-evaluation workgroups)
-    if (MODE == XMODE_SPLIT && idx_list) {                             // tier 1's list: its length decides on the device (kSplitSmallList)
+    if ((MODE == XMODE_SPLIT || MODE == XMODE_SCREEN) && idx_list) {   // tier 1's / tier 0b's list: its length decides on the device (kSplitSmallList)
         const long cap_small = std::min<long>(max_evals, kSplitSmallList);
         long nb = ((cap_small + kBlock - 1) / kBlock) * (kBlock / kSmEvals);
         hipLaunchKernelGGL(k_features_small<MODE>, dim3((unsigned)nb), dim3(kSmWaves * 64), 0, s, ii, evalcell, counters, fd, X, ax, d,
