@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_t1_compact(const unsigned char *__restr
             if (t < o) part[t] += part[t + o];
             __syncthreads();
         }
-        if (t == 0) counters_rw[CNT_FLAGGED] = part[0];
+        if (t == 0) counters_rw[CNT_FLAGGED] = part[0] + counters_rw[CNT_T1_ADD];   // (+ what the short-list gate put in front: kernels.h)
         __syncthreads();
     }
     const long b = (long)blockIdx.x * kT1Chunk + t * 16;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kListCompactThreads) void k_t1_handover_small(const
             }
         }
     }
-    if (t == 0) counters_rw[CNT_FLAGGED] = total;
+    if (t == 0) counters_rw[CNT_FLAGGED] = total + counters_rw[CNT_T1_ADD];
 }
 // the flag buffer's layout (engine_tables.cpp sizes it with t1_flag_bytes): [max_entries bytes, rounded up to 64][one int per 4096 entries]
 static int *t1_blkcount(unsigned char *flags, long max_entries) { return reinterpret_cast<int *>(flags + (((size_t)max_entries + 63) / 64) * 64); }
@@ -310,6 +310,30 @@ static void launch_t1_handover(const unsigned char *flags, const int *counters, 
     }
     hipLaunchKernelGGL(k_t1_count, dim3(n_blk), dim3(256), 0, s, flags, counters, count_slot, in_cap, blkcount);
     hipLaunchKernelGGL(k_t1_compact, dim3(n_blk), dim3(256), 0, s, flags, counters, count_slot, in_cap, blkcount, idx_list, flag_list, flag_cap, counters_rw);
+}
+
+__global__ __launch_bounds__(256) void k_short_list_gate(int *__restrict__ counters, int src_slot, const int *__restrict__ src_list, int src_cap,
+                                                         int *__restrict__ dst_list, int dst_slot, int dst_direct, int max_entries)
+{
+    const int n = counters[src_slot];
+    const bool take = n > 0 && n <= max_entries && n <= src_cap;
+    if (take)
+        for (int i = threadIdx.x; i < n; i += 256) dst_list[i] = src_list[i];
+    __syncthreads();                                       // (every thread has read the source counter)
+    if (threadIdx.x == 0) {
+        counters[CNT_T1_N] = take ? 0 : n;
+        if (take) {
+            counters[CNT_BYPASS] = n;
+            counters[dst_direct ? dst_slot : CNT_T1_ADD] = n;
+        }
+    }
+}
+
+void launch_short_list_gate(int *counters, int src_slot, const int *src_list, int src_cap, int *dst_list, int dst_slot, bool dst_direct,
+                            int max_entries, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_short_list_gate, dim3(1), dim3(256), 0, s, counters, src_slot, src_list, src_cap, dst_list, dst_slot, dst_direct ? 1 : 0,
+                       max_entries);
 }
 
 void launch_svm(const float *X, const float *ax, const float *svt, const int *evalcell, const int *counters, SvmParams p,

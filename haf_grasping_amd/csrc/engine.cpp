@@ -217,6 +217,7 @@ static int calibrate(haf_engine *e)
     e->last_B = e->last_R = e->last_roll_first = 0;
     e->last_evals = e->last_flagged = e->last_flagged2 = e->last_flagged0 = e->last_inexact = e->last_host_resolved = 0;
     e->last_flaggedi = 0;
+    e->last_bypass = 0;
     e->last_i8 = false;
     e->last_screened = false;
     e->last_inputs.clear();
@@ -328,6 +329,7 @@ static int create_impl(const haf_config *cfg, haf_engine **out)
     if (test_env("HAF_NO_FUSED_PRE")) e->no_fused_pre = true;
     if (const char *v = test_env("HAF_REPROBE_EVERY")) e->reprobe_every = std::max(1, atoi(v));
     if (const char *v = test_env("HAF_SCREEN_PARTS")) e->screen_parts = std::max(0, atoi(v));
+    if (test_env("HAF_NO_SHORT_GATE")) e->short_gate = false;
     if (const char *v = test_env("HAF_SCREEN_VARIANT")) { e->screen_variant = std::max(0, std::min(SCREEN_VARIANTS - 1, atoi(v))); e->variant_forced = true; e->direct_work = 0; }
     int rc = build_tables(e);
     if (rc != HAF_OK) return bail(rc);
@@ -399,7 +401,7 @@ int haf_last_counts(const haf_engine *e, int64_t *n_evals, int64_t *n_rechecked,
 {
     if (!e) return HAF_E_ARG;
     if (n_evals) *n_evals = e->last_evals;
-    if (n_rechecked) *n_rechecked = e->last_flagged;
+    if (n_rechecked) *n_rechecked = e->last_flagged + (e->last_i8 ? e->last_bypass : 0);   // (the short-list gate's entries skip the exact-integer tier's input list)
     if (n_strict) *n_strict = e->last_flagged2;
     return HAF_OK;
 }
@@ -409,7 +411,7 @@ int haf_last_tiers(const haf_engine *e, int64_t *n_evals, int64_t *n_refined, in
     if (!e) return HAF_E_ARG;
     if (n_evals) *n_evals = e->last_evals;
     if (n_refined) *n_refined = e->last_flagged0;
-    if (n_rechecked) *n_rechecked = e->last_flagged;
+    if (n_rechecked) *n_rechecked = e->last_flagged + (e->last_i8 ? e->last_bypass : 0);   // (the short-list gate's entries skip the exact-integer tier's input list)
     if (n_strict) *n_strict = e->last_flagged2;
     return HAF_OK;
 }

@@ -428,6 +428,18 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
                 t1_run = !skip1;
                 t0b_used = true;
             }
+            // Round 5, the short-list gate: a SMALL request against a BIG model leaves the screening passes a handful of evaluations (C3
+            // against the headline's 4 096-SV model: 31), and tier 1 and the exact-integer tier behind it are then ~120 us of launches and
+            // minimum chains -- feature kernels, sweeps over thousands of SVs by a few workgroups -- for nothing the fp64 tier would
+            // not do in the one pass it makes anyway.  At most kShortListGate entries go straight to its list; tier 1 reads its list's
+            // length from CNT_T1_N (0 then), the exact-integer tier finds an empty input.  Not while the engine calibrates (the
+            // calibration measures what tier 1 decides).
+            if (t1_run && e->calibrated && e->short_gate && d.n_sv >= kShortGateMinSv && evals_cap <= 65536 && !e->generic_kernel) {
+                const bool i8_next = e->i8_active && !(e->screen_variant == SCREEN_CR_POLY && e->t1_cr_available);
+                launch_short_list_gate(e->d_counters.p, t1_counter, t1_list, e->flag0_cap, i8_next ? e->d_flagi_list.p : e->d_flag_list.p,
+                                       CNT_FLAGGEDI, i8_next, std::min(kShortListGate, e->flag_cap), s);
+                t1_counter = CNT_T1_N;
+            }
             if (t1_run) {
             // (the list is short whenever screening is worth its while: always the group-parallel feature kernel, whose
             // workgroups beyond the list's end exit at once)
@@ -680,6 +692,7 @@ int score_rolls_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
     e->last_lr = lr_used;
     e->last_flagged0 = t0b_used ? std::min(e->h_counters[CNT_FLAGGED0B], e->h_counters[CNT_FLAGGED0]) : e->h_counters[CNT_FLAGGED0];   // what leaves the screening passes
     e->last_flaggedi = i8_used ? e->h_counters[CNT_FLAGGEDI] : e->h_counters[CNT_FLAGGED];
+    e->last_bypass = e->h_counters[CNT_BYPASS];                            // (the short-list gate: entries that went around tier 1 and the exact-integer tier)
     e->last_inexact = inexact_grids;
     e->last_screened = (mode == MODE_SCREEN) && !e->prob_mode && !direct && e->h_counters[CNT_FLAGGED0] <= e->flag0_cap;
     // zero the counters for the next request now, behind this one's copy-out: off that request's critical path
@@ -719,6 +732,7 @@ int score_batch_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
     if (none_runs) {
         e->last_B = e->last_R = e->last_roll_first = 0;
         e->last_evals = e->last_flagged = e->last_flagged2 = e->last_flagged0 = e->last_flaggedi = e->last_inexact = e->last_host_resolved = 0;
+        e->last_bypass = 0;
         e->last_i8 = e->last_screened = false;
     } else {
         rc = haf_score_rolls(e, n_clouds, clouds, in, 0, e->cfg.n_rolls, rec.data());
@@ -729,7 +743,7 @@ int score_batch_impl(haf_engine *e, int32_t n_clouds, const haf_cloud *clouds, c
         if (rc != HAF_OK) return rc;
     }
     // rechecks are counted per batch; attribute them to the first cloud's output and leave the others at 0
-    out[0].n_rechecked = e->last_flagged;
+    out[0].n_rechecked = e->last_flagged + (e->last_i8 ? e->last_bypass : 0);
     return HAF_OK;
 }
 

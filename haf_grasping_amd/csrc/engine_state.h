@@ -239,6 +239,8 @@ struct haf_engine {
     I8Params i8{};
     bool i8_active = false;
     int last_flaggedi = 0;          // evaluations that entered the fp64 MFMA tier in the last call
+    int last_bypass = 0;            // ... of them through the short-list gate (engine_request.cpp), around tier 1 and the exact-integer tier
+    bool short_gate = true;         // testing build: HAF_NO_SHORT_GATE switches the gate off
     bool last_i8 = false;           // the last call ran tier 2a (then d_dec_exact holds ITS values and d_dec_exacti the fp64 tier's)
     DevBuf<short> d_ev16;
     DevBuf<float> d_margin;         // HAF_FLAG_KEEP_DEBUG, default mode: |dec^| / band of every evaluation the screening tier decided
@@ -313,6 +315,8 @@ constexpr double kUndecidedCost = 8.5;
 // against 28.9 ms (plain equivalent at 8964 SVs); SUMSQ has no low-rank form
 constexpr double kVariantCostLr[SCREEN_VARIANTS] = {0.80, 1.12, 0.90, 0.87};
 
+constexpr int kShortListGate = 256;  // the short-list gate (engine_request.cpp): lists of at most this many entries in front of tier 1 ...
+constexpr int kShortGateMinSv = 2048; // ... of a model with at least this many support vectors go straight to the fp64 MFMA tier
 constexpr int kStrictSlots = 64;     // evaluations per pass of the strict tier's spread form (a few per request reach it at most)
 
 constexpr size_t kCntBytes = (CNT_COUNT * sizeof(int) + 15) / 16 * 16;      // the counters' share of the output block (d_out)

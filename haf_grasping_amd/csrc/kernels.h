@@ -317,7 +317,11 @@ enum { CNT_EVALS = 0, CNT_FLAGGED = 1, CNT_ERROR = 2, CNT_FLAGGED2 = 3, CNT_FLAG
        CNT_INEXACT = 5,    // (cloud, roll) grids whose integral image needed the sequential summation order
        CNT_FLAGGEDI = 6,   // evaluations the exact-integer tier (exact8.hip) handed on to the fp64 MFMA tier
        CNT_FLAGGED0B = 7,  // evaluations the second screening pass (centred-remainder form on the first one's list, "tier 0b") could not decide
-       CNT_COUNT = 8 };
+       // the short-list gate in front of tier 1 (launch_short_list_gate, contraction.hip):
+       CNT_BYPASS = 8,     // evaluations it sent straight to the fp64 MFMA tier
+       CNT_T1_N = 9,       // the length of tier 1's input list as tier 1 sees it (0 when the gate took the list)
+       CNT_T1_ADD = 10,    // what tier 1's hand-over adds to CNT_FLAGGED (the gate's entries when no exact-integer tier stands in between)
+       CNT_COUNT = 12 };
 
 // ---- tier 2a: the decision function on EXACT integer dot products (exact8.hip) ------------------------------------------
 // What limits the fp16 contractions is the fp32 accumulation inside the matrix core (~2.6e-6 relative per kernel value); what
@@ -432,6 +436,13 @@ void launch_svm(const float *X, const float *ax, const float *svt, const int *ev
                 SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,
                 long max_evals, hipStream_t s,
                 unsigned char *t1flags = nullptr);   // != nullptr: one byte per entry -> ORDERED hand-over to the exact tiers' list (contraction.hip: k_t1_handover)
+// A SHORT list in front of tier 1 (a small request against a big model: a handful of undecided evaluations, three tiers of launches and
+// minimum chains behind them) goes straight to the fp64 MFMA tier's list: at most max_entries entries of src_list (counters[src_slot] of
+// them) are copied to dst_list and counters[CNT_T1_N] -- what tier 1 reads as its list's length from then on -- is 0, else the length.
+// dst_direct: the count goes to counters[dst_slot] (the exact-integer tier's OUTPUT list: that tier then sees an empty input);
+// otherwise to CNT_T1_ADD, which tier 1's hand-over adds to the CNT_FLAGGED it publishes (dst_list is the list it appends to).
+void launch_short_list_gate(int *counters, int src_slot, const int *src_list, int src_cap, int *dst_list, int dst_slot, bool dst_direct,
+                            int max_entries, hipStream_t s);
 size_t t1_flag_bytes(long max_entries);                   // size of the t1flags buffer for launches of up to max_entries entries (flags + per-block counts)
 void launch_svm_h(const void *Xh, const float *ax, const void *svt_h, const int *evalcell, const int *counters,
                   SvmParams p, float *dec, int8_t *labels, int *flag_list, int flag_cap, int *counters_rw, Dims d,

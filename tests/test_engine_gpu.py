@@ -66,7 +66,7 @@ TEST_KNOBS = ("HAF_GUARD_REL", "HAF_GUARD0_REL", "HAF_GUARD2_REL", "HAF_LARGE_EV
               "HAF_SCREEN_NO_CENTRE", "HAF_NO_DIRECT", "HAF_NO_FUSED_PRE", "HAF_HOST_EXP_ALL",
               "HAF_NO_CALIBRATE", "HAF_NO_I8", "HAF_GUARD_I8_REL", "HAF_SCREEN_VARIANT", "HAF_NO_CR", "HAF_CR_NO_CENTRE", "HAF_KAPPA",
               "HAF_KAPPA_T1_MEASURED", "HAF_NO_CR_T1", "HAF_T0B", "HAF_T1_SKIP", "HAF_PROB_HOST_ALL", "HAF_REPROBE_EVERY", "HAF_SCREEN_PARTS",
-              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN", "HAF_CANARY_CHECK", "HAF_FLAG0_CAP", "HAF_T0B_NO_GATHER")
+              "HAF_NO_LR", "HAF_LR_UNFUSED", "HAF_NO_LR_PLAIN", "HAF_CANARY_CHECK", "HAF_FLAG0_CAP", "HAF_T0B_NO_GATHER", "HAF_NO_SHORT_GATE")
 
 
 def make_engine(data_dir, model, mode=0, **cfg):
@@ -1007,6 +1007,42 @@ def test_low_rank_form_of_the_screening_pass(data_dir, tmp_path, monkeypatch):
             assert np.array_equal(d0, d1, equal_nan=True) and np.array_equal(m0, m1, equal_nan=True), "fused and two-launch forms differ"
             assert (np.nan_to_num(m0) > 0).any()
     STATS["low_rank_undecided"] = stats
+
+
+def test_short_lists_of_a_big_model_go_straight_to_the_fp64_tier(data_dir, tmp_path, monkeypatch):
+    """Round 5, the short-list gate (engine_request.cpp, k_short_list_gate): a SMALL request against a BIG model -- the reference's C3
+    request (table1, 56 x 56 cm, 20 rolls) against the bench's 4 096-SV model -- leaves the screening passes a few dozen evaluations;
+    tier 1 and the exact-integer tier behind it would be ~120 us of launches and minimum chains for them.  At most 256 entries in front
+    of tier 1 of a model of >= 2 048 SVs go straight to the fp64 MFMA tier's list.  Every stage and label the oracle's with the gate
+    (the product's rule) and without it (HAF_NO_SHORT_GATE); with it nothing enters tier 1's successor lists except through the gate:
+    the exact-integer tier sees no entry, the fp64 tier sees exactly what the screening passes left; guard zones intact."""
+    monkeypatch.setenv("HAF_CANARY_CHECK", "1")
+    path = models.write_random_model(str(tmp_path / "rand4096.model"), 4096, seed=42, balanced=True)
+    f, r = _files(data_dir)
+    o = O.Oracle(f, r, path)
+    xyz = pcdio.load_pcd(os.path.join(data_dir, "table1_mult_obj_rcs_1428580506606673.pcd"))
+    cfg = dict(n_rolls=20, roll_step_deg=9, max_points=1 << 18)
+    inp = dict(grasp_area_length_x=56, grasp_area_length_y=56, grasp_area_center=(0.13, 0.25, 0.0))
+    seen = {}
+    for gate in (True, False):
+        if gate:
+            monkeypatch.delenv("HAF_NO_SHORT_GATE", raising=False)
+        else:
+            monkeypatch.setenv("HAF_NO_SHORT_GATE", "1")
+        eng = make_engine(data_dir, path, testing=True, **cfg)
+        compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+        cnt, ex = eng.last_counts(), eng.last_exact_tiers()
+        seen[gate] = (cnt, ex)
+        assert 0 < cnt["n_refined"] <= 256, cnt                      # (what the screening passes left: the gate's range)
+        if gate:
+            assert ex["n_integer"] == 0 and ex["n_fp64"] == cnt["n_refined"] == cnt["n_rechecked"], (cnt, ex)
+        else:
+            assert cnt["n_rechecked"] <= cnt["n_refined"] and ex["n_integer"] == cnt["n_rechecked"], (cnt, ex)
+        bad, rep, _ = capi.check_canaries()
+        assert bad == 0, rep
+        eng.close()
+    assert seen[True][0]["n_refined"] == seen[False][0]["n_refined"]
+    STATS["short_list_gate"] = {"with": seen[True], "without": seen[False]}
 
 
 def test_tier_0b_gathers_from_the_low_rank_first_pass(data_dir, tmp_path, monkeypatch):
