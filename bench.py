@@ -627,6 +627,50 @@ def main():
                                                            r2["out"]["best_row"] == res["out"]["best_row"] and
                                                            r2["out"]["best_col"] == res["out"]["best_col"] and
                                                            r2["out"]["best_roll"] == res["out"]["best_roll"])}
+        if world == 1 and not args.no_f32_side and args.precision == "f16s":
+            # Two requests in flight on the one GPU (two engines, each its own stream and device state, one host thread each) against
+            # one engine serving the same requests one after the other: a request's tail -- the tiers behind the sweep, pre-stages,
+            # vote: ~1.4 ms of short lists and small launches -- leaves most of the chip idle, the other request's kernels fill it.
+            # A SERVING figure next to the headline (which stays one request at a time), never the headline itself.
+            try:
+                import threading
+                pair = [make_engine("f16s"), make_engine("f16s")]
+                n_req = max(4, args.steps)
+
+                def serve(e_, n_, acc_):
+                    ev_ = 0
+                    for _ in range(n_):
+                        rec_ = e_.score_rolls([cloud], [inp], 0, args.rolls)[0]
+                        ev_ += int(rec_["n_evals"].sum())
+                    acc_.append((ev_, e_.finalize(inp, rec_)))
+                for e_ in pair:
+                    serve(e_, 2, [])
+                fence()
+                acc1 = []
+                t0 = time.perf_counter()
+                serve(pair[0], 2 * n_req, acc1)
+                fence()
+                t_seq = time.perf_counter() - t0
+                acc2 = []
+                ths = [threading.Thread(target=serve, args=(e_, n_req, acc2)) for e_ in pair]
+                t0 = time.perf_counter()
+                for t_ in ths:
+                    t_.start()
+                for t_ in ths:
+                    t_.join()
+                fence()
+                t_par = time.perf_counter() - t0
+                for e_ in pair:
+                    e_.close()
+                v_seq, v_par = acc1[0][0] / t_seq, sum(q[0] for q in acc2) / t_par
+                line["two_requests_in_flight"] = {
+                    "value": v_par, "ms_per_request": 1e3 * t_par / (2 * n_req), "one_at_a_time": v_seq,
+                    "ms_per_request_one_at_a_time": 1e3 * t_seq / (2 * n_req), "ratio": v_par / v_seq, "requests": 2 * n_req,
+                    "same_best": bool(all(q[1]["best_vote"] == acc1[0][1]["best_vote"] and q[1]["best_roll"] == acc1[0][1]["best_roll"] for q in acc2)),
+                    "note": "two engines on this GPU, one host thread each, the same cloud and model as the headline (median seed): "
+                            "throughput of a server that keeps two requests in flight; the headline is one request at a time"}
+            except Exception as ex:      # noqa: BLE001 -- a side measurement must never cost the main line
+                line["two_requests_in_flight"] = {"value": None, "note": "unavailable: %r" % (ex,)}
         if world == 1 and not args.no_hard_side and args.precision == "f16s":
             # The headline model is benign (seeded random coefficients: decisions spread wide against sum|coef|K).  The only
             # genuinely libsvm-trained model in the repo (tests/golden/surrogate.model, svm-train -c 512: most coefficients at
