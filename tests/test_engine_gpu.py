@@ -1045,6 +1045,94 @@ def test_short_lists_of_a_big_model_go_straight_to_the_fp64_tier(data_dir, tmp_p
     STATS["short_list_gate"] = {"with": seen[True], "without": seen[False]}
 
 
+def test_low_rank_pass_never_trusts_a_negative_computed_region_sum(data_dir, tmp_path, monkeypatch):
+    """ADVICE r4 (features.hip, path A of the low-rank feature kernel): a wave of 64 neighbouring cells whose windows pass three wave-wide
+    checks takes every region sum ((a - b) - c) + d as EXACT.  The checks take R >= 0 from the monotone TRUE integral image; the STORED
+    corners are fp32 roundings of fp64 sums, and over an area without heights that has heights beside it (true R = 0, a - b = c - d
+    only before rounding) the computed R comes out at -1 ... -2 ulp for a good part of the regions -- and then (a - b) - c may have
+    rounded without the band being charged.  Since round 5 the smallest computed region sum rides along and a negative one voids
+    the evaluation's pass.  The adversarial scene: a 128 x 128 grid with eight-row stripes without points to the right of column 30
+    (corners up to ~3 000: an ulp of 2.4e-4; every cell keeps heights within its 9 x 9 box, so every cell of the area is evaluated), a
+    grasp area 100 cells wide (a wave that starts in column 0 of the integral image never passes the wave-wide checks on a grid this
+    small), roll 0 only, centred-remainder/exp form, no tier 0b behind it.  From the oracle's integral image the test rebuilds the
+    device's evaluation order (k_compact: the whole 64-cell chunks of every row first), recomputes -- fp32, the reference's order --
+    the kernel's wave-wide rule and every region sum of every HAF attribute svm-scale keeps, and asserts: path-A waves and evaluations
+    with a negative computed sum exist in number, NONE of those was decided by the pass (screening margin not above 1), evaluations
+    of the same waves without one were -- and every label is the oracle's (compare_full)."""
+    monkeypatch.setenv("HAF_NO_DIRECT", "1")
+    monkeypatch.setenv("HAF_LARGE_EVALS", "1")
+    monkeypatch.setenv("HAF_SCREEN_VARIANT", "2")
+    monkeypatch.setenv("HAF_T0B", "0")
+    G = 128
+    f, r = _files(data_dir)
+    model = models.write_random_model(str(tmp_path / "rand300.model"), 300, seed=3, balanced=True)
+    o = O.Oracle(f, r, model)
+    xyz = models.synthetic_cloud(grid=G, k=2, seed=4).reshape(G, G, 2, 3)
+    keep = np.ones((G, G), bool)
+    for a0 in range(30, 120, 12):
+        keep[a0:a0 + 8, 30:] = False                                  # (first grid index = the integral image's row)
+    xyz = np.ascontiguousarray(xyz[keep].reshape(-1, 3))
+    cfg = dict(n_rolls=1, roll_step_deg=25, grid_h=G, grid_w=G, max_points=2 * G * G)
+    inp = dict(grasp_area_length_x=G, grasp_area_length_y=100)
+    eng = make_engine(data_dir, model, testing=True, **cfg)
+    _, want = compare_full(eng, o, xyz, cfg, inp, check_dec=False)
+    assert eng.screen_low_rank()["last_used"]
+    margin = eng.debug(capi.DBG_SCREEN_MARGIN, 0, 0)
+    cnt = eng.last_counts()
+    eng.close()
+    II, msk = want["integral"][0], want["mask"][0] == 1
+    assert (want["heights"][0] >= 0).all()
+    # the waves of the thread-per-evaluation feature kernel that are 64 neighbours of one row (prestages.hip, k_compact: of every
+    # row the first floor(count / 64) * 64 masked cells, in chunks of 64; the remainders follow behind all of them)
+    ci, cj = [], []
+    for i in range(G):
+        cols = np.nonzero(msk[i])[0]
+        for c0 in range(0, len(cols) // 64 * 64, 64):
+            ch = cols[c0:c0 + 64]
+            if (np.diff(ch) == 1).all():
+                ci.append(np.full(64, i))
+                cj.append(ch)
+    ci, cj = np.concatenate(ci), np.concatenate(cj)
+    # the kernel's wave-wide rule, recomputed (features.hip: bottom row <= 2 x top row per column of the window, window total -- rounded
+    # up -- below the window's first corner; a window that starts in column 0 of the integral image takes its second corner)
+    tl, bl = II[ci - 7, cj - 7], II[ci + 7, cj - 7]
+    tr, br = II[ci - 7, cj + 7], II[ci + 7, cj + 7]
+    colok = np.ones(len(ci), bool)
+    for c in range(15):
+        colok &= II[ci + 7, cj - 7 + c] <= np.float32(2.0) * II[ci - 7, cj - 7 + c]
+    tA, tB = (br - tr).astype(np.float32), (bl - tl).astype(np.float32)
+    T = ((tA - tB).astype(np.float32) + np.float32(2.0e-7) * (np.abs(tA) + np.abs(tB))) * np.float32(1.0001)
+    lane = np.tile(np.arange(64), len(ci) // 64)
+    dmin = np.where((cj - 7 == 0) & (lane == 0), II[ci - 7, 1], tl)
+    clear = colok & (T * np.float32(1.01) < dmin)                      # (a margin: only waves that pass the rule beyond doubt are looked at)
+    path_a = clear.reshape(-1, 64).all(axis=1)
+    assert path_a.sum() >= 40, int(path_a.sum())
+    sel = np.repeat(path_a, 64)
+    si, sj = ci[sel], cj[sel]
+    reg, wgt = o.feature_table()
+    _, _, fmin, fmax, present = o.range_table()
+    rmin = np.zeros(len(si), np.float32)
+    for fi in range(min(reg.shape[0], 302)):                           # (the HAF attributes: a SHAF slot is passed through, not bounded)
+        if fi + 1 < len(present) and present[fi + 1] and fmin[fi + 1] == fmax[fi + 1]:
+            continue                                                  # (an attribute svm-scale drops: the screening pass has no slot for it)
+        for k in range(4):
+            x1, x2, y1, y2 = (int(v) for v in reg[fi, 4 * k:4 * k + 4])
+            if wgt[fi, k] == 0.0 or x2 < x1 or y2 < y1 or (x2 == 0 and y2 == 0):
+                continue
+            a, b = II[si - 7 + x2 + 1, sj - 7 + y2 + 1], II[si - 7 + x1, sj - 7 + y2 + 1]
+            c, d0 = II[si - 7 + x2 + 1, sj - 7 + y1], II[si - 7 + x1, sj - 7 + y1]
+            R = (((a - b).astype(np.float32) - c).astype(np.float32) + d0).astype(np.float32)    # fv.cpp:161-162, fp32, left to right
+            rmin = np.minimum(rmin, R)
+    neg = rmin < 0
+    decided = np.nan_to_num(margin[si, sj]) > 1.0
+    assert neg.sum() >= 1000, int(neg.sum())
+    assert not decided[neg].any(), "the low-rank pass decided %d evaluations whose computed region sums include a negative one" % int(decided[neg].sum())
+    assert decided[~neg].sum() > 0.5 * (~neg).sum(), (int(decided[~neg].sum()), int((~neg).sum()))
+    STATS["low_rank_negative_region_sums"] = dict(path_a_waves=int(path_a.sum()), evaluations=int(len(si)), with_a_negative_sum=int(neg.sum()),
+                                                  decided_with=int(decided[neg].sum()), decided_without=int(decided[~neg].sum()),
+                                                  without=int((~neg).sum()), smallest=float(rmin.min()), left_by_the_pass=int(cnt["n_refined"]))
+
+
 def test_tier_0b_gathers_from_the_low_rank_first_pass(data_dir, tmp_path, monkeypatch):
     """Round 5: behind a low-rank first pass with the plain epilogue, tier 0b is the low-rank sweep with the centred-remainder epilogue in
     its GATHER form (k_svm_screen_lr<CR_EXP, FUSED, GATHER>): operand images and raw sums of the first pass by evaluation id (L = ln2 p.g
