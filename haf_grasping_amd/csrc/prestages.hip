@@ -830,8 +830,12 @@ __global__ __launch_bounds__(64 * kRowsPerWg) void k_compact(const uint8_t *__re
     const int H = d.H, W = d.W, n = d.B * d.R * H;
     if (i >= H) return;
     const uint8_t *mrow = mask + ((size_t)br * H + i) * W;
-    const int whole = rowcount[br * H + i] & ~63;
-    const int base_a = rowoff[br * H + i], base_b = rowoff[n + 1 + br * H + i] - whole;
+    // (round 5: the row's REMAINDER -- its count modulo 64 -- is taken from the row's START, the whole waves from behind it: a row of a
+    // full-grid request starts in column 7, and a wave whose first window starts in column 0 of the integral image never passes the
+    // low-rank feature kernel's wave-wide exactness test (features.hip: T < dmin) -- at C5 that was one of the seven whole waves of
+    // every row on the slower per-region bounds.  The remainders form waves that are no run of neighbours either way.)
+    const int cnt = rowcount[br * H + i], whole = cnt & ~63, rem = cnt - whole;
+    const int base_a = rowoff[br * H + i] - rem, base_b = rowoff[n + 1 + br * H + i];
     int done = 0;
     for (int j0 = 0; j0 < W; j0 += 64) {
         int j = j0 + lane;
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(64 * kRowsPerWg) void k_compact(const uint8_t *__re
         unsigned long long bal = __ballot(m);
         if (m) {
             const int rank = done + __popcll(bal & ((1ull << lane) - 1ull));
-            evalcell[(rank < whole ? base_a : base_b) + rank] = (br * H + i) * W + j;
+            evalcell[(rank >= rem ? base_a : base_b) + rank] = (br * H + i) * W + j;
         }
         done += __popcll(bal);
     }

@@ -1055,7 +1055,7 @@ def test_low_rank_pass_never_trusts_a_negative_computed_region_sum(data_dir, tmp
     (corners up to ~3 000: an ulp of 2.4e-4; every cell keeps heights within its 9 x 9 box, so every cell of the area is evaluated), a
     grasp area 100 cells wide (a wave that starts in column 0 of the integral image never passes the wave-wide checks on a grid this
     small), roll 0 only, centred-remainder/exp form, no tier 0b behind it.  From the oracle's integral image the test rebuilds the
-    device's evaluation order (k_compact: the whole 64-cell chunks of every row first), recomputes -- fp32, the reference's order --
+    device's evaluation order (k_compact: the whole 64-cell chunks of every row first, taken from the row's END), recomputes -- fp32, the reference's order --
     the kernel's wave-wide rule and every region sum of every HAF attribute svm-scale keeps, and asserts: path-A waves and evaluations
     with a negative computed sum exist in number, NONE of those was decided by the pass (screening margin not above 1), evaluations
     of the same waves without one were -- and every label is the oracle's (compare_full)."""
@@ -1083,11 +1083,11 @@ def test_low_rank_pass_never_trusts_a_negative_computed_region_sum(data_dir, tmp
     II, msk = want["integral"][0], want["mask"][0] == 1
     assert (want["heights"][0] >= 0).all()
     # the waves of the thread-per-evaluation feature kernel that are 64 neighbours of one row (prestages.hip, k_compact: of every
-    # row the first floor(count / 64) * 64 masked cells, in chunks of 64; the remainders follow behind all of them)
+    # row the masked cells behind its first count % 64, in chunks of 64; the remainders follow behind all of them)
     ci, cj = [], []
     for i in range(G):
         cols = np.nonzero(msk[i])[0]
-        for c0 in range(0, len(cols) // 64 * 64, 64):
+        for c0 in range(len(cols) % 64, len(cols), 64):
             ch = cols[c0:c0 + 64]
             if (np.diff(ch) == 1).all():
                 ci.append(np.full(64, i))
