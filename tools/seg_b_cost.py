@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What do the row remainders cost the thread-per-evaluation feature kernel?  Of every grid row the first floor(count / 64) * 64 masked
 cells are waves of 64 neighbours (the band path: windows staged per wave, corners by ds_read_addtid); the remainder of every row ends
-up in waves that are NOT a run of neighbours (per-lane corner loads, per-region rounding bounds).  One roll, roll 0, grasp areas whose
+up in waves that are NOT a run of neighbours (per-lane corner loads, per-region rounding bounds).  All 36 rolls (the rotated area cuts the rows differently per roll: the remainders are ~32 cells on average then), grasp areas whose
 rows hold 448 (= 7 x 64: no remainder), 498 (the bench's: 50 left over) and 480 (32 left over) masked cells: feature-stage time per
 evaluation.  On a GPU box: python tools/seg_b_cost.py"""
 import os, sys, tempfile
@@ -18,12 +18,12 @@ G = 512
 xyz = models.synthetic_cloud(grid=G, k=2, seed=0)
 d_xyz = torch.from_numpy(xyz).cuda()
 cloud = (d_xyz.data_ptr(), xyz.shape[0], 3)
-eng = capi.Engine(feat, rng, mp, device=0, grid_h=G, grid_w=G, n_rolls=4, roll_step_deg=90, max_clouds=1, max_points=G * G * 2, flags=capi.FLAG_PROFILE)
+eng = capi.Engine(feat, rng, mp, device=0, grid_h=G, grid_w=G, n_rolls=36, roll_step_deg=5, max_clouds=1, max_points=G * G * 2, flags=capi.FLAG_PROFILE)
 for ly in (462, 512, 494, 462, 512):
     inp = capi.default_input(grasp_area_length_x=G, grasp_area_length_y=ly)
     ts, ev = [], 0
     for _ in range(6):
-        rec = eng.score_rolls([cloud], [inp], 0, 1)[0]
+        rec = eng.score_rolls([cloud], [inp], 0, 36)[0]
         ev = int(rec["n_evals"].sum())
         ts.append(eng.stage_ms()["features"])
     t = float(np.median(ts[2:]))
