@@ -834,8 +834,13 @@ __global__ __launch_bounds__(64 * kRowsPerWg) void k_compact(const uint8_t *__re
     // full-grid request starts in column 7, and a wave whose first window starts in column 0 of the integral image never passes the
     // low-rank feature kernel's wave-wide exactness test (features.hip: T < dmin) -- at C5 that was one of the seven whole waves of
     // every row on the slower per-region bounds.  The remainders form waves that are no run of neighbours either way.)
+#ifdef HAF_OLD_CHUNKING      // (variant builds only: the A/B of the round-5 change -- the remainder at the row's END, as until then)
+    const int cnt = rowcount[br * H + i], whole = cnt & ~63, rem = 0;
+    const int base_a = rowoff[br * H + i], base_b = rowoff[n + 1 + br * H + i] - whole;
+#else
     const int cnt = rowcount[br * H + i], whole = cnt & ~63, rem = cnt - whole;
     const int base_a = rowoff[br * H + i] - rem, base_b = rowoff[n + 1 + br * H + i];
+#endif
     int done = 0;
     for (int j0 = 0; j0 < W; j0 += 64) {
         int j = j0 + lane;
@@ -843,7 +848,11 @@ __global__ __launch_bounds__(64 * kRowsPerWg) void k_compact(const uint8_t *__re
         unsigned long long bal = __ballot(m);
         if (m) {
             const int rank = done + __popcll(bal & ((1ull << lane) - 1ull));
+#ifdef HAF_OLD_CHUNKING
+            evalcell[(rank < whole ? base_a : base_b) + rank] = (br * H + i) * W + j;
+#else
             evalcell[(rank >= rem ? base_a : base_b) + rank] = (br * H + i) * W + j;
+#endif
         }
         done += __popcll(bal);
     }
