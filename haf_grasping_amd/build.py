@@ -144,6 +144,56 @@ def check_exp_hazard(lib=None, verbose=False):
     return rep
 
 
+# Round 5: the group-parallel feature kernels (k_features<MODE, WAVES>) read the descriptor words of a wave's attribute group by SCALAR
+# loads -- the wave index is held in an SGPR (readfirstlane).  As a VGPR expression the compiler fetched them with ~17 vector loads and
+# as many s_waitcnt vmcnt per slot (138 global_load in the slot loop of k_features<2, 8>, 40 us of a 49 us launch at C3).  The build
+# refuses an instance with more vector loads than the staging, list and operand traffic account for.
+DESCRIPTOR_LOAD_KERNELS = "k_featuresILi"
+MAX_VECTOR_LOADS = 80
+
+
+def descriptor_load_report(lib=None):
+    """{kernel symbol: vector load instructions (global_load / buffer_load)} of every k_features<., .> instance"""
+    import glob
+    import shutil
+    import tempfile
+    lib = lib or LIB
+    tmp = tempfile.mkdtemp(prefix="haf_isa_")
+    try:
+        shutil.copy(lib, os.path.join(tmp, "lib.so"))
+        subprocess.check_call([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, stdout=subprocess.DEVNULL)
+        text = ""
+        for co in sorted(glob.glob(os.path.join(tmp, "*gfx950*"))):
+            text += subprocess.check_output([OBJDUMP, "-d", co]).decode(errors="replace")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rep, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1) if (DESCRIPTOR_LOAD_KERNELS in m.group(1) and not m.group(1).endswith(".kd")) else None
+            if cur:
+                rep[cur] = 0
+            continue
+        if cur and line.split("//")[0].strip().startswith(("global_load", "buffer_load")):
+            rep[cur] += 1
+    return rep
+
+
+def check_descriptor_loads(lib=None, verbose=False):
+    rep = descriptor_load_report(lib)
+    if verbose:
+        for k, n in sorted(rep.items()):
+            print("  descriptor-load check: %-60s %3d vector loads" % (k[:60], n))
+    if not rep:
+        raise RuntimeError("check_descriptor_loads: no %s instance found in %s" % (DESCRIPTOR_LOAD_KERNELS, lib or LIB))
+    bad = {k: n for k, n in rep.items() if n > MAX_VECTOR_LOADS}
+    if bad:
+        raise RuntimeError("build check failed: the group-parallel feature kernels fetch descriptor words by vector loads again "
+                           "(> %d global/buffer loads): %r" % (MAX_VECTOR_LOADS, bad))
+    return rep
+
+
 READELF = os.path.join(ROCM, "lib", "llvm", "bin", "llvm-readelf")
 # kernels that live at the edge of the register file (two waves of ~250 VGPRs per SIMD): a scratch spill in their inner loops
 # would be a silent 2x -- the build refuses it (round 4: a packed-fp32 form of the polynomial epilogue compiled to 54 spills)
@@ -233,6 +283,7 @@ def _compile_and_link(out_lib, out_testing, obj_dir, extra_flags=(), verbose=Fal
         if checks:
             check_exp_hazard(staged[0][0], verbose=verbose)
             check_no_spills(staged[0][0], verbose=verbose)
+            check_descriptor_loads(staged[0][0], verbose=verbose)
         for tmp, out in staged:
             os.replace(tmp, out)
     finally:

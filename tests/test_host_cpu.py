@@ -544,6 +544,7 @@ def test_failed_exp_hazard_check_leaves_no_library(tmp_path, monkeypatch):
             f.write("built")
     monkeypatch.setattr(b.subprocess, "check_call", fake_call)
     monkeypatch.setattr(b, "check_no_spills", lambda *a, **k: {})       # (the faked libraries have no code objects)
+    monkeypatch.setattr(b, "check_descriptor_loads", lambda *a, **k: {})
 
     def failing(*a, **k):
         raise RuntimeError("build check failed: hazard")
@@ -572,6 +573,18 @@ def test_contraction_kernels_do_not_spill():
               "k_svm_rbf_hILb0ELb0", "k_recheck_i8"):
         assert k in names, (k, sorted(rep))
     assert all(sp == 0 and 0 < vg <= 256 for vg, sp in rep.values()), rep
+
+
+def test_group_parallel_feature_kernels_read_descriptors_by_scalar_loads():
+    """Round 5: every instance of k_features<MODE, WAVES> keeps its wave index in an SGPR, so the descriptor words of the wave's attribute
+    group are scalar loads; as a VGPR expression they were ~17 vector loads and waits per slot (138 in the slot loop of k_features<2, 8>:
+    40 of a C3 request's 250 us).  build() counts the vector loads of every instance in the disassembly and refuses more than the
+    staging, list and operand traffic account for; on the library as built: all ten instances, 18-49 loads each."""
+    from haf_grasping_amd import build as b
+    if not b.up_to_date():
+        b.build()
+    rep = b.check_descriptor_loads()
+    assert len(rep) == 10 and all(0 < n <= b.MAX_VECTOR_LOADS for n in rep.values()), rep
 
 
 def test_ros_adapter_translation_unit_parses():
