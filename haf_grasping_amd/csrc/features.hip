@@ -319,8 +319,14 @@ __device__ __forceinline__ void i8_store(float *X, long e, int g, const unsigned
 // total below its top-left corner (then |s2| = d - R <= d and s3 = R are multiples of ulp(d) below 2^24 ulp(d)) -- pays three
 // instructions per slot; (B) any other run of neighbours tests every region on its own four corners (region_round_bound); (C) a wave
 // that is not a run of neighbours does the same through the per-lane loads.
+// (round 5: SEVEN waves per SIMD -- 72 registers; the low-rank screening instance sat at 73, one register above it, and runs 5 % faster
+// with three of them spilled: 3.34 -> 3.18 ms at C5, A/B on one box, profiles/r05_serial_waves_ab.txt.  HAF_SERIAL_WAVES: variant builds)
+#ifndef HAF_SERIAL_WAVES
+#define HAF_SERIAL_WAVES 7
+#endif
 template <int MODE, bool LR>
-__global__ __launch_bounds__(256) void k_features_serial(const float *__restrict__ ii, const int *__restrict__ evalcell,
+__global__ __launch_bounds__(256, HAF_SERIAL_WAVES) void k_features_serial(
+const float *__restrict__ ii, const int *__restrict__ evalcell,
                                                   const int *__restrict__ counters, const FeatDesc *__restrict__ fd,
                                                   float *__restrict__ X, float *__restrict__ ax, Dims d, double lower,
                                                   double upper, float neg_gamma2, ScreenParams sp,
